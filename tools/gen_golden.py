@@ -1,0 +1,310 @@
+#!/usr/bin/env python
+"""Generate golden vectors for the Group-KNN hot path FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  It imports the reference's
+own ``vig_model`` / ``gkgnet`` code through ``tools/ref_import.py`` and stores inputs +
+expected outputs as small ``.npz`` fixtures under ``tests/golden/``.  The fixtures are
+data only (tensors + ctor kwargs); no reference source is stored.
+
+Case matrix: SURVEY.md §8(c) F1..F10.
+
+    python tools/gen_golden.py            # regenerate everything
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_import import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def keyed_fill_(state_dict, seed: int = 0):
+    """Deterministic, construction-order-independent parameter fill: every tensor is drawn from a
+    generator seeded with crc32(key) ^ seed.  The product side applies the same rule
+    (tests/util.py) so no weights need to be stored for the large F10 case."""
+    for key in sorted(state_dict.keys()):
+        t = state_dict[key]
+        if key.endswith("num_batches_tracked") or key.endswith("relative_pos"):
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+        if key.endswith("running_var"):
+            v = torch.rand(t.shape, generator=g) + 0.5
+        elif key.endswith("running_mean"):
+            v = torch.randn(t.shape, generator=g) * 0.1
+        elif ".1.weight" in key or key.endswith("bn.weight"):      # norm scale
+            v = torch.rand(t.shape, generator=g) + 0.5
+        elif key.endswith(".bias"):
+            v = torch.randn(t.shape, generator=g) * 0.1
+        elif t.dim() >= 2:
+            fan_in = t[0].numel()
+            v = torch.randn(t.shape, generator=g) * (1.0 / max(fan_in, 1)) ** 0.5
+        else:
+            v = torch.randn(t.shape, generator=g) * 0.1
+        t.copy_(v.to(t.dtype))
+
+
+def randomize_norm_(module, gen):
+    """Give every norm layer non-trivial affine + running statistics (seeded)."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+
+
+def ref_top_distances(ref, knn_in_x, knn_in_y, relpos, kd):
+    """Sorted top-(kd+1) distances of the matrix the reference's topk sees (for the near-tie protocol)."""
+    te = ref.torch_edge
+    with torch.no_grad():
+        xn = F.normalize(knn_in_x, p=2.0, dim=1).transpose(2, 1).squeeze(-1)
+        if knn_in_y is None:
+            dist = te.pairwise_distance(xn)
+        else:
+            yn = F.normalize(knn_in_y, p=2.0, dim=1).transpose(2, 1).squeeze(-1)
+            dist = te.xy_pairwise_distance(xn, yn)
+        if relpos is not None:
+            dist = dist + relpos
+        kk = min(kd + 1, dist.shape[-1])
+        vals, idx = torch.topk(-dist, k=kk)
+    return (-vals).numpy(), idx.numpy()
+
+
+def np_state(module):
+    return {"sd/" + k: v.detach().cpu().clone().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, meta, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **arrays)
+    print(f"{name:32s} {os.path.getsize(path) / 1024:8.1f} KB")
+
+
+# ----------------------------------------------------------------------------- Grapher cases
+def grapher_case(ref, name, *, C, k, d, r, hw, G, multi, B=2, seed=0, bf16_round=False, conv="mr"):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    n = hw * hw
+    mod = ref.vig.Grapher(C, k, d, conv, "gelu", "batch", True, False, 0.2, r, n=n, drop_path=0.0,
+                          relative_pos=True, use_multi_group=multi, num_group=G)
+    randomize_norm_(mod, gen)
+    x = torch.randn(B, C, hw, hw, generator=gen)
+    if bf16_round:
+        x = x.to(torch.bfloat16).to(torch.float32)
+    cot = torch.randn(B, C, hw, hw, generator=gen)
+    sd0 = np_state(mod)                      # before any running-stat update
+
+    cap = {}
+    h1 = mod.graph_conv.register_forward_hook(lambda m, i, o: cap.update(knn_in=i[0].detach().clone(),
+                                                                         edge_index=o[1].detach().clone(),
+                                                                         graph=o[0].detach().clone()))
+    h2 = mod.graph_conv.gconv.nn.register_forward_hook(lambda m, i, o: cap.update(nn_in=i[0].detach().clone()))
+    mod.eval()
+    with torch.no_grad():
+        out_eval = mod(x)
+    eval_edge = cap["edge_index"].clone()
+    mod.train()
+    xg = x.clone().requires_grad_(True)
+    out = mod(xg)
+    (out * cot).sum().backward()
+    h1.remove(); h2.remove()
+
+    groups = G if multi else 1
+    knn_in = cap["knn_in"]                                   # (B,C,H,W) output of fc1 (train-mode BN)
+    xq = knn_in.reshape(B * groups, C // groups, n, 1)
+    yk = None
+    if r > 1:
+        yk = F.avg_pool2d(knn_in, r, r).reshape(B * groups, C // groups, -1, 1)
+    topd, topi = ref_top_distances(ref, xq, yk, mod.relative_pos, k * d)
+    arrays = dict(x=x.numpy(), cot=cot.numpy(), out_eval=out_eval.numpy(), out=out.detach().numpy(),
+                  dx=xg.grad.numpy(), knn_in=knn_in.numpy(), edge_index=cap["edge_index"].numpy().astype(np.int32),
+                  edge_index_eval=eval_edge.numpy().astype(np.int32),
+                  graph=cap["graph"].numpy(), topd=topd, topi=topi.astype(np.int32))
+    if conv == "mr":
+        arrays["m"] = cap["nn_in"][:, 1::2, :, 0].numpy()    # (B,C,N) max-relative half of the interleave
+    arrays.update(sd0)
+    for pn, p in mod.named_parameters():
+        if p.grad is not None:
+            arrays["grad/" + pn] = p.grad.numpy()
+    meta = dict(kind="grapher", C=C, k=k, dilation=d, r=r, n=n, G=G, use_multi_group=multi, B=B, hw=hw,
+                conv=conv, ref="torch_vertex.py:278-333")
+    save(name, meta, **arrays)
+
+
+def label_case(ref, name, *, C, k, hw, L, G, multi, B=2, seed=0):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    mod = ref.vig.GrapherLabel(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=hw * hw, drop_path=0.0,
+                               relative_pos=False, num_nodes=L, use_multi_group=multi, num_group=G)
+    randomize_norm_(mod, gen)
+    e = torch.randn(B, L, C, generator=gen)
+    feat = torch.randn(B, C, hw, hw, generator=gen)
+    cot = torch.randn(B, L, C, generator=gen)
+    sd0 = np_state(mod)
+    cap = {}
+    h1 = mod.graph_conv.register_forward_hook(lambda m, i, o: cap.update(knn_in=i[0].detach().clone()))
+    h2 = mod.graph_conv.gconv.nn.register_forward_hook(lambda m, i, o: cap.update(nn_in=i[0].detach().clone()))
+    mod.eval()
+    with torch.no_grad():
+        out_eval, idx_eval = mod(e, feat)
+    mod.train()
+    eg = e.clone().requires_grad_(True)
+    fg = feat.clone().requires_grad_(True)
+    out, idx = mod(eg, fg)
+    (out * cot).sum().backward()
+    h1.remove(); h2.remove()
+    groups = G if multi else 1
+    xq = cap["knn_in"].reshape(B * groups, C // groups, L, 1)
+    yk = feat.reshape(B * groups, C // groups, hw * hw, 1)
+    topd, topi = ref_top_distances(ref, xq, yk, None, k)
+    arrays = dict(e=e.numpy(), feat=feat.numpy(), cot=cot.numpy(), out_eval=out_eval.numpy(),
+                  nn_idx_eval=idx_eval.numpy().astype(np.int32), out=out.detach().numpy(),
+                  nn_idx=idx.numpy().astype(np.int32), de=eg.grad.numpy(), dfeat=fg.grad.numpy(),
+                  knn_in=cap["knn_in"].numpy(), m=cap["nn_in"][:, 1::2, :, 0].numpy(), topd=topd,
+                  topi=topi.astype(np.int32))
+    arrays.update(sd0)
+    for pn, p in mod.named_parameters():
+        if p.grad is not None:
+            arrays["grad/" + pn] = p.grad.numpy()
+    meta = dict(kind="grapher_label", C=C, k=k, n=hw * hw, hw=hw, L=L, G=G, use_multi_group=multi, B=B,
+                ref="torch_vertex.py:361-403")
+    save(name, meta, **arrays)
+
+
+# ----------------------------------------------------------------------------- op-level cases
+def knn_op_case(ref, name, *, BG, c, N, M, k, d, relpos, seed, bf16_round=False):
+    """DenseDilatedKnnGraph + MRConv2d's gather/max on raw tensors (op-level pin for a1..a7)."""
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(BG, c, N, 1, generator=gen)
+    y = None if M is None else torch.randn(BG, c, M, 1, generator=gen)
+    if bf16_round:
+        x = x.to(torch.bfloat16).float()
+        y = None if y is None else y.to(torch.bfloat16).float()
+    rp = None
+    if relpos:
+        rp = -torch.rand(1, N, N if M is None else M, generator=gen)
+    g = ref.torch_edge.DenseDilatedKnnGraph(k, d, False, 0.0)
+    edge = g(x, y, rp)
+    bis = ref.torch_nn.batched_index_select
+    x_i = bis(x, edge[1])
+    x_j = bis(x if y is None else y, edge[0])
+    rel, arg = torch.max(x_j - x_i, -1)
+    gcot = torch.randn(BG, c, N, generator=gen)
+    xg = x.clone().requires_grad_(True)
+    yg = None if y is None else y.clone().requires_grad_(True)
+    xi = bis(xg, edge[1]); xj = bis(xg if yg is None else yg, edge[0])
+    mm, _ = torch.max(xj - xi, -1)
+    (mm * gcot).sum().backward()
+    topd, topi = ref_top_distances(ref, x, y, rp, k * d)
+    arrays = dict(x=x.squeeze(-1).numpy(), edge_index=edge.numpy().astype(np.int32), m=rel.numpy(),
+                  gcot=gcot.numpy(), dx=xg.grad.squeeze(-1).numpy(), topd=topd, topi=topi.astype(np.int32))
+    if y is not None:
+        arrays["y"] = y.squeeze(-1).numpy()
+        arrays["dy"] = yg.grad.squeeze(-1).numpy()
+    if rp is not None:
+        arrays["relpos"] = rp.numpy()
+    meta = dict(kind="knn_op", BG=BG, c=c, N=N, M=M, k=k, dilation=d, bf16_round=bf16_round,
+                ref="torch_edge.py:164-176; torch_vertex.py:49-54")
+    save(name, meta, **arrays)
+
+
+def integer_kat(ref, name):
+    """F8: small-integer features straight into the UN-normalised op-level functions
+    (dense_knn_matrix / xy_dense_knn_matrix, torch_edge.py:54,89) where fp32 math is exact.
+    Tie-free by rejection sampling: all squared distances are integers < 2^24 and the sorted
+    top-(k+1) of every query is strictly increasing."""
+    te = ref.torch_edge
+    c, N, M, k = 6, 24, 40, 7
+
+    def tie_free(dist):
+        srt = torch.sort(dist, dim=-1).values
+        return bool((srt[..., 1:k + 1] - srt[..., :k]).min() >= 1.0)
+
+    for seed in range(1000):                       # rejection-sample a tie-free instance
+        rng = np.random.RandomState(seed)
+        x = rng.randint(-30, 31, size=(2, c, N, 1)).astype(np.float32)
+        y = rng.randint(-30, 31, size=(2, c, M, 1)).astype(np.float32)
+        xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+        dist = te.xy_pairwise_distance(xt.transpose(2, 1).squeeze(-1), yt.transpose(2, 1).squeeze(-1))
+        dself = te.pairwise_distance(yt.transpose(2, 1).squeeze(-1))
+        if tie_free(dist) and tie_free(dself):
+            break
+    else:
+        raise RuntimeError("no tie-free KAT instance found")
+    e_xy = te.xy_dense_knn_matrix(xt, yt, k, None)
+    e_self = te.dense_knn_matrix(yt, k, None)
+    meta = dict(kind="integer_kat", c=c, N=N, M=M, k=k, ref="torch_edge.py:54-106 (no normalisation)")
+    save(name, meta, x=x[..., 0], y=y[..., 0], edge_xy=e_xy.numpy().astype(np.int32),
+         edge_self=e_self.numpy().astype(np.int32), dist_xy=dist.numpy(), dist_self=dself.numpy())
+
+
+def relpos_case(ref, name, combos):
+    arrays = {}
+    metas = []
+    for (C, n, r) in combos:
+        mod = ref.vig.Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, r, n=n, relative_pos=True)
+        arrays[f"rp_{C}_{n}_{r}"] = mod.relative_pos.detach().numpy()
+        metas.append([C, n, r])
+    # runtime re-interpolation path (torch_vertex.py:317-323): built for n=64, run at 10x10
+    mod = ref.vig.Grapher(32, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 2, n=64, relative_pos=True)
+    arrays["rp_runtime_32_64_2_to_10x10"] = mod._get_relative_pos(mod.relative_pos, 10, 10).detach().numpy()
+    save(name, dict(kind="relpos", combos=metas, ref="pos_embed.py:21-85; torch_vertex.py:309-323"), **arrays)
+
+
+def backbone_case(ref, name):
+    """F10: tiny full GKGNet forward (wiring pin).  Weights are NOT stored: both sides fill the
+    state_dict with keyed_fill_ (crc32(key)-seeded)."""
+    torch.manual_seed(0)
+    kw = dict(choice="t", k=4, k_label_gcn=4, n_classes=8, size=128, drop_path=0.0)
+    net = ref.gkgnet.GKGNet(**kw)
+    sd = net.state_dict()
+    with torch.no_grad():
+        keyed_fill_(sd, seed=10)
+    net.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(123)
+    img = torch.randn(2, 3, 128, 128, generator=gen)
+    net.eval()
+    with torch.no_grad():
+        e, gap, edge = net(img)
+    keys = sorted(sd.keys())
+    shapes = {k: list(sd[k].shape) for k in keys}
+    meta = dict(kind="backbone", ctor=kw, state_shapes=shapes, ref="gkgnet.py:150-284")
+    save(name, meta, img=img.numpy(), label_tokens=e.numpy(), gap=gap.numpy(), edge_index=edge.numpy().astype(np.int32))
+
+
+def main():
+    ref = load_reference(with_backbone=True)
+    grapher_case(ref, "f1_grapher_cfg1", C=64, k=9, d=1, r=1, hw=14, G=1, multi=False)
+    grapher_case(ref, "f2_grapher_g4", C=64, k=9, d=1, r=1, hw=8, G=4, multi=True, seed=2)
+    grapher_case(ref, "f3_grapher_dil3", C=64, k=9, d=3, r=1, hw=12, G=2, multi=True, seed=3)
+    grapher_case(ref, "f4a_grapher_r2", C=32, k=9, d=1, r=2, hw=16, G=2, multi=True, seed=4)
+    grapher_case(ref, "f4b_grapher_r4", C=32, k=9, d=1, r=4, hw=16, G=2, multi=True, seed=5)
+    grapher_case(ref, "f7_grapher_bf16in", C=64, k=9, d=2, r=1, hw=8, G=2, multi=True, seed=7, bf16_round=True)
+    grapher_case(ref, "f11_grapher_edgeconv", C=32, k=6, d=1, r=1, hw=6, G=1, multi=False, seed=11, conv="edge")
+    label_case(ref, "f5_label_g2", C=64, k=9, hw=8, L=80, G=2, multi=True, seed=5)
+    label_case(ref, "f5b_label_g1", C=32, k=5, hw=6, L=12, G=1, multi=False, seed=6)
+    knn_op_case(ref, "op_self_relpos", BG=3, c=20, N=70, M=None, k=5, d=2, relpos=True, seed=21)
+    knn_op_case(ref, "op_xy_norelpos", BG=4, c=12, N=33, M=150, k=9, d=1, relpos=False, seed=22)
+    knn_op_case(ref, "op_xy_relpos_dil", BG=2, c=48, N=100, M=25, k=4, d=3, relpos=True, seed=23)
+    knn_op_case(ref, "op_self_bf16", BG=2, c=40, N=96, M=None, k=9, d=1, relpos=False, seed=24, bf16_round=True)
+    knn_op_case(ref, "op_label_like", BG=2, c=32, N=80, M=400, k=9, d=1, relpos=False, seed=25)
+    integer_kat(ref, "f8_integer_kat")
+    relpos_case(ref, "f9_relpos", [(64, 196, 1), (80, 144, 1), (32, 256, 2), (32, 256, 4)])
+    backbone_case(ref, "f10_backbone_tiny")
+
+
+if __name__ == "__main__":
+    main()
