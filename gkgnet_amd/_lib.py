@@ -1,0 +1,56 @@
+"""ctypes binding of libgkg_hip.so (C ABI: include/gkg_hip.h).
+
+The product has NO CPU fallback: if the library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
+
+ABI_VERSION = 1
+F32, BF16 = 0, 1
+KNN_NORMALIZE = 1
+
+EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
+           "gkg_mr_bwd")
+
+_lib = None
+
+
+class GkgError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library (once).  Raises GkgError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GkgError(f"{LIB_PATH} not found: build it with `python -m gkgnet_amd._build` "
+                       "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.gkg_version.restype = C.c_int
+    lib.gkg_last_error_string.restype = C.c_char_p
+    lib.gkg_knn_workspace_bytes.restype = C.c_size_t
+    lib.gkg_knn_workspace_bytes.argtypes = [C.c_int] * 7 + [C.c_uint]
+    lib.gkg_knn_fwd.restype = C.c_int
+    lib.gkg_knn_fwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.gkg_mr_fwd.restype = C.c_int
+    lib.gkg_mr_fwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
+    lib.gkg_mr_bwd.restype = C.c_int
+    lib.gkg_mr_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
+    v = lib.gkg_version()
+    if v != ABI_VERSION:
+        raise GkgError(f"libgkg_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gkg_last_error_string().decode(errors="replace")
+        raise GkgError(f"{what} failed (rc={rc}): {msg}")

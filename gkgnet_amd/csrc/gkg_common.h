@@ -1,0 +1,24 @@
+// gkg_common.h — shared device helpers + error plumbing for libgkg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gkg_hip.h"
+
+namespace gkg {
+
+// Feature element load/store: fp32 as is, bf16 carried as raw uint16_t (widening is exact).
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const uint16_t* p) { return __uint_as_float(((uint32_t)*p) << 16); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(uint16_t* p, float v) {
+  // round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+  const __bf16 b = (__bf16)v;
+  *p = __builtin_bit_cast(uint16_t, b);
+}
+
+}  // namespace gkg
+
+// Records the message for gkg_last_error_string() and returns `code`.
+int gkg_fail(int code, const char* msg);
+int gkg_fail_hip(hipError_t e, const char* where);

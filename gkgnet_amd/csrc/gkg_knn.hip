@@ -1,0 +1,451 @@
+// gkg_knn.hip — fused dilated k-NN graph construction for MI355X (gfx950 / CDNA4).
+//
+// Replaces the reference's  F.normalize -> (|x|^2 - 2 x.y^T + |y|^2) -> += relative_pos -> topk -> [::d]
+// chain (mmcls/models/backbones/vig_model/torch_edge.py:9-51, 54-106, 139-176) without ever
+// materialising the (BG,N,M) distance matrix.
+//
+// Pipeline (all on the caller's stream):
+//   1. token_prep_kernel   : per token, ordered-fma L2 norm over the group's channels, normalised fp32
+//                            copy th (BG,cpad,T) (cpad = c rounded up to even, zero padded) + |th|^2.
+//   2. knn_tile_kernel<KD> : one workgroup = 64 queries of one (b,g) problem x one key split; its 4 waves
+//                            take key tiles of 32 round-robin.  Per key tile a wave runs the contraction on
+//                            the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, == an ordered fmaf
+//                            chain over channels) with keys as the A operand (streamed from L2/HBM in the
+//                            reference's native channel-major layout: a lane reads y[ch][m0+lane]) and the
+//                            64 staged queries as two B operands from LDS.  The two 32x32 accumulators are
+//                            exchanged with v_permlane32_swap so that lane l owns query n0+l and all 32
+//                            key distances of the tile; each lane keeps a sorted top-KD list (value via
+//                            v_med3_f32, index via v_cndmask) in registers.  The 4 per-wave lists of a
+//                            query are merged through LDS; ranks 0,d,2d,.. go out as int64.
+//   3. knn_merge_kernel    : only when the keys were split over several workgroups (few queries, many
+//                            keys — the label graph): merges the S partial lists of each query.
+//
+// Arithmetic contract: include/gkg_hip.h (restated in oracle/gkg_oracle.c).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gkg_common.h"
+
+namespace gkg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int QT = 64;   // queries per workgroup (one per lane)
+constexpr int KT = 32;   // keys per MFMA tile
+constexpr int NW = 4;    // waves per workgroup
+
+// ------------------------------------------------------------------------------------------ prep
+template <typename T, bool NORM>
+__global__ __launch_bounds__(256) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
+                                                         float* __restrict__ sq, int c, int cpad, int Tn) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int bg = blockIdx.y;
+  if (n >= Tn) return;
+  const T* tp = t + (size_t)bg * c * Tn + n;
+  float den = 1.0f;
+  if (NORM) {
+    float s = 0.0f;
+    for (int ch = 0; ch < c; ++ch) {
+      const float v = ldf(tp + (size_t)ch * Tn);
+      s = __builtin_fmaf(v, v, s);
+    }
+    den = fmaxf(sqrtf(s), 1e-12f);
+  }
+  float q = 0.0f;
+  float* op = th + (size_t)bg * cpad * Tn + n;
+  for (int ch = 0; ch < c; ++ch) {
+    float v = ldf(tp + (size_t)ch * Tn);
+    if (NORM) v = v / den;
+    op[(size_t)ch * Tn] = v;
+    q = __builtin_fmaf(v, v, q);
+  }
+  for (int ch = c; ch < cpad; ++ch) op[(size_t)ch * Tn] = 0.0f;
+  sq[(size_t)bg * Tn + n] = q;
+}
+
+// ------------------------------------------------------------------------------------------ top-KD list
+// Sorted ascending (v[0] smallest).  Candidates of one lane arrive in increasing key index, so the strict
+// '<' keeps the smaller index first among equal distances (the documented tie rule).
+template <int KD>
+struct TopList {
+  float v[KD];
+  int id[KD];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KD; ++j) { v[j] = INFINITY; id[j] = 0x7fffffff; }
+  }
+  __device__ __forceinline__ void insert(float d, int m) {
+    // wave-uniform early-out: nobody beats their current worst
+    if (__builtin_amdgcn_ballot_w64(d < v[KD - 1]) == 0ull) return;
+    bool lt_j = d < v[KD - 1];
+#pragma unroll
+    for (int j = KD - 1; j >= 1; --j) {
+      const bool lt_jm1 = d < v[j - 1];
+      v[j] = __builtin_amdgcn_fmed3f(v[j - 1], d, v[j]);
+      id[j] = lt_jm1 ? id[j - 1] : (lt_j ? m : id[j]);
+      lt_j = lt_jm1;
+    }
+    v[0] = lt_j ? d : v[0];
+    id[0] = lt_j ? m : id[0];
+  }
+};
+
+// ------------------------------------------------------------------------------------------ main kernel
+struct KnnArgs {
+  const float* xh;      // (BG, cpad, N) normalised queries
+  const float* yh;      // (BG, cpad, M) normalised keys (== xh for the self graph)
+  const float* sqx;     // (BG, N)
+  const float* sqy;     // (BG, M)
+  const float* relpos;  // (N, M) or null
+  int64_t* nn_idx;      // (BG, N, k)
+  int64_t* center;      // (BG, N, k) or null
+  float* part_v;        // (S, BG, N, KD) partial lists when S > 1
+  int* part_i;
+  int BG, cpad, N, M, k, dilation, kd;
+  int splits, tiles_per_split;
+};
+
+template <int KD, bool HAS_RP>
+__global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bg = blockIdx.y;
+  const int split = blockIdx.z;
+  const int n0 = blockIdx.x * QT;
+  const int N = a.N, M = a.M, cpad = a.cpad;
+
+  // ---- stage the query tile: xs[ch][64] (zero for n >= N)
+  {
+    const float* xp = a.xh + (size_t)bg * cpad * N;
+    for (int i = tid; i < cpad * QT; i += 256) {
+      const int ch = i >> 6, q = i & 63;
+      smem[i] = (n0 + q < N) ? xp[(size_t)ch * N + n0 + q] : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  const int n = n0 + lane;
+  const int nc = n < N ? n : N - 1;
+  const float sqx = a.sqx[(size_t)bg * N + nc];
+  const float* sqy = a.sqy + (size_t)bg * M;
+  const float* yp = a.yh + (size_t)bg * cpad * M;
+  const int kk = lane >> 5;       // which k of the k-pair this lane feeds
+  const int l31 = lane & 31;
+
+  TopList<KD> top;
+  top.init();
+
+  const int ktiles = (M + KT - 1) / KT;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, ktiles);
+
+  for (int t = t_begin + w; t < t_end; t += NW) {
+    const int m0 = t * KT;
+    // ---- contraction: acc0 = keys x queries[0..31], acc1 = keys x queries[32..63]
+    f32x16 acc0 = {0}, acc1 = {0};
+    {
+      const int mk = min(m0 + l31, M - 1);
+      const float* ykp = yp + (size_t)kk * M + mk;
+      const float* xsp = smem + kk * QT + l31;
+#pragma unroll 8
+      for (int s = 0; s < cpad / 2; ++s) {
+        const float av = ykp[(size_t)(2 * s) * M];
+        const float b0 = xsp[(2 * s) * QT];
+        const float b1 = xsp[(2 * s) * QT + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+      }
+    }
+    // ---- positional bias for this lane's query row, keys m0..m0+31
+    float rp[KT];
+    if (HAS_RP) {
+      const float* rpp = a.relpos + (size_t)nc * M + m0;
+      if (m0 + KT <= M && (M & 3) == 0) {
+#pragma unroll
+        for (int j = 0; j < KT / 4; ++j) {
+          const float4 v4 = *reinterpret_cast<const float4*>(rpp + 4 * j);
+          rp[4 * j + 0] = v4.x; rp[4 * j + 1] = v4.y; rp[4 * j + 2] = v4.z; rp[4 * j + 3] = v4.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) rp[j] = rpp[min(j, M - 1 - m0)];
+      }
+    }
+    // ---- lane l now needs all 32 keys of ITS query: swap the 32-lane halves of the two accumulators.
+    //      afterwards lo[r] = dot(key row (r&3)+8(r>>2)), hi[r] = dot(key row (r&3)+8(r>>2)+4), query n0+lane.
+    float lo[16], hi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // v_permlane32_swap: vdst.hi <-> src.lo
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
+      lo[r] = __uint_as_float(sw[0]);
+      hi[r] = __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const float dot = hh ? hi[r] : lo[r];
+          const int row = 8 * g + 4 * hh + j;
+          const int m = m0 + row;                       // wave-uniform
+          const float sy = sqy[min(m, M - 1)];
+          float dist = (sqx + (-2.0f * dot)) + sy;
+          if (HAS_RP) dist = dist + rp[row];
+          if (m >= M) dist = INFINITY;
+          top.insert(dist, m);
+        }
+      }
+    }
+  }
+
+  // ---- merge the 4 per-wave lists of each query through LDS
+  __syncthreads();                       // everyone is done with xs
+  float* lv = smem;                      // [NW][KD][64]
+  int* li = reinterpret_cast<int*>(smem + NW * KD * 64);
+#pragma unroll
+  for (int j = 0; j < KD; ++j) {
+    lv[(w * KD + j) * 64 + lane] = top.v[j];
+    li[(w * KD + j) * 64 + lane] = top.id[j];
+  }
+  __syncthreads();
+  if (w != 0) return;
+
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  float h0 = lv[(0 * KD) * 64 + lane], h1 = lv[(1 * KD) * 64 + lane], h2 = lv[(2 * KD) * 64 + lane],
+        h3 = lv[(3 * KD) * 64 + lane];
+  int i0 = li[(0 * KD) * 64 + lane], i1 = li[(1 * KD) * 64 + lane], i2 = li[(2 * KD) * 64 + lane],
+      i3 = li[(3 * KD) * 64 + lane];
+  const int kd = a.kd;
+  const bool partial = a.splits > 1;
+  const size_t obase = ((size_t)bg * N + nc) * a.k;
+  const size_t pbase = (((size_t)split * a.BG + bg) * N + nc) * (size_t)kd;
+  int next_rank = 0, outj = 0;
+  for (int j = 0; j < kd; ++j) {
+    // lexicographic (dist, idx) minimum of the four heads
+    int sel = 0; float bv = h0; int bi = i0;
+    if (h1 < bv || (h1 == bv && i1 < bi)) { sel = 1; bv = h1; bi = i1; }
+    if (h2 < bv || (h2 == bv && i2 < bi)) { sel = 2; bv = h2; bi = i2; }
+    if (h3 < bv || (h3 == bv && i3 < bi)) { sel = 3; bv = h3; bi = i3; }
+    if (sel == 0) { ++p0; h0 = p0 < KD ? lv[(0 * KD + p0) * 64 + lane] : INFINITY; i0 = p0 < KD ? li[(0 * KD + p0) * 64 + lane] : 0x7fffffff; }
+    else if (sel == 1) { ++p1; h1 = p1 < KD ? lv[(1 * KD + p1) * 64 + lane] : INFINITY; i1 = p1 < KD ? li[(1 * KD + p1) * 64 + lane] : 0x7fffffff; }
+    else if (sel == 2) { ++p2; h2 = p2 < KD ? lv[(2 * KD + p2) * 64 + lane] : INFINITY; i2 = p2 < KD ? li[(2 * KD + p2) * 64 + lane] : 0x7fffffff; }
+    else { ++p3; h3 = p3 < KD ? lv[(3 * KD + p3) * 64 + lane] : INFINITY; i3 = p3 < KD ? li[(3 * KD + p3) * 64 + lane] : 0x7fffffff; }
+    if (n < N) {
+      if (partial) {
+        a.part_v[pbase + j] = bv;
+        a.part_i[pbase + j] = bi;
+      } else if (j == next_rank) {
+        a.nn_idx[obase + outj] = bi;
+        if (a.center) a.center[obase + outj] = n;
+        ++outj;
+        next_rank += a.dilation;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ split merge
+// One thread per query: S-finger merge of the partial lists (each sorted, length kd).
+__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i,
+                                                        int64_t* __restrict__ nn_idx, int64_t* __restrict__ center,
+                                                        int S, int BG, int N, int k, int dilation, int kd) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;       // bg*N + n
+  if (q >= (size_t)BG * N) return;
+  const size_t stride = (size_t)BG * N * kd;                      // between splits
+  const float* pv = part_v + q * kd;
+  const int* pi = part_i + q * kd;
+  // lower bound of already-consumed (dist, idx): the next output is the smallest pair strictly greater
+  float last_v = -INFINITY; int last_i = -1;
+  int next_rank = 0, outj = 0;
+  for (int j = 0; j < kd; ++j) {
+    float bv = INFINITY; int bi = 0x7fffffff;
+    for (int s = 0; s < S; ++s) {
+      const float* v = pv + s * stride;
+      const int* id = pi + s * stride;
+      // binary search the first entry > (last_v, last_i) in this sorted list
+      int lo = 0, hi = kd;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float mv = v[mid]; const int mi = id[mid];
+        const bool gt = (mv > last_v) || (mv == last_v && mi > last_i);
+        if (gt) hi = mid; else lo = mid + 1;
+      }
+      if (lo < kd) {
+        const float cv = v[lo]; const int ci = id[lo];
+        if (cv < bv || (cv == bv && ci < bi)) { bv = cv; bi = ci; }
+      }
+    }
+    last_v = bv; last_i = bi;
+    if (j == next_rank) {
+      nn_idx[q * k + outj] = bi;
+      if (center) center[q * k + outj] = (int64_t)(q % N);
+      ++outj;
+      next_rank += dilation;
+    }
+  }
+}
+
+}  // namespace gkg
+
+// ================================================================================================ host side
+using namespace gkg;
+
+static const int kListSizes[] = {9, 12, 16, 18, 24, 27, 32, 36, 48, 64};
+
+static int pick_list(int kd) {
+  for (int s : kListSizes) if (s >= kd) return s;
+  return -1;
+}
+
+static int pick_splits(int BG, int N, int M) {
+  const int qtiles = (N + QT - 1) / QT;
+  const int ktiles = (M + KT - 1) / KT;
+  const long wgs = (long)qtiles * BG;
+  int S = 1;
+  if (wgs < 512) {
+    S = (int)((512 + wgs - 1) / wgs);
+    const int smax = (ktiles + 7) / 8;          // keep >= 8 key tiles (2 per wave) per split
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+  }
+  return S;
+}
+
+struct KnnPlan {
+  int cpad, kd, KD, S, tps;
+  size_t off_xh, off_yh, off_sqx, off_sqy, off_pv, off_pi, total;
+};
+
+static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_y, KnnPlan* p) {
+  if (BG <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || dilation <= 0) return GKG_ERR_SHAPE;
+  if ((long)k * dilation > M) return GKG_ERR_SHAPE;
+  if (!has_y && M != N) return GKG_ERR_SHAPE;
+  p->cpad = (c + 1) & ~1;
+  p->kd = k * dilation;
+  p->KD = pick_list(p->kd);
+  if (p->KD < 0) return GKG_ERR_UNSUPPORTED;
+  if ((size_t)p->cpad * QT * sizeof(float) > 150 * 1024) return GKG_ERR_UNSUPPORTED;   // c <= 600
+  if (BG > 65535) return GKG_ERR_UNSUPPORTED;
+  p->S = pick_splits(BG, N, M);
+  const int ktiles = (M + KT - 1) / KT;
+  p->tps = (ktiles + p->S - 1) / p->S;
+  p->S = (ktiles + p->tps - 1) / p->tps;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t o = 0;
+  p->off_xh = o; o = al(o + sizeof(float) * (size_t)BG * p->cpad * N);
+  p->off_sqx = o; o = al(o + sizeof(float) * (size_t)BG * N);
+  if (has_y) {
+    p->off_yh = o; o = al(o + sizeof(float) * (size_t)BG * p->cpad * M);
+    p->off_sqy = o; o = al(o + sizeof(float) * (size_t)BG * M);
+  } else {
+    p->off_yh = p->off_xh; p->off_sqy = p->off_sqx;
+  }
+  if (p->S > 1) {
+    p->off_pv = o; o = al(o + sizeof(float) * (size_t)p->S * BG * N * p->kd);
+    p->off_pi = o; o = al(o + sizeof(int) * (size_t)p->S * BG * N * p->kd);
+  } else {
+    p->off_pv = p->off_pi = 0;
+  }
+  p->total = o;
+  return 0;
+}
+
+extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags) {
+  (void)dtype; (void)flags;
+  KnnPlan p;
+  // y presence is unknown here: budget for it (upper bound) unless the shapes make it impossible
+  if (make_plan(BG, c, N, M, k, dilation, true, &p) != 0) return 0;
+  return p.total;
+}
+
+template <int KD>
+static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (a.relpos) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((knn_tile_kernel<KD, true>), grid, dim3(256), lds, st, a);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((knn_tile_kernel<KD, false>), grid, dim3(256), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_prep(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
+                              hipStream_t st) {
+  dim3 grid((Tn + 255) / 256, BG);
+  if (norm)
+    hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, th, sq, c, cpad, Tn);
+  else
+    hipLaunchKernelGGL((token_prep_kernel<T, false>), grid, dim3(256), 0, st, (const T*)t, th, sq, c, cpad, Tn);
+  return hipGetLastError();
+}
+
+extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+                           int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !nn_idx || !workspace) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
+  if (dtype != GKG_F32 && dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32 or GKG_BF16");
+  KnnPlan p;
+  int rc = make_plan(BG, c, N, M, k, dilation, y != nullptr, &p);
+  if (rc == GKG_ERR_SHAPE) return gkg_fail(rc, "gkg_knn_fwd: bad sizes (need >0, k*dilation <= M, M == N for the self graph)");
+  if (rc != 0) return gkg_fail(rc, "gkg_knn_fwd: unsupported size (k*dilation <= 64, c <= 600, BG <= 65535)");
+  if (workspace_bytes < p.total) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_knn_fwd: workspace too small (see gkg_knn_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* xh = (float*)(ws + p.off_xh);
+  float* yh = (float*)(ws + p.off_yh);
+  float* sqx = (float*)(ws + p.off_sqx);
+  float* sqy = (float*)(ws + p.off_sqy);
+  const bool norm = (flags & GKG_KNN_NORMALIZE) != 0;
+  hipError_t e;
+  if (dtype == GKG_F32) e = launch_prep<float>(x, xh, sqx, BG, c, p.cpad, N, norm, st);
+  else e = launch_prep<uint16_t>(x, xh, sqx, BG, c, p.cpad, N, norm, st);
+  if (e != hipSuccess) return gkg_fail_hip(e, "token_prep(x)");
+  if (y) {
+    if (dtype == GKG_F32) e = launch_prep<float>(y, yh, sqy, BG, c, p.cpad, M, norm, st);
+    else e = launch_prep<uint16_t>(y, yh, sqy, BG, c, p.cpad, M, norm, st);
+    if (e != hipSuccess) return gkg_fail_hip(e, "token_prep(y)");
+  }
+  KnnArgs a;
+  a.xh = xh; a.yh = yh; a.sqx = sqx; a.sqy = sqy; a.relpos = relpos;
+  a.nn_idx = nn_idx; a.center = center;
+  a.part_v = (float*)(ws + p.off_pv); a.part_i = (int*)(ws + p.off_pi);
+  a.BG = BG; a.cpad = p.cpad; a.N = N; a.M = M; a.k = k; a.dilation = dilation; a.kd = p.kd;
+  a.splits = p.S; a.tiles_per_split = p.tps;
+  dim3 grid((N + QT - 1) / QT, BG, p.S);
+  size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
+  size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
+  size_t lds = lds_q > lds_m ? lds_q : lds_m;
+  switch (p.KD) {
+    case 9: e = launch_tile<9>(a, grid, lds, st); break;
+    case 12: e = launch_tile<12>(a, grid, lds, st); break;
+    case 16: e = launch_tile<16>(a, grid, lds, st); break;
+    case 18: e = launch_tile<18>(a, grid, lds, st); break;
+    case 24: e = launch_tile<24>(a, grid, lds, st); break;
+    case 27: e = launch_tile<27>(a, grid, lds, st); break;
+    case 32: e = launch_tile<32>(a, grid, lds, st); break;
+    case 36: e = launch_tile<36>(a, grid, lds, st); break;
+    case 48: e = launch_tile<48>(a, grid, lds, st); break;
+    default: e = launch_tile<64>(a, grid, lds, st); break;
+  }
+  if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");
+  if (p.S > 1) {
+    const size_t nq = (size_t)BG * N;
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
+                       nn_idx, center, p.S, BG, N, k, dilation, p.kd);
+    e = hipGetLastError();
+    if (e != hipSuccess) return gkg_fail_hip(e, "knn_merge_kernel");
+  }
+  return 0;
+}

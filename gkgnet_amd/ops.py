@@ -1,0 +1,152 @@
+"""PyTorch-facing operators of the Group-KNN hot path, backed by libgkg_hip.so (HIP, gfx950).
+
+    knn_graph(x, y, relative_pos, k, dilation)  ==  DenseDilatedKnnGraph.forward   (reference torch_edge.py:164-176)
+    max_relative(x, nn_idx, y)                  ==  max_k(gather(y|x, idx) - x)    (reference torch_vertex.py:49-54)
+
+Tensors keep the reference layout (B*G, c, N, 1) / (B*G, c, N).  torch is used only for device
+memory and the current HIP stream; all arithmetic runs in the library.  There is no CPU path:
+CPU tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+# optional per-kernel timing hooks used by bench.py: name -> list of (start_event, end_event)
+_timers = None
+
+
+def enable_timers(on: bool = True):
+    global _timers
+    _timers = {} if on else None
+
+
+def timers():
+    return _timers
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timers is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if _timers is not None:
+            self.e.record()
+            _timers.setdefault(self.name, []).append((self.s, self.e))
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GkgError("gkgnet_amd ops run on the GPU only (HIP kernels); got a CPU tensor — "
+                                "there is no CPU fallback")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _tokens(t: torch.Tensor) -> torch.Tensor:
+    """(BG,c,N,1) or (BG,c,N) -> contiguous (BG,c,N)."""
+    if t.dim() == 4:
+        t = t.reshape(t.shape[0], t.shape[1], -1)
+    return t.contiguous()
+
+
+@torch.no_grad()
+def knn_graph(x: torch.Tensor, y: Optional[torch.Tensor] = None, relative_pos: Optional[torch.Tensor] = None,
+              k: int = 9, dilation: int = 1, normalize: bool = True, want_center: bool = True) -> torch.Tensor:
+    """Dilated k-NN graph.  Returns edge_index (2, BG, N, k) int64 ([0] neighbours sorted by ascending
+    distance, every ``dilation``-th of the top k*dilation kept; [1] centre index), like the reference."""
+    _need_cuda(x, y, relative_pos)
+    lib = _lib.load()
+    xq = _tokens(x.detach())
+    yk = None if y is None else _tokens(y.detach())
+    if xq.dtype not in _DT:
+        raise _lib.GkgError(f"unsupported dtype {xq.dtype} (fp32 / bf16)")
+    if yk is not None and (yk.dtype != xq.dtype or yk.shape[:2] != xq.shape[:2]):
+        raise _lib.GkgError("y must match x in dtype, batch*groups and channels")
+    BG, c, N = xq.shape
+    M = N if yk is None else yk.shape[2]
+    rp = None
+    if relative_pos is not None:
+        rp = relative_pos.detach().to(torch.float32).reshape(-1, relative_pos.shape[-1]).contiguous()
+        if tuple(rp.shape) != (N, M):
+            raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+    flags = _lib.KNN_NORMALIZE if normalize else 0
+    dt = _DT[xq.dtype]
+    edge = torch.empty((2 if want_center else 1, BG, N, k), dtype=torch.int64, device=xq.device)
+    nbytes = lib.gkg_knn_workspace_bytes(BG, c, N, M, k, dilation, dt, flags)
+    # nbytes == 0 means the sizes are unsupported: pass a token buffer and let the call produce the diagnostic
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=xq.device)
+    with _timed("knn"):
+        rc = lib.gkg_knn_fwd(_ptr(xq), _ptr(yk), _ptr(rp), edge[0].data_ptr(),
+                             edge[1].data_ptr() if want_center else None, BG, c, N, M, k, dilation, dt, flags,
+                             ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "gkg_knn_fwd")
+    return edge
+
+
+class _MaxRelative(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, src, nn_idx):
+        lib = _lib.load()
+        BG, c, N = x.shape
+        M = N if src is None else src.shape[2]
+        k = nn_idx.shape[2]
+        m = torch.empty_like(x)
+        need_grad = any(ctx.needs_input_grad[:2])
+        arg = torch.empty((BG, c, N), dtype=torch.uint8, device=x.device) if need_grad else None
+        with _timed("mr_fwd"):
+            rc = lib.gkg_mr_fwd(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(m), _ptr(arg), BG, c, N, M, k, _DT[x.dtype],
+                                _stream())
+        _lib.check(rc, "gkg_mr_fwd")
+        ctx.save_for_backward(nn_idx, arg)
+        ctx.dims = (BG, c, N, M, k, src is not None, x.dtype)
+        return m
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        nn_idx, arg = ctx.saved_tensors
+        BG, c, N, M, k, has_src, dtype = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty((BG, c, N), dtype=dtype, device=g.device)
+        gsrc = torch.empty((BG, c, M), dtype=dtype, device=g.device) if has_src else None
+        with _timed("mr_bwd"):
+            rc = lib.gkg_mr_bwd(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), BG, c, N, M, k, _DT[dtype],
+                                _stream())
+        _lib.check(rc, "gkg_mr_bwd")
+        return gx, gsrc, None
+
+
+def max_relative(x: torch.Tensor, nn_idx: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """m[b,ch,n] = max_j (src[b,ch,nn_idx[b,n,j]] - x[b,ch,n]), src = y if given else x.  Differentiable
+    w.r.t. x and y (the indices are constants, as in the reference).  x (BG,c,N[,1]) -> (BG,c,N)."""
+    _need_cuda(x, y, nn_idx)
+    xs = _tokens(x)
+    ys = None if y is None else _tokens(y)
+    if xs.dtype not in _DT:
+        raise _lib.GkgError(f"unsupported dtype {xs.dtype} (fp32 / bf16)")
+    if ys is not None and ys.dtype != xs.dtype:
+        raise _lib.GkgError("y must match x in dtype")
+    idx = nn_idx.contiguous()
+    if idx.dtype != torch.int64 or idx.dim() != 3 or tuple(idx.shape[:2]) != (xs.shape[0], xs.shape[2]):
+        raise _lib.GkgError(f"nn_idx must be int64 (BG,N,k); got {idx.dtype} {tuple(idx.shape)}")
+    return _MaxRelative.apply(xs, ys, idx)

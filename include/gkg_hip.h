@@ -1,0 +1,105 @@
+/*
+ * gkg_hip.h — C ABI of libgkg_hip.so: the MI355X (gfx950) implementation of GKGNet's
+ * Group-KNN graph-convolution hot path.
+ *
+ * The reference (jin-s13/GKGNet) has no native boundary: the path is a chain of ATen ops inside
+ * DyGraphConv2d*.forward.  The operator boundary this library introduces sits exactly at the two
+ * calls made there (paths relative to the reference tree):
+ *
+ *   self.dilated_knn_graph(x, y, relative_pos)        mmcls/models/backbones/vig_model/torch_vertex.py:203,226,247,272
+ *        -> DenseDilatedKnnGraph.forward              .../vig_model/torch_edge.py:164-176   ==> gkg_knn_fwd
+ *   GraphConv2d.forward(x, edge_index, y) / MRConv2d  .../vig_model/torch_vertex.py:47-54   ==> gkg_mr_fwd
+ *        (batched_index_select x2 + max(x_j - x_i))   .../vig_model/torch_nn.py:84-105
+ *   autograd of the above (max_backward, index_put_)  (ATen; SURVEY.md §8a "Backward contract")  ==> gkg_mr_bwd
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller; tensors are contiguous, channel-major
+ *     exactly like the reference's (B*G, c, N, 1) layout:   x[bg][ch][n].
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*); the library never
+ *     synchronises, allocates or frees, and keeps no mutable global state besides the last-error
+ *     string (thread-local).  Workspace, when needed, is passed in by the caller.
+ *   - Return value: 0 on success; >0 a hipError_t from a launch; <0 an argument error
+ *     (GKG_ERR_*).  Nothing throws or exits.
+ *   - dtype: element type of the feature tensors x / y / src / g / outputs.  Distances are always
+ *     accumulated in fp32 (SURVEY.md §5 AMP row).
+ *
+ * Arithmetic contract of gkg_knn_fwd (restated bit-for-bit by oracle/gkg_oracle.c):
+ *     s      = fma-chain_{ch} t[ch]^2            den = max(sqrt(s), 1e-12)       (GKG_KNN_NORMALIZE)
+ *     th[ch] = t[ch] / den                       sq  = fma-chain_{ch} th[ch]^2
+ *     dot    = fma-chain_{ch=0..c-1} yh[ch][m] * xh[ch][n]      (fp32 MFMA == ordered fmaf chain)
+ *     dist   = ((sqx[n] + (-2*dot)) + sqy[m]) + relpos[n][m]    (reference op order, torch_edge.py:17-20,82)
+ *     neighbours = the k*dilation smallest (dist, m) pairs in ascending lexicographic order
+ *                  (tie rule: smaller key index first); ranks 0, d, 2d, ... are emitted.
+ */
+#ifndef GKG_HIP_H_
+#define GKG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKG_ABI_VERSION 1
+
+/* dtype codes */
+#define GKG_F32 0
+#define GKG_BF16 1
+
+/* gkg_knn_fwd flags */
+#define GKG_KNN_NORMALIZE 1u /* L2-normalise tokens over the group's channels first (torch_edge.py:167-173) */
+
+/* argument errors */
+#define GKG_ERR_NULL -1        /* required pointer is NULL */
+#define GKG_ERR_SHAPE -2       /* non-positive / inconsistent sizes, k*dilation > M, ... */
+#define GKG_ERR_UNSUPPORTED -3 /* dtype / size outside what this build supports */
+#define GKG_ERR_WORKSPACE -4   /* workspace too small */
+
+/* ABI version of the loaded library (== GKG_ABI_VERSION it was built with). */
+int gkg_version(void);
+
+/* Human-readable description of the last non-zero return on this thread ("" if none). */
+const char* gkg_last_error_string(void);
+
+/* Bytes of scratch gkg_knn_fwd needs for these sizes (normalised token copies, squared norms,
+ * split-key partial lists).  Pure function of its arguments. */
+size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags);
+
+/*
+ * Dilated k-NN graph.  Replaces DenseDilatedKnnGraph.forward (torch_edge.py:164-176) including
+ * dense_knn_matrix / xy_dense_knn_matrix (:54-106), pairwise distance (:9-51) and DenseDilated (:139-149).
+ *   x        (BG, c, N)      query tokens
+ *   y        (BG, c, M)      key tokens, or NULL for the self graph (then M must equal N)
+ *   relpos   (N, M) fp32     positional bias shared by all BG problems, or NULL
+ *   nn_idx   (BG, N, k) i64  out: neighbour index per query, ascending distance  (== edge_index[0])
+ *   center   (BG, N, k) i64  out, optional (NULL to skip): centre index n         (== edge_index[1])
+ */
+int gkg_knn_fwd(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+                int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Max-relative aggregation: m[bg][ch][n] = max_j ( src[bg][ch][nn_idx[bg][n][j]] - x[bg][ch][n] ).
+ * Replaces batched_index_select x2 + torch.max(x_j - x_i, -1) (torch_vertex.py:49-54, torch_nn.py:84-105).
+ *   src      (BG, c, M) or NULL (-> src = x, M = N)
+ *   m_out    (BG, c, N)
+ *   argmax   (BG, c, N) u8   out, optional: first j attaining the max (needed by gkg_mr_bwd)
+ */
+int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx, void* m_out, uint8_t* argmax,
+               int BG, int c, int N, int M, int k, int dtype, void* stream);
+
+/*
+ * Backward of gkg_mr_fwd for upstream gradient g (BG,c,N) on m:
+ *     gx[bg][ch][n]                        = -g[bg][ch][n]
+ *     gsrc[bg][ch][nn_idx[bg][n][argmax]] +=  g[bg][ch][n]
+ *   gsrc == NULL  -> self graph: both terms are accumulated into gx (M must equal N).
+ *   gx, gsrc are fully overwritten (no pre-zeroing needed).
+ */
+int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void* gx, void* gsrc,
+               int BG, int c, int N, int M, int k, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKG_HIP_H_ */

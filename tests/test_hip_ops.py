@@ -1,0 +1,146 @@
+"""GPU parity tests of the HIP operators (through the C ABI) against the C oracle (bit-exact) and the
+reference's golden vectors (near-tie protocol).  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from util import check_indices, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+OP_CASES = ["op_self_relpos", "op_xy_norelpos", "op_xy_relpos_dil", "op_self_bf16", "op_label_like"]
+
+
+def _dev(a, dtype=torch.float32):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def _rand_case(seed, BG, c, N, M, relpos, scale=1.0):
+    rng = np.random.RandomState(seed)
+    x = (rng.standard_normal((BG, c, N)) * scale).astype(np.float32)
+    y = None if M is None else (rng.standard_normal((BG, c, M)) * scale).astype(np.float32)
+    rp = None
+    if relpos:
+        rp = -rng.random_sample((N, N if M is None else M)).astype(np.float32)
+    return x, y, rp
+
+
+# (BG, c, N, M(None=self), k, d, relpos)
+KNN_SHAPES = [
+    (2, 64, 196, None, 9, 1, True),      # cfg1
+    (3, 20, 70, None, 5, 2, True),
+    (4, 12, 33, 150, 9, 1, False),
+    (2, 48, 100, 25, 4, 3, True),        # M % 4 != 0 with relpos, kd == 12
+    (2, 7, 65, 130, 3, 1, True),         # odd c (zero-padded k-pair), M % 4 != 0
+    (1, 80, 324, None, 9, 1, True),      # cfg2-literal group problem
+    (1, 320, 324, None, 9, 3, True),     # cfg2-ref: c=320, top-27
+    (2, 40, 80, 1000, 9, 1, False),      # label-like: few queries, many keys -> split-key path
+    (1, 16, 200, 81, 18, 2, True),       # kd = 36
+    (1, 8, 50, 70, 32, 2, False),        # kd = 64 (largest list)
+    (5, 200, 130, None, 9, 2, True),     # stage-3-like c=200, kd=18
+]
+
+
+@pytest.mark.parametrize("shape", KNN_SHAPES)
+def test_knn_bit_exact_vs_c_oracle(shape):
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    BG, c, N, M, k, d, relpos = shape
+    x, y, rp = _rand_case(hash(shape) & 0xFFFF, BG, c, N, M, relpos)
+    want_idx, want_center = O.knn(x, y, rp, k, d)
+    edge = ops.knn_graph(_dev(x), _dev(y), None if rp is None else _dev(rp).unsqueeze(0), k, d)
+    torch.cuda.synchronize()
+    got = edge.cpu().numpy()
+    assert got.shape == (2, BG, N, k) and got.dtype == np.int64
+    assert np.array_equal(got[0], want_idx)
+    assert np.array_equal(got[1], want_center)
+
+
+@pytest.mark.parametrize("shape", KNN_SHAPES)
+def test_max_relative_bit_exact_and_backward(shape):
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    BG, c, N, M, k, d, relpos = shape
+    x, y, rp = _rand_case((hash(shape) >> 3) & 0xFFFF, BG, c, N, M, False)
+    idx, _ = O.knn(x, y, None, k, d)
+    want_m, want_arg = O.mr_fwd(x, y, idx)
+    xd = _dev(x).requires_grad_(True)
+    yd = None if y is None else _dev(y).requires_grad_(True)
+    m = ops.max_relative(xd, _dev(idx, torch.int64), yd)
+    assert np.array_equal(m.detach().cpu().numpy(), want_m)
+    g = np.random.RandomState(5).standard_normal(want_m.shape).astype(np.float32)
+    m.backward(_dev(g))
+    want_gx, want_gsrc = O.mr_bwd(g, idx, want_arg, None if y is None else y.shape[2])
+    assert np.allclose(xd.grad.cpu().numpy(), want_gx, atol=1e-5, rtol=1e-5)
+    if y is not None:
+        assert np.allclose(yd.grad.cpu().numpy(), want_gsrc, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", OP_CASES)
+def test_ops_against_reference_golden(name):
+    from gkgnet_amd import ops
+    meta, a = load_fixture(name)
+    x, y, rp = a["x"], a.get("y"), a.get("relpos")
+    edge = ops.knn_graph(_dev(x), _dev(y), _dev(rp), meta["k"], meta["dilation"]).cpu().numpy()
+    swaps = check_indices(edge[0], a["edge_index"][0], a["topd"], a["topi"], meta["dilation"])
+    assert swaps <= 2
+    assert np.array_equal(edge[1], a["edge_index"][1])
+    xd = _dev(x).requires_grad_(True)
+    yd = None if y is None else _dev(y).requires_grad_(True)
+    m = ops.max_relative(xd, _dev(a["edge_index"][0], torch.int64), yd)
+    assert np.array_equal(m.detach().cpu().numpy(), a["m"])
+    m.backward(_dev(a["gcot"]))
+    assert np.allclose(xd.grad.cpu().numpy(), a["dx"], atol=1e-5)
+    if y is not None:
+        assert np.allclose(yd.grad.cpu().numpy(), a["dy"], atol=1e-5)
+
+
+def test_integer_known_answer_and_tie_rule():
+    from gkgnet_amd import ops
+    meta, a = load_fixture("f8_integer_kat")
+    e = ops.knn_graph(_dev(a["x"]), _dev(a["y"]), None, meta["k"], 1, normalize=False).cpu().numpy()
+    assert np.array_equal(e, a["edge_xy"])
+    e = ops.knn_graph(_dev(a["y"]), None, None, meta["k"], 1, normalize=False).cpu().numpy()
+    assert np.array_equal(e, a["edge_self"])
+    # documented tie rule: smaller key index first (hand-derived expectation)
+    y = np.zeros((1, 2, 6), np.float32); y[0, 0] = [1, 1, 1, 1, 5, 7]
+    x = np.zeros((1, 2, 1), np.float32)
+    assert ops.knn_graph(_dev(x), _dev(y), None, 3, 1, normalize=False)[0].cpu().tolist() == [[[0, 1, 2]]]
+    assert ops.knn_graph(_dev(x), _dev(y), None, 3, 2, normalize=False)[0].cpu().tolist() == [[[0, 2, 4]]]
+    # ties across key tiles / waves / splits: 200 identical keys
+    y = np.ones((1, 4, 200), np.float32); x = np.zeros((1, 4, 3), np.float32)
+    got = ops.knn_graph(_dev(x), _dev(y), None, 9, 2, normalize=False)[0].cpu().numpy()
+    assert np.array_equal(got, np.broadcast_to(np.arange(0, 18, 2), (1, 3, 9)))
+    # aggregation argmax tie rule: first neighbour attaining the max gets the gradient
+    src = _dev(np.array([[[2.0, 2.0, 1.0]]], np.float32)).requires_grad_(True)
+    xz = _dev(np.zeros((1, 1, 1), np.float32)).requires_grad_(True)
+    m = ops.max_relative(xz, _dev(np.array([[[2, 1, 0]]]), torch.int64), src)
+    m.backward(torch.ones_like(m))
+    assert m.item() == 2.0 and src.grad.cpu().tolist() == [[[0.0, 1.0, 0.0]]] and xz.grad.item() == -1.0
+
+
+def test_bf16_inputs_match_fp32_math_on_rounded_values():
+    """bf16 I/O: distances are still accumulated in fp32 -> same graph as fp32 math on the rounded values
+    (fixture F7 semantics)."""
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    x, y, rp = _rand_case(77, 2, 40, 96, 150, False)
+    xb = torch.from_numpy(x).to(torch.bfloat16)
+    yb = torch.from_numpy(y).to(torch.bfloat16)
+    want_idx, _ = O.knn(xb.float().numpy(), yb.float().numpy(), None, 9, 1)
+    got = ops.knn_graph(xb.cuda(), yb.cuda(), None, 9, 1)[0].cpu().numpy()
+    assert np.array_equal(got, want_idx)
+    want_m, _ = O.mr_fwd(xb.float().numpy(), yb.float().numpy(), want_idx)
+    m = ops.max_relative(xb.cuda(), torch.from_numpy(want_idx).cuda(), yb.cuda())
+    assert m.dtype == torch.bfloat16
+    assert np.array_equal(m.float().cpu().numpy(), torch.from_numpy(want_m).to(torch.bfloat16).float().numpy())
+
+
+def test_errors_are_loud():
+    from gkgnet_amd import _lib, ops
+    with pytest.raises(_lib.GkgError):
+        ops.knn_graph(torch.zeros(1, 4, 8), None, None, 3, 1)               # CPU tensor: no fallback
+    with pytest.raises(_lib.GkgError):
+        ops.knn_graph(torch.zeros(1, 4, 8, device="cuda"), None, None, 9, 1)  # k > M
+    with pytest.raises(_lib.GkgError):
+        ops.knn_graph(torch.zeros(1, 4, 8, device="cuda", dtype=torch.float16), None, None, 3, 1)
