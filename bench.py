@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py — Grapher fwd+bwd images/sec on MI355X (BASELINE.json metric).
+
+One "step" = one forward + backward pass of the Group-KNN hot path over one synthetic batch:
+    Grapher(C=320, k=9, G=4, d=1, r=1, 18x18, relative_pos)  ->  GrapherLabel(C=320, k=9, G=4, L=80 label tokens)
+in train mode (batch-statistics BN), fp32, B=32 images per GPU — BASELINE.json configs[1] ("cfg2-literal").
+With N>1 GPUs every rank runs its own B=32 shard (weak scaling) and the step ends with ONE flat RCCL
+all-reduce of the parameter gradients.  Inputs are resident in HBM before the timed region.
+
+    python bench.py                       # 1 GPU, default steps
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract: task description / DESIGN.md §Measurement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (C, G, H, k, d, r, L)
+    "cfg2": dict(C=320, G=4, H=18, k=9, d=1, r=1, L=80,
+                 desc="BASELINE cfg2-literal: Grapher(C320,G4,k9,d1,18x18,relpos)+GrapherLabel(L80) fwd+bwd"),
+    "cfg2ref": dict(C=640, G=2, H=18, k=9, d=3, r=1, L=80,
+                    desc="reference stage-4 shape: Grapher(C640,G2,k9,d3,18x18)+GrapherLabel(L80) fwd+bwd"),
+    "stage3": dict(C=400, G=2, H=36, k=9, d=2, r=1, L=80,
+                   desc="reference stage-3 shape: Grapher(C400,G2,k9,d2,36x36)+GrapherLabel(L80) fwd+bwd"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_modules(w, device):
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    n = w["H"] * w["H"]
+    g = Grapher(w["C"], w["k"], w["d"], "mr", "gelu", "batch", True, False, 0.2, w["r"], n=n, drop_path=0.0,
+                relative_pos=True, use_multi_group=True, num_group=w["G"])
+    gl = GrapherLabel(w["C"], w["k"], 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0,
+                      relative_pos=False, num_nodes=w["L"], use_multi_group=True, num_group=w["G"])
+    return g.to(device).train(), gl.to(device).train()
+
+
+def cpu_baseline(w, B, grapher, label, x, e, cot_x, cot_e, budget_s=20.0):
+    """Oracle (torch-CPU restatement of the reference) timed on this box's host cores: the reported baseline."""
+    from oracle import torch_ref as R
+    pg = {k: v.detach().cpu().clone() for k, v in grapher.state_dict().items()}
+    pl = {k: v.detach().cpu().clone() for k, v in label.state_dict().items()}
+    for d in (pg, pl):
+        for k, v in d.items():
+            if v.dtype.is_floating_point and "running" not in k and k != "relative_pos":
+                v.requires_grad_(True)
+    xc, ec = x.detach().cpu(), e.detach().cpu()
+    cx, ce = cot_x.cpu(), cot_e.cpu()
+
+    def step():
+        xg, eg = xc.clone().requires_grad_(True), ec.clone().requires_grad_(True)
+        out = R.grapher_forward(xg, pg, k=w["k"], dilation=w["d"], r=w["r"], groups=w["G"], training=True)
+        e2, _ = R.grapher_label_forward(eg, out, pl, k=w["k"], groups=w["G"], training=True)
+        torch.autograd.backward([out, e2], [cx, ce])
+
+    step()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if (n >= 3 and dt > budget_s * 0.5) or dt > budget_s or n >= 50:
+            break
+    return dict(value=round(B * n / dt, 2), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} fwd+bwd steps of the same workload (B={B}) on the oracle (oracle/torch_ref.py), "
+                       f"{dt:.1f}s, torch CPU fp32, {os.cpu_count()} logical cpus visible")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (reference DDP semantics)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from gkgnet_amd import _lib, layers, parallel
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    layers.norm_cfg["type"] = "SyncBN" if (args.sync_bn and world > 1) else "BN"
+    w = WORKLOADS[args.workload]
+    B, C, H, L = args.batch, w["C"], w["H"], w["L"]
+
+    torch.manual_seed(0)
+    grapher, label = build_modules(w, dev)
+    parallel.broadcast_parameters(grapher)
+    parallel.broadcast_parameters(label)
+    params = list(grapher.parameters()) + list(label.parameters())
+    bucket = parallel.GradBucket(params)
+
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)       # every rank its own shard
+    x = torch.randn(B, C, H, H, generator=gen).to(dev).requires_grad_(True)
+    e = torch.randn(B, L, C, generator=gen).to(dev).requires_grad_(True)
+    cot_x = torch.randn(B, C, H, H, generator=gen).to(dev)
+    cot_e = torch.randn(B, L, C, generator=gen).to(dev)
+
+    def step():
+        bucket.zero()
+        x.grad = None
+        e.grad = None
+        out = grapher(x)
+        e2, _ = label(e, out)
+        torch.autograd.backward([out, e2], [cot_x, cot_e])
+        bucket.all_reduce()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_read()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        N = H * H
+        M = N // (w["r"] ** 2)
+        BG = B * w["G"]
+        # algorithmic work of the k-NN tile kernel per step: Grapher graph + label graph
+        flops_knn = 2.0 * BG * (C // w["G"]) * (N * M + L * N)
+        tile_ms, tile_n = prof["knn_tile"]
+        roof = None
+        if tile_n:
+            per_step_ms = tile_ms / args.steps
+            ach = flops_knn / (per_step_ms * 1e-3) / 1e12
+            roof = dict(kernel="knn_tile_kernel", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        avg_launch_us=round(1e3 * tile_ms / tile_n, 2), launches_per_step=tile_n // args.steps,
+                        algorithmic_flops_per_step=flops_knn)
+        kernels = {k: dict(us_per_step=round(1e3 * v[0] / args.steps, 2), launches_per_step=v[1] // args.steps)
+                   for k, v in prof.items() if v[1]}
+        res = dict(metric="Grapher fwd+bwd images/sec", value=round(value, 1), unit="images/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 4), higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=w["desc"], batch_per_gpu=B, global_batch=B * world, C=C, G=w["G"],
+                               HW=f"{H}x{H}", k=w["k"], dilation=w["d"], label_tokens=L, bn="sync" if
+                               layers.norm_cfg["type"] == "SyncBN" else "local", parallelism=f"dp{world}",
+                               grad_allreduce="one flat RCCL all-reduce per step" if world > 1 else "none (1 GPU)"),
+                   roofline=roof, hip_kernels=kernels)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w, B, grapher, label, x, e, cot_x, cot_e)
+            res["speedup_vs_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,8 @@ F32, BF16 = 0, 1
 KNN_NORMALIZE = 1
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
-           "gkg_mr_bwd")
+           "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read")
+PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
 
 _lib = None
 
@@ -29,6 +30,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must own the process's HIP runtime: import it BEFORE dlopen-ing our library so that our
+    # DT_NEEDED libamdhip64 resolves to the runtime torch already loaded (two runtimes in one process
+    # -> "no ROCm-capable device" on the second one).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GkgError(f"{LIB_PATH} not found: build it with `python -m gkgnet_amd._build` "
                        "(or __graft_entry__.build()); there is no CPU fallback")
@@ -43,6 +48,11 @@ def load():
     lib.gkg_mr_fwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
     lib.gkg_mr_bwd.restype = C.c_int
     lib.gkg_mr_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
+    lib.gkg_prof_enable.restype = None
+    lib.gkg_prof_enable.argtypes = [C.c_int]
+    lib.gkg_prof_reset.restype = None
+    lib.gkg_prof_read.restype = C.c_int
+    lib.gkg_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     v = lib.gkg_version()
     if v != ABI_VERSION:
         raise GkgError(f"libgkg_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
@@ -54,3 +64,22 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().gkg_last_error_string().decode(errors="replace")
         raise GkgError(f"{what} failed (rc={rc}): {msg}")
+
+
+def prof_enable(on: bool = True):
+    load().gkg_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    load().gkg_prof_reset()
+
+
+def prof_read():
+    """{kernel name: (total_ms, launches)} measured with HIP events on the launch stream."""
+    lib = load()
+    out = {}
+    for i, name in enumerate(PROF_KERNELS):
+        ms, cnt = C.c_double(0), C.c_long(0)
+        check(lib.gkg_prof_read(i, C.byref(ms), C.byref(cnt)), "gkg_prof_read")
+        out[name] = (ms.value, cnt.value)
+    return out

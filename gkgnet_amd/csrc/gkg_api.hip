@@ -19,3 +19,72 @@ int gkg_fail_hip(hipError_t e, const char* where) {
 extern "C" int gkg_version(void) { return GKG_ABI_VERSION; }
 
 extern "C" const char* gkg_last_error_string(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ profiling
+#include <mutex>
+#include <vector>
+
+namespace {
+struct ProfRec { int kernel; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_recs;          // recorded, not yet read
+std::vector<hipEvent_t> g_free;       // event pool
+double g_ms[GKG_PROF_NUM] = {0};
+long g_cnt[GKG_PROF_NUM] = {0};
+constexpr size_t kMaxPending = 1 << 16;
+
+hipEvent_t get_event() {
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+void drain_locked() {
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_ms[r.kernel] += ms;
+      g_cnt[r.kernel] += 1;
+    }
+    g_free.push_back(r.a);
+    g_free.push_back(r.b);
+  }
+  g_recs.clear();
+}
+}  // namespace
+
+GkgProfScope::GkgProfScope(int kernel_id, hipStream_t s) : slot(-1), st(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_recs.size() >= kMaxPending) return;
+  ProfRec r{kernel_id, get_event(), get_event()};
+  if (!r.a || !r.b) return;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+}
+
+GkgProfScope::~GkgProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if ((size_t)slot < g_recs.size()) (void)hipEventRecord(g_recs[slot].b, st);
+}
+
+extern "C" void gkg_prof_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" void gkg_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  drain_locked();
+  for (int i = 0; i < GKG_PROF_NUM; ++i) { g_ms[i] = 0; g_cnt[i] = 0; }
+}
+
+extern "C" int gkg_prof_read(int kernel_id, double* total_ms, long* launches) {
+  if (kernel_id < 0 || kernel_id >= GKG_PROF_NUM || !total_ms || !launches)
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_prof_read: bad kernel id / null output");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  drain_locked();
+  *total_ms = g_ms[kernel_id];
+  *launches = g_cnt[kernel_id];
+  return 0;
+}

@@ -22,3 +22,11 @@ __device__ __forceinline__ void stf(uint16_t* p, float v) {
 // Records the message for gkg_last_error_string() and returns `code`.
 int gkg_fail(int code, const char* msg);
 int gkg_fail_hip(hipError_t e, const char* where);
+
+// Opt-in launch timing (gkg_prof_*): RAII bracket around one kernel launch on `st`.
+struct GkgProfScope {
+  GkgProfScope(int kernel_id, hipStream_t st);
+  ~GkgProfScope();
+  int slot;
+  hipStream_t st;
+};

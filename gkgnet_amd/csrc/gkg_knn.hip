@@ -366,6 +366,7 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
 
 template <int KD>
 static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   if (a.relpos) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, true>),
@@ -383,6 +384,7 @@ static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream
 template <typename T>
 static hipError_t launch_prep(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
                               hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
   dim3 grid((Tn + 255) / 256, BG);
   if (norm)
     hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, th, sq, c, cpad, Tn);
@@ -442,6 +444,7 @@ extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, in
   if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");
   if (p.S > 1) {
     const size_t nq = (size_t)BG * N;
+    GkgProfScope prof(GKG_PROF_KNN_MERGE, st);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
                        nn_idx, center, p.S, BG, N, k, dilation, p.kd);
     e = hipGetLastError();

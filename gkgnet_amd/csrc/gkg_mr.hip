@@ -116,6 +116,7 @@ static int pick_ch(int c, int M, int extra_bytes) {
 template <typename T>
 static hipError_t mr_fwd_launch(const void* x, const void* src, const int64_t* nn_idx, void* m_out, uint8_t* argmax,
                                 int BG, int c, int N, int M, int k, int CH, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_MR_FWD, st);
   const size_t lds = (size_t)CH * M * 4 + (size_t)k * 256 * 4;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -147,6 +148,7 @@ extern "C" int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx,
 template <typename T>
 static hipError_t mr_bwd_launch(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void* gx, void* gsrc,
                                 int BG, int c, int N, int M, int k, int CH, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_MR_BWD, st);
   const size_t lds = (size_t)CH * M * 4 + (size_t)k * 256 * 4;
   dim3 grid((c + CH - 1) / CH, BG);
   if (gsrc) {

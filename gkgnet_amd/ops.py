@@ -17,36 +17,6 @@ from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
-# optional per-kernel timing hooks used by bench.py: name -> list of (start_event, end_event)
-_timers = None
-
-
-def enable_timers(on: bool = True):
-    global _timers
-    _timers = {} if on else None
-
-
-def timers():
-    return _timers
-
-
-class _timed:
-    def __init__(self, name):
-        self.name = name
-
-    def __enter__(self):
-        if _timers is not None:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
-            self.s.record()
-        return self
-
-    def __exit__(self, *a):
-        if _timers is not None:
-            self.e.record()
-            _timers.setdefault(self.name, []).append((self.s, self.e))
-
-
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -95,10 +65,9 @@ def knn_graph(x: torch.Tensor, y: Optional[torch.Tensor] = None, relative_pos: O
     nbytes = lib.gkg_knn_workspace_bytes(BG, c, N, M, k, dilation, dt, flags)
     # nbytes == 0 means the sizes are unsupported: pass a token buffer and let the call produce the diagnostic
     ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=xq.device)
-    with _timed("knn"):
-        rc = lib.gkg_knn_fwd(_ptr(xq), _ptr(yk), _ptr(rp), edge[0].data_ptr(),
-                             edge[1].data_ptr() if want_center else None, BG, c, N, M, k, dilation, dt, flags,
-                             ws.data_ptr(), ws.numel(), _stream())
+    rc = lib.gkg_knn_fwd(_ptr(xq), _ptr(yk), _ptr(rp), edge[0].data_ptr(),
+                         edge[1].data_ptr() if want_center else None, BG, c, N, M, k, dilation, dt, flags,
+                         ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "gkg_knn_fwd")
     return edge
 
@@ -113,9 +82,8 @@ class _MaxRelative(torch.autograd.Function):
         m = torch.empty_like(x)
         need_grad = any(ctx.needs_input_grad[:2])
         arg = torch.empty((BG, c, N), dtype=torch.uint8, device=x.device) if need_grad else None
-        with _timed("mr_fwd"):
-            rc = lib.gkg_mr_fwd(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(m), _ptr(arg), BG, c, N, M, k, _DT[x.dtype],
-                                _stream())
+        rc = lib.gkg_mr_fwd(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(m), _ptr(arg), BG, c, N, M, k, _DT[x.dtype],
+                            _stream())
         _lib.check(rc, "gkg_mr_fwd")
         ctx.save_for_backward(nn_idx, arg)
         ctx.dims = (BG, c, N, M, k, src is not None, x.dtype)
@@ -129,9 +97,8 @@ class _MaxRelative(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.empty((BG, c, N), dtype=dtype, device=g.device)
         gsrc = torch.empty((BG, c, M), dtype=dtype, device=g.device) if has_src else None
-        with _timed("mr_bwd"):
-            rc = lib.gkg_mr_bwd(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), BG, c, N, M, k, _DT[dtype],
-                                _stream())
+        rc = lib.gkg_mr_bwd(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), BG, c, N, M, k, _DT[dtype],
+                            _stream())
         _lib.check(rc, "gkg_mr_bwd")
         return gx, gsrc, None
 

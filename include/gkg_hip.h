@@ -99,6 +99,23 @@ int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx, void* m_ou
 int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void* gx, void* gsrc,
                int BG, int c, int N, int M, int k, int dtype, void* stream);
 
+/*
+ * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).
+ * When enabled, every kernel launch made by this library is bracketed by hipEventRecord on the SAME
+ * stream it is launched on.  gkg_prof_read synchronises on the recorded events (so call it outside any
+ * timed / captured region) and accumulates per kernel id.
+ */
+#define GKG_PROF_TOKEN_PREP 0
+#define GKG_PROF_KNN_TILE 1
+#define GKG_PROF_KNN_MERGE 2
+#define GKG_PROF_MR_FWD 3
+#define GKG_PROF_MR_BWD 4
+#define GKG_PROF_NUM 5
+void gkg_prof_enable(int on);
+void gkg_prof_reset(void);
+/* total milliseconds and number of launches recorded for `kernel_id` since the last reset; 0 on success. */
+int gkg_prof_read(int kernel_id, double* total_ms, long* launches);
+
 #ifdef __cplusplus
 }
 #endif

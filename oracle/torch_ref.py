@@ -112,11 +112,24 @@ def interleave_channels(x: Tensor, m: Tensor, full_c: int) -> Tensor:
 
 
 # ------------------------------------------------------------------ dense pieces
+class _DenseGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 def _bn(t: Tensor, p: Dict[str, Tensor], prefix: str, training: bool) -> Tensor:
     """BatchNorm2d / SyncBatchNorm without a process group (eps 1e-5, momentum 0.1).
-    Running statistics are NOT updated here (oracle is stateless)."""
-    return F.batch_norm(t, p[prefix + ".running_mean"].clone(), p[prefix + ".running_var"].clone(),
-                        p[prefix + ".weight"], p[prefix + ".bias"], training, 0.1, 1e-5)
+    Running statistics are NOT updated here (oracle is stateless).
+    Input and incoming gradient are made dense NCHW first: torch 2.10's CPU batch_norm backward is wrong
+    for mixed memory formats (see tools/gen_golden.py); values and the forward result are unaffected."""
+    out = F.batch_norm(t.contiguous(), p[prefix + ".running_mean"].clone(), p[prefix + ".running_var"].clone(),
+                       p[prefix + ".weight"], p[prefix + ".bias"], training, 0.1, 1e-5)
+    return _DenseGrad.apply(out) if out.requires_grad else out
 
 
 def conv_bn(t: Tensor, p: Dict[str, Tensor], prefix: str, training: bool, groups: int = 1) -> Tensor:

@@ -1,0 +1,111 @@
+"""GPU parity of the drop-in modules (Grapher / GrapherLabel) against the reference's golden vectors:
+forward within 1e-3 (fp32), exact neighbour indices (near-tie protocol), input + parameter gradients."""
+import numpy as np
+import pytest
+import torch
+
+from test_modules_host import GRAPHER_CASES, LABEL_CASES, make_grapher, make_label
+from util import check_indices, grads_from, load_fixture, state_from
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-3, rtol=1e-3)          # north_star: within 1e-3 fp32
+
+
+def _t(a):
+    return torch.from_numpy(np.array(a)).cuda()
+
+
+@pytest.mark.parametrize("name", GRAPHER_CASES)
+def test_grapher_forward_backward(name):
+    meta, a = load_fixture(name)
+    mod = make_grapher(meta)
+    mod.load_state_dict(state_from(a))
+    mod.cuda()
+    cap = {}
+    h = mod.graph_conv.register_forward_hook(lambda m, i, o: cap.update(edge=o[1].detach()))
+    x = _t(a["x"])
+    mod.eval()
+    with torch.no_grad():
+        out_eval = mod(x)
+    assert torch.allclose(out_eval, _t(a["out_eval"]), **TOL)
+    mod.train()
+    xg = x.clone().requires_grad_(True)
+    out = mod(xg)
+    edge = cap["edge"].cpu().numpy()
+    h.remove()
+    assert edge.shape == a["edge_index"].shape
+    swaps = check_indices(edge[0], a["edge_index"][0], a["topd"], a["topi"], meta["dilation"])
+    assert np.array_equal(edge[1], a["edge_index"][1])
+    assert swaps == 0, "fixtures are tie-free at fp32 resolution; a swap here means a numerics change"
+    assert torch.allclose(out, _t(a["out"]), **TOL)
+    assert (out - _t(a["out"])).abs().max().item() < 2e-4        # in practice far inside the 1e-3 bar
+    (out * _t(a["cot"])).sum().backward()
+    assert torch.allclose(xg.grad, _t(a["dx"]), **TOL)
+    named = dict(mod.named_parameters())
+    for k, g in grads_from(a).items():
+        assert torch.allclose(named[k].grad, g.cuda(), atol=2e-3, rtol=2e-3), k
+
+
+@pytest.mark.parametrize("name", LABEL_CASES)
+def test_grapher_label_forward_backward(name):
+    meta, a = load_fixture(name)
+    mod = make_label(meta)
+    mod.load_state_dict(state_from(a))
+    mod.cuda()
+    e, feat = _t(a["e"]), _t(a["feat"])
+    mod.eval()
+    with torch.no_grad():
+        out_eval, idx_eval = mod(e, feat)
+    assert torch.allclose(out_eval, _t(a["out_eval"]), **TOL)
+    assert idx_eval.shape == a["nn_idx_eval"].shape
+    mod.train()
+    eg, fg = e.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    out, idx = mod(eg, fg)
+    assert idx.shape == a["nn_idx"].shape and idx.dtype == torch.int64
+    mine = idx.cpu().numpy() if meta["use_multi_group"] else idx[0].cpu().numpy()
+    ref = a["nn_idx"] if meta["use_multi_group"] else a["nn_idx"][0]
+    assert check_indices(mine, ref, a["topd"], a["topi"]) == 0
+    assert torch.allclose(out, _t(a["out"]), **TOL)
+    (out * _t(a["cot"])).sum().backward()
+    assert torch.allclose(eg.grad, _t(a["de"]), **TOL)
+    assert torch.allclose(fg.grad, _t(a["dfeat"]), **TOL)
+    named = dict(mod.named_parameters())
+    for k, g in grads_from(a).items():
+        assert torch.allclose(named[k].grad, g.cuda(), atol=2e-3, rtol=2e-3), k
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE cfg2-literal (B32 C320 18x18 k9 G4) at full size: size-independent properties of the graph
+    + the aggregation against a dense torch evaluation on the GPU."""
+    from gkgnet_amd import ops
+    torch.manual_seed(0)
+    B, C, G, H, k = 32, 320, 4, 18, 9
+    N = H * H
+    x = torch.randn(B * G, C // G, N, device="cuda")
+    from gkgnet_amd.relpos import build_relative_pos
+    rp = build_relative_pos(C, N, 1).cuda()
+    edge = ops.knn_graph(x, None, rp, k, 1)
+    nn_idx = edge[0]
+    # (1) the self token is rank 0 in a self graph (relative_pos diagonal is the row minimum, -1)
+    assert torch.equal(nn_idx[:, :, 0], torch.arange(N, device="cuda").expand(B * G, N))
+    # (2) distinct neighbours, in range
+    srt = nn_idx.sort(dim=-1).values
+    assert (srt[..., 1:] != srt[..., :-1]).all() and nn_idx.min() >= 0 and nn_idx.max() < N
+    # (3) ascending distances & top-k optimality against a dense fp64 distance matrix
+    xn = torch.nn.functional.normalize(x.double(), dim=1)
+    dist = (xn * xn).sum(1).unsqueeze(-1) - 2 * xn.transpose(1, 2) @ xn + (xn * xn).sum(1).unsqueeze(1) + rp.double()
+    dsel = torch.gather(dist, 2, nn_idx)
+    assert (dsel[..., 1:] - dsel[..., :-1]).min().item() > -1e-6
+    kth = dsel[..., -1:]
+    n_better = (dist < kth - 1e-6).sum(-1)
+    assert (n_better <= k - 1).all()
+    # (4) aggregation equals the dense gather/max, bit for bit
+    m = ops.max_relative(x, nn_idx)
+    want = (torch.gather(x.unsqueeze(2).expand(-1, -1, N, -1), 3, nn_idx.unsqueeze(1).expand(-1, C // G, -1, -1))
+            - x.unsqueeze(-1)).max(-1).values
+    assert torch.equal(m, want)
+    # (5) backward: gradient mass is conserved (every g is subtracted once and added once)
+    xr = x.clone().requires_grad_(True)
+    g = torch.randn_like(x)
+    ops.max_relative(xr, nn_idx).backward(g)
+    assert xr.grad.sum(-1).abs().max().item() < 1e-2
