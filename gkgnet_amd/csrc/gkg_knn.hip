@@ -35,31 +35,65 @@ constexpr int KT = 32;   // keys per MFMA tile
 constexpr int NW = 4;    // waves per workgroup
 
 // ------------------------------------------------------------------------------------------ prep
+constexpr int PREP_T = 64;   // tokens (threads) per token_prep workgroup
+
+// One thread per token.  The two ordered fma chains over the channels are inherently serial per token, so
+// the kernel is latency-bound: loads are batched 8 deep ahead of the chains, the first pass parks the
+// values in a thread-private LDS column so the second pass never goes back to L2, and small 64-token
+// workgroups keep all CUs busy at N = 324.
 template <typename T, bool NORM>
-__global__ __launch_bounds__(256) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
-                                                         float* __restrict__ sq, int c, int cpad, int Tn) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
+                                                            float* __restrict__ sq, int c, int cpad, int Tn,
+                                                            int use_lds) {
+  extern __shared__ float col[];          // [c][PREP_T] when use_lds
+  const int n = blockIdx.x * PREP_T + threadIdx.x;
   const int bg = blockIdx.y;
   if (n >= Tn) return;
   const T* tp = t + (size_t)bg * c * Tn + n;
+  float* cp = col + threadIdx.x;
   float den = 1.0f;
   if (NORM) {
     float s = 0.0f;
-    for (int ch = 0; ch < c; ++ch) {
+    int ch = 0;
+    for (; ch + 8 <= c; ch += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ldf(tp + (size_t)(ch + u) * Tn);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s = __builtin_fmaf(v[u], v[u], s);
+        if (use_lds) cp[(ch + u) * PREP_T] = v[u];
+      }
+    }
+    for (; ch < c; ++ch) {
       const float v = ldf(tp + (size_t)ch * Tn);
       s = __builtin_fmaf(v, v, s);
+      if (use_lds) cp[ch * PREP_T] = v;
     }
     den = fmaxf(sqrtf(s), 1e-12f);
   }
   float q = 0.0f;
   float* op = th + (size_t)bg * cpad * Tn + n;
-  for (int ch = 0; ch < c; ++ch) {
-    float v = ldf(tp + (size_t)ch * Tn);
+  const bool from_lds = NORM && use_lds;
+  int ch = 0;
+  for (; ch + 8 <= c; ch += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = from_lds ? cp[(ch + u) * PREP_T] : ldf(tp + (size_t)(ch + u) * Tn);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (NORM) v[u] = v[u] / den;
+      op[(size_t)(ch + u) * Tn] = v[u];
+      q = __builtin_fmaf(v[u], v[u], q);
+    }
+  }
+  for (; ch < c; ++ch) {
+    float v = from_lds ? cp[ch * PREP_T] : ldf(tp + (size_t)ch * Tn);
     if (NORM) v = v / den;
     op[(size_t)ch * Tn] = v;
     q = __builtin_fmaf(v, v, q);
   }
-  for (int ch = c; ch < cpad; ++ch) op[(size_t)ch * Tn] = 0.0f;
+  for (int chp = c; chp < cpad; ++chp) op[(size_t)chp * Tn] = 0.0f;
   sq[(size_t)bg * Tn + n] = q;
 }
 
@@ -385,11 +419,14 @@ template <typename T>
 static hipError_t launch_prep(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
                               hipStream_t st) {
   GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
-  dim3 grid((Tn + 255) / 256, BG);
+  dim3 grid((Tn + PREP_T - 1) / PREP_T, BG);
+  const size_t col_bytes = (size_t)c * PREP_T * sizeof(float);
+  const int use_lds = norm && col_bytes <= 48 * 1024;
+  const size_t lds = use_lds ? col_bytes : 0;
   if (norm)
-    hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, th, sq, c, cpad, Tn);
+    hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds);
   else
-    hipLaunchKernelGGL((token_prep_kernel<T, false>), grid, dim3(256), 0, st, (const T*)t, th, sq, c, cpad, Tn);
+    hipLaunchKernelGGL((token_prep_kernel<T, false>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds);
   return hipGetLastError();
 }
 

@@ -6,13 +6,14 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .dense import PointwiseConv2d
 from .graph import DyGraphConv2d, DyGraphConv2dMultiGroup, DyGraphLabel, DyGraphLabelMultiGroup
 from .layers import DropPath, act_layer, build_norm
 from .relpos import build_relative_pos, resize_relative_pos
 
 
 def _conv_norm(cin, cout):
-    return nn.Sequential(nn.Conv2d(cin, cout, 1, stride=1, padding=0), build_norm(cout))
+    return nn.Sequential(PointwiseConv2d(cin, cout, 1, stride=1, padding=0), build_norm(cout))
 
 
 class Grapher(nn.Module):

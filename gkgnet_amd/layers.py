@@ -6,6 +6,8 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .dense import PointwiseConv2d
+
 # Reference default (torch_nn.py:8, torch_vertex.py:14, gkgnet.py:23).  Without an initialised process
 # group SyncBatchNorm behaves as plain BatchNorm; set type='BN' to force local statistics under DDP.
 norm_cfg = dict(type="SyncBN", requires_grad=True)
@@ -91,7 +93,7 @@ class BasicConv(nn.Sequential):
     def __init__(self, channels, act="relu", norm=None, bias=True, drop=0.0):
         layers = []
         for cin, cout in zip(channels[:-1], channels[1:]):
-            layers.append(nn.Conv2d(cin, cout, 1, bias=bias, groups=4))
+            layers.append(PointwiseConv2d(cin, cout, 1, bias=bias, groups=4))
             if norm is not None and norm.lower() != "none":
                 layers.append(norm_layer(norm, channels[-1]))
             if act is not None and act.lower() != "none":
