@@ -6,7 +6,7 @@
 //
 // Pipeline (all on the caller's stream):
 //   1. token_prep_kernel   : per token, ordered-fma L2 norm over the group's channels, normalised fp32
-//                            copy th (BG,cpad,T) (cpad = c rounded up to even, zero padded) + |th|^2.
+//                            copy th (BG,cpad,T) (cpad = c rounded up to a multiple of 8, zero padded) + |th|^2.
 //   2. knn_tile_kernel<KD> : one workgroup = 64 queries of one (b,g) problem x one key split; its 4 waves
 //                            take key tiles of 32 round-robin.  Per key tile a wave runs the contraction on
 //                            the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, == an ordered fmaf
@@ -23,6 +23,7 @@
 // Arithmetic contract: include/gkg_hip.h (restated in oracle/gkg_oracle.c).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gkg_common.h"
 
@@ -108,8 +109,8 @@ struct TopList {
 #pragma unroll
     for (int j = 0; j < KD; ++j) { v[j] = INFINITY; id[j] = 0x7fffffff; }
   }
+  // Sorted insert; a no-op for lanes with d >= v[KD-1], skipped when no lane of the wave improves.
   __device__ __forceinline__ void insert(float d, int m) {
-    // wave-uniform early-out: nobody beats their current worst
     if (__builtin_amdgcn_ballot_w64(d < v[KD - 1]) == 0ull) return;
     bool lt_j = d < v[KD - 1];
 #pragma unroll
@@ -129,7 +130,7 @@ struct KnnArgs {
   const float* xh;      // (BG, cpad, N) normalised queries
   const float* yh;      // (BG, cpad, M) normalised keys (== xh for the self graph)
   const float* sqx;     // (BG, N)
-  const float* sqy;     // (BG, M)
+  const float* sqy;     // (BG, M) (+ >= 32 floats of readable slack)
   const float* relpos;  // (N, M) or null
   int64_t* nn_idx;      // (BG, N, k)
   int64_t* center;      // (BG, N, k) or null
@@ -139,7 +140,15 @@ struct KnnArgs {
   int splits, tiles_per_split;
 };
 
-template <int KD, bool HAS_RP>
+// Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
+// waves of one SIMD do NOT overlap (they share the fp32 datapath) — every vector instruction spent on the
+// selection adds to the matrix time, so the per-candidate work is kept minimal: 3 adds for the distance
+// (the -2 is folded into the staged queries, |y|^2 is broadcast with v_readlane and doubles as the
+// out-of-range mask) and a 4-instruction-per-slot sorted insert.  A sparse variant (per-lane clz walk over a
+// "beats my k-th best" mask with the distances parked in LDS) was measured 1.5-1.7x SLOWER: per-wave lists
+// see only a quarter of the keys, so some lane of 64 passes for almost every candidate and the divergent
+// loop serialises on LDS latency.
+template <int KD, bool HAS_RP, int KU>
 __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
@@ -150,12 +159,41 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
   const int n0 = blockIdx.x * QT;
   const int N = a.N, M = a.M, cpad = a.cpad;
 
-  // ---- stage the query tile: xs[ch][64] (zero for n >= N)
+  // ---- stage the query tile scaled by -2 (exact): xs[ch][64] = -2 * xh (zero for n >= N).
+  //      All loads of a pass are issued before the first LDS store.
   {
     const float* xp = a.xh + (size_t)bg * cpad * N;
-    for (int i = tid; i < cpad * QT; i += 256) {
-      const int ch = i >> 6, q = i & 63;
-      smem[i] = (n0 + q < N) ? xp[(size_t)ch * N + n0 + q] : 0.0f;
+    if ((N & 3) == 0) {
+      const int q4 = (tid & 15) * 4;               // 16 float4 per 64-query row, 16 rows per pass
+      const bool inb = n0 + q4 < N;                 // N % 4 == 0: a float4 is entirely in or out
+      const float* src = xp + (size_t)(tid >> 4) * N + n0 + q4;
+      float4* dst = reinterpret_cast<float4*>(smem + (tid >> 4) * QT + q4);
+      for (int ch = 0; ch < cpad; ch += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = ch + 16 * u + (tid >> 4);
+          v[u] = (inb && row < cpad) ? *reinterpret_cast<const float4*>(src + (size_t)(ch + 16 * u) * N)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ch + 16 * u + (tid >> 4) < cpad)
+            dst[(ch + 16 * u) * (QT / 4)] = make_float4(-2.f * v[u].x, -2.f * v[u].y, -2.f * v[u].z, -2.f * v[u].w);
+      }
+    } else {
+      for (int i = tid; i < cpad * QT; i += 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = i + 256 * u;
+          const int ch = j >> 6, q = j & 63;
+          v[u] = (j < cpad * QT && n0 + q < N) ? xp[(size_t)ch * N + n0 + q] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + 256 * u < cpad * QT) smem[i + 256 * u] = -2.f * v[u];
+      }
     }
   }
   __syncthreads();
@@ -174,25 +212,15 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
   const int ktiles = (M + KT - 1) / KT;
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, ktiles);
+  const int CP = cpad / 2;          // k-pairs; cpad % 8 == 0 -> CP % 4 == 0
 
   for (int t = t_begin + w; t < t_end; t += NW) {
     const int m0 = t * KT;
-    // ---- contraction: acc0 = keys x queries[0..31], acc1 = keys x queries[32..63]
-    f32x16 acc0 = {0}, acc1 = {0};
-    {
-      const int mk = min(m0 + l31, M - 1);
-      const float* ykp = yp + (size_t)kk * M + mk;
-      const float* xsp = smem + kk * QT + l31;
-#pragma unroll 8
-      for (int s = 0; s < cpad / 2; ++s) {
-        const float av = ykp[(size_t)(2 * s) * M];
-        const float b0 = xsp[(2 * s) * QT];
-        const float b1 = xsp[(2 * s) * QT + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
-      }
-    }
-    // ---- positional bias for this lane's query row, keys m0..m0+31
+    const int mk = min(m0 + l31, M - 1);
+    // ---- side inputs of this tile, issued first so their latency hides under the contraction:
+    //      |y|^2 of key m0+l31 (broadcast per candidate with v_readlane; +inf masks keys past M) and the
+    //      positional bias of this lane's query row
+    const float sy32 = (m0 + l31 < M) ? sqy[mk] : INFINITY;
     float rp[KT];
     if (HAS_RP) {
       const float* rpp = a.relpos + (size_t)nc * M + m0;
@@ -207,38 +235,60 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
         for (int j = 0; j < KT; ++j) rp[j] = rpp[min(j, M - 1 - m0)];
       }
     }
-    // ---- lane l now needs all 32 keys of ITS query: swap the 32-lane halves of the two accumulators.
-    //      afterwards lo[r] = dot(key row (r&3)+8(r>>2)), hi[r] = dot(key row (r&3)+8(r>>2)+4), query n0+lane.
-    float lo[16], hi[16];
+    // ---- contraction: acc0 = keys x (-2 queries[0..31]), acc1 = keys x (-2 queries[32..63]).
+    //      Key operand double-buffered in registers (KU k-pairs per batch).
+    f32x16 acc0 = {0}, acc1 = {0};
+    {
+      const float* ykp = yp + (size_t)kk * M + mk;
+      const float* xsp = smem + kk * QT + l31;
+      float an[KU], ac[KU];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // v_permlane32_swap: vdst.hi <-> src.lo
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
-      lo[r] = __uint_as_float(sw[0]);
-      hi[r] = __uint_as_float(sw[1]);
+      for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * u) * M];
+      for (int s = 0; s < CP; s += KU) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) ac[u] = an[u];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * min(s + KU + u, CP - 1)) * M];
+        __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const float b0 = xsp[(2 * (s + u)) * QT];
+          const float b1 = xsp[(2 * (s + u)) * QT + 32];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, acc1, 0, 0, 0);
+        }
+      }
     }
+    // ---- lane l needs all 32 keys of ITS query: v_permlane32_swap exchanges the 32-lane halves of the two
+    //      accumulators (vdst.hi <-> src.lo); afterwards lo = key rows (r&3)+8(r>>2), hi = those + 4.
+    //      dist = ((|x|^2 + (-2 x.y)) + |y|^2) + relpos in the reference's order; |y|^2 comes through the
+    //      scalar cache (the key row is wave-uniform) and is +inf for keys past M, which also masks them.
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      float lo[4], hi[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * g + j]),
+                                                         __float_as_uint(acc1[4 * g + j]), false, false);
+        lo[j] = __uint_as_float(sw[0]);
+        hi[j] = __uint_as_float(sw[1]);
+      }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          const float dot = hh ? hi[r] : lo[r];
-          const int row = 8 * g + 4 * hh + j;
-          const int m = m0 + row;                       // wave-uniform
-          const float sy = sqy[min(m, M - 1)];
-          float dist = (sqx + (-2.0f * dot)) + sy;
+          const int row = 8 * g + 4 * hh + j;                              // increasing key order (tie rule)
+          const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
+          float dist = (sqx + (hh ? hi[j] : lo[j])) + sy;
           if (HAS_RP) dist = dist + rp[row];
-          if (m >= M) dist = INFINITY;
-          top.insert(dist, m);
+          top.insert(dist, m0 + row);
         }
       }
     }
   }
 
   // ---- merge the 4 per-wave lists of each query through LDS
-  __syncthreads();                       // everyone is done with xs
+  __syncthreads();                       // everyone is done with xs / dmat
   float* lv = smem;                      // [NW][KD][64]
   int* li = reinterpret_cast<int*>(smem + NW * KD * 64);
 #pragma unroll
@@ -360,7 +410,7 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   if (BG <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || dilation <= 0) return GKG_ERR_SHAPE;
   if ((long)k * dilation > M) return GKG_ERR_SHAPE;
   if (!has_y && M != N) return GKG_ERR_SHAPE;
-  p->cpad = (c + 1) & ~1;
+  p->cpad = (c + 7) & ~7;          // zero-padded channels: fma(0,0,acc) == acc keeps the chain exact
   p->kd = k * dilation;
   p->KD = pick_list(p->kd);
   if (p->KD < 0) return GKG_ERR_UNSUPPORTED;
@@ -373,10 +423,10 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = 0;
   p->off_xh = o; o = al(o + sizeof(float) * (size_t)BG * p->cpad * N);
-  p->off_sqx = o; o = al(o + sizeof(float) * (size_t)BG * N);
+  p->off_sqx = o; o = al(o + sizeof(float) * ((size_t)BG * N + 32));
   if (has_y) {
     p->off_yh = o; o = al(o + sizeof(float) * (size_t)BG * p->cpad * M);
-    p->off_sqy = o; o = al(o + sizeof(float) * (size_t)BG * M);
+    p->off_sqy = o; o = al(o + sizeof(float) * ((size_t)BG * M + 32));
   } else {
     p->off_yh = p->off_xh; p->off_sqy = p->off_sqx;
   }
@@ -398,21 +448,21 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
   return p.total;
 }
 
+template <int KD, bool HAS_RP, int KU>
+static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU>), grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 template <int KD>
 static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
-  if (a.relpos) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((knn_tile_kernel<KD, true>), grid, dim3(256), lds, st, a);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((knn_tile_kernel<KD, false>), grid, dim3(256), lds, st, a);
-  }
-  return hipGetLastError();
+  const bool deep = (a.cpad % 16) == 0;      // 8 k-pairs per register batch when the channel count allows
+  if (a.relpos) return deep ? launch_tile_v<KD, true, 8>(a, grid, lds, st) : launch_tile_v<KD, true, 4>(a, grid, lds, st);
+  return deep ? launch_tile_v<KD, false, 8>(a, grid, lds, st) : launch_tile_v<KD, false, 4>(a, grid, lds, st);
 }
 
 template <typename T>
