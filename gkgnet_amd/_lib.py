@@ -15,7 +15,9 @@ F32, BF16 = 0, 1
 KNN_NORMALIZE = 1
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
-           "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read")
+           "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
+           "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
+           "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
 
 _lib = None
@@ -48,6 +50,27 @@ def load():
     lib.gkg_mr_fwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
     lib.gkg_mr_bwd.restype = C.c_int
     lib.gkg_mr_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
+    V, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+    lib.gkg_knn_fwd_tm.restype = I
+    lib.gkg_knn_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V, Z, V]
+    lib.gkg_mr_fwd_tm.restype = I
+    lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 7 + [V]
+    lib.gkg_mr_bwd_tm.restype = I
+    lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 7 + [V]
+    lib.gkg_nchw_to_tm.restype = I
+    lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, V]
+    lib.gkg_tm_affine_to_nchw.restype = I
+    lib.gkg_tm_affine_to_nchw.argtypes = [V] * 5 + [I, I, I, V]
+    lib.gkg_bn_workspace_bytes.restype = Z
+    lib.gkg_bn_workspace_bytes.argtypes = [I, I, I]
+    lib.gkg_bn_train_stats.restype = I
+    lib.gkg_bn_train_stats.argtypes = [V] * 10 + [I, I, I, F, F, V, Z, V]
+    lib.gkg_bn_eval_affine.restype = I
+    lib.gkg_bn_eval_affine.argtypes = [V] * 7 + [I, F, V]
+    lib.gkg_affine_act.restype = I
+    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, V]
+    lib.gkg_bn_bwd.restype = I
+    lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_prof_enable.restype = None
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None

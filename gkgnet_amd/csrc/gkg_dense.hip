@@ -1,0 +1,444 @@
+// gkg_dense.hip — token-major (rows = tokens, columns = channels) helpers around the dense 1x1 projections
+// of the Grapher block (reference torch_vertex.py:290-306, torch_nn.py:57-69, :334-360).
+//
+// The projections themselves are plain fp32 GEMMs  Y(T,Cout) = X(T,Cin) W^T  and run in the vendor GEMM
+// library on the MFMA units (one large GEMM per layer instead of 32 per-image ones).  Everything between two
+// GEMMs is bandwidth work on L2/MALL-resident activations and lives here, fused as far as train-mode
+// batch-norm allows (its batch statistics are a global reduction, so every BN costs one reduce pass and one
+// apply pass in each direction):
+//
+//   nchw_to_tm / tm_affine_to_nchw   layout change at the module boundary, the latter fused with BN-apply + residual
+//   col_stats + bn_finalize          per-channel sum / sum-of-squares (deterministic two-stage) -> scale/shift,
+//                                    saved mean/invstd, running-stat update (momentum, unbiased var)
+//   affine_act                       out = act(a*y + c) (+ residual); act = none | GELU(erf)
+//   bn_bwd_stats / bn_bwd_apply      dz = dout * act'(z);  sum dz, sum dz*yhat;  dy = a*(dz - mean(dz) - yhat*mean(dz*yhat))
+#include "gkg_common.h"
+
+namespace gkg {
+
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+
+// ------------------------------------------------------------------------------------------ layout
+// (B, C, N) channel-major -> (B*N, C) token-major through a padded 32x32 LDS tile (coalesced both sides).
+__global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         int C, int N) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = c0 + ty + 8 * i, n = n0 + tx;
+    tile[ty + 8 * i][tx] = (ch < C && n < N) ? x[((size_t)b * C + ch) * N + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, ch = c0 + tx;
+    if (ch < C && n < N) out[((size_t)b * N + n) * C + ch] = tile[tx][ty + 8 * i];
+  }
+}
+
+// out(B,C,N) = act(a[ch]*y_tm[t][ch] + c[ch]) + res(B,C,N)     (a/c/res optional)
+__global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ a,
+                                                                const float* __restrict__ cs, const float* __restrict__ res,
+                                                                float* __restrict__ out, int C, int N) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, ch = c0 + tx;
+    float v = 0.f;
+    if (ch < C && n < N) {
+      v = y[((size_t)b * N + n) * C + ch];
+      if (a) v = __builtin_fmaf(a[ch], v, cs[ch]);
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = c0 + ty + 8 * i, n = n0 + tx;
+    if (ch < C && n < N) {
+      const size_t o = ((size_t)b * C + ch) * N + n;
+      float v = tile[tx][ty + 8 * i];
+      if (res) v += res[o];
+      out[o] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ column statistics
+// part[q][blk][0][c] = sum_r y[q][r][c], part[q][blk][1][c] = sum_r y^2 over this block's row range.
+// Thread layout: CGT = min(C/4, 256) column groups (float4) x RL = 256/CGT row lanes; q = blockIdx.y selects
+// one of `nb` stacked (R, C) matrices (the 4 groups of the grouped projection).
+struct StatsGeom { int C4, CGT, RL; };
+__device__ __forceinline__ StatsGeom stats_geom(int C) {
+  StatsGeom g; g.C4 = C >> 2; g.CGT = min(g.C4, 256); g.RL = 256 / g.CGT; return g;
+}
+
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, float* __restrict__ part,
+                                                        int R, int C, int rows_per_block) {
+  extern __shared__ float red[];                    // [RL][2][C]
+  const StatsGeom gm = stats_geom(C);
+  const int tid = threadIdx.x;
+  const int cg = tid % gm.CGT, rl = tid / gm.CGT;
+  const int q = blockIdx.y;
+  y += (size_t)q * R * C;
+  part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(R, r0 + rows_per_block);
+  if (rl < gm.RL) {
+    for (int cgi = cg; cgi < gm.C4; cgi += gm.CGT) {
+      float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+      const float* p = y + (size_t)4 * cgi;
+      int r = r0 + rl;
+      for (; r + 3 * gm.RL < r1; r += 4 * gm.RL) {        // 4 independent loads in flight
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)r * C);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(r + gm.RL) * C);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(r + 2 * gm.RL) * C);
+        const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(r + 3 * gm.RL) * C);
+        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        sq.x += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
+        sq.y += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
+        sq.z += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
+        sq.w += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
+      }
+      for (; r < r1; r += gm.RL) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)r * C);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+      }
+      float* rr = red + (size_t)rl * 2 * C;
+      *reinterpret_cast<float4*>(rr + 4 * cgi) = s;
+      *reinterpret_cast<float4*>(rr + C + 4 * cgi) = sq;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < gm.RL; ++l) acc += red[(size_t)l * 2 * C + i];
+    part[i] = acc;
+  }
+}
+
+// Same two-stage scheme for the backward statistics: sum dz and sum dz*yhat, dz = dout * act'(a*y + c),
+// yhat = (y - mean) * invstd.  dout[q] may be a column slice of a wider matrix (row pitch ldg).
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           const float* __restrict__ a, const float* __restrict__ cs,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ part, int R, int C, int rows_per_block,
+                                                           int ldg, size_t g_bstride) {
+  extern __shared__ float red[];
+  const StatsGeom gm = stats_geom(C);
+  const int tid = threadIdx.x;
+  const int cg = tid % gm.CGT, rl = tid / gm.CGT;
+  const int q = blockIdx.y;
+  y += (size_t)q * R * C; dout += (size_t)q * g_bstride;
+  a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C;
+  part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(R, r0 + rows_per_block);
+  if (rl < gm.RL) {
+    for (int cgi = cg; cgi < gm.C4; cgi += gm.CGT) {
+      const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cgi);
+      const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cgi);
+      const float4 m4 = *reinterpret_cast<const float4*>(mean + 4 * cgi);
+      const float4 i4 = *reinterpret_cast<const float4*>(invstd + 4 * cgi);
+      float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+#pragma unroll 4
+      for (int r = r0 + rl; r < r1; r += gm.RL) {
+        const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)r * ldg + 4 * cgi);
+        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
+        float4 dz = g;
+        if (ACT == 1) {
+          dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
+          dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
+        }
+        s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
+        sq.x += dz.x * ((v.x - m4.x) * i4.x); sq.y += dz.y * ((v.y - m4.y) * i4.y);
+        sq.z += dz.z * ((v.z - m4.z) * i4.z); sq.w += dz.w * ((v.w - m4.w) * i4.w);
+      }
+      float* rr = red + (size_t)rl * 2 * C;
+      *reinterpret_cast<float4*>(rr + 4 * cgi) = s;
+      *reinterpret_cast<float4*>(rr + C + 4 * cgi) = sq;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < gm.RL; ++l) acc += red[(size_t)l * 2 * C + i];
+    part[i] = acc;
+  }
+}
+
+// sums[q][0][c], sums[q][1][c] = fixed-order (deterministic) double-precision reduction of the block partials.
+// 64 columns x 4 partial-lanes per workgroup; each lane sums every 4th partial with 8 loads in flight, the 4
+// lane sums are combined in a fixed order.  Optionally also scatters the two halves to out0/out1 ([nb][C]),
+// which is how the BN backward gets dbeta / dgamma.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ sums,
+                                                              int nblk, int C2, float* __restrict__ out0,
+                                                              float* __restrict__ out1) {
+  __shared__ double lane_sum[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ln = threadIdx.x >> 6;
+  const int q = blockIdx.y;
+  double acc = 0.0;
+  if (col < C2) {
+    const float* p = part + (size_t)q * nblk * C2 + col;
+    int b = ln;
+    for (; b + 28 < nblk; b += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + 4 * u) * C2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < nblk; b += 4) acc += (double)p[(size_t)b * C2];
+  }
+  lane_sum[ln][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (ln == 0 && col < C2) {
+    const int t = threadIdx.x;
+    const float r = (float)(((lane_sum[0][t] + lane_sum[1][t]) + lane_sum[2][t]) + lane_sum[3][t]);
+    sums[(size_t)q * C2 + col] = r;
+    const int C = C2 >> 1;
+    if (out0) { if (col < C) out0[(size_t)q * C + col] = r; else out1[(size_t)q * C + col - C] = r; }
+  }
+}
+
+// Train-mode BN parameters from the column sums of Y (which EXCLUDES the conv bias `bias`, folded here):
+//   mean_y = S/R, var = Q/R - mean_y^2 (biased), invstd = rsqrt(var + eps)
+//   a = gamma*invstd, c = beta - a*mean_y             (bias cancels in train mode)
+//   running_mean <- (1-mom)*rm + mom*(mean_y + bias), running_var <- (1-mom)*rv + mom*var*R/(R-1)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ bias,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ a, float* __restrict__ cs, float* __restrict__ mean,
+                                   float* __restrict__ invstd, int R, int C, float momentum, float eps) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  const int q = blockIdx.y;
+  sums += (size_t)q * 2 * C; gamma += (size_t)q * C; beta += (size_t)q * C; a += (size_t)q * C; cs += (size_t)q * C;
+  mean += (size_t)q * C; invstd += (size_t)q * C;
+  if (bias) bias += (size_t)q * C;
+  if (running_mean) { running_mean += (size_t)q * C; running_var += (size_t)q * C; }
+  const double m = (double)sums[ch] / R;
+  double var = (double)sums[C + ch] / R - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[ch] * is;
+  a[ch] = av;
+  cs[ch] = beta[ch] - av * (float)m;
+  mean[ch] = (float)m;
+  invstd[ch] = is;
+  if (running_mean) {
+    const float b = bias ? bias[ch] : 0.f;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * ((float)m + b);
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  }
+}
+
+// Eval-mode BN folded to an affine: a = gamma/sqrt(rv+eps), c = beta + a*(bias - rm)
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ bias, const float* __restrict__ running_mean,
+                                      const float* __restrict__ running_var, float* __restrict__ a,
+                                      float* __restrict__ cs, int C, float eps) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  const float av = gamma[ch] / sqrtf(running_var[ch] + eps);
+  a[ch] = av;
+  cs[ch] = beta[ch] + av * ((bias ? bias[ch] : 0.f) - running_mean[ch]);
+}
+
+// ------------------------------------------------------------------------------------------ apply
+// out[r][c] = act(a[c]*y[r][c] + cs[c]) (+ res[r][c]); out may have a different row pitch / column offset
+// (ldo, used to write the grouped conv's output straight into the next layer's (T, 2C) input).
+template <int ACT>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ y, const float* __restrict__ a,
+                                                         const float* __restrict__ cs, const float* __restrict__ res,
+                                                         float* __restrict__ out, size_t total4, int C, int ldo,
+                                                         size_t o_bstride) {
+  const int C4 = C >> 2;
+  const int q = blockIdx.y;
+  y += (size_t)q * total4 * 4; a += (size_t)q * C; cs += (size_t)q * C; out += (size_t)q * o_bstride;
+  if (res) res += (size_t)q * total4 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / C4;
+    const int cg = (int)(i - r * C4);
+    const float4 v = *reinterpret_cast<const float4*>(y + 4 * i);
+    const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cg);
+    const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cg);
+    float4 o;
+    o.x = __builtin_fmaf(a4.x, v.x, c4.x); o.y = __builtin_fmaf(a4.y, v.y, c4.y);
+    o.z = __builtin_fmaf(a4.z, v.z, c4.z); o.w = __builtin_fmaf(a4.w, v.w, c4.w);
+    if (ACT == 1) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
+    if (res) {
+      const float4 rv = *reinterpret_cast<const float4*>(res + 4 * i);
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    *reinterpret_cast<float4*>(out + r * (size_t)ldo + 4 * cg) = o;
+  }
+}
+
+// dy[r][c] = a[c] * (dz - sdz[c]/R - yhat*sdzy[c]/R), dz = dout*act'(a*y+c).  dout may be strided (ldg).
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           const float* __restrict__ a, const float* __restrict__ cs,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ sums, float* __restrict__ dy,
+                                                           size_t total4, int C, int R, int ldg, size_t g_bstride) {
+  const int C4 = C >> 2;
+  const float invR = 1.0f / (float)R;
+  const int q = blockIdx.y;
+  y += (size_t)q * total4 * 4; dy += (size_t)q * total4 * 4; dout += (size_t)q * g_bstride;
+  a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C; sums += (size_t)q * 2 * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / C4;
+    const int cg = (int)(i - r * C4);
+    const float4 g = *reinterpret_cast<const float4*>(dout + r * (size_t)ldg + 4 * cg);
+    const float4 v = *reinterpret_cast<const float4*>(y + 4 * i);
+    const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cg);
+    const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cg);
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + 4 * cg);
+    const float4 i4 = *reinterpret_cast<const float4*>(invstd + 4 * cg);
+    const float4 s4 = *reinterpret_cast<const float4*>(sums + 4 * cg);
+    const float4 q4 = *reinterpret_cast<const float4*>(sums + C + 4 * cg);
+    float4 dz = g;
+    if (ACT == 1) {
+      dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
+      dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
+    }
+    float4 o;
+    o.x = a4.x * (dz.x - s4.x * invR - ((v.x - m4.x) * i4.x) * (q4.x * invR));
+    o.y = a4.y * (dz.y - s4.y * invR - ((v.y - m4.y) * i4.y) * (q4.y * invR));
+    o.z = a4.z * (dz.z - s4.z * invR - ((v.z - m4.z) * i4.z) * (q4.z * invR));
+    o.w = a4.w * (dz.w - s4.w * invR - ((v.w - m4.w) * i4.w) * (q4.w * invR));
+    *reinterpret_cast<float4*>(dy + 4 * i) = o;
+  }
+}
+
+}  // namespace gkg
+
+using namespace gkg;
+
+static int stats_blocks(int R, int nb, int* rows_per_block) {
+  int nblk = (R + 31) / 32;                  // >= 32 rows per block
+  const int cap = nb > 1 ? 64 : 256;
+  if (nblk > cap) nblk = cap;
+  if (nblk < 1) nblk = 1;
+  *rows_per_block = (R + nblk - 1) / nblk;
+  return (R + *rows_per_block - 1) / *rows_per_block;
+}
+
+static bool bad_c(int C) { return C <= 0 || (C & 3) != 0 || C > 4096; }
+static size_t stats_lds(int C) {
+  const int C4 = C >> 2, CGT = C4 < 256 ? C4 : 256, RL = 256 / CGT;
+  return (size_t)RL * 2 * C * sizeof(float);
+}
+
+extern "C" size_t gkg_bn_workspace_bytes(int R, int C, int nb) {
+  if (R <= 0 || bad_c(C) || nb <= 0) return 0;
+  int rpb;
+  const int nblk = stats_blocks(R, nb, &rpb);
+  return (size_t)nb * (nblk + 1) * 2 * C * sizeof(float);
+}
+
+extern "C" int gkg_nchw_to_tm(const float* x, float* out, int B, int C, int N, void* stream) {
+  if (!x || !out) return gkg_fail(GKG_ERR_NULL, "gkg_nchw_to_tm: null pointer");
+  if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_nchw_to_tm: bad sizes");
+  dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(nchw_to_tm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, N);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "nchw_to_tm_kernel");
+}
+
+extern "C" int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
+                                     int B, int C, int N, void* stream) {
+  if (!y || !out || ((a == nullptr) != (c == nullptr))) return gkg_fail(GKG_ERR_NULL, "gkg_tm_affine_to_nchw: null pointer");
+  if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_tm_affine_to_nchw: bad sizes");
+  dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, C, N);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "tm_affine_to_nchw_kernel");
+}
+
+extern "C" int gkg_bn_train_stats(const float* y, const float* gamma, const float* beta, const float* bias,
+                                  float* running_mean, float* running_var, float* a, float* c, float* mean,
+                                  float* invstd, int R, int C, int nb, float momentum, float eps, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!y || !gamma || !beta || !a || !c || !mean || !invstd || !workspace)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_train_stats: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_train_stats: need R > 0, C % 4 == 0, C <= 4096, 1 <= nb <= 64");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_train_stats: running stats come in pairs");
+  int rpb;
+  const int nblk = stats_blocks(R, nb, &rpb);
+  if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float))
+    return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_train_stats: workspace too small (gkg_bn_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* sums = part + (size_t)nb * nblk * 2 * C;
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, nb), dim3(256), stats_lds(C), st, y, part, R, C, rpb);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256, nb), dim3(256), 0, st, sums, gamma, beta, bias, running_mean,
+                     running_var, a, c, mean, invstd, R, C, momentum, eps);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_train_stats");
+}
+
+extern "C" int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias, const float* running_mean,
+                                  const float* running_var, float* a, float* c, int C, float eps, void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !a || !c) return gkg_fail(GKG_ERR_NULL, "gkg_bn_eval_affine: null pointer");
+  if (C <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_eval_affine: bad C");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, bias,
+                     running_mean, running_var, a, c, C, eps);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_eval_affine_kernel");
+}
+
+extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, float* out, int R, int C,
+                              int nb, int ldo, size_t out_bstride, int act, void* stream) {
+  if (!y || !a || !c || !out) return gkg_fail(GKG_ERR_NULL, "gkg_affine_act: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldo < C || (ldo & 3) || (out_bstride & 3) || (act != 0 && act != 1))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: bad sizes");
+  const size_t total4 = (size_t)R * (C >> 2);
+  const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1>), dim3(blocks, nb), dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, total4, C, ldo, out_bstride);
+  else hipLaunchKernelGGL((affine_act_kernel<0>), dim3(blocks, nb), dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, total4, C, ldo, out_bstride);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");
+}
+
+extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                          const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                          size_t dout_bstride, int act, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !dy || !dgamma || !dbeta || !workspace)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd: bad sizes");
+  int rpb;
+  const int nblk = stats_blocks(R, nb, &rpb);
+  if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float)) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* sums = part + (size_t)nb * nblk * 2 * C;
+  const size_t lds = stats_lds(C);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride);
+  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride);
+  // dbeta[q] = sum dz ; dgamma[q] = sum dz*yhat
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
+  const size_t total4 = (size_t)R * (C >> 2);
+  const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd");
+}

@@ -38,6 +38,8 @@ constexpr int NW = 4;    // waves per workgroup
 // ------------------------------------------------------------------------------------------ prep
 constexpr int PREP_T = 64;   // tokens (threads) per token_prep workgroup
 
+struct PrepStrides { int G; size_t sb, sg, sc, sn; };
+
 // One thread per token.  The two ordered fma chains over the channels are inherently serial per token, so
 // the kernel is latency-bound: loads are batched 8 deep ahead of the chains, the first pass parks the
 // values in a thread-private LDS column so the second pass never goes back to L2, and small 64-token
@@ -45,12 +47,14 @@ constexpr int PREP_T = 64;   // tokens (threads) per token_prep workgroup
 template <typename T, bool NORM>
 __global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
                                                             float* __restrict__ sq, int c, int cpad, int Tn,
-                                                            int use_lds) {
+                                                            int use_lds, PrepStrides ps) {
   extern __shared__ float col[];          // [c][PREP_T] when use_lds
   const int n = blockIdx.x * PREP_T + threadIdx.x;
   const int bg = blockIdx.y;
   if (n >= Tn) return;
-  const T* tp = t + (size_t)bg * c * Tn + n;
+  // element (bg = b*G + g, ch, n) of the input lives at  b*sb + g*sg + ch*sc + n*sn
+  const T* tp = t + (size_t)(bg / ps.G) * ps.sb + (size_t)(bg % ps.G) * ps.sg + (size_t)n * ps.sn;
+  const size_t Tn_in = ps.sc;            // channel stride of the INPUT (outputs stay channel-major, stride Tn)
   float* cp = col + threadIdx.x;
   float den = 1.0f;
   if (NORM) {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict_
     for (; ch + 8 <= c; ch += 8) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ldf(tp + (size_t)(ch + u) * Tn);
+      for (int u = 0; u < 8; ++u) v[u] = ldf(tp + (size_t)(ch + u) * Tn_in);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         s = __builtin_fmaf(v[u], v[u], s);
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict_
       }
     }
     for (; ch < c; ++ch) {
-      const float v = ldf(tp + (size_t)ch * Tn);
+      const float v = ldf(tp + (size_t)ch * Tn_in);
       s = __builtin_fmaf(v, v, s);
       if (use_lds) cp[ch * PREP_T] = v;
     }
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict_
   for (; ch + 8 <= c; ch += 8) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = from_lds ? cp[(ch + u) * PREP_T] : ldf(tp + (size_t)(ch + u) * Tn);
+    for (int u = 0; u < 8; ++u) v[u] = from_lds ? cp[(ch + u) * PREP_T] : ldf(tp + (size_t)(ch + u) * Tn_in);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (NORM) v[u] = v[u] / den;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict_
     }
   }
   for (; ch < c; ++ch) {
-    float v = from_lds ? cp[ch * PREP_T] : ldf(tp + (size_t)ch * Tn);
+    float v = from_lds ? cp[ch * PREP_T] : ldf(tp + (size_t)ch * Tn_in);
     if (NORM) v = v / den;
     op[(size_t)ch * Tn] = v;
     q = __builtin_fmaf(v, v, q);
@@ -334,42 +338,42 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ split merge
-// One thread per query: S-finger merge of the partial lists (each sorted, length kd).
+// One thread per partial-list ELEMENT: its final rank = its position in its own (sorted) list + the number of
+// lexicographically smaller (dist, idx) pairs in every other split's list (binary search).  Ranks are unique,
+// so ranks 0,d,2d,.. < kd are written straight to their output slot — no serial merge.
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i,
                                                         int64_t* __restrict__ nn_idx, int64_t* __restrict__ center,
                                                         int S, int BG, int N, int k, int dilation, int kd) {
-  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;       // bg*N + n
-  if (q >= (size_t)BG * N) return;
-  const size_t stride = (size_t)BG * N * kd;                      // between splits
-  const float* pv = part_v + q * kd;
-  const int* pi = part_i + q * kd;
-  // lower bound of already-consumed (dist, idx): the next output is the smallest pair strictly greater
-  float last_v = -INFINITY; int last_i = -1;
-  int next_rank = 0, outj = 0;
-  for (int j = 0; j < kd; ++j) {
-    float bv = INFINITY; int bi = 0x7fffffff;
-    for (int s = 0; s < S; ++s) {
-      const float* v = pv + s * stride;
-      const int* id = pi + s * stride;
-      // binary search the first entry > (last_v, last_i) in this sorted list
-      int lo = 0, hi = kd;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const float mv = v[mid]; const int mi = id[mid];
-        const bool gt = (mv > last_v) || (mv == last_v && mi > last_i);
-        if (gt) hi = mid; else lo = mid + 1;
-      }
-      if (lo < kd) {
-        const float cv = v[lo]; const int ci = id[lo];
-        if (cv < bv || (cv == bv && ci < bi)) { bv = cv; bi = ci; }
-      }
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;        // (s, q, p) flattened as s*nq*kd + q*kd + p
+  const size_t nq = (size_t)BG * N;
+  const size_t stride = nq * kd;                                   // between splits
+  if (e >= stride * S) return;
+  const int s = (int)(e / stride);
+  const size_t rem = e - (size_t)s * stride;
+  const size_t q = rem / kd;
+  const int p = (int)(rem - q * kd);
+  const float v = part_v[e];
+  const int id = part_i[e];
+  if (id == 0x7fffffff) return;                                    // padding of a short list
+  int rank = p;
+  for (int s2 = 0; s2 < S && rank < kd; ++s2) {
+    if (s2 == s) continue;
+    const float* ov = part_v + (size_t)s2 * stride + q * kd;
+    const int* oi = part_i + (size_t)s2 * stride + q * kd;
+    int lo = 0, hi = kd;                                           // first entry >= (v, id)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const float mv = ov[mid]; const int mi = oi[mid];
+      const bool less = (mv < v) || (mv == v && mi < id);
+      if (less) lo = mid + 1; else hi = mid;
     }
-    last_v = bv; last_i = bi;
-    if (j == next_rank) {
-      nn_idx[q * k + outj] = bi;
+    rank += lo;
+  }
+  if (rank < kd && rank % dilation == 0) {
+    const int outj = rank / dilation;
+    if (outj < k) {
+      nn_idx[q * k + outj] = id;
       if (center) center[q * k + outj] = (int64_t)(q % N);
-      ++outj;
-      next_rank += dilation;
     }
   }
 }
@@ -391,7 +395,7 @@ static int pick_splits(int BG, int N, int M) {
   const int ktiles = (M + KT - 1) / KT;
   const long wgs = (long)qtiles * BG;
   int S = 1;
-  if (wgs < 512) {
+  if (wgs < 256) {                                 // fewer workgroups than CUs: split the keys
     S = (int)((512 + wgs - 1) / wgs);
     const int smax = (ktiles + 7) / 8;          // keep >= 8 key tiles (2 per wave) per split
     if (S > smax) S = smax;
@@ -467,22 +471,22 @@ static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream
 
 template <typename T>
 static hipError_t launch_prep(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
-                              hipStream_t st) {
+                              hipStream_t st, PrepStrides ps) {
   GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
   dim3 grid((Tn + PREP_T - 1) / PREP_T, BG);
   const size_t col_bytes = (size_t)c * PREP_T * sizeof(float);
   const int use_lds = norm && col_bytes <= 48 * 1024;
   const size_t lds = use_lds ? col_bytes : 0;
   if (norm)
-    hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds);
+    hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds, ps);
   else
-    hipLaunchKernelGGL((token_prep_kernel<T, false>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds);
+    hipLaunchKernelGGL((token_prep_kernel<T, false>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds, ps);
   return hipGetLastError();
 }
 
-extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
-                           int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+                        int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
+                        void* workspace, size_t workspace_bytes, void* stream, int G_tm) {
   if (!x || !nn_idx || !workspace) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
   if (dtype != GKG_F32 && dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32 or GKG_BF16");
   KnnPlan p;
@@ -498,12 +502,19 @@ extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, in
   float* sqy = (float*)(ws + p.off_sqy);
   const bool norm = (flags & GKG_KNN_NORMALIZE) != 0;
   hipError_t e;
-  if (dtype == GKG_F32) e = launch_prep<float>(x, xh, sqx, BG, c, p.cpad, N, norm, st);
-  else e = launch_prep<uint16_t>(x, xh, sqx, BG, c, p.cpad, N, norm, st);
+  // input addressing: channel-major (BG,c,T)  or  token-major (B,T,C=G*c) when G_tm > 0
+  auto strides = [&](int Tn) {
+    PrepStrides ps;
+    if (G_tm > 0) { ps.G = G_tm; ps.sb = (size_t)Tn * G_tm * c; ps.sg = c; ps.sc = 1; ps.sn = (size_t)G_tm * c; }
+    else { ps.G = 1; ps.sb = (size_t)c * Tn; ps.sg = 0; ps.sc = Tn; ps.sn = 1; }
+    return ps;
+  };
+  if (dtype == GKG_F32) e = launch_prep<float>(x, xh, sqx, BG, c, p.cpad, N, norm, st, strides(N));
+  else e = launch_prep<uint16_t>(x, xh, sqx, BG, c, p.cpad, N, norm, st, strides(N));
   if (e != hipSuccess) return gkg_fail_hip(e, "token_prep(x)");
   if (y) {
-    if (dtype == GKG_F32) e = launch_prep<float>(y, yh, sqy, BG, c, p.cpad, M, norm, st);
-    else e = launch_prep<uint16_t>(y, yh, sqy, BG, c, p.cpad, M, norm, st);
+    if (dtype == GKG_F32) e = launch_prep<float>(y, yh, sqy, BG, c, p.cpad, M, norm, st, strides(M));
+    else e = launch_prep<uint16_t>(y, yh, sqy, BG, c, p.cpad, M, norm, st, strides(M));
     if (e != hipSuccess) return gkg_fail_hip(e, "token_prep(y)");
   }
   KnnArgs a;
@@ -530,12 +541,27 @@ extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, in
   }
   if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");
   if (p.S > 1) {
-    const size_t nq = (size_t)BG * N;
+    const size_t ne = (size_t)BG * N * p.kd * p.S;
     GkgProfScope prof(GKG_PROF_KNN_MERGE, st);
-    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
                        nn_idx, center, p.S, BG, N, k, dilation, p.kd);
     e = hipGetLastError();
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_merge_kernel");
   }
   return 0;
+}
+
+extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+                           int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  return knn_fwd_impl(x, y, relpos, nn_idx, center, BG, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
+                      stream, 0);
+}
+
+extern "C" int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+                              int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm: bad B / G");
+  return knn_fwd_impl(x, y, relpos, nn_idx, center, B * G, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
+                      stream, G);
 }

@@ -19,6 +19,11 @@ namespace gkg {
 constexpr int MR_LDS_BUDGET = 96 * 1024;   // bytes of LDS for source rows / accumulators
 
 // ------------------------------------------------------------------------------------------ forward
+// These kernels move ~1 flop per byte and, at the sizes of this path, every operand is L2/MALL resident:
+// they are bound by memory *latency*, so each thread issues all of its independent loads before the
+// first use (index row, centre values, then k gathers per channel from the LDS-staged source rows).
+constexpr int MR_CB = 4;        // channels processed together per thread (loads batched across them)
+
 template <typename T>
 __global__ __launch_bounds__(256) void mr_fwd_kernel(const T* __restrict__ x, const T* __restrict__ src,
                                                      const int64_t* __restrict__ nn_idx, T* __restrict__ m_out,
@@ -33,31 +38,62 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const T* __restrict__ x, co
   const int n0 = blockIdx.x * 256;
   const int n = n0 + tid;
 
-  const T* sp = src + ((size_t)bg * c + ch0) * M;
-  for (int i = tid; i < nch * M; i += 256) rows[i] = ldf(sp + i);
   {
+    const T* sp = src + ((size_t)bg * c + ch0) * M;
+    const int total = nch * M;
+    for (int i = tid; i < total; i += 1024) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i + 256 * u < total) ? ldf(sp + i + 256 * u) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i + 256 * u < total) rows[i + 256 * u] = v[u];
+    }
     // indices of this tile: (256, k) int64 contiguous -> idx_s[j][q]
     const int64_t* ip = nn_idx + ((size_t)bg * N + n0) * k;
     const int cnt = min(256, N - n0) * k;
-    for (int i = tid; i < cnt; i += 256) {
-      const int q = i / k, j = i - q * k;
-      idx_s[j * 256 + q] = (int)ip[i];
+    for (int i = tid; i < cnt; i += 1024) {
+      int64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i + 256 * u < cnt) ? ip[i + 256 * u] : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = i + 256 * u;
+        if (e < cnt) { const int q = e / k; idx_s[(e - q * k) * 256 + q] = (int)v[u]; }
+      }
     }
   }
   __syncthreads();
   if (n >= N) return;
-  for (int ch = 0; ch < nch; ++ch) {
-    const size_t o = ((size_t)bg * c + ch0 + ch) * N + n;
-    const float xi = ldf(x + o);
-    const float* r = rows + (size_t)ch * M;
-    float best = r[idx_s[tid]] - xi;
-    int arg = 0;
-    for (int j = 1; j < k; ++j) {
-      const float v = r[idx_s[j * 256 + tid]] - xi;
-      if (v > best) { best = v; arg = j; }
+  for (int cb = 0; cb < nch; cb += MR_CB) {
+    float xi[MR_CB], best[MR_CB];
+    int arg[MR_CB];
+#pragma unroll
+    for (int u = 0; u < MR_CB; ++u) {
+      const int ch = min(cb + u, nch - 1);
+      xi[u] = ldf(x + ((size_t)bg * c + ch0 + ch) * N + n);
     }
-    stf(m_out + o, best);
-    if (argmax) argmax[o] = (uint8_t)arg;
+#pragma unroll
+    for (int u = 0; u < MR_CB; ++u) {
+      const float* r = rows + (size_t)min(cb + u, nch - 1) * M;
+      best[u] = r[idx_s[tid]] - xi[u];
+      arg[u] = 0;
+    }
+    for (int j = 1; j < k; ++j) {
+      const int id = idx_s[j * 256 + tid];
+#pragma unroll
+      for (int u = 0; u < MR_CB; ++u) {
+        const float v = rows[(size_t)min(cb + u, nch - 1) * M + id] - xi[u];
+        if (v > best[u]) { best[u] = v; arg[u] = j; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MR_CB; ++u) {
+      if (cb + u < nch) {
+        const size_t o = ((size_t)bg * c + ch0 + cb + u) * N + n;
+        stf(m_out + o, best[u]);
+        if (argmax) argmax[o] = (uint8_t)arg[u];
+      }
+    }
   }
 }
 
@@ -68,31 +104,53 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ g, co
                                                      T* __restrict__ gsrc, int c, int N, int M, int k, int CH) {
   extern __shared__ float smem[];
   float* acc = smem;                                    // [CH][M]
-  int* idx_s = reinterpret_cast<int*>(smem + (size_t)CH * M);   // [256][k+?] as [q*k + j]
+  int* idx_s = reinterpret_cast<int*>(smem + (size_t)CH * M);   // [256][k] as [q*k + j]
   const int tid = threadIdx.x;
   const int bg = blockIdx.y;
   const int ch0 = blockIdx.x * CH;
   const int nch = min(CH, c - ch0);
   const size_t gbase = ((size_t)bg * c + ch0) * N;
 
-  if (SELF) {
-    for (int i = tid; i < nch * M; i += 256) acc[i] = -ldf(g + gbase + i);      // centre term (N == M)
-  } else {
-    for (int i = tid; i < nch * M; i += 256) acc[i] = 0.0f;
-    for (int i = tid; i < nch * N; i += 256) stf(gx + gbase + i, -ldf(g + gbase + i));
+  {
+    const int total = nch * N;                          // centre term: gx = -g (self: seeds the accumulator)
+    for (int i = tid; i < total; i += 1024) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i + 256 * u < total) ? ldf(g + gbase + i + 256 * u) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = i + 256 * u;
+        if (e < total) { if (SELF) acc[e] = -v[u]; else stf(gx + gbase + e, -v[u]); }
+      }
+    }
+    if (!SELF) for (int i = tid; i < nch * M; i += 256) acc[i] = 0.0f;
   }
   for (int n0 = 0; n0 < N; n0 += 256) {
     __syncthreads();                                    // acc init done / previous tile's idx consumed
     const int64_t* ip = nn_idx + ((size_t)bg * N + n0) * k;
     const int cnt = min(256, N - n0) * k;
-    for (int i = tid; i < cnt; i += 256) idx_s[i] = (int)ip[i];
+    for (int i = tid; i < cnt; i += 1024) {
+      int64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i + 256 * u < cnt) ? ip[i + 256 * u] : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i + 256 * u < cnt) idx_s[i + 256 * u] = (int)v[u];
+    }
     __syncthreads();
     const int n = n0 + tid;
     if (n < N) {
-      for (int ch = 0; ch < nch; ++ch) {
-        const size_t o = gbase + (size_t)ch * N + n;
-        const int j = idx_s[tid * k + argmax[o]];
-        atomicAdd(&acc[(size_t)ch * M + j], ldf(g + o));
+      for (int cb = 0; cb < nch; cb += MR_CB) {
+        float gv[MR_CB];
+        int am[MR_CB];
+#pragma unroll
+        for (int u = 0; u < MR_CB; ++u) {
+          const size_t o = gbase + (size_t)min(cb + u, nch - 1) * N + n;
+          gv[u] = ldf(g + o);
+          am[u] = argmax[o];
+        }
+#pragma unroll
+        for (int u = 0; u < MR_CB; ++u)
+          if (cb + u < nch) atomicAdd(&acc[(size_t)(cb + u) * M + idx_s[tid * k + am[u]]], gv[u]);
       }
     }
   }
@@ -100,6 +158,161 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ g, co
   T* out = SELF ? gx : gsrc;
   const size_t obase = ((size_t)bg * c + ch0) * M;
   for (int i = tid; i < nch * M; i += 256) stf(out + obase + i, acc[i]);
+}
+
+// ------------------------------------------------------------------------------------------ token-major variants
+// Inside the fused Grapher block activations are token-major (B, N, C): a neighbour is then ONE contiguous row
+// segment of c floats, so the aggregation is a coalesced row gather — no LDS staging.  One thread = one token x
+// 4 consecutive channels (one group): k float4 gathers + centre float4, all issued before the max chain.
+//   mode 0: m (B,N,C) token-major.
+//   mode 1: the grouped 1x1 projection's input directly, U[q][t][2i] = x[t][q*C/4+i], U[q][t][2i+1] = m[...]
+//           (reference interleave torch_vertex.py:57-61 + Conv2d(groups=4) channel split torch_nn.py:61).
+__global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
+                                                        const int64_t* __restrict__ nn_idx, float* __restrict__ out,
+                                                        uint8_t* __restrict__ argmax, int B, int G, int c, int N, int M,
+                                                        int k, int mode) {
+  const int C = G * c, C4 = C >> 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // (t, cq)
+  const size_t T = (size_t)B * N;
+  if (i >= T * C4) return;
+  const size_t t = i / C4;
+  const int cq = (int)(i - t * C4);
+  const int ch = 4 * cq;
+  const int b = (int)(t / N), n = (int)(t - (size_t)b * N);
+  const int g = ch / c;
+  const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+  const float4 xi = *reinterpret_cast<const float4*>(x + t * C + ch);
+  const float* sb = src + (size_t)b * M * C + ch;
+  float4 best;
+  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  {
+    const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[0] * C);
+    best = make_float4(v.x - xi.x, v.y - xi.y, v.z - xi.z, v.w - xi.w);
+  }
+  for (int j = 1; j < k; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[j] * C);
+    const float d0 = v.x - xi.x, d1 = v.y - xi.y, d2 = v.z - xi.z, d3 = v.w - xi.w;
+    if (d0 > best.x) { best.x = d0; a0 = j; }
+    if (d1 > best.y) { best.y = d1; a1 = j; }
+    if (d2 > best.z) { best.z = d2; a2 = j; }
+    if (d3 > best.w) { best.w = d3; a3 = j; }
+  }
+  if (argmax) *reinterpret_cast<uint32_t*>(argmax + t * C + ch) = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
+  if (mode == 0) {
+    *reinterpret_cast<float4*>(out + t * C + ch) = best;
+  } else {
+    const int Cq = C >> 2;                      // original channels per conv group
+    const int q = ch / Cq, il = ch - q * Cq;    // 4 channels never straddle a conv group (C % 16 == 0)
+    float* o = out + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
+    *reinterpret_cast<float4*>(o) = make_float4(xi.x, best.x, xi.y, best.y);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(xi.z, best.z, xi.w, best.w);
+  }
+}
+
+// Backward, pass 1: gx[t][ch] = direct[t][ch] - gm[t][ch]   (mode 1: direct/gm are the even/odd columns of dU)
+__global__ __launch_bounds__(256) void mr_bwd_tm_init_kernel(const float* __restrict__ gin, float* __restrict__ gx,
+                                                             int C, size_t T, int mode) {
+  const int C4 = C >> 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * C4) return;
+  const size_t t = i / C4;
+  const int ch = 4 * (int)(i - t * C4);
+  float4 o;
+  if (mode == 0) {
+    const float4 g = *reinterpret_cast<const float4*>(gin + t * C + ch);
+    o = make_float4(-g.x, -g.y, -g.z, -g.w);
+  } else {
+    const int Cq = C >> 2;
+    const int q = ch / Cq, il = ch - q * Cq;
+    const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
+    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
+    o = make_float4(u0.x - u0.y, u0.z - u0.w, u1.x - u1.y, u1.z - u1.w);
+  }
+  *reinterpret_cast<float4*>(gx + t * C + ch) = o;
+}
+
+// Backward, pass 2: dst[b][nn_idx[bg][n][argmax[t][ch]]][ch] += gm[t][ch].
+// One workgroup = one image x a chunk of CW channels: the destination rows of that (image, chunk) live in LDS
+// ([M][CW] fp32, seeded from `dst`, which pass 1 / the memset already initialised), all N queries are swept with
+// ds_add_f32, then the rows are stored back — no global atomics.  Threads: 256 = (CW/4) channel quads x tokens.
+__global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                                const uint8_t* __restrict__ argmax, float* __restrict__ dst,
+                                                                int B, int G, int c, int N, int M, int k, int mode, int CW) {
+  extern __shared__ float acc[];                  // [M][CW]
+  const int C = G * c;
+  const int b = blockIdx.y;
+  const int ch0 = blockIdx.x * CW;
+  const int cw4 = CW >> 2;                        // quads per row chunk
+  const int tid = threadIdx.x;
+  const int qd = tid % cw4, tl = tid / cw4, TL = 256 / cw4;
+  const size_t T = (size_t)B * N;
+  float* db = dst + (size_t)b * M * C + ch0;
+  if (tl < TL) {
+    for (int m = tl; m < M; m += TL)
+      *reinterpret_cast<float4*>(acc + (size_t)m * CW + 4 * qd) = *reinterpret_cast<const float4*>(db + (size_t)m * C + 4 * qd);
+  }
+  __syncthreads();
+  if (tl < TL) {
+    const int ch = ch0 + 4 * qd;
+    const int g = ch / c;
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+      const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+      float4 gm;
+      if (mode == 0) {
+        gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
+      } else {
+        const int Cq = C >> 2;
+        const int q = ch / Cq, il = ch - q * Cq;
+        const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
+        const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
+        gm = make_float4(u0.y, u0.w, u1.y, u1.w);
+      }
+      const int j0 = (int)ip[am & 0xff], j1 = (int)ip[(am >> 8) & 0xff], j2 = (int)ip[(am >> 16) & 0xff],
+                j3 = (int)ip[(am >> 24) & 0xff];
+      atomicAdd(acc + (size_t)j0 * CW + 4 * qd + 0, gm.x);
+      atomicAdd(acc + (size_t)j1 * CW + 4 * qd + 1, gm.y);
+      atomicAdd(acc + (size_t)j2 * CW + 4 * qd + 2, gm.z);
+      atomicAdd(acc + (size_t)j3 * CW + 4 * qd + 3, gm.w);
+    }
+  }
+  __syncthreads();
+  if (tl < TL) {
+    for (int m = tl; m < M; m += TL)
+      *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = *reinterpret_cast<const float4*>(acc + (size_t)m * CW + 4 * qd);
+  }
+}
+
+// Fallback when a destination image does not fit in LDS even for a 4-channel chunk: fp32 global atomics.
+__global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                                       const uint8_t* __restrict__ argmax, float* __restrict__ dst,
+                                                                       int B, int G, int c, int N, int M, int k, int mode) {
+  const int C = G * c, C4 = C >> 2;
+  const size_t T = (size_t)B * N;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * C4) return;
+  const size_t t = i / C4;
+  const int ch = 4 * (int)(i - t * C4);
+  const int b = (int)(t / N), n = (int)(t - (size_t)b * N);
+  const int g = ch / c;
+  const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+  const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+  float4 gm;
+  if (mode == 0) {
+    gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
+  } else {
+    const int Cq = C >> 2;
+    const int q = ch / Cq, il = ch - q * Cq;
+    const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
+    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
+    gm = make_float4(u0.y, u0.w, u1.y, u1.w);
+  }
+  float* db = dst + (size_t)b * M * C + ch;
+  atomicAdd(db + (size_t)ip[am & 0xff] * C + 0, gm.x);
+  atomicAdd(db + (size_t)ip[(am >> 8) & 0xff] * C + 1, gm.y);
+  atomicAdd(db + (size_t)ip[(am >> 16) & 0xff] * C + 2, gm.z);
+  atomicAdd(db + (size_t)ip[(am >> 24) & 0xff] * C + 3, gm.w);
 }
 
 }  // namespace gkg
@@ -178,4 +391,53 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
                                   : mr_bwd_launch<uint16_t>(g, nn_idx, argmax, gx, gsrc, BG, c, N, M, k, CH, (hipStream_t)stream);
   if (e != hipSuccess) return gkg_fail_hip(e, "mr_bwd_kernel");
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------ token-major entry points
+extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, float* out, uint8_t* argmax,
+                             int B, int G, int c, int N, int M, int k, int mode, void* stream) {
+  if (!x || !nn_idx || !out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_fwd_tm: x, nn_idx and out must be non-null");
+  if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: bad sizes (c % 4 == 0, k <= 255)");
+  if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode is 0 or 1");
+  if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode 1 needs C % 16 == 0");
+  if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
+  GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
+  const size_t total = (size_t)B * N * (G * c / 4);
+  hipLaunchKernelGGL(mr_fwd_tm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, src, nn_idx,
+                     out, argmax, B, G, c, N, M, k, mode);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
+}
+
+extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
+                             int B, int G, int c, int N, int M, int k, int mode, void* stream) {
+  if (!gin || !nn_idx || !argmax || !gx) return gkg_fail(GKG_ERR_NULL, "gkg_mr_bwd_tm: gin, nn_idx, argmax and gx must be non-null");
+  if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: bad sizes");
+  if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode is 0 or 1");
+  if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode 1 needs C % 16 == 0");
+  if (!gsrc && M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: self graph needs M == N");
+  hipStream_t st = (hipStream_t)stream;
+  GkgProfScope prof(GKG_PROF_MR_BWD, st);
+  const int C = G * c;
+  const size_t T = (size_t)B * N;
+  const size_t total = T * (C / 4);
+  hipLaunchKernelGGL(mr_bwd_tm_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, gx, C, T, mode);
+  if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * M * C, st);
+  // channel chunk: largest power-of-two multiple of 4 (<= 64, dividing C, not straddling a k-NN group) whose
+  // [M][CW] fp32 image fits the LDS budget, shrunk until the grid has ~2 workgroups per CU
+  int CW = 64;
+  while (CW > 4 && ((size_t)M * CW * 4 > (size_t)MR_LDS_BUDGET || C % CW || c % CW)) CW >>= 1;
+  while (CW > 8 && (long)(C / CW) * B < 512) CW >>= 1;
+  if ((size_t)M * CW * 4 <= (size_t)MR_LDS_BUDGET && C % CW == 0 && c % CW == 0 && B <= 65535) {
+    const size_t lds = (size_t)M * CW * 4;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mr_bwd_tm_scatter_kernel, dim3(C / CW, B), dim3(256), lds, st, gin, nn_idx, argmax,
+                       gsrc ? gsrc : gx, B, G, c, N, M, k, mode, CW);
+  } else {
+    hipLaunchKernelGGL(mr_bwd_tm_scatter_atomic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, nn_idx,
+                       argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_bwd_tm");
 }

@@ -1,0 +1,335 @@
+"""Fused token-major execution of the Grapher / GrapherLabel blocks on the GPU.
+
+Same math as the composable modules in ``graph.py`` / ``grapher.py`` (and therefore as the reference,
+torch_vertex.py:278-403), restructured for MI355X:
+
+* activations inside the block are token-major ``(B*N, C)``: every 1x1 projection is ONE large fp32 GEMM
+  (vendor library, MFMA) instead of 32 per-image ones, and a graph neighbour is one contiguous row segment;
+* everything between two GEMMs is a hand-written bandwidth kernel from ``libgkg_hip.so``
+  (``csrc/gkg_dense.hip``): train-mode BN statistics (deterministic two-stage), BN-apply (+GELU) (+residual),
+  the BN/GELU backward pair, layout changes fused into the first/last kernel of the block;
+* the max-relative kernel writes the grouped projection's interleaved input directly (no ``stack``/``cat``),
+  its backward consumes the grouped projection's input gradient directly.
+
+Autograd sees four custom Functions (layout, linear+BN+act, grouped linear+BN+act, max-relative) with
+hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabel`` when supported
+(``fused_supported``); everything else takes the composable path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import _ptr, _stream
+
+_F32 = torch.float32
+ENABLED = True          # set False to force the composable (per-op) path, e.g. in A/B tests
+
+
+def _wgrad(dY: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW (Cout, Cin) = dY^T (Cout x R) @ x (R x Cin).  The output is tiny and the contraction long (R = B*N),
+    so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials."""
+    R = x.shape[0]
+    for S in (8, 6, 4, 3, 2):
+        if R % S == 0 and R // S >= 512:
+            part = torch.bmm(dY.view(S, R // S, -1).transpose(1, 2), x.view(S, R // S, -1))
+            return part.sum(0)
+    return torch.mm(dY.t(), x)
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------------- layout
+class _ToTokenMajor(torch.autograd.Function):
+    """(B, C, *spatial) -> (B*N, C)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C = x.shape[:2]
+        N = x[0, 0].numel()
+        x = x.contiguous()
+        out = torch.empty((B * N, C), dtype=_F32, device=x.device)
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _stream()), "gkg_nchw_to_tm")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C = ctx.shape[:2]
+        N = g.shape[0] // B
+        g = g.contiguous()
+        out = torch.empty(ctx.shape, dtype=_F32, device=g.device)
+        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g), None, None, None, _ptr(out), B, C, N, _stream()),
+                   "gkg_tm_affine_to_nchw")
+        return out
+
+
+def to_token_major(x):
+    return _ToTokenMajor.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------- BN helpers
+def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
+    """Returns (a, c, mean, invstd) for out = a*Y + c; updates running statistics in train mode."""
+    dev = Y.device
+    a = torch.empty(nb * C, dtype=_F32, device=dev)
+    c = torch.empty_like(a)
+    if bn.training or not bn.track_running_stats:
+        mean = torch.empty_like(a)
+        invstd = torch.empty_like(a)
+        ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), dev)
+        track = bn.training and bn.track_running_stats
+        _lib.check(lib.gkg_bn_train_stats(_ptr(Y), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                          _ptr(bn.running_mean) if track else None,
+                                          _ptr(bn.running_var) if track else None,
+                                          _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), R, C, nb,
+                                          float(bn.momentum), float(bn.eps), _ptr(ws), ws.numel(), _stream()),
+                   "gkg_bn_train_stats")
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return a, c, mean, invstd
+    _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
+                                      _ptr(bn.running_var), _ptr(a), _ptr(c), nb * C, float(bn.eps), _stream()),
+               "gkg_bn_eval_affine")
+    return a, c, None, None
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """out = act(BN(x @ W^T + b)) (+ residual), token-major.  ``nchw``: write the result (and read the
+    residual) in (B, C, N) layout — the block's last layer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw):
+        lib = _lib.load()
+        R, cin = x.shape
+        cout = weight.shape[0]
+        W = weight.view(cout, cin)
+        Y = torch.mm(x, W.t())
+        a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
+        if nchw is None:
+            out = torch.empty((R, cout), dtype=_F32, device=x.device)
+            res = None if residual is None else residual.contiguous()
+            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
+                                          _stream()), "gkg_affine_act")
+        else:
+            assert act == 0
+            B = nchw[0]
+            out = torch.empty(nchw, dtype=_F32, device=x.device)
+            res = None if residual is None else residual.contiguous()
+            _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), B, cout, R // B,
+                                                 _stream()), "gkg_tm_affine_to_nchw")
+        ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
+        ctx.meta = (act, nchw, residual is not None, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, weight, Y, a, c, mean, invstd = ctx.saved_tensors
+        act, nchw, has_res, has_bias = ctx.meta
+        R, cin = x.shape
+        cout = weight.shape[0]
+        dres = dout if has_res else None
+        if nchw is not None:
+            g = torch.empty((R, cout), dtype=_F32, device=dout.device)
+            _lib.check(lib.gkg_nchw_to_tm(_ptr(dout.contiguous()), _ptr(g), nchw[0], cout, R // nchw[0], _stream()),
+                       "gkg_nchw_to_tm")
+        else:
+            g = dout.contiguous()
+        if mean is None:
+            raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
+        dY = torch.empty_like(Y)
+        dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = _ws(lib.gkg_bn_workspace_bytes(R, cout, 1), Y.device)
+        _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
+                                  _ptr(dgamma), _ptr(dbeta), R, cout, 1, cout, 0, act, _ptr(ws), ws.numel(),
+                                  _stream()), "gkg_bn_bwd")
+        # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean)
+        dbias = torch.zeros(cout, dtype=_F32, device=Y.device) if has_bias else None
+        W = weight.view(cout, cin)
+        dx = torch.mm(dY, W)
+        dW = _wgrad(dY, x).view_as(weight)
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None
+
+
+class _GroupedLinearBNAct(torch.autograd.Function):
+    """The reference's BasicConv: Conv2d(1x1, groups=4) + BN + act on the interleaved [x, m] channels.
+    U (4, R, ci) group-major -> out (R, 4*co) token-major (column q*co + j)."""
+
+    @staticmethod
+    def forward(ctx, U, weight, bias, gamma, beta, bn, act):
+        lib = _lib.load()
+        nb, R, ci = U.shape
+        cout = weight.shape[0]
+        co = cout // nb
+        Wg = weight.view(nb, co, ci)
+        Y = torch.bmm(U, Wg.transpose(1, 2))                           # (nb, R, co)
+        a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
+        out = torch.empty((R, cout), dtype=_F32, device=U.device)
+        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
+                                      _stream()), "gkg_affine_act")
+        ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
+        ctx.meta = (act, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        U, weight, Y, a, c, mean, invstd = ctx.saved_tensors
+        act, has_bias = ctx.meta
+        nb, R, ci = U.shape
+        cout = weight.shape[0]
+        co = cout // nb
+        g = dout.contiguous()
+        if mean is None:
+            raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
+        dY = torch.empty_like(Y)
+        dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = _ws(lib.gkg_bn_workspace_bytes(R, co, nb), Y.device)
+        _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
+                                  _ptr(dgamma), _ptr(dbeta), R, co, nb, cout, co, act, _ptr(ws), ws.numel(),
+                                  _stream()), "gkg_bn_bwd")
+        Wg = weight.view(nb, co, ci)
+        dU = torch.bmm(dY, Wg)
+        dW = torch.bmm(dY.transpose(1, 2), U).view_as(weight)
+        dbias = torch.zeros(cout, dtype=_F32, device=Y.device) if has_bias else None
+        return dU, dW, dbias, dgamma, dbeta, None, None
+
+
+# ----------------------------------------------------------------------------------------------- graph ops
+@torch.no_grad()
+def knn_graph_tm(x, y, relative_pos, k, dilation, G):
+    """x (B,N,C), y (B,M,C)|None token-major -> edge_index (2, B*G, N, k) int64."""
+    lib = _lib.load()
+    B, N, C = x.shape
+    c = C // G
+    M = N if y is None else y.shape[1]
+    rp = None
+    if relative_pos is not None:
+        rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
+        if tuple(rp.shape) != (N, M):
+            raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+    edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device=x.device)
+    ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
+    rc = lib.gkg_knn_fwd_tm(_ptr(x), _ptr(y), _ptr(rp), edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k,
+                            dilation, _lib.F32, _lib.KNN_NORMALIZE, _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gkg_knn_fwd_tm")
+    return edge
+
+
+class _MaxRelativeTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, src, nn_idx, G, mode):
+        lib = _lib.load()
+        B, N, C = x.shape
+        M = N if src is None else src.shape[1]
+        k = nn_idx.shape[2]
+        T = B * N
+        out = torch.empty((4, T, C // 2) if mode == 1 else (B, N, C), dtype=_F32, device=x.device)
+        need = any(ctx.needs_input_grad[:2])
+        arg = torch.empty((B, N, C), dtype=torch.uint8, device=x.device) if need else None
+        _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
+                                     _stream()), "gkg_mr_fwd_tm")
+        ctx.save_for_backward(nn_idx, arg)
+        ctx.meta = (B, G, C, N, M, k, mode, src is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        nn_idx, arg = ctx.saved_tensors
+        B, G, C, N, M, k, mode, has_src = ctx.meta
+        g = g.contiguous()
+        gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
+        gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
+        _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode,
+                                     _stream()), "gkg_mr_bwd_tm")
+        return gx, gsrc, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- block drivers
+def _bn_ok(bn) -> bool:
+    if not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) or not bn.affine or bn.momentum is None:
+        return False
+    if isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and dist.is_available() and dist.is_initialized() \
+            and dist.get_world_size() > 1:
+        return False            # cross-rank statistics: composable path (torch SyncBatchNorm collectives)
+    return True
+
+
+def fused_supported(mod, x, groups: int) -> bool:
+    """Fused path preconditions: fp32 CUDA input, 'mr' aggregation with GELU+BN, channel counts that keep
+    float4 / group boundaries aligned, local batch statistics, inactive DropPath."""
+    from .graph import MRConv2d
+    gc = mod.graph_conv
+    C = mod.channels
+    if not (x.is_cuda and x.dtype == _F32):
+        return False
+    if not isinstance(gc.gconv, MRConv2d) or len(gc.gconv.nn) != 3 or not isinstance(gc.gconv.nn[2], torch.nn.GELU):
+        return False
+    if C % 16 or (C // groups) % 4 or getattr(gc.dilated_knn_graph, "stochastic", False):
+        return False
+    if isinstance(mod.drop_path, torch.nn.Identity) is False and mod.training and mod.drop_path.drop_prob > 0:
+        return False
+    bns = [mod.fc1[1], gc.gconv.nn[1], mod.fc2[1]]
+    if hasattr(mod, "ffn"):
+        bns += [mod.ffn.fc1[1], mod.ffn.fc2[1]]
+        if not isinstance(mod.ffn.act, torch.nn.GELU):
+            return False
+    if not all(_bn_ok(b) for b in bns):
+        return False
+    if torch.is_grad_enabled() and not mod.training and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+        return False            # gradients through eval-mode BN: composable path
+    return ENABLED
+
+
+def _lin(x, seq, act=0, residual=None, nchw=None):
+    conv, bn = seq[0], seq[1]
+    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw)
+
+
+def grapher_forward(mod, x, relative_pos, groups: int):
+    """Fused Grapher.forward (reference torch_vertex.py:325-333).  Returns (out (B,C,H,W), edge_index)."""
+    B, C, H, W = x.shape
+    N = H * W
+    gc = mod.graph_conv
+    x = x.contiguous()
+    xt = to_token_major(x)                                          # (T, C)
+    x1 = _lin(xt, mod.fc1)                                          # fc1 + BN
+    x1b = x1.view(B, N, C)
+    yb = None
+    if gc.r > 1:                                                    # pooled keys (torch_vertex.py:194-196)
+        pooled = F.avg_pool2d(x1.view(B, H, W, C).permute(0, 3, 1, 2), gc.r, gc.r)
+        yb = pooled.permute(0, 2, 3, 1).reshape(B, -1, C)
+    edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
+    U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1)           # (4, T, C/2) interleaved [x, m]
+    nn_ = gc.gconv.nn
+    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1)   # (T, 2C)
+    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W))          # fc2 + BN + residual, back to NCHW
+    return out, edge
+
+
+def grapher_label_forward(mod, e, features, groups: int):
+    """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
+    B, L, C = e.shape
+    gc = mod.graph_conv
+    ft = to_token_major(features.contiguous()).view(B, -1, C)       # keys / values (B, HW, C)
+    e2 = e.reshape(B * L, C).contiguous()
+    x1 = _lin(e2, mod.fc1)
+    x1b = x1.view(B, L, C)
+    edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
+    U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1)
+    nn_ = gc.gconv.nn
+    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1)
+    h2 = _lin(a2, mod.fc2, residual=e2)
+    f1 = _lin(h2, mod.ffn.fc1, act=1)
+    out = _lin(f1, mod.ffn.fc2, residual=h2)
+    return out.view(B, L, C), edge

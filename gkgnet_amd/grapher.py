@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import fused
 from .dense import PointwiseConv2d
 from .graph import DyGraphConv2d, DyGraphConv2dMultiGroup, DyGraphLabel, DyGraphLabelMultiGroup
 from .layers import DropPath, act_layer, build_norm
@@ -41,10 +42,14 @@ class Grapher(nn.Module):
         return resize_relative_pos(relative_pos, self.n, self.r, H, W)
 
     def forward(self, x):
+        H, W = x.shape[2:]
+        relative_pos = self._get_relative_pos(self.relative_pos, H, W)
+        groups = self.graph_conv.num_head
+        if fused.fused_supported(self, x, groups):
+            return fused.grapher_forward(self, x, relative_pos, groups)[0]
         shortcut = x
         x = self.fc1(x)
-        H, W = x.shape[2:]
-        x, _ = self.graph_conv(x, self._get_relative_pos(self.relative_pos, H, W))
+        x, _ = self.graph_conv(x, relative_pos)
         x = self.fc2(x)
         return self.drop_path(x) + shortcut
 
@@ -90,6 +95,11 @@ class GrapherLabel(nn.Module):
 
     def forward(self, x, features):
         B, C = features.shape[:2]
+        groups = self.graph_conv.num_head
+        if fused.fused_supported(self, x, groups) and features.is_cuda and features.dtype == x.dtype:
+            out, edge = fused.grapher_label_forward(self, x, features, groups)
+            from .graph import DyGraphLabel
+            return out, (edge if isinstance(self.graph_conv, DyGraphLabel) else edge[0])
         features = features.reshape(B, C, -1)
         x = x.transpose(2, 1).unsqueeze(-1)
         shortcut = x

@@ -49,6 +49,22 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def release(self):
+        """Detach ``p.grad`` from the bucket so the next backward writes fresh gradients (no zero-fill and no
+        per-parameter accumulate kernels); follow the backward with :meth:`pack`."""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        """Gather the freshly produced ``p.grad`` tensors into the flat bucket with one batched copy and
+        re-point ``p.grad`` at the bucket views."""
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(grads, out=self.flat)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
     def all_reduce(self, async_op: bool = False):
         """Average over ranks.  No-op in a single process."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

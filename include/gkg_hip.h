@@ -99,6 +99,55 @@ int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx, void* m_ou
 int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void* gx, void* gsrc,
                int BG, int c, int N, int M, int k, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Token-major variants used inside the fused Grapher block (activations (B, N, C), C = G*c, fp32).
+ * Same arithmetic contracts as above; only the addressing differs.
+ *   gkg_knn_fwd_tm : x (B,N,C), y (B,M,C) or NULL; nn_idx/center (B*G, N, k)
+ *   gkg_mr_fwd_tm  : mode 0 -> out = m (B,N,C);
+ *                    mode 1 -> out = U (4, B*N, C/2): the grouped projection's input, U[q][t][2i] = x[t][q*C/4+i],
+ *                              U[q][t][2i+1] = m[t][q*C/4+i]  (reference interleave torch_vertex.py:57-61 followed by
+ *                              Conv2d(groups=4)'s channel split torch_nn.py:61); needs C % 16 == 0
+ *                    argmax (B,N,C) u8
+ *   gkg_mr_bwd_tm  : mode 0: gin = g (B,N,C); mode 1: gin = dU (4,B*N,C/2) (even columns = gradient reaching x
+ *                    directly, odd columns = gradient of m).  gx (B,N,C) and gsrc (B,M,C)|NULL fully overwritten.
+ */
+int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+                   int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, float* out, uint8_t* argmax,
+                  int B, int G, int c, int N, int M, int k, int mode, void* stream);
+int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
+                  int B, int G, int c, int N, int M, int k, int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bandwidth kernels between the dense 1x1 projections (Conv2d 1x1 + SyncBN [+ GELU], reference
+ * torch_vertex.py:290-306,334-360; torch_nn.py:57-69).  The projections themselves are plain GEMMs run by the
+ * caller in the vendor library on token-major (rows = tokens) fp32 matrices.  `nb` stacks nb independent
+ * (R, C) matrices (the 4 groups of the grouped projection) with parameters laid out [nb][C].
+ */
+int gkg_nchw_to_tm(const float* x, float* out, int B, int C, int N, void* stream);          /* (B,C,N) -> (B*N,C) */
+/* out(B,C,N) = a[ch]*y[t][ch] + c[ch] + res(B,C,N); a/c and res optional (NULL) */
+int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
+                          int B, int C, int N, void* stream);
+size_t gkg_bn_workspace_bytes(int R, int C, int nb);
+/* Train-mode batch statistics of y (R,C) (conv bias NOT included in y; it is folded: it cancels in the output and
+ * is added to running_mean).  Writes scale a, shift c (out = a*y + c), saved mean / invstd; updates running stats
+ * (momentum, unbiased variance) when given.  Deterministic two-stage reduction. */
+int gkg_bn_train_stats(const float* y, const float* gamma, const float* beta, const float* bias,
+                       float* running_mean, float* running_var, float* a, float* c, float* mean, float* invstd,
+                       int R, int C, int nb, float momentum, float eps, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* Eval mode: a = gamma/sqrt(rv+eps), c = beta + a*(bias - rm) */
+int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias, const float* running_mean,
+                       const float* running_var, float* a, float* c, int C, float eps, void* stream);
+/* out = act(a*y + c) (+ res); act 0 = identity, 1 = GELU(erf).  out[q] has row pitch ldo and batch stride out_bstride */
+int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, float* out, int R, int C,
+                   int nb, int ldo, size_t out_bstride, int act, void* stream);
+/* Backward of out = act(BN_train(y)): dy, dgamma, dbeta from dout (row pitch ldg, batch stride dout_bstride). */
+int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+               const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+               size_t dout_bstride, int act, void* workspace, size_t workspace_bytes, void* stream);
+
 /*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).
  * When enabled, every kernel launch made by this library is bracketed by hipEventRecord on the SAME

@@ -15,14 +15,32 @@ def _t(a):
     return torch.from_numpy(np.array(a)).cuda()
 
 
+@pytest.fixture(params=["fused", "composable"])
+def path(request):
+    """Run every module test on the fused token-major path and on the per-op composable path."""
+    from gkgnet_amd import fused
+    old = fused.ENABLED
+    fused.ENABLED = request.param == "fused"
+    yield request.param
+    fused.ENABLED = old
+
+
 @pytest.mark.parametrize("name", GRAPHER_CASES)
-def test_grapher_forward_backward(name):
+def test_grapher_forward_backward(name, path):
     meta, a = load_fixture(name)
     mod = make_grapher(meta)
     mod.load_state_dict(state_from(a))
     mod.cuda()
+    from gkgnet_amd import fused
     cap = {}
     h = mod.graph_conv.register_forward_hook(lambda m, i, o: cap.update(edge=o[1].detach()))
+    real_fused = fused.grapher_forward
+
+    def spy(*args, **kw):                     # the fused path bypasses graph_conv: capture its edge_index here
+        out = real_fused(*args, **kw)
+        cap.update(edge=out[1].detach())
+        return out
+    fused.grapher_forward = spy
     x = _t(a["x"])
     mod.eval()
     with torch.no_grad():
@@ -33,6 +51,7 @@ def test_grapher_forward_backward(name):
     out = mod(xg)
     edge = cap["edge"].cpu().numpy()
     h.remove()
+    fused.grapher_forward = real_fused
     assert edge.shape == a["edge_index"].shape
     swaps = check_indices(edge[0], a["edge_index"][0], a["topd"], a["topi"], meta["dilation"])
     assert np.array_equal(edge[1], a["edge_index"][1])
@@ -47,7 +66,7 @@ def test_grapher_forward_backward(name):
 
 
 @pytest.mark.parametrize("name", LABEL_CASES)
-def test_grapher_label_forward_backward(name):
+def test_grapher_label_forward_backward(name, path):
     meta, a = load_fixture(name)
     mod = make_label(meta)
     mod.load_state_dict(state_from(a))

@@ -27,8 +27,10 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(0)
     data = torch.randn(6, 4, 3, 3, generator=g)         # global batch, same on both ranks
     mine = data[list(shard_batch(6, rank, world))]
-    bucket.zero()
+    bucket.release()
     net(mine).square().sum().backward()
+    bucket.pack()
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
     bucket.all_reduce()
     out[rank] = (bucket.flat.clone(), [p.detach().clone() for p in net.parameters()])
     dist.destroy_process_group()
