@@ -135,13 +135,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ a, const float* __restrict__ cs,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ part, int R, int C, int rows_per_block,
-                                                           int ldg, size_t g_bstride) {
+                                                           int ldg, size_t g_bstride, float* __restrict__ dz_out) {
   extern __shared__ float red[];
   const StatsGeom gm = stats_geom(C);
   const int tid = threadIdx.x;
   const int cg = tid % gm.CGT, rl = tid / gm.CGT;
   const int q = blockIdx.y;
   y += (size_t)q * R * C; dout += (size_t)q * g_bstride;
+  if (dz_out) dz_out += (size_t)q * R * C;
   a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C;
   part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
   const int r0 = blockIdx.x * rows_per_block;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
         if (ACT == 1) {
           dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
           dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
+          *reinterpret_cast<float4*>(dz_out + (size_t)r * C + 4 * cgi) = dz;
         }
         s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
         sq.x += dz.x * ((v.x - m4.x) * i4.x); sq.y += dz.y * ((v.y - m4.y) * i4.y);
@@ -211,6 +213,55 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     sums[(size_t)q * C2 + col] = r;
     const int C = C2 >> 1;
     if (out0) { if (col < C) out0[(size_t)q * C + col] = r; else out1[(size_t)q * C + col - C] = r; }
+  }
+}
+
+// Forward statistics: fixed-order reduction of the partials (sum and sum-of-squares of 64 channels per
+// workgroup, 2 lanes each) fused with the BN parameter computation of bn_finalize_kernel below.
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int nblk,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float* __restrict__ a,
+                                                              float* __restrict__ cs, float* __restrict__ mean,
+                                                              float* __restrict__ invstd, int R, int C, float momentum, float eps) {
+  __shared__ double lane_sum[4][64];
+  const int t = threadIdx.x & 63;
+  const int ch = blockIdx.x * 64 + t;
+  const int ln = threadIdx.x >> 6;                 // lanes 0,1: sum (even / odd partials); lanes 2,3: sum of squares
+  const int q = blockIdx.y;
+  const int C2 = 2 * C;
+  double acc = 0.0;
+  if (ch < C) {
+    const float* p = part + (size_t)q * nblk * C2 + (ln >> 1) * C + ch;
+    int b = ln & 1;
+    for (; b + 14 < nblk; b += 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + 2 * u) * C2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < nblk; b += 2) acc += (double)p[(size_t)b * C2];
+  }
+  lane_sum[ln][t] = acc;
+  __syncthreads();
+  if (ln != 0 || ch >= C) return;
+  const double S = lane_sum[0][t] + lane_sum[1][t], Q = lane_sum[2][t] + lane_sum[3][t];
+  const size_t o = (size_t)q * C + ch;
+  const double m = S / R;
+  double var = Q / R - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[o] * is;
+  a[o] = av;
+  cs[o] = beta[o] - av * (float)m;
+  mean[o] = (float)m;
+  invstd[o] = is;
+  if (running_mean) {
+    const float bv = bias ? bias[o] : 0.f;
+    running_mean[o] = (1.f - momentum) * running_mean[o] + momentum * ((float)m + bv);
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    running_var[o] = (1.f - momentum) * running_var[o] + momentum * (float)unb;
   }
 }
 
@@ -291,10 +342,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 
 // dy[r][c] = a[c] * (dz - sdz[c]/R - yhat*sdzy[c]/R), dz = dout*act'(a*y+c).  dout may be strided (ldg).
 template <int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ y,
                                                            const float* __restrict__ a, const float* __restrict__ cs,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ sums, float* __restrict__ dy,
+                                                           const float* __restrict__ sums, float* dy,
                                                            size_t total4, int C, int R, int ldg, size_t g_bstride) {
   const int C4 = C >> 2;
   const float invR = 1.0f / (float)R;
@@ -332,7 +383,7 @@ using namespace gkg;
 
 static int stats_blocks(int R, int nb, int* rows_per_block) {
   int nblk = (R + 31) / 32;                  // >= 32 rows per block
-  const int cap = nb > 1 ? 64 : 256;
+  const int cap = nb > 1 ? 128 : 256;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   *rows_per_block = (R + nblk - 1) / nblk;
@@ -387,9 +438,8 @@ extern "C" int gkg_bn_train_stats(const float* y, const float* gamma, const floa
   float* part = (float*)workspace;
   float* sums = part + (size_t)nb * nblk * 2 * C;
   hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, nb), dim3(256), stats_lds(C), st, y, part, R, C, rpb);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256, nb), dim3(256), 0, st, sums, gamma, beta, bias, running_mean,
-                     running_var, a, c, mean, invstd, R, C, momentum, eps);
+  hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, st, part, nblk, gamma, beta, bias,
+                     running_mean, running_var, a, c, mean, invstd, R, C, momentum, eps);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_train_stats");
 }
@@ -431,13 +481,15 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
   float* part = (float*)workspace;
   float* sums = part + (size_t)nb * nblk * 2 * C;
   const size_t lds = stats_lds(C);
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride);
-  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride);
+  // With an activation the statistics pass also stores dz = dout*act'(z) into `dy`; the apply pass then runs in
+  // place on it, so erf/exp are evaluated once per element in the whole backward.
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dy);
+  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
   // dbeta[q] = sum dz ; dgamma[q] = sum dz*yhat
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dy, y, a, c, mean, invstd, sums, dy, total4, C, R, C, (size_t)R * C);
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd");

@@ -35,7 +35,7 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials."""
     R = x.shape[0]
     for S in (8, 6, 4, 3, 2):
-        if R % S == 0 and R // S >= 512:
+        if R % S == 0 and R // S >= 1024:
             part = torch.bmm(dY.view(S, R // S, -1).transpose(1, 2), x.view(S, R // S, -1))
             return part.sum(0)
     return torch.mm(dY.t(), x)
