@@ -203,12 +203,22 @@ def main():
         # algorithmic work of the k-NN tile kernel per step: Grapher graph + label graph
         flops_knn = 2.0 * BG * (C // w["G"]) * (N * M + L * N)
         tile_ms, tile_n = prof["knn_tile"]
+        # HBM-side traffic of the same kernel comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
+        # from inside the process); the committed measurement for this workload is profiles/r01_knn_tile_pmc.json.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_knn_tile_pmc.json")
+        if args.workload == "cfg2" and B == 32 and os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as fh:
+                    traffic = json.load(fh)["knn_tile_per_step_traffic_bytes"] / 2      # per launch, like `achieved`
+            except Exception:
+                traffic = None
         roof = None
         if tile_n:
             per_step_ms = tile_ms / prof_steps
             ach = flops_knn / (per_step_ms * 1e-3) / 1e12
             roof = dict(kernel="knn_tile_kernel", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         avg_launch_us=round(1e3 * tile_ms / tile_n, 2), launches_per_step=tile_n // prof_steps,
                         algorithmic_flops_per_step=flops_knn)
         kernels = {k: dict(us_per_step=round(1e3 * v[0] / prof_steps, 2), launches_per_step=v[1] // prof_steps)

@@ -142,6 +142,7 @@ struct KnnArgs {
   int* part_i;
   int BG, cpad, N, M, k, dilation, kd;
   int splits, tiles_per_split;
+  int nqt;              // query tiles per problem
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
@@ -158,9 +159,17 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bg = blockIdx.y;
+  // XCD-aware workgroup -> (problem, query tile) map.  Workgroups are dealt round-robin over the 8 XCDs, each with
+  // its own L2; all query tiles of one (b,g) problem stream the SAME keys, so they are given linear ids that are
+  // congruent mod 8 (same XCD) and adjacent in dispatch order: the keys are then fetched into one L2 once instead
+  // of once per query tile (measured: FETCH_SIZE 53 -> see profiles/).  Placement only affects speed.
+  const int nqt = a.nqt;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, jj = lin >> 3;
+  const int bg = (jj / nqt) * 8 + xcd;
+  if (bg >= a.BG) return;                       // grid is padded to a multiple of 8 problems (uniform exit)
   const int split = blockIdx.z;
-  const int n0 = blockIdx.x * QT;
+  const int n0 = (jj % nqt) * QT;
   const int N = a.N, M = a.M, cpad = a.cpad;
 
   // ---- stage the query tile scaled by -2 (exact): xs[ch][64] = -2 * xh (zero for n >= N).
@@ -210,6 +219,8 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
   const int kk = lane >> 5;       // which k of the k-pair this lane feeds
   const int l31 = lane & 31;
 
+  const bool two_blocks = n0 + 32 < N;   // wave-uniform
+
   TopList<KD> top;
   top.init();
 
@@ -248,18 +259,31 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
       float an[KU], ac[KU];
 #pragma unroll
       for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * u) * M];
-      for (int s = 0; s < CP; s += KU) {
+      if (two_blocks) {
+        for (int s = 0; s < CP; s += KU) {
 #pragma unroll
-        for (int u = 0; u < KU; ++u) ac[u] = an[u];
+          for (int u = 0; u < KU; ++u) ac[u] = an[u];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * min(s + KU + u, CP - 1)) * M];
-        __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
+          for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * min(s + KU + u, CP - 1)) * M];
+          __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-          const float b0 = xsp[(2 * (s + u)) * QT];
-          const float b1 = xsp[(2 * (s + u)) * QT + 32];
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, acc1, 0, 0, 0);
+          for (int u = 0; u < KU; ++u) {
+            const float b0 = xsp[(2 * (s + u)) * QT];
+            const float b1 = xsp[(2 * (s + u)) * QT + 32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, acc1, 0, 0, 0);
+          }
+        }
+      } else {                                    // tail query tile with <= 32 queries: one query block only
+        for (int s = 0; s < CP; s += KU) {
+#pragma unroll
+          for (int u = 0; u < KU; ++u) ac[u] = an[u];
+#pragma unroll
+          for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * min(s + KU + u, CP - 1)) * M];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < KU; ++u)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], xsp[(2 * (s + u)) * QT], acc0, 0, 0, 0);
         }
       }
     }
@@ -419,7 +443,7 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   p->KD = pick_list(p->kd);
   if (p->KD < 0) return GKG_ERR_UNSUPPORTED;
   if ((size_t)p->cpad * QT * sizeof(float) > 150 * 1024) return GKG_ERR_UNSUPPORTED;   // c <= 600
-  if (BG > 65535) return GKG_ERR_UNSUPPORTED;
+  if (BG > (1 << 20)) return GKG_ERR_UNSUPPORTED;
   p->S = pick_splits(BG, N, M);
   const int ktiles = (M + KT - 1) / KT;
   p->tps = (ktiles + p->S - 1) / p->S;
@@ -523,7 +547,8 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.part_v = (float*)(ws + p.off_pv); a.part_i = (int*)(ws + p.off_pi);
   a.BG = BG; a.cpad = p.cpad; a.N = N; a.M = M; a.k = k; a.dilation = dilation; a.kd = p.kd;
   a.splits = p.S; a.tiles_per_split = p.tps;
-  dim3 grid((N + QT - 1) / QT, BG, p.S);
+  a.nqt = (N + QT - 1) / QT;
+  dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
   size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
   size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
   size_t lds = lds_q > lds_m ? lds_q : lds_m;
