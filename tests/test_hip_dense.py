@@ -1,0 +1,112 @@
+"""GPU unit tests of the token-major bandwidth kernels (csrc/gkg_dense.hip) and the fused autograd Functions
+against plain PyTorch fp32 references of the same ops (floating-point tolerance 1e-4 / 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(C):
+    torch.manual_seed(C)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    return bn
+
+
+@pytest.mark.parametrize("R,cin,cout,act,with_res", [(1000, 64, 32, 0, False), (777, 32, 64, 1, True),
+                                                     (2560, 320, 1280, 1, False), (2560, 1280, 320, 0, True)])
+def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res):
+    from gkgnet_amd import fused
+    torch.manual_seed(0)
+    x = torch.randn(R, cin, device="cuda", requires_grad=True)
+    conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+    bn = _bn(cout)
+    res = torch.randn(R, cout, device="cuda", requires_grad=True) if with_res else None
+    ref_bn = _bn(cout)
+    ref_bn.load_state_dict(bn.state_dict())
+    out = fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, bn, act, None)
+    g = torch.randn_like(out)
+    out.backward(g)
+    got = [out.detach(), x.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad, bn.bias.grad]
+    if with_res:
+        got.append(res.grad)
+    # reference: the reference's op chain Conv2d(1x1) -> BN(train) -> GELU on the (R,cin) rows viewed as (1,cin,R,1)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = conv.weight.detach().clone().requires_grad_(True)
+    b2 = conv.bias.detach().clone().requires_grad_(True)
+    res2 = res.detach().clone().requires_grad_(True) if with_res else None
+    y = F.conv2d(x2.t().reshape(1, cin, R, 1), w2, b2)
+    y = F.batch_norm(y, ref_bn.running_mean, ref_bn.running_var, ref_bn.weight, ref_bn.bias, True, 0.1, 1e-5)
+    if act:
+        y = F.gelu(y)
+    y = y.reshape(cout, R).t()
+    if with_res:
+        y = y + res2
+    y.backward(g)
+    want = [y.detach(), x2.grad, w2.grad, b2.grad, ref_bn.weight.grad, ref_bn.bias.grad]
+    if with_res:
+        want.append(res2.grad)
+    names = ["out", "dx", "dW", "dbias", "dgamma", "dbeta", "dres"]
+    for n, a, b in zip(names, got, want):
+        tol = 2e-3 if n in ("dW", "dgamma", "dbeta", "dbias") else 2e-4
+        assert torch.allclose(a, b, atol=tol, rtol=1e-3), (n, float((a - b).abs().max()))
+    # running statistics follow nn.BatchNorm semantics (momentum 0.1, unbiased variance, conv bias included)
+    assert torch.allclose(bn.running_mean, ref_bn.running_mean, atol=1e-5)
+    assert torch.allclose(bn.running_var, ref_bn.running_var, atol=1e-4, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_grouped_linear_matches_grouped_conv():
+    """_GroupedLinearBNAct on the interleaved group-major input == Conv2d(groups=4)+BN+GELU on (B,2C,N,1)."""
+    from gkgnet_amd import fused
+    torch.manual_seed(1)
+    R, C = 900, 64                       # 2C = 128 channels, 4 groups of 32
+    U = torch.randn(4, R, C // 2, device="cuda", requires_grad=True)
+    conv = torch.nn.Conv2d(2 * C, 2 * C, 1, groups=4).cuda()
+    bn, ref_bn = _bn(2 * C), _bn(2 * C)
+    ref_bn.load_state_dict(bn.state_dict())
+    out = fused._GroupedLinearBNAct.apply(U, conv.weight, conv.bias, bn.weight, bn.bias, bn, 1)
+    g = torch.randn_like(out)
+    out.backward(g)
+    U2 = U.detach().clone().requires_grad_(True)
+    w2 = conv.weight.detach().clone().requires_grad_(True)
+    xin = U2.permute(0, 2, 1).reshape(1, 2 * C, R, 1)           # channel q*(C/2)+i  <- U[q][:, i]
+    y = F.gelu(F.batch_norm(F.conv2d(xin, w2, conv.bias.detach(), groups=4), ref_bn.running_mean, ref_bn.running_var,
+                            ref_bn.weight, ref_bn.bias, True, 0.1, 1e-5))
+    y = y.reshape(2 * C, R).t()
+    y.backward(g)
+    assert torch.allclose(out, y, atol=2e-4, rtol=1e-3)
+    assert torch.allclose(U.grad, U2.grad, atol=2e-4, rtol=1e-3)
+    assert torch.allclose(conv.weight.grad, w2.grad, atol=2e-3, rtol=1e-3)
+    assert torch.allclose(bn.weight.grad, ref_bn.weight.grad, atol=2e-3, rtol=1e-3)
+    assert torch.allclose(bn.bias.grad, ref_bn.bias.grad, atol=2e-3, rtol=1e-3)
+
+
+def test_layout_round_trip_and_token_major_graph_ops():
+    """to_token_major / its backward are exact transposes; the token-major k-NN and aggregation return exactly
+    what the channel-major operators (already pinned to the oracle) return."""
+    from gkgnet_amd import fused, ops
+    torch.manual_seed(2)
+    B, C, H, G, k = 3, 32, 10, 2, 5
+    N = H * H
+    x = torch.randn(B, C, H, H, device="cuda", requires_grad=True)
+    xt = fused.to_token_major(x)
+    assert torch.equal(xt, x.detach().permute(0, 2, 3, 1).reshape(B * N, C))
+    xt.backward(xt.detach())
+    assert torch.equal(x.grad, x.detach())
+    rp = -torch.rand(1, N, N, device="cuda")
+    xtm = xt.detach().view(B, N, C)
+    edge_tm = fused.knn_graph_tm(xtm, None, rp, k, 2, G)
+    edge_cm = ops.knn_graph(x.detach().reshape(B * G, C // G, N), None, rp, k, 2)
+    assert torch.equal(edge_tm, edge_cm)
+    m_cm = ops.max_relative(x.detach().reshape(B * G, C // G, N), edge_cm[0])            # (BG, c, N)
+    m_tm = fused._MaxRelativeTM.apply(xtm, None, edge_tm[0], G, 0)                       # (B, N, C)
+    assert torch.equal(m_tm.permute(0, 2, 1).reshape(B * G, C // G, N), m_cm)
+    U = fused._MaxRelativeTM.apply(xtm, None, edge_tm[0], G, 1)                          # (4, T, C/2) interleaved
+    Cq = C // 4
+    for q in range(4):
+        assert torch.equal(U[q][:, 0::2], xtm.reshape(B * N, C)[:, q * Cq:(q + 1) * Cq])
+        assert torch.equal(U[q][:, 1::2], m_tm.reshape(B * N, C)[:, q * Cq:(q + 1) * Cq])

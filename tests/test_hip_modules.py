@@ -38,7 +38,7 @@ def test_grapher_forward_backward(name, path):
 
     def spy(*args, **kw):                     # the fused path bypasses graph_conv: capture its edge_index here
         out = real_fused(*args, **kw)
-        cap.update(edge=out[1].detach())
+        cap.update(edge=out[1].detach(), fused_calls=cap.get("fused_calls", 0) + 1)
         return out
     fused.grapher_forward = spy
     x = _t(a["x"])
@@ -52,6 +52,8 @@ def test_grapher_forward_backward(name, path):
     edge = cap["edge"].cpu().numpy()
     h.remove()
     fused.grapher_forward = real_fused
+    if path == "fused" and meta["conv"] == "mr":
+        assert cap.get("fused_calls", 0) >= 2, "the fused token-major path was expected to run"
     assert edge.shape == a["edge_index"].shape
     swaps = check_indices(edge[0], a["edge_index"][0], a["topd"], a["topi"], meta["dilation"])
     assert np.array_equal(edge[1], a["edge_index"][1])
