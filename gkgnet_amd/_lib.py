@@ -64,7 +64,7 @@ def load():
     lib.gkg_bn_workspace_bytes.restype = Z
     lib.gkg_bn_workspace_bytes.argtypes = [I, I, I]
     lib.gkg_bn_train_stats.restype = I
-    lib.gkg_bn_train_stats.argtypes = [V] * 10 + [I, I, I, F, F, V, Z, V]
+    lib.gkg_bn_train_stats.argtypes = [V] * 10 + [I, I, I, F, F, V, V, Z, V]
     lib.gkg_bn_eval_affine.restype = I
     lib.gkg_bn_eval_affine.argtypes = [V] * 7 + [I, F, V]
     lib.gkg_affine_act.restype = I

@@ -223,8 +223,10 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
                                                               const float* __restrict__ bias, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, float* __restrict__ a,
                                                               float* __restrict__ cs, float* __restrict__ mean,
-                                                              float* __restrict__ invstd, int R, int C, float momentum, float eps) {
+                                                              float* __restrict__ invstd, int R, int C, float momentum, float eps,
+                                                              long long* __restrict__ num_batches_tracked) {
   __shared__ double lane_sum[4][64];
+  if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   const int t = threadIdx.x & 63;
   const int ch = blockIdx.x * 64 + t;
   const int ln = threadIdx.x >> 6;                 // lanes 0,1: sum (even / odd partials); lanes 2,3: sum of squares
@@ -424,8 +426,8 @@ extern "C" int gkg_tm_affine_to_nchw(const float* y, const float* a, const float
 
 extern "C" int gkg_bn_train_stats(const float* y, const float* gamma, const float* beta, const float* bias,
                                   float* running_mean, float* running_var, float* a, float* c, float* mean,
-                                  float* invstd, int R, int C, int nb, float momentum, float eps, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  float* invstd, int R, int C, int nb, float momentum, float eps,
+                                  long long* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream) {
   if (!y || !gamma || !beta || !a || !c || !mean || !invstd || !workspace)
     return gkg_fail(GKG_ERR_NULL, "gkg_bn_train_stats: null pointer");
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_train_stats: need R > 0, C % 4 == 0, C <= 4096, 1 <= nb <= 64");
@@ -439,7 +441,7 @@ extern "C" int gkg_bn_train_stats(const float* y, const float* gamma, const floa
   float* sums = part + (size_t)nb * nblk * 2 * C;
   hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, nb), dim3(256), stats_lds(C), st, y, part, R, C, rpb);
   hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, st, part, nblk, gamma, beta, bias,
-                     running_mean, running_var, a, c, mean, invstd, R, C, momentum, eps);
+                     running_mean, running_var, a, c, mean, invstd, R, C, momentum, eps, num_batches_tracked);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_train_stats");
 }

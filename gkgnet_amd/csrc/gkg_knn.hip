@@ -154,7 +154,7 @@ struct KnnArgs {
 // see only a quarter of the keys, so some lane of 64 passes for almost every candidate and the divergent
 // loop serialises on LDS latency.
 template <int KD, bool HAS_RP, int KU>
-__global__ __launch_bounds__(256) void knn_tile_kernel(KnnArgs a) {
+__global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_tile_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;

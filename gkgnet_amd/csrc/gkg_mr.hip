@@ -167,10 +167,12 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ g, co
 //   mode 0: m (B,N,C) token-major.
 //   mode 1: the grouped 1x1 projection's input directly, U[q][t][2i] = x[t][q*C/4+i], U[q][t][2i+1] = m[...]
 //           (reference interleave torch_vertex.py:57-61 + Conv2d(groups=4) channel split torch_nn.py:61).
+template <int KS>      // KS > 0: k known at compile time (all k index loads and row gathers issued up front)
 __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
                                                         const int64_t* __restrict__ nn_idx, float* __restrict__ out,
                                                         uint8_t* __restrict__ argmax, int B, int G, int c, int N, int M,
-                                                        int k, int mode) {
+                                                        int k_rt, int mode) {
+  const int k = KS > 0 ? KS : k_rt;
   const int C = G * c, C4 = C >> 2;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // (t, cq)
   const size_t T = (size_t)B * N;
@@ -185,17 +187,35 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
   const float* sb = src + (size_t)b * M * C + ch;
   float4 best;
   int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  {
-    const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[0] * C);
-    best = make_float4(v.x - xi.x, v.y - xi.y, v.z - xi.z, v.w - xi.w);
-  }
-  for (int j = 1; j < k; ++j) {
-    const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[j] * C);
-    const float d0 = v.x - xi.x, d1 = v.y - xi.y, d2 = v.z - xi.z, d3 = v.w - xi.w;
-    if (d0 > best.x) { best.x = d0; a0 = j; }
-    if (d1 > best.y) { best.y = d1; a1 = j; }
-    if (d2 > best.z) { best.z = d2; a2 = j; }
-    if (d3 > best.w) { best.w = d3; a3 = j; }
+  if (KS > 0) {
+    int id[KS > 0 ? KS : 1];
+    float4 v[KS > 0 ? KS : 1];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) id[j] = (int)ip[j];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C);
+    best = make_float4(v[0].x - xi.x, v[0].y - xi.y, v[0].z - xi.z, v[0].w - xi.w);
+#pragma unroll
+    for (int j = 1; j < KS; ++j) {
+      const float d0 = v[j].x - xi.x, d1 = v[j].y - xi.y, d2 = v[j].z - xi.z, d3 = v[j].w - xi.w;
+      if (d0 > best.x) { best.x = d0; a0 = j; }
+      if (d1 > best.y) { best.y = d1; a1 = j; }
+      if (d2 > best.z) { best.z = d2; a2 = j; }
+      if (d3 > best.w) { best.w = d3; a3 = j; }
+    }
+  } else {
+    {
+      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[0] * C);
+      best = make_float4(v.x - xi.x, v.y - xi.y, v.z - xi.z, v.w - xi.w);
+    }
+    for (int j = 1; j < k; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[j] * C);
+      const float d0 = v.x - xi.x, d1 = v.y - xi.y, d2 = v.z - xi.z, d3 = v.w - xi.w;
+      if (d0 > best.x) { best.x = d0; a0 = j; }
+      if (d1 > best.y) { best.y = d1; a1 = j; }
+      if (d2 > best.z) { best.z = d2; a2 = j; }
+      if (d3 > best.w) { best.w = d3; a3 = j; }
+    }
   }
   if (argmax) *reinterpret_cast<uint32_t*>(argmax + t * C + ch) = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
   if (mode == 0) {
@@ -403,8 +423,9 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
   GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
   const size_t total = (size_t)B * N * (G * c / 4);
-  hipLaunchKernelGGL(mr_fwd_tm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, src, nn_idx,
-                     out, argmax, B, G, c, N, M, k, mode);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9>), grid, dim3(256), 0, (hipStream_t)stream, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
+  else hipLaunchKernelGGL((mr_fwd_tm_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
 }

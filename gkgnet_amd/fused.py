@@ -89,10 +89,10 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
                                           _ptr(bn.running_mean) if track else None,
                                           _ptr(bn.running_var) if track else None,
                                           _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), R, C, nb,
-                                          float(bn.momentum), float(bn.eps), _ptr(ws), ws.numel(), _stream()),
+                                          float(bn.momentum), float(bn.eps),
+                                          _ptr(bn.num_batches_tracked) if track else None,
+                                          _ptr(ws), ws.numel(), _stream()),
                    "gkg_bn_train_stats")
-        if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
         return a, c, mean, invstd
     _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
                                       _ptr(bn.running_var), _ptr(a), _ptr(c), nb * C, float(bn.eps), _stream()),
@@ -151,8 +151,8 @@ class _LinearBNAct(torch.autograd.Function):
         _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
                                   _ptr(dgamma), _ptr(dbeta), R, cout, 1, cout, 0, act, _ptr(ws), ws.numel(),
                                   _stream()), "gkg_bn_bwd")
-        # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean)
-        dbias = torch.zeros(cout, dtype=_F32, device=Y.device) if has_bias else None
+        # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean): not materialised
+        dbias = None
         W = weight.view(cout, cin)
         dx = torch.mm(dY, W)
         dW = _wgrad(dY, x).view_as(weight)
@@ -200,8 +200,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         Wg = weight.view(nb, co, ci)
         dU = torch.bmm(dY, Wg)
         dW = torch.bmm(dY.transpose(1, 2), U).view_as(weight)
-        dbias = torch.zeros(cout, dtype=_F32, device=Y.device) if has_bias else None
-        return dU, dW, dbias, dgamma, dbeta, None, None
+        return dU, dW, None, dgamma, dbeta, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 
 # ----------------------------------------------------------------------------------------------- graph ops

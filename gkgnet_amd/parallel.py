@@ -41,6 +41,7 @@ class GradBucket:
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self._zeros = None
         o = 0
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
@@ -58,7 +59,9 @@ class GradBucket:
     def pack(self):
         """Gather the freshly produced ``p.grad`` tensors into the flat bucket with one batched copy and
         re-point ``p.grad`` at the bucket views."""
-        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        if self._zeros is None:          # parameters whose gradient is identically zero come back as None
+            self._zeros = torch.zeros(max(p.numel() for p in self.params), device=self.flat.device, dtype=self.flat.dtype)
+        grads = [(p.grad.reshape(-1) if p.grad is not None else self._zeros[:p.numel()]) for p in self.params]
         torch.cat(grads, out=self.flat)
         o = 0
         for p in self.params:

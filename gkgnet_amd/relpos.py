@@ -6,6 +6,7 @@ with bicubic interpolation to (n, n / r^2) when keys are pooled (r > 1).  Pinned
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -32,11 +33,31 @@ def relative_pos_matrix(embed_dim: int, grid: int) -> np.ndarray:
     return 2.0 * (pe @ pe.T) / pe.shape[1]
 
 
+_cache = {}
+
+
 def build_relative_pos(in_channels: int, n: int, r: int) -> torch.Tensor:
-    """(1, n, n // r^2) fp32, already negated (it is *added* to squared distances)."""
-    base = torch.from_numpy(relative_pos_matrix(in_channels, int(n ** 0.5)).astype(np.float32))[None, None]
-    base = F.interpolate(base, size=(n, n // (r * r)), mode="bicubic", align_corners=False)
-    return -base.squeeze(1)
+    """(1, n, n // r^2) fp32, already negated (it is *added* to squared distances).
+
+    Default: numpy float64 + CPU bicubic, bit-identical to what the reference stores in its checkpoints
+    (pinned by tests/golden/f9_relpos).  At 576x576 inputs the first stage needs a 20736 x 20736 float64
+    intermediate (3.4 GB, ~40 s on the host), so results are cached per (C, n, r) and ``GKG_RELPOS_DEVICE=cuda``
+    evaluates the same formula on the GPU (float64 GEMM + bicubic resize; equal to ~1e-7, not bitwise) for
+    random-init benchmarking.  Real checkpoints carry ``relative_pos`` themselves."""
+    key = (in_channels, n, r, os.environ.get("GKG_RELPOS_DEVICE", "cpu"))
+    if key not in _cache:
+        grid = int(n ** 0.5)
+        if key[3] != "cpu" and torch.cuda.is_available():
+            pe = torch.from_numpy(grid_embedding(in_channels, grid)).to(key[3])
+            base = (2.0 * (pe @ pe.T) / pe.shape[1]).to(torch.float32)[None, None]
+            del pe
+            out = F.interpolate(base, size=(n, n // (r * r)), mode="bicubic", align_corners=False)
+            _cache[key] = (-out.squeeze(1)).cpu()
+        else:
+            base = torch.from_numpy(relative_pos_matrix(in_channels, grid).astype(np.float32))[None, None]
+            base = F.interpolate(base, size=(n, n // (r * r)), mode="bicubic", align_corners=False)
+            _cache[key] = -base.squeeze(1)
+    return _cache[key].clone()
 
 
 def resize_relative_pos(relative_pos: Optional[torch.Tensor], n_built: int, r: int, H: int, W: int):

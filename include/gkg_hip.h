@@ -135,8 +135,8 @@ size_t gkg_bn_workspace_bytes(int R, int C, int nb);
  * (momentum, unbiased variance) when given.  Deterministic two-stage reduction. */
 int gkg_bn_train_stats(const float* y, const float* gamma, const float* beta, const float* bias,
                        float* running_mean, float* running_var, float* a, float* c, float* mean, float* invstd,
-                       int R, int C, int nb, float momentum, float eps, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       int R, int C, int nb, float momentum, float eps, long long* num_batches_tracked /* += 1, or NULL */,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* Eval mode: a = gamma/sqrt(rv+eps), c = beta + a*(bias - rm) */
 int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias, const float* running_mean,
                        const float* running_var, float* a, float* c, int C, float eps, void* stream);

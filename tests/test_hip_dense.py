@@ -30,7 +30,8 @@ def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res):
     out = fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, bn, act, None)
     g = torch.randn_like(out)
     out.backward(g)
-    got = [out.detach(), x.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad, bn.bias.grad]
+    assert conv.bias.grad is None            # identically zero, not materialised
+    got = [out.detach(), x.grad, conv.weight.grad, torch.zeros_like(conv.bias), bn.weight.grad, bn.bias.grad]
     if with_res:
         got.append(res.grad)
     # reference: the reference's op chain Conv2d(1x1) -> BN(train) -> GELU on the (R,cin) rows viewed as (1,cin,R,1)

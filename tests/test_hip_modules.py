@@ -62,9 +62,17 @@ def test_grapher_forward_backward(name, path):
     assert (out - _t(a["out"])).abs().max().item() < 2e-4        # in practice far inside the 1e-3 bar
     (out * _t(a["cot"])).sum().backward()
     assert torch.allclose(xg.grad, _t(a["dx"]), **TOL)
+    _check_param_grads(mod, a)
+
+
+def _check_param_grads(mod, a):
     named = dict(mod.named_parameters())
     for k, g in grads_from(a).items():
-        assert torch.allclose(named[k].grad, g.cuda(), atol=2e-3, rtol=2e-3), k
+        got = named[k].grad
+        if got is None:      # fused path: the bias of a conv feeding train-mode BN has an identically zero gradient
+            assert k.endswith(".0.bias") and float(g.abs().max()) < 2e-3, k
+            continue
+        assert torch.allclose(got, g.cuda(), atol=2e-3, rtol=2e-3), k
 
 
 @pytest.mark.parametrize("name", LABEL_CASES)
@@ -90,9 +98,7 @@ def test_grapher_label_forward_backward(name, path):
     (out * _t(a["cot"])).sum().backward()
     assert torch.allclose(eg.grad, _t(a["de"]), **TOL)
     assert torch.allclose(fg.grad, _t(a["dfeat"]), **TOL)
-    named = dict(mod.named_parameters())
-    for k, g in grads_from(a).items():
-        assert torch.allclose(named[k].grad, g.cuda(), atol=2e-3, rtol=2e-3), k
+    _check_param_grads(mod, a)
 
 
 def test_full_size_properties_cfg2():
