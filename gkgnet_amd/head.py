@@ -1,0 +1,98 @@
+"""Label-query classification head and its losses — what sits right after the backbone in
+``configs/gkgnet/gkgnet_coco_576.py:27-38``.  Dense Linear + element-wise math; plain PyTorch (runs on any device).
+
+    LabelQueryHead      reference mmcls/models/heads/label_query_head.py:10-85
+    asymmetric_loss     reference mmcls/models/losses/asymmetric_loss.py:9-71
+    smoothed multi-label BCE = LabelSmoothLoss(0.1, mode='multi_label')   reference losses/label_smooth_loss.py:97-99,122-175
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def asymmetric_loss(pred, target, gamma_pos=0.0, gamma_neg=4.0, clip=0.05, eps=1e-8, avg_factor=None):
+    """ASL (https://arxiv.org/abs/2009.14119) on logits: probability-shifted negatives, focal-style weights."""
+    p = pred.sigmoid()
+    target = target.type_as(pred)
+    neg = (1 - p + clip).clamp(max=1) if clip and clip > 0 else (1 - p)
+    pt = neg * (1 - target) + p * target
+    weight = (1 - pt).pow(gamma_pos * target + gamma_neg * (1 - target))
+    loss = -torch.log(pt.clamp(min=eps)) * weight
+    return loss.sum() / avg_factor if avg_factor is not None else loss.mean()
+
+
+class AsymmetricLoss(nn.Module):
+    def __init__(self, gamma_pos=0.0, gamma_neg=4.0, clip=0.05, reduction="mean", loss_weight=1.0, use_sigmoid=True,
+                 eps=1e-8, scale=1.0):
+        super().__init__()
+        assert use_sigmoid and reduction == "mean", "only the configuration GKGNet uses is implemented"
+        self.gamma_pos, self.gamma_neg, self.clip, self.eps = gamma_pos, gamma_neg, clip, eps
+        self.loss_weight, self.scale = loss_weight, scale
+
+    def forward(self, pred, target, avg_factor=None, **kwargs):
+        return self.loss_weight * self.scale * asymmetric_loss(pred, target, self.gamma_pos, self.gamma_neg, self.clip,
+                                                               self.eps, avg_factor)
+
+
+def smoothed_multilabel_bce(cls_score, label, label_smooth_val=0.1, avg_factor=None):
+    """BCE-with-logits against labels smoothed to {eps, 1-eps}."""
+    smooth = torch.full_like(cls_score, label_smooth_val)
+    smooth = smooth.masked_fill(label > 0, 1 - label_smooth_val)
+    loss = F.binary_cross_entropy_with_logits(cls_score, smooth, reduction="none")
+    return loss.sum() / avg_factor if avg_factor is not None else loss.mean()
+
+
+class LabelQueryHead(nn.Module):
+    """score[b,l] = <fc1.weight[l], E[b,l]> + fc1.bias[l]  +  fc2(gap)[b,l]
+    (the reference evaluates fc1 on all (label token, class) pairs and keeps the diagonal; only the diagonal is
+    computed here).  ``forward_train`` returns the reference's double loss: smoothed BCE + 10 x ASL."""
+
+    def __init__(self, num_classes, in_channels, softmax=False, double_loss=True,
+                 loss=dict(type="AsymmetricLoss", gamma_pos=0.0, gamma_neg=2.0, clip=0.05), topk=(1,), init_cfg=None):
+        super().__init__()
+        if num_classes <= 0:
+            raise ValueError(f"num_classes={num_classes} must be a positive integer")
+        assert not softmax, "GKGNet uses the sigmoid head"
+        self.num_classes, self.in_channels, self.double_loss = num_classes, in_channels, double_loss
+        cfg = dict(loss)
+        assert cfg.pop("type") == "AsymmetricLoss"
+        self.compute_loss = AsymmetricLoss(**cfg)
+        self.fc1 = nn.Linear(in_channels, num_classes)
+        self.fc2 = nn.Linear(in_channels, num_classes)
+        for m in (self.fc1, self.fc2):            # init_cfg Normal(std=0.01) on Linear layers
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.zeros_(m.bias)
+
+    def get_score(self, x):
+        e, gap = x[0], x[1]
+        diag = (e * self.fc1.weight.unsqueeze(0)).sum(-1) + self.fc1.bias
+        return diag + self.fc2(gap)
+
+    def simple_test(self, x, post_process=False):
+        pred = torch.sigmoid(self.get_score(x))
+        return list(pred.detach().cpu().numpy()) if post_process else pred
+
+    def forward_train(self, x, gt_label, **kwargs):
+        score = self.get_score(x)
+        n = len(score)
+        asy = self.compute_loss(score, gt_label, avg_factor=n)
+        if not self.double_loss:
+            return {"loss": asy}
+        return {"bce_loss": smoothed_multilabel_bce(score, gt_label, 0.1, avg_factor=n), "asy_loss": asy * 10.0}
+
+
+def build_optimizer(modules, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8):
+    """AdamW with the reference's paramwise config: no weight decay on norm layers and biases
+    (configs/gkgnet/gkgnet_coco_576.py:110-126)."""
+    decay, no_decay = [], []
+    for mod in modules:
+        for m in mod.modules():
+            is_norm = isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.LayerNorm, nn.GroupNorm))
+            for name, p in m.named_parameters(recurse=False):
+                if not p.requires_grad:
+                    continue
+                (no_decay if (is_norm or name == "bias") else decay).append(p)
+    return torch.optim.AdamW([dict(params=decay, weight_decay=weight_decay), dict(params=no_decay, weight_decay=0.0)],
+                             lr=lr, betas=betas, eps=eps)

@@ -1,0 +1,50 @@
+"""Head + losses against the reference's own output (fixture F12).  Plain torch math: runs on CPU."""
+import numpy as np
+import torch
+
+from util import grads_from, load_fixture, state_from
+
+
+def _t(a):
+    return torch.from_numpy(np.array(a))
+
+
+def test_label_query_head_scores_losses_and_grads():
+    from gkgnet_amd.head import LabelQueryHead
+    meta, a = load_fixture("f12_head_loss")
+    head = LabelQueryHead(meta["num_classes"], meta["in_channels"], softmax=False,
+                          loss=dict(type="AsymmetricLoss", gamma_pos=0.0, gamma_neg=2.0, clip=0.05), topk=(1, 1))
+    sd = state_from(a)
+    assert set(sd) == set(head.state_dict())
+    head.load_state_dict(sd)
+    e = _t(a["e"]).requires_grad_(True)
+    gap = _t(a["gap"]).requires_grad_(True)
+    gt = _t(a["gt"])
+    assert torch.allclose(head.get_score((e, gap)), _t(a["score"]), atol=1e-5)
+    assert torch.allclose(head.simple_test((e, gap, None)), _t(a["pred"]), atol=1e-6)
+    losses = head.forward_train((e, gap, None), gt)
+    assert torch.allclose(losses["bce_loss"], _t(a["bce_loss"]), atol=1e-5)
+    assert torch.allclose(losses["asy_loss"], _t(a["asy_loss"]), atol=1e-5)
+    (losses["bce_loss"] + losses["asy_loss"]).backward()
+    assert torch.allclose(e.grad, _t(a["de"]), atol=1e-5)
+    assert torch.allclose(gap.grad, _t(a["dgap"]), atol=1e-5)
+    named = dict(head.named_parameters())
+    for k, g in grads_from(a).items():
+        assert torch.allclose(named[k].grad, g, atol=1e-5), k
+
+
+def test_optimizer_param_groups_follow_reference_paramwise_cfg():
+    from gkgnet_amd.grapher import Grapher
+    from gkgnet_amd.head import LabelQueryHead, build_optimizer
+    g = Grapher(32, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=64, relative_pos=True, use_multi_group=True,
+                num_group=2)
+    h = LabelQueryHead(8, 32)
+    opt = build_optimizer([g, h])
+    decay, no_decay = opt.param_groups
+    assert decay["weight_decay"] == 0.05 and no_decay["weight_decay"] == 0.0 and decay["lr"] == 1e-4
+    nd = {id(p) for p in no_decay["params"]}
+    for name, p in list(g.named_parameters()) + list(h.named_parameters()):
+        if not p.requires_grad:
+            continue
+        expect_nd = name.endswith("bias") or ".1." in name          # conv/linear biases and all BN parameters
+        assert (id(p) in nd) == expect_nd, name

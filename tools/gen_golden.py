@@ -330,8 +330,39 @@ def backbone_case(ref, name):
          **arrays)
 
 
+def head_case(ref, name):
+    """F12: LabelQueryHead scores + double loss (ASL x10 + smoothed multi-label BCE) and gradients.
+    Config as in configs/gkgnet/gkgnet_coco_576.py:27-38 at a small size."""
+    torch.manual_seed(12)
+    L, C, B = 8, 32, 5
+    head = ref.head.LabelQueryHead(num_classes=L, in_channels=C, softmax=False,
+                                   loss=dict(type="AsymmetricLoss", gamma_pos=0.0, gamma_neg=2.0, clip=0.05), topk=(1, 1))
+    gen = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for p in head.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+    e = (torch.randn(B, L, C, generator=gen)).requires_grad_(True)
+    gap = (torch.randn(B, C, generator=gen)).requires_grad_(True)
+    gt = (torch.rand(B, L, generator=gen) < 0.3).float()
+    losses = head.forward_train((e, gap, None), gt)
+    total = losses["bce_loss"] + losses["asy_loss"]
+    total.backward()
+    with torch.no_grad():
+        score = head.get_score((e, gap))
+        pred = head.simple_test((e, gap, None), post_process=False)
+    arrays = dict(e=e.detach().numpy(), gap=gap.detach().numpy(), gt=gt.numpy(), score=score.numpy(), pred=pred.numpy(),
+                  bce_loss=losses["bce_loss"].detach().numpy(), asy_loss=losses["asy_loss"].detach().numpy(),
+                  de=e.grad.numpy(), dgap=gap.grad.numpy())
+    for k, v in head.state_dict().items():
+        arrays["sd/" + k] = v.detach().clone().numpy()
+    for k, p in head.named_parameters():
+        arrays["grad/" + k] = p.grad.numpy()
+    save(name, dict(kind="head", num_classes=L, in_channels=C, B=B, ref="heads/label_query_head.py:10-85; "
+                    "losses/asymmetric_loss.py:9-71; losses/label_smooth_loss.py:122-175"), **arrays)
+
+
 def main():
-    ref = load_reference(with_backbone=True)
+    ref = load_reference(with_backbone=True, with_head=True)
     grapher_case(ref, "f1_grapher_cfg1", C=64, k=9, d=1, r=1, hw=14, G=1, multi=False)
     grapher_case(ref, "f2_grapher_g4", C=64, k=9, d=1, r=1, hw=8, G=4, multi=True, seed=2)
     grapher_case(ref, "f3_grapher_dil3", C=64, k=9, d=3, r=1, hw=12, G=2, multi=True, seed=3)
@@ -349,6 +380,7 @@ def main():
     integer_kat(ref, "f8_integer_kat")
     relpos_case(ref, "f9_relpos", [(64, 196, 1), (80, 144, 1), (32, 256, 2), (32, 256, 4)])
     backbone_case(ref, "f10_backbone_tiny")
+    head_case(ref, "f12_head_loss")
 
 
 if __name__ == "__main__":

@@ -70,10 +70,20 @@ def _build_norm_layer(cfg, num_features, postfix=""):
 
 
 class _Registry:
+    """Records registered classes by name so that build_loss(dict(type=...)) works."""
+
+    def __init__(self):
+        self.classes = {}
+
     def register_module(self, *a, **k):
         def deco(cls):
+            self.classes[cls.__name__] = cls
             return cls
         return deco
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.classes[cfg.pop("type")](**cfg)
 
 
 def _mod(name, **attrs):
@@ -103,10 +113,10 @@ def _exec(name, relpath, search=None):
 _LOADED = None
 
 
-def load_reference(with_backbone: bool = True):
+def load_reference(with_backbone: bool = True, with_head: bool = False):
     """Returns a namespace with the reference's vig_model (and gkgnet) modules."""
     global _LOADED
-    if _LOADED is not None:
+    if _LOADED is not None and (not with_head or hasattr(_LOADED, "head")):
         return _LOADED
     if not os.path.isdir(REF_ROOT):
         raise RuntimeError(f"reference tree not found at {REF_ROOT}")
@@ -129,7 +139,8 @@ def load_reference(with_backbone: bool = True):
     _pkg("mmcls.models")
     _pkg("mmcls.models.utils")
     _pkg("mmcls.models.backbones")
-    _mod("mmcls.models.builder", BACKBONES=_Registry())
+    _reg = _Registry()
+    _mod("mmcls.models.builder", BACKBONES=_reg, HEADS=_reg, LOSSES=_reg, build_loss=_reg.build)
 
     base = "mmcls/models"
     _exec("mmcls.models.utils.differentiable_topk", f"{base}/utils/differentiable_topk.py")
@@ -145,6 +156,27 @@ def load_reference(with_backbone: bool = True):
         _exec("mmcls.models.backbones.base_backbone", f"{base}/backbones/base_backbone.py")
         ns.gkgnet = _exec("mmcls.models.backbones.gkgnet", f"{base}/backbones/gkgnet.py")
         # gkgnet.py:264 hard-codes .cuda(); neutralise on a CPU-only host.
+        if not torch.cuda.is_available():
+            torch.Tensor.cuda = lambda self, *a, **k: self
+    if with_head:
+        # head + losses: heads/label_query_head.py, heads/cls_head.py, losses/{utils,accuracy,
+        # cross_entropy_loss,label_smooth_loss,asymmetric_loss}.py
+        sys.modules["mmcls.models.utils"].is_tracing = lambda: False
+        losses_dir = os.path.join(REF_ROOT, base, "losses")
+        lp = _pkg("mmcls.models.losses")
+        lp.__path__ = [losses_dir]
+        for name in ("utils", "accuracy", "cross_entropy_loss", "label_smooth_loss", "asymmetric_loss"):
+            m = _exec(f"mmcls.models.losses.{name}", f"{base}/losses/{name}.py")
+            setattr(lp, name, m)
+        lp.Accuracy = lp.accuracy.Accuracy
+        lp.LabelSmoothLoss = lp.label_smooth_loss.LabelSmoothLoss
+        lp.AsymmetricLoss = lp.asymmetric_loss.AsymmetricLoss
+        hp = _pkg("mmcls.models.heads")
+        hp.__path__ = [os.path.join(REF_ROOT, base, "heads")]
+        _exec("mmcls.models.heads.base_head", f"{base}/heads/base_head.py")
+        _exec("mmcls.models.heads.cls_head", f"{base}/heads/cls_head.py")
+        ns.head = _exec("mmcls.models.heads.label_query_head", f"{base}/heads/label_query_head.py")
+        ns.losses = lp
         if not torch.cuda.is_available():
             torch.Tensor.cuda = lambda self, *a, **k: self
     _LOADED = ns
