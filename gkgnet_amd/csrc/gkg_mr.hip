@@ -160,6 +160,52 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ g, co
   for (int i = tid; i < nch * M; i += 256) stf(out + obase + i, acc[i]);
 }
 
+// ------------------------------------------------------------------------------------------ large-M fallbacks
+// When one source row (M*4 B) does not fit the LDS budget (label graph over >24k image tokens) the rows stay in
+// L2: the forward gathers straight from global memory, the backward scatters with fp32 global atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void mr_fwd_gather_kernel(const T* __restrict__ x, const T* __restrict__ src,
+                                                            const int64_t* __restrict__ nn_idx, T* __restrict__ m_out,
+                                                            uint8_t* __restrict__ argmax, int c, int N, int M, int k) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int bg = blockIdx.z;
+  if (n >= N) return;
+  const int64_t* ip = nn_idx + ((size_t)bg * N + n) * k;
+  for (int ch = blockIdx.y; ch < c; ch += gridDim.y) {
+    const size_t o = ((size_t)bg * c + ch) * N + n;
+    const T* r = src + ((size_t)bg * c + ch) * M;
+    const float xi = ldf(x + o);
+    float best = ldf(r + ip[0]) - xi;
+    int arg = 0;
+    for (int j = 1; j < k; ++j) {
+      const float v = ldf(r + ip[j]) - xi;
+      if (v > best) { best = v; arg = j; }
+    }
+    stf(m_out + o, best);
+    if (argmax) argmax[o] = (uint8_t)arg;
+  }
+}
+
+__global__ __launch_bounds__(256) void mr_bwd_atomic_kernel(const float* __restrict__ g, const int64_t* __restrict__ nn_idx,
+                                                            const uint8_t* __restrict__ argmax, float* __restrict__ gx,
+                                                            float* __restrict__ dst, int c, int N, int M, int k, int self) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int bg = blockIdx.z;
+  if (n >= N) return;
+  const int64_t* ip = nn_idx + ((size_t)bg * N + n) * k;
+  for (int ch = blockIdx.y; ch < c; ch += gridDim.y) {
+    const size_t o = ((size_t)bg * c + ch) * N + n;
+    const float gv = g[o];
+    if (!self) gx[o] = -gv;
+    atomicAdd(dst + ((size_t)bg * c + ch) * M + ip[argmax[o]], gv);
+  }
+}
+
+__global__ __launch_bounds__(256) void negate_kernel(const float* __restrict__ g, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = -g[i];
+}
+
 // ------------------------------------------------------------------------------------------ token-major variants
 // Inside the fused Grapher block activations are token-major (B, N, C): a neighbour is then ONE contiguous row
 // segment of c floats, so the aggregation is a coalesced row gather — no LDS staging.  One thread = one token x
@@ -369,7 +415,14 @@ extern "C" int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx,
   const int extra = k * 256 * 4;
   // channels per workgroup: as many source rows as fit, but keep enough workgroups to fill the chip
   int CH = pick_ch(c, M, extra);
-  if (CH < 1) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd: M too large for the LDS-resident source row");
+  if (CH < 1) {                      // source row does not fit in LDS: gather from L2
+    GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
+    dim3 grid((N + 255) / 256, c < 64 ? c : 64, BG);
+    if (dtype == GKG_F32) hipLaunchKernelGGL((mr_fwd_gather_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)src, nn_idx, (float*)m_out, argmax, c, N, M, k);
+    else hipLaunchKernelGGL((mr_fwd_gather_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)src, nn_idx, (uint16_t*)m_out, argmax, c, N, M, k);
+    hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? 0 : gkg_fail_hip(e2, "mr_fwd_gather_kernel");
+  }
   const long ntiles = (N + 255) / 256;
   while (CH > 4 && ntiles * ((c + CH - 1) / CH) * BG < 1024) CH = (CH + 1) / 2;
   hipError_t e = dtype == GKG_F32 ? mr_fwd_launch<float>(x, src, nn_idx, m_out, argmax, BG, c, N, M, k, CH, (hipStream_t)stream)
@@ -405,7 +458,19 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
   if (BG > 65535) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd: BG <= 65535");
   const int extra = k * 256 * 4;
   int CH = pick_ch(c, M, extra);
-  if (CH < 1) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd: M too large for the LDS-resident accumulator row");
+  if (CH < 1) {                      // accumulator row does not fit in LDS: fp32 global atomics (fp32 tensors only)
+    if (dtype != GKG_F32) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd: M too large for the LDS accumulator and dtype is not fp32");
+    hipStream_t st = (hipStream_t)stream;
+    GkgProfScope prof(GKG_PROF_MR_BWD, st);
+    const size_t nx = (size_t)BG * c * N;
+    if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)BG * c * M, st);
+    else hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, (const float*)g, (float*)gx, nx);
+    dim3 grid((N + 255) / 256, c < 64 ? c : 64, BG);
+    hipLaunchKernelGGL(mr_bwd_atomic_kernel, grid, dim3(256), 0, st, (const float*)g, nn_idx, argmax, (float*)gx,
+                       gsrc ? (float*)gsrc : (float*)gx, c, N, M, k, gsrc ? 0 : 1);
+    hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? 0 : gkg_fail_hip(e2, "mr_bwd_atomic_kernel");
+  }
   while (CH > 2 && (long)((c + CH - 1) / CH) * BG < 1024) CH = (CH + 1) / 2;
   hipError_t e = dtype == GKG_F32 ? mr_bwd_launch<float>(g, nn_idx, argmax, gx, gsrc, BG, c, N, M, k, CH, (hipStream_t)stream)
                                   : mr_bwd_launch<uint16_t>(g, nn_idx, argmax, gx, gsrc, BG, c, N, M, k, CH, (hipStream_t)stream);

@@ -272,6 +272,8 @@ def fused_supported(mod, x, groups: int) -> bool:
     C = mod.channels
     if not (x.is_cuda and x.dtype == _F32):
         return False
+    if torch.is_autocast_enabled():
+        return False            # mixed precision requested: the composable path runs the projections in bf16
     if not isinstance(gc.gconv, MRConv2d) or len(gc.gconv.nn) != 3 or not isinstance(gc.gconv.nn[2], torch.nn.GELU):
         return False
     if C % 16 or (C // groups) % 4 or getattr(gc.dilated_knn_graph, "stochastic", False):

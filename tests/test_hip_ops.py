@@ -38,6 +38,7 @@ KNN_SHAPES = [
     (1, 16, 200, 81, 18, 2, True),       # kd = 36
     (1, 8, 50, 70, 32, 2, False),        # kd = 64 (largest list)
     (5, 200, 130, None, 9, 2, True),     # stage-3-like c=200, kd=18
+    (1, 4, 40, 30000, 9, 1, False),      # keys beyond the LDS-resident row budget: gather / atomic fallbacks
 ]
 
 
