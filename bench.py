@@ -147,16 +147,27 @@ def main():
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    compute()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            g = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog thread may poll events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 compute()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+            graph = g
+        except Exception as exc:                       # capture is an optimisation: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
             compute()
+            torch.cuda.synchronize()
 
     def step():
         if graph is None:

@@ -36,70 +36,74 @@ constexpr int KT = 32;   // keys per MFMA tile
 constexpr int NW = 4;    // waves per workgroup
 
 // ------------------------------------------------------------------------------------------ prep
-constexpr int PREP_T = 64;   // tokens (threads) per token_prep workgroup
-
 struct PrepStrides { int G; size_t sb, sg, sc, sn; };
 
-// One thread per token.  The two ordered fma chains over the channels are inherently serial per token, so
-// the kernel is latency-bound: loads are batched 8 deep ahead of the chains, the first pass parks the
-// values in a thread-private LDS column so the second pass never goes back to L2, and small 64-token
-// workgroups keep all CUs busy at N = 324.
-template <typename T, bool NORM>
-__global__ __launch_bounds__(PREP_T) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
-                                                            float* __restrict__ sq, int c, int cpad, int Tn,
-                                                            int use_lds, PrepStrides ps) {
-  extern __shared__ float col[];          // [c][PREP_T] when use_lds
-  const int n = blockIdx.x * PREP_T + threadIdx.x;
+// One thread per token.  The two ordered fma chains over the channels are inherently serial per token and the
+// problem has few tokens per CU (cfg2: 160), so the kernel is latency-bound.  Structure: (1) pull the token's
+// whole channel column into a thread-private LDS column with 16 loads in flight and no arithmetic in between
+// (token-major input: float4 loads of the contiguous channel run), (2) run both chains out of LDS, (3) store
+// the normalised copy coalesced along the token axis.  PT (tokens per workgroup) shrinks with c so the column
+// block always fits: PT * c * 4 B <= 48 KB.
+template <typename T, bool NORM, int PT>
+__global__ __launch_bounds__(PT) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
+                                                        float* __restrict__ sq, int c, int cpad, int Tn,
+                                                        PrepStrides ps) {
+  extern __shared__ float col[];          // [c][PT]
+  const int n = blockIdx.x * PT + threadIdx.x;
   const int bg = blockIdx.y;
   if (n >= Tn) return;
   // element (bg = b*G + g, ch, n) of the input lives at  b*sb + g*sg + ch*sc + n*sn
   const T* tp = t + (size_t)(bg / ps.G) * ps.sb + (size_t)(bg % ps.G) * ps.sg + (size_t)n * ps.sn;
-  const size_t Tn_in = ps.sc;            // channel stride of the INPUT (outputs stay channel-major, stride Tn)
   float* cp = col + threadIdx.x;
+  // ---- (1) gather the column
+  if (sizeof(T) == 4 && ps.sc == 1 && (c & 3) == 0 && ((ps.sn | ps.sg | ps.sb) & 3) == 0) {
+    const float4* tp4 = reinterpret_cast<const float4*>(tp);
+    int q = 0;
+    for (; q + 8 <= (c >> 2); q += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = tp4[q + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        cp[(4 * (q + u) + 0) * PT] = v[u].x; cp[(4 * (q + u) + 1) * PT] = v[u].y;
+        cp[(4 * (q + u) + 2) * PT] = v[u].z; cp[(4 * (q + u) + 3) * PT] = v[u].w;
+      }
+    }
+    for (; q < (c >> 2); ++q) {
+      const float4 v = tp4[q];
+      cp[(4 * q + 0) * PT] = v.x; cp[(4 * q + 1) * PT] = v.y; cp[(4 * q + 2) * PT] = v.z; cp[(4 * q + 3) * PT] = v.w;
+    }
+  } else {
+    int ch = 0;
+    for (; ch + 16 <= c; ch += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = ldf(tp + (size_t)(ch + u) * ps.sc);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) cp[(ch + u) * PT] = v[u];
+    }
+    for (; ch < c; ++ch) cp[ch * PT] = ldf(tp + (size_t)ch * ps.sc);
+  }
+  // ---- (2) ordered chains out of LDS (own column: no barrier needed)
   float den = 1.0f;
   if (NORM) {
     float s = 0.0f;
-    int ch = 0;
-    for (; ch + 8 <= c; ch += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ldf(tp + (size_t)(ch + u) * Tn_in);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        s = __builtin_fmaf(v[u], v[u], s);
-        if (use_lds) cp[(ch + u) * PREP_T] = v[u];
-      }
-    }
-    for (; ch < c; ++ch) {
-      const float v = ldf(tp + (size_t)ch * Tn_in);
-      s = __builtin_fmaf(v, v, s);
-      if (use_lds) cp[ch * PREP_T] = v;
-    }
+#pragma unroll 8
+    for (int ch = 0; ch < c; ++ch) { const float v = cp[ch * PT]; s = __builtin_fmaf(v, v, s); }
     den = fmaxf(sqrtf(s), 1e-12f);
   }
-  float q = 0.0f;
+  // ---- (3) normalise, store, |th|^2
+  float q2 = 0.0f;
   float* op = th + (size_t)bg * cpad * Tn + n;
-  const bool from_lds = NORM && use_lds;
-  int ch = 0;
-  for (; ch + 8 <= c; ch += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = from_lds ? cp[(ch + u) * PREP_T] : ldf(tp + (size_t)(ch + u) * Tn_in);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (NORM) v[u] = v[u] / den;
-      op[(size_t)(ch + u) * Tn] = v[u];
-      q = __builtin_fmaf(v[u], v[u], q);
-    }
-  }
-  for (; ch < c; ++ch) {
-    float v = from_lds ? cp[ch * PREP_T] : ldf(tp + (size_t)ch * Tn_in);
+#pragma unroll 8
+  for (int ch = 0; ch < c; ++ch) {
+    float v = cp[ch * PT];
     if (NORM) v = v / den;
     op[(size_t)ch * Tn] = v;
-    q = __builtin_fmaf(v, v, q);
+    q2 = __builtin_fmaf(v, v, q2);
   }
   for (int chp = c; chp < cpad; ++chp) op[(size_t)chp * Tn] = 0.0f;
-  sq[(size_t)bg * Tn + n] = q;
+  sq[(size_t)bg * Tn + n] = q2;
 }
 
 // ------------------------------------------------------------------------------------------ top-KD list
@@ -493,18 +497,22 @@ static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream
   return deep ? launch_tile_v<KD, false, 8>(a, grid, lds, st) : launch_tile_v<KD, false, 4>(a, grid, lds, st);
 }
 
+template <typename T, int PT>
+static void launch_prep_pt(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
+                           hipStream_t st, PrepStrides ps) {
+  dim3 grid((Tn + PT - 1) / PT, BG);
+  const size_t lds = (size_t)c * PT * sizeof(float);
+  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, (const T*)t, th, sq, c, cpad, Tn, ps);
+  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, (const T*)t, th, sq, c, cpad, Tn, ps);
+}
+
 template <typename T>
 static hipError_t launch_prep(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
                               hipStream_t st, PrepStrides ps) {
   GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
-  dim3 grid((Tn + PREP_T - 1) / PREP_T, BG);
-  const size_t col_bytes = (size_t)c * PREP_T * sizeof(float);
-  const int use_lds = norm && col_bytes <= 48 * 1024;
-  const size_t lds = use_lds ? col_bytes : 0;
-  if (norm)
-    hipLaunchKernelGGL((token_prep_kernel<T, true>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds, ps);
-  else
-    hipLaunchKernelGGL((token_prep_kernel<T, false>), grid, dim3(PREP_T), lds, st, (const T*)t, th, sq, c, cpad, Tn, use_lds, ps);
+  if (c <= 192) launch_prep_pt<T, 64>(t, th, sq, BG, c, cpad, Tn, norm, st, ps);          // <= 48 KB column block
+  else if (c <= 384) launch_prep_pt<T, 32>(t, th, sq, BG, c, cpad, Tn, norm, st, ps);
+  else launch_prep_pt<T, 16>(t, th, sq, BG, c, cpad, Tn, norm, st, ps);                    // c <= 600 (plan limit)
   return hipGetLastError();
 }
 
