@@ -234,6 +234,16 @@ def main():
                         algorithmic_flops_per_step=flops_knn)
         kernels = {k: dict(us_per_step=round(1e3 * v[0] / prof_steps, 2), launches_per_step=v[1] // prof_steps)
                    for k, v in prof.items() if v[1]}
+        # HBM-bound companions of the k-NN kernel: algorithmic bytes / measured time, vs 8 TB/s
+        e4, Cq = 4, C
+        by_fwd = e4 * B * Cq * N * 2 + 8 * BG * N * w["k"] + B * Cq * N \
+            + e4 * B * Cq * (L + N) + e4 * B * Cq * L + 8 * BG * L * w["k"] + B * Cq * L
+        by_bwd = e4 * B * Cq * N * 3 + 8 * BG * N * w["k"] + B * Cq * N \
+            + e4 * B * Cq * L * 2 + e4 * B * Cq * N + 8 * BG * L * w["k"] + B * Cq * L
+        for name, nbytes in (("mr_fwd", by_fwd), ("mr_bwd", by_bwd)):
+            if name in kernels and kernels[name]["us_per_step"] > 0:
+                gbs = nbytes / kernels[name]["us_per_step"] / 1e3
+                kernels[name].update(bound="hbm", achieved_GBps=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBPS, 4))
         res = dict(metric="Grapher fwd+bwd images/sec", value=round(value, 1), unit="images/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 4), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
