@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import fused
 from .grapher import Grapher, GrapherLabel
 from .layers import DropPath, act_layer, build_norm
 from .registry import BACKBONES, register_with_mmcls
@@ -30,6 +31,8 @@ class FFN(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x):
+        if fused.ffn_supported(self, x):
+            return fused.ffn_forward(self, x)
         return self.drop_path(self.fc2(self.act(self.fc1(x)))) + x
 
 

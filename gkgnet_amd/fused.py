@@ -334,3 +334,26 @@ def grapher_label_forward(mod, e, features, groups: int):
     f1 = _lin(h2, mod.ffn.fc1, act=1)
     out = _lin(f1, mod.ffn.fc2, residual=h2)
     return out.view(B, L, C), edge
+
+
+def ffn_supported(mod, x) -> bool:
+    """Fused path for the backbone's FFN block (1x1 conv + BN + GELU -> 1x1 conv + BN -> + residual)."""
+    if not (ENABLED and x.is_cuda and x.dtype == _F32 and x.dim() == 4) or torch.is_autocast_enabled():
+        return False
+    if not isinstance(mod.act, torch.nn.GELU) or not (_bn_ok(mod.fc1[1]) and _bn_ok(mod.fc2[1])):
+        return False
+    if any(conv.weight.shape[0] % 4 or conv.weight.shape[1] % 4 for conv in (mod.fc1[0], mod.fc2[0])):
+        return False
+    if not isinstance(mod.drop_path, torch.nn.Identity) and mod.training and mod.drop_path.drop_prob > 0:
+        return False
+    if torch.is_grad_enabled() and not mod.training and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+        return False
+    return True
+
+
+def ffn_forward(mod, x):
+    """reference gkgnet.py:66-72 on token-major activations: two library GEMMs + the BN/GELU/residual kernels."""
+    x = x.contiguous()
+    xt = to_token_major(x)
+    h = _lin(xt, mod.fc1, act=1)
+    return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape))

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--no-tune", action="store_true")
     args = ap.parse_args()
     os.environ.setdefault("GKG_RELPOS_DEVICE", "cuda")
     from gkgnet_amd import layers, parallel
@@ -28,6 +29,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     layers.norm_cfg["type"] = "BN"                      # local batch statistics
+    if not args.no_tune:                                # library GEMM selection per shape, tuned in the warm-up steps
+        import torch.cuda.tunable as tunable
+        tunable.enable(True); tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30); tunable.set_max_tuning_iterations(10)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_train_rank{rank}.csv"))
     torch.manual_seed(0)
     net = GKGNet(choice=args.choice, n_classes=args.classes, size=args.size, drop_path=0.0).to(dev).train()
     head = LabelQueryHead(args.classes, GKGNet.arch_settings[args.choice]["channels"][-1]).to(dev).train()
