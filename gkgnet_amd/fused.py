@@ -110,7 +110,9 @@ class _LinearBNAct(torch.autograd.Function):
         R, cin = x.shape
         cout = weight.shape[0]
         W = weight.view(cout, cin)
-        Y = torch.mm(x, W.t())
+        Y = torch.mm(x, W.t())              # under autocast: bf16 operands, fp32 accumulate
+        if Y.dtype != _F32:
+            Y = Y.float()
         a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
         if nchw is None:
             out = torch.empty((R, cout), dtype=_F32, device=x.device)
@@ -171,6 +173,8 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         co = cout // nb
         Wg = weight.view(nb, co, ci)
         Y = torch.bmm(U, Wg.transpose(1, 2))                           # (nb, R, co)
+        if Y.dtype != _F32:
+            Y = Y.float()
         a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
         out = torch.empty((R, cout), dtype=_F32, device=U.device)
         _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
@@ -270,10 +274,10 @@ def fused_supported(mod, x, groups: int) -> bool:
     from .graph import MRConv2d
     gc = mod.graph_conv
     C = mod.channels
-    if not (x.is_cuda and x.dtype == _F32):
+    # fp32 activations; under autocast (mixed precision) bf16 inputs are accepted too: the block then keeps its
+    # activations in fp32 and only the projection GEMMs run on bf16 operands (fp32 accumulation)
+    if not x.is_cuda or not (x.dtype == _F32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled())):
         return False
-    if torch.is_autocast_enabled():
-        return False            # mixed precision requested: the composable path runs the projections in bf16
     if not isinstance(gc.gconv, MRConv2d) or len(gc.gconv.nn) != 3 or not isinstance(gc.gconv.nn[2], torch.nn.GELU):
         return False
     if C % 16 or (C // groups) % 4 or getattr(gc.dilated_knn_graph, "stochastic", False):
@@ -302,7 +306,7 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     B, C, H, W = x.shape
     N = H * W
     gc = mod.graph_conv
-    x = x.contiguous()
+    x = x.float().contiguous()
     xt = to_token_major(x)                                          # (T, C)
     x1 = _lin(xt, mod.fc1)                                          # fc1 + BN
     x1b = x1.view(B, N, C)
@@ -322,8 +326,8 @@ def grapher_label_forward(mod, e, features, groups: int):
     """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
     B, L, C = e.shape
     gc = mod.graph_conv
-    ft = to_token_major(features.contiguous()).view(B, -1, C)       # keys / values (B, HW, C)
-    e2 = e.reshape(B * L, C).contiguous()
+    ft = to_token_major(features.float().contiguous()).view(B, -1, C)       # keys / values (B, HW, C)
+    e2 = e.float().reshape(B * L, C).contiguous()
     x1 = _lin(e2, mod.fc1)
     x1b = x1.view(B, L, C)
     edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
@@ -338,7 +342,9 @@ def grapher_label_forward(mod, e, features, groups: int):
 
 def ffn_supported(mod, x) -> bool:
     """Fused path for the backbone's FFN block (1x1 conv + BN + GELU -> 1x1 conv + BN -> + residual)."""
-    if not (ENABLED and x.is_cuda and x.dtype == _F32 and x.dim() == 4) or torch.is_autocast_enabled():
+    if not (ENABLED and x.is_cuda and x.dim() == 4):
+        return False
+    if not (x.dtype == _F32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled())):
         return False
     if not isinstance(mod.act, torch.nn.GELU) or not (_bn_ok(mod.fc1[1]) and _bn_ok(mod.fc2[1])):
         return False
@@ -353,7 +359,7 @@ def ffn_supported(mod, x) -> bool:
 
 def ffn_forward(mod, x):
     """reference gkgnet.py:66-72 on token-major activations: two library GEMMs + the BN/GELU/residual kernels."""
-    x = x.contiguous()
+    x = x.float().contiguous()
     xt = to_token_major(x)
     h = _lin(xt, mod.fc1, act=1)
     return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape))

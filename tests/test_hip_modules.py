@@ -136,3 +136,29 @@ def test_full_size_properties_cfg2():
     g = torch.randn_like(x)
     ops.max_relative(xr, nn_idx).backward(g)
     assert xr.grad.sum(-1).abs().max().item() < 1e-2
+
+
+def test_autocast_bf16_fused_vs_composable():
+    """Mixed precision: under bf16 autocast the fused block (bf16 GEMM operands, fp32 activations) stays close to the
+    composable per-op path (bf16 convolutions) and to the fp32 result."""
+    from gkgnet_amd import fused
+    meta, a = load_fixture("f2_grapher_g4")
+    mod = make_grapher(meta)
+    mod.load_state_dict(state_from(a))
+    mod.cuda().eval()
+    x = _t(a["x"])
+    with torch.no_grad():
+        ref32 = mod(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out_f = mod(x)
+            old = fused.ENABLED
+            fused.ENABLED = False
+            try:
+                out_c = mod(x)
+            finally:
+                fused.ENABLED = old
+    assert out_f.dtype == torch.float32
+    scale = ref32.abs().max().item()
+    # bf16 has 8 significand bits: a flipped near-tie neighbour moves single elements by O(1e-1 * scale)
+    assert (out_f - ref32).abs().mean().item() < 2e-2 * scale
+    assert (out_f.float() - out_c.float()).abs().mean().item() < 3e-2 * scale

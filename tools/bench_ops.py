@@ -19,6 +19,7 @@ SHAPES = {   # name: (BG, c, N, M(None=self), k, d, relpos_C)
     "stage3_d2": (64, 200, 1296, None, 9, 2, 400),
     "stage2": (64, 80, 5184, 1296, 9, 1, "rand"),
     "stage1": (64, 40, 20736, 1296, 9, 1, "rand"),
+    "stage1_norp": (64, 40, 20736, 1296, 9, 1, None),
     "label_stage1": (64, 40, 80, 20736, 9, 1, None),
 }
 
