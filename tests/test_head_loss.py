@@ -48,3 +48,13 @@ def test_optimizer_param_groups_follow_reference_paramwise_cfg():
             continue
         expect_nd = name.endswith("bias") or ".1." in name          # conv/linear biases and all BN parameters
         assert (id(p) in nd) == expect_nd, name
+
+
+def test_map_matches_reference():
+    """F13: multi-label mAP incl. 'difficult' (-1) labels and a single-positive class."""
+    from gkgnet_amd.evaluation import average_precision, mAP
+    meta, a = load_fixture("f13_map")
+    assert abs(mAP(a["pred"], a["target"]) - float(a["mAP"])) < 1e-9
+    for k in range(a["pred"].shape[1]):
+        assert abs(average_precision(a["pred"][:, k], a["target"][:, k]) - a["ap"][k]) < 1e-12
+    assert abs(mAP(_t(a["pred"]), _t(a["target"])) - float(a["mAP"])) < 1e-9

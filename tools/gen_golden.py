@@ -381,7 +381,26 @@ def main():
     relpos_case(ref, "f9_relpos", [(64, 196, 1), (80, 144, 1), (32, 256, 2), (32, 256, 4)])
     backbone_case(ref, "f10_backbone_tiny")
     head_case(ref, "f12_head_loss")
+    map_case("f13_map")
 
+
+
+def map_case(name="f13_map"):
+    """F13: mAP of random scores vs the reference's mean_ap.py (numpy-only file, imported by path)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_mean_ap", os.path.join(
+        os.environ.get("GKG_REFERENCE_ROOT", "/root/reference"), "mmcls/core/evaluation/mean_ap.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.RandomState(4)
+    pred = rng.rand(200, 12).astype(np.float32)
+    target = (rng.rand(200, 12) < 0.15).astype(np.int64)
+    target[rng.rand(200, 12) < 0.03] = -1
+    target[:, 5] = 0
+    target[3, 5] = 1
+    aps = [m.average_precision(pred[:, k], target[:, k]) for k in range(12)]
+    save(name, dict(kind="map", ref="core/evaluation/mean_ap.py:6-74"), pred=pred, target=target,
+         mAP=np.float64(m.mAP(pred, target)), ap=np.array(aps))
 
 if __name__ == "__main__":
     main()
