@@ -157,3 +157,27 @@ class GKGNet(nn.Module):
 
 
 register_with_mmcls(GKGNet)
+
+
+def load_checkpoint(model: nn.Module, path_or_state, prefix: str = "", strict: bool = False):
+    """Load a reference checkpoint by key: ``pvig_s_82.1.pth.tar`` (plain ViG backbone weights) or a
+    GKGNet-576 ``.pth`` written by mmcv (``{'state_dict': {'backbone.*': ...}}``).  Handles the ``state_dict`` nesting,
+    an optional key ``prefix`` (``'backbone.'``; auto-detected when empty) and tensors whose spatial size differs only
+    in ``pos_embed`` / ``relative_pos`` (kept from the freshly built model, like mmcv's non-strict load).
+    Returns (missing_keys, unexpected_keys, skipped_shape_mismatch)."""
+    state = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, str) else path_or_state
+    for key in ("state_dict", "model"):
+        if isinstance(state, dict) and key in state and isinstance(state[key], dict):
+            state = state[key]
+    own = model.state_dict()
+    if not prefix and not any(k in own for k in state) and any(k.startswith("backbone.") for k in state):
+        prefix = "backbone."
+    if prefix:
+        state = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
+    skipped = [k for k, v in state.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
+    state = {k: v for k, v in state.items() if k not in skipped}
+    result = model.load_state_dict(state, strict=False)
+    missing = [k for k in result.missing_keys if k not in skipped]
+    if strict and (missing or result.unexpected_keys):
+        raise RuntimeError(f"checkpoint mismatch: missing {missing[:5]}, unexpected {result.unexpected_keys[:5]}")
+    return missing, list(result.unexpected_keys), skipped

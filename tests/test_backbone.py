@@ -109,3 +109,25 @@ def test_wiring_reproduces_reference_with_oracle_operators():
     assert torch.equal(gap, torch.from_numpy(a["gap"]))
     assert torch.equal(labels, torch.from_numpy(a["label_tokens"]))
     assert np.array_equal(edge.numpy(), a["edge_index"])
+
+
+def test_load_checkpoint_by_key(tmp_path):
+    """f3: mmcv-style checkpoint ({'state_dict': {'backbone.*'}}) built for another input size loads by key; tensors whose
+    size depends on the input resolution (pos_embed, relative_pos) are kept from the freshly built model."""
+    from gkgnet_amd.backbone import GKGNet, load_checkpoint
+    kw = dict(choice="t", k=4, k_label_gcn=4, n_classes=8)
+    src = GKGNet(size=128, **kw)
+    with torch.no_grad():
+        keyed_fill_(src.state_dict(), seed=3)
+    ckpt = {"state_dict": {"backbone." + k: v for k, v in src.state_dict().items()}, "meta": {}}
+    ckpt["state_dict"]["head.fc1.weight"] = torch.zeros(8, 384)
+    path = str(tmp_path / "ckpt.pth")
+    torch.save(ckpt, path)
+    dst = GKGNet(size=192, **kw)
+    missing, unexpected, skipped = load_checkpoint(dst, path)
+    assert not missing and not unexpected
+    assert "pos_embed" in skipped and all(k == "pos_embed" or k.endswith("relative_pos") for k in skipped)
+    a, b = src.state_dict(), dst.state_dict()
+    for k in a:
+        if k not in skipped:
+            assert torch.equal(a[k], b[k]), k
