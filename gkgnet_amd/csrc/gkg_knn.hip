@@ -233,9 +233,20 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   const int t_end = min(t_begin + a.tiles_per_split, ktiles);
   const int CP = cpad / 2;          // k-pairs; cpad % 8 == 0 -> CP % 4 == 0
 
+  // The first key batch of a tile is loaded during the PREVIOUS tile's last MFMA batch (before its selection phase),
+  // so no tile starts with an exposed L2 round trip.
+  float an[KU];
+  {
+    const int t0 = t_begin + w;
+    const int mk0 = min(t0 * KT + l31, M - 1);
+    const float* y0 = yp + (size_t)kk * M + mk0;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) an[u] = y0[(size_t)(2 * u) * M];
+  }
   for (int t = t_begin + w; t < t_end; t += NW) {
     const int m0 = t * KT;
     const int mk = min(m0 + l31, M - 1);
+    const int mk_next = min((t + NW < t_end ? t + NW : t) * KT + l31, M - 1);
     // ---- side inputs of this tile, issued first so their latency hides under the contraction:
     //      |y|^2 of key m0+l31 (broadcast per candidate with v_readlane; +inf masks keys past M) and the
     //      positional bias of this lane's query row
@@ -259,16 +270,17 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     f32x16 acc0 = {0}, acc1 = {0};
     {
       const float* ykp = yp + (size_t)kk * M + mk;
+      const float* ykn = yp + (size_t)kk * M + mk_next;
       const float* xsp = smem + kk * QT + l31;
-      float an[KU], ac[KU];
-#pragma unroll
-      for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * u) * M];
+      float ac[KU];
       if (two_blocks) {
         for (int s = 0; s < CP; s += KU) {
+          const bool last = s + KU >= CP;                       // uniform: prefetch the NEXT tile's first batch
+          const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
 #pragma unroll
           for (int u = 0; u < KU; ++u) ac[u] = an[u];
 #pragma unroll
-          for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * min(s + KU + u, CP - 1)) * M];
+          for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
           __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
 #pragma unroll
           for (int u = 0; u < KU; ++u) {
@@ -280,10 +292,12 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
         }
       } else {                                    // tail query tile with <= 32 queries: one query block only
         for (int s = 0; s < CP; s += KU) {
+          const bool last = s + KU >= CP;
+          const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
 #pragma unroll
           for (int u = 0; u < KU; ++u) ac[u] = an[u];
 #pragma unroll
-          for (int u = 0; u < KU; ++u) an[u] = ykp[(size_t)(2 * min(s + KU + u, CP - 1)) * M];
+          for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < KU; ++u)
