@@ -145,3 +145,52 @@ def test_errors_are_loud():
         ops.knn_graph(torch.zeros(1, 4, 8, device="cuda"), None, None, 9, 1)  # k > M
     with pytest.raises(_lib.GkgError):
         ops.knn_graph(torch.zeros(1, 4, 8, device="cuda", dtype=torch.float16), None, None, 3, 1)
+
+
+def test_fuzz_random_shapes_bit_exact():
+    """60 random (BG, c, N, M, k, d, relpos, dtype) problems incl. ragged sizes (c not a multiple of 8, N/M not multiples
+    of the 64/32 tiles, k*d up to 64, self and bipartite graphs): graph, aggregation and argmax bit-exact vs the C
+    oracle, backward within rounding."""
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    rng = np.random.RandomState(2024)
+    for it in range(60):
+        BG = int(rng.randint(1, 5))
+        c = int(rng.choice([1, 3, 4, 7, 8, 12, 20, 33, 48, 64, 100]))
+        N = int(rng.randint(1, 200))
+        self_graph = rng.rand() < 0.4
+        M = N if self_graph else int(rng.randint(1, 300))
+        kd_max = min(M, 64)
+        d = int(rng.randint(1, 4))
+        k = int(rng.randint(1, max(2, kd_max // d + 1)))
+        if k * d > kd_max:
+            d = 1
+            k = min(k, kd_max)
+        use_rp = rng.rand() < 0.5
+        bf16 = rng.rand() < 0.25
+        x = rng.standard_normal((BG, c, N)).astype(np.float32)
+        y = None if self_graph else rng.standard_normal((BG, c, M)).astype(np.float32)
+        rp = -rng.random_sample((N, M)).astype(np.float32) if use_rp else None
+        tdt = torch.bfloat16 if bf16 else torch.float32
+        xd = torch.from_numpy(x).to(tdt)
+        yd = None if y is None else torch.from_numpy(y).to(tdt)
+        xo = xd.float().numpy()
+        yo = None if yd is None else yd.float().numpy()
+        tag = (it, BG, c, N, M, k, d, use_rp, bf16)
+        want_idx, want_center = O.knn(xo, yo, rp, k, d)
+        edge = ops.knn_graph(xd.cuda(), None if yd is None else yd.cuda(), None if rp is None else _dev(rp).unsqueeze(0), k, d)
+        assert np.array_equal(edge[0].cpu().numpy(), want_idx), tag
+        assert np.array_equal(edge[1].cpu().numpy(), want_center), tag
+        want_m, want_arg = O.mr_fwd(xo, yo, want_idx)
+        xg = xd.cuda().requires_grad_(True)
+        yg = None if yd is None else yd.cuda().requires_grad_(True)
+        m = ops.max_relative(xg, edge[0], yg)
+        ref_m = torch.from_numpy(want_m).to(tdt).float().numpy()
+        assert np.array_equal(m.detach().float().cpu().numpy(), ref_m), tag
+        if not bf16:
+            g = rng.standard_normal(want_m.shape).astype(np.float32)
+            m.backward(_dev(g))
+            gx, gs = O.mr_bwd(g, want_idx, want_arg, None if y is None else M)
+            assert np.allclose(xg.grad.cpu().numpy(), gx, atol=1e-5, rtol=1e-5), tag
+            if y is not None:
+                assert np.allclose(yg.grad.cpu().numpy(), gs, atol=1e-5, rtol=1e-5), tag
