@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
         a.part_v[pbase + j] = bv;
         a.part_i[pbase + j] = bi;
       } else if (j == next_rank) {
-        a.nn_idx[obase + outj] = bi;
+        a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;   // non-finite distances only: stay in range
         if (a.center) a.center[obase + outj] = n;
         ++outj;
         next_rank += a.dilation;
@@ -590,6 +590,8 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   if (p.S > 1) {
     const size_t ne = (size_t)BG * N * p.kd * p.S;
     GkgProfScope prof(GKG_PROF_KNN_MERGE, st);
+    // ranks that no finite candidate claims (non-finite inputs only) must still hold a valid index
+    (void)hipMemsetAsync(nn_idx, 0, sizeof(int64_t) * (size_t)BG * N * k, st);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
                        nn_idx, center, p.S, BG, N, k, dilation, p.kd);
     e = hipGetLastError();

@@ -18,6 +18,10 @@ namespace gkg {
 
 constexpr int MR_LDS_BUDGET = 96 * 1024;   // bytes of LDS for source rows / accumulators
 
+// Caller-provided neighbour indices are trusted to be in [0, M); clamping costs two integer ops per index and keeps a
+// corrupted index tensor from becoming an out-of-bounds access.
+__device__ __forceinline__ int clamp_idx(int64_t v, int M) { return (int)(v < 0 ? 0 : (v >= M ? M - 1 : v)); }
+
 // ------------------------------------------------------------------------------------------ forward
 // These kernels move ~1 flop per byte and, at the sizes of this path, every operand is L2/MALL resident:
 // they are bound by memory *latency*, so each thread issues all of its independent loads before the
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = i + 256 * u;
-        if (e < cnt) { const int q = e / k; idx_s[(e - q * k) * 256 + q] = (int)v[u]; }
+        if (e < cnt) { const int q = e / k; idx_s[(e - q * k) * 256 + q] = clamp_idx(v[u], M); }
       }
     }
   }
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ g, co
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = (i + 256 * u < cnt) ? ip[i + 256 * u] : 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (i + 256 * u < cnt) idx_s[i + 256 * u] = (int)v[u];
+      for (int u = 0; u < 4; ++u) if (i + 256 * u < cnt) idx_s[i + 256 * u] = clamp_idx(v[u], M);
     }
     __syncthreads();
     const int n = n0 + tid;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ g, co
         }
 #pragma unroll
         for (int u = 0; u < MR_CB; ++u)
-          if (cb + u < nch) atomicAdd(&acc[(size_t)(cb + u) * M + idx_s[tid * k + am[u]]], gv[u]);
+          if (cb + u < nch) atomicAdd(&acc[(size_t)(cb + u) * M + idx_s[tid * k + min(am[u], k - 1)]], gv[u]);
       }
     }
   }
@@ -175,10 +179,10 @@ __global__ __launch_bounds__(256) void mr_fwd_gather_kernel(const T* __restrict_
     const size_t o = ((size_t)bg * c + ch) * N + n;
     const T* r = src + ((size_t)bg * c + ch) * M;
     const float xi = ldf(x + o);
-    float best = ldf(r + ip[0]) - xi;
+    float best = ldf(r + clamp_idx(ip[0], M)) - xi;
     int arg = 0;
     for (int j = 1; j < k; ++j) {
-      const float v = ldf(r + ip[j]) - xi;
+      const float v = ldf(r + clamp_idx(ip[j], M)) - xi;
       if (v > best) { best = v; arg = j; }
     }
     stf(m_out + o, best);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void mr_bwd_atomic_kernel(const float* __restr
     const size_t o = ((size_t)bg * c + ch) * N + n;
     const float gv = g[o];
     if (!self) gx[o] = -gv;
-    atomicAdd(dst + ((size_t)bg * c + ch) * M + ip[argmax[o]], gv);
+    atomicAdd(dst + ((size_t)bg * c + ch) * M + clamp_idx(ip[min((int)argmax[o], k - 1)], M), gv);
   }
 }
 
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
     int id[KS > 0 ? KS : 1];
     float4 v[KS > 0 ? KS : 1];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) id[j] = (int)ip[j];
+    for (int j = 0; j < KS; ++j) id[j] = clamp_idx(ip[j], M);
 #pragma unroll
     for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C);
     best = make_float4(v[0].x - xi.x, v[0].y - xi.y, v[0].z - xi.z, v[0].w - xi.w);
@@ -251,11 +255,11 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
     }
   } else {
     {
-      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[0] * C);
+      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)clamp_idx(ip[0], M) * C);
       best = make_float4(v.x - xi.x, v.y - xi.y, v.z - xi.z, v.w - xi.w);
     }
     for (int j = 1; j < k; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)ip[j] * C);
+      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)clamp_idx(ip[j], M) * C);
       const float d0 = v.x - xi.x, d1 = v.y - xi.y, d2 = v.z - xi.z, d3 = v.w - xi.w;
       if (d0 > best.x) { best.x = d0; a0 = j; }
       if (d1 > best.y) { best.y = d1; a1 = j; }
@@ -335,8 +339,9 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
         const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
         gm = make_float4(u0.y, u0.w, u1.y, u1.w);
       }
-      const int j0 = (int)ip[am & 0xff], j1 = (int)ip[(am >> 8) & 0xff], j2 = (int)ip[(am >> 16) & 0xff],
-                j3 = (int)ip[(am >> 24) & 0xff];
+      const int km = k - 1;
+      const int j0 = clamp_idx(ip[min((int)(am & 0xff), km)], M), j1 = clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M),
+                j2 = clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M), j3 = clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M);
       atomicAdd(acc + (size_t)j0 * CW + 4 * qd + 0, gm.x);
       atomicAdd(acc + (size_t)j1 * CW + 4 * qd + 1, gm.y);
       atomicAdd(acc + (size_t)j2 * CW + 4 * qd + 2, gm.z);
@@ -375,10 +380,11 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const flo
     gm = make_float4(u0.y, u0.w, u1.y, u1.w);
   }
   float* db = dst + (size_t)b * M * C + ch;
-  atomicAdd(db + (size_t)ip[am & 0xff] * C + 0, gm.x);
-  atomicAdd(db + (size_t)ip[(am >> 8) & 0xff] * C + 1, gm.y);
-  atomicAdd(db + (size_t)ip[(am >> 16) & 0xff] * C + 2, gm.z);
-  atomicAdd(db + (size_t)ip[(am >> 24) & 0xff] * C + 3, gm.w);
+  const int km = k - 1;
+  atomicAdd(db + (size_t)clamp_idx(ip[min((int)(am & 0xff), km)], M) * C + 0, gm.x);
+  atomicAdd(db + (size_t)clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M) * C + 1, gm.y);
+  atomicAdd(db + (size_t)clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M) * C + 2, gm.z);
+  atomicAdd(db + (size_t)clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M) * C + 3, gm.w);
 }
 
 }  // namespace gkg

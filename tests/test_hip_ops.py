@@ -194,3 +194,31 @@ def test_fuzz_random_shapes_bit_exact():
             assert np.allclose(xg.grad.cpu().numpy(), gx, atol=1e-5, rtol=1e-5), tag
             if y is not None:
                 assert np.allclose(yg.grad.cpu().numpy(), gs, atol=1e-5, rtol=1e-5), tag
+
+
+def test_non_finite_inputs_do_not_crash_or_leave_the_index_range():
+    """NaN / Inf features give unspecified neighbours (the reference's topk order with NaN is unspecified too), but the
+    operators must stay in range and must not fault: indices in [0, M), aggregation finite where the inputs are."""
+    from gkgnet_amd import ops
+    torch.manual_seed(3)
+    for N, M in ((50, None), (20, 3000)):                # single-workgroup path and split-key + merge path
+        x = torch.randn(2, 8, N, device="cuda")
+        y = None if M is None else torch.randn(2, 8, M, device="cuda")
+        x[0, :, 3] = float("nan")
+        x[1, 2, 7] = float("inf")
+        if y is not None:
+            y[0, :, 5] = float("nan")
+        e = ops.knn_graph(x, y, None, 9, 1)
+        Mk = N if M is None else M
+        assert int(e[0].min()) >= 0 and int(e[0].max()) < Mk
+        m = ops.max_relative(x, e[0], y)
+        torch.cuda.synchronize()
+        assert m.shape == x.shape
+    # corrupted index tensors are clamped instead of read out of bounds
+    x = torch.randn(1, 4, 10, device="cuda", requires_grad=True)
+    bad = torch.full((1, 10, 3), 10**9, dtype=torch.int64, device="cuda")
+    bad[0, :, 1] = -5
+    m = ops.max_relative(x, bad)
+    m.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(m).all() and torch.isfinite(x.grad).all()
