@@ -217,65 +217,67 @@ __global__ __launch_bounds__(256) void negate_kernel(const float* __restrict__ g
 //   mode 0: m (B,N,C) token-major.
 //   mode 1: the grouped 1x1 projection's input directly, U[q][t][2i] = x[t][q*C/4+i], U[q][t][2i+1] = m[...]
 //           (reference interleave torch_vertex.py:57-61 + Conv2d(groups=4) channel split torch_nn.py:61).
-template <int KS>      // KS > 0: k known at compile time (all k index loads and row gathers issued up front)
+template <int KS, int QP>   // KS: compile-time k (all k index loads and row gathers issued up front);
+                            // QP: channel quads per thread (share one index row; QP*4 channels stay inside a group)
 __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
                                                         const int64_t* __restrict__ nn_idx, float* __restrict__ out,
                                                         uint8_t* __restrict__ argmax, int B, int G, int c, int N, int M,
                                                         int k_rt, int mode) {
   const int k = KS > 0 ? KS : k_rt;
-  const int C = G * c, C4 = C >> 2;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // (t, cq)
+  const int C = G * c, CT = C / (4 * QP);                         // thread-columns per token
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // (t, column)
   const size_t T = (size_t)B * N;
-  if (i >= T * C4) return;
-  const size_t t = i / C4;
-  const int cq = (int)(i - t * C4);
-  const int ch = 4 * cq;
+  if (i >= T * CT) return;
+  const size_t t = i / CT;
+  const int ch = 4 * QP * (int)(i - t * CT);
   const int b = (int)(t / N), n = (int)(t - (size_t)b * N);
   const int g = ch / c;
   const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
-  const float4 xi = *reinterpret_cast<const float4*>(x + t * C + ch);
   const float* sb = src + (size_t)b * M * C + ch;
-  float4 best;
-  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  float4 xi[QP], best[QP];
+  uint32_t arg[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) { xi[q] = *reinterpret_cast<const float4*>(x + t * C + ch + 4 * q); arg[q] = 0; }
+  auto upd = [&](int q, const float4& v, int j) {
+    const float d0 = v.x - xi[q].x, d1 = v.y - xi[q].y, d2 = v.z - xi[q].z, d3 = v.w - xi[q].w;
+    if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); return; }
+    if (d0 > best[q].x) { best[q].x = d0; arg[q] = (arg[q] & 0xffffff00u) | (uint32_t)j; }
+    if (d1 > best[q].y) { best[q].y = d1; arg[q] = (arg[q] & 0xffff00ffu) | ((uint32_t)j << 8); }
+    if (d2 > best[q].z) { best[q].z = d2; arg[q] = (arg[q] & 0xff00ffffu) | ((uint32_t)j << 16); }
+    if (d3 > best[q].w) { best[q].w = d3; arg[q] = (arg[q] & 0x00ffffffu) | ((uint32_t)j << 24); }
+  };
   if (KS > 0) {
     int id[KS > 0 ? KS : 1];
-    float4 v[KS > 0 ? KS : 1];
 #pragma unroll
     for (int j = 0; j < KS; ++j) id[j] = clamp_idx(ip[j], M);
 #pragma unroll
-    for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C);
-    best = make_float4(v[0].x - xi.x, v[0].y - xi.y, v[0].z - xi.z, v[0].w - xi.w);
+    for (int q = 0; q < QP; ++q) {
+      float4 v[KS > 0 ? KS : 1];
 #pragma unroll
-    for (int j = 1; j < KS; ++j) {
-      const float d0 = v[j].x - xi.x, d1 = v[j].y - xi.y, d2 = v[j].z - xi.z, d3 = v[j].w - xi.w;
-      if (d0 > best.x) { best.x = d0; a0 = j; }
-      if (d1 > best.y) { best.y = d1; a1 = j; }
-      if (d2 > best.z) { best.z = d2; a2 = j; }
-      if (d3 > best.w) { best.w = d3; a3 = j; }
+      for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C + 4 * q);
+#pragma unroll
+      for (int j = 0; j < KS; ++j) upd(q, v[j], j);
     }
   } else {
-    {
-      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)clamp_idx(ip[0], M) * C);
-      best = make_float4(v.x - xi.x, v.y - xi.y, v.z - xi.z, v.w - xi.w);
-    }
-    for (int j = 1; j < k; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)clamp_idx(ip[j], M) * C);
-      const float d0 = v.x - xi.x, d1 = v.y - xi.y, d2 = v.z - xi.z, d3 = v.w - xi.w;
-      if (d0 > best.x) { best.x = d0; a0 = j; }
-      if (d1 > best.y) { best.y = d1; a1 = j; }
-      if (d2 > best.z) { best.z = d2; a2 = j; }
-      if (d3 > best.w) { best.w = d3; a3 = j; }
+    for (int j = 0; j < k; ++j) {
+      const size_t row = (size_t)clamp_idx(ip[j], M) * C;
+#pragma unroll
+      for (int q = 0; q < QP; ++q) upd(q, *reinterpret_cast<const float4*>(sb + row + 4 * q), j);
     }
   }
-  if (argmax) *reinterpret_cast<uint32_t*>(argmax + t * C + ch) = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
-  if (mode == 0) {
-    *reinterpret_cast<float4*>(out + t * C + ch) = best;
-  } else {
-    const int Cq = C >> 2;                      // original channels per conv group
-    const int q = ch / Cq, il = ch - q * Cq;    // 4 channels never straddle a conv group (C % 16 == 0)
-    float* o = out + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
-    *reinterpret_cast<float4*>(o) = make_float4(xi.x, best.x, xi.y, best.y);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(xi.z, best.z, xi.w, best.w);
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int chq = ch + 4 * q;
+    if (argmax) *reinterpret_cast<uint32_t*>(argmax + t * C + chq) = arg[q];
+    if (mode == 0) {
+      *reinterpret_cast<float4*>(out + t * C + chq) = best[q];
+    } else {
+      const int Cq = C >> 2;                      // original channels per conv group
+      const int qc = chq / Cq, il = chq - qc * Cq;   // 4 channels never straddle a conv group (C % 16 == 0)
+      float* o = out + ((size_t)qc * T + t) * (size_t)(2 * Cq) + 2 * il;
+      *reinterpret_cast<float4*>(o) = make_float4(xi[q].x, best[q].x, xi[q].y, best[q].y);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(xi[q].z, best[q].z, xi[q].w, best[q].w);
+    }
   }
 }
 
@@ -301,13 +303,31 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_init_kernel(const float* __rest
   *reinterpret_cast<float4*>(gx + t * C + ch) = o;
 }
 
-// Backward, pass 2: dst[b][nn_idx[bg][n][argmax[t][ch]]][ch] += gm[t][ch].
-// One workgroup = one image x a chunk of CW channels: the destination rows of that (image, chunk) live in LDS
-// ([M][CW] fp32, seeded from `dst`, which pass 1 / the memset already initialised), all N queries are swept with
-// ds_add_f32, then the rows are stored back — no global atomics.  Threads: 256 = (CW/4) channel quads x tokens.
+// Backward in ONE kernel.  One workgroup = one image x a chunk of CW channels; the destination rows of that (image,
+// chunk) live in LDS ([M][CW] fp32).  Phase 1 seeds the image: self graph -> gx seed = direct - gm (read straight
+// from the upstream gradient), bipartite graph -> zeros.  Phase 2 sweeps all N queries: gm is added at
+// idx[n][argmax] with ds_add_f32 and, for the bipartite graph, gx = direct - gm is stored on the way.  Phase 3
+// stores the image rows.  gx / gsrc are fully overwritten, no global atomics, no separate init pass.
+__device__ __forceinline__ void load_grad(const float* __restrict__ gin, size_t T, size_t t, int C, int ch, int mode,
+                                          float4& direct, float4& gm) {
+  if (mode == 0) {
+    gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
+    direct = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    const int Cq = C >> 2;
+    const int q = ch / Cq, il = ch - q * Cq;
+    const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
+    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
+    direct = make_float4(u0.x, u0.z, u1.x, u1.z);
+    gm = make_float4(u0.y, u0.w, u1.y, u1.w);
+  }
+}
+
+template <bool SELF>
 __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
-                                                                const uint8_t* __restrict__ argmax, float* __restrict__ dst,
-                                                                int B, int G, int c, int N, int M, int k, int mode, int CW) {
+                                                                const uint8_t* __restrict__ argmax, float* __restrict__ gx,
+                                                                float* __restrict__ gsrc, int B, int G, int c, int N, int M,
+                                                                int k, int mode, int CW) {
   extern __shared__ float acc[];                  // [M][CW]
   const int C = G * c;
   const int b = blockIdx.y;
@@ -316,30 +336,30 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
   const int tid = threadIdx.x;
   const int qd = tid % cw4, tl = tid / cw4, TL = 256 / cw4;
   const size_t T = (size_t)B * N;
-  float* db = dst + (size_t)b * M * C + ch0;
+  const int ch = ch0 + 4 * qd;
   if (tl < TL) {
-    for (int m = tl; m < M; m += TL)
-      *reinterpret_cast<float4*>(acc + (size_t)m * CW + 4 * qd) = *reinterpret_cast<const float4*>(db + (size_t)m * C + 4 * qd);
+    for (int m = tl; m < M; m += TL) {
+      float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SELF) {
+        float4 direct, gm;
+        load_grad(gin, T, (size_t)b * N + m, C, ch, mode, direct, gm);
+        seed = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+      }
+      *reinterpret_cast<float4*>(acc + (size_t)m * CW + 4 * qd) = seed;
+    }
   }
   __syncthreads();
   if (tl < TL) {
-    const int ch = ch0 + 4 * qd;
     const int g = ch / c;
+    const int km = k - 1;
     for (int n = tl; n < N; n += TL) {
       const size_t t = (size_t)b * N + n;
       const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
       const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
-      float4 gm;
-      if (mode == 0) {
-        gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
-      } else {
-        const int Cq = C >> 2;
-        const int q = ch / Cq, il = ch - q * Cq;
-        const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
-        const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
-        gm = make_float4(u0.y, u0.w, u1.y, u1.w);
-      }
-      const int km = k - 1;
+      float4 direct, gm;
+      load_grad(gin, T, t, C, ch, mode, direct, gm);
+      if (!SELF)
+        *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
       const int j0 = clamp_idx(ip[min((int)(am & 0xff), km)], M), j1 = clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M),
                 j2 = clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M), j3 = clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M);
       atomicAdd(acc + (size_t)j0 * CW + 4 * qd + 0, gm.x);
@@ -350,6 +370,7 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
   }
   __syncthreads();
   if (tl < TL) {
+    float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch0;
     for (int m = tl; m < M; m += TL)
       *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = *reinterpret_cast<const float4*>(acc + (size_t)m * CW + 4 * qd);
   }
@@ -494,9 +515,12 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
   GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
   const size_t total = (size_t)B * N * (G * c / 4);
+  // one channel quad per thread: two quads per thread (shared index row) measured 20 % slower at cfg2 — the kernel
+  // wants more threads in flight, not fewer index loads
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9>), grid, dim3(256), 0, (hipStream_t)stream, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
-  else hipLaunchKernelGGL((mr_fwd_tm_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1>), grid, dim3(256), 0, st, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
+  else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1>), grid, dim3(256), 0, st, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
 }
@@ -513,20 +537,27 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   const int C = G * c;
   const size_t T = (size_t)B * N;
   const size_t total = T * (C / 4);
-  hipLaunchKernelGGL(mr_bwd_tm_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, gx, C, T, mode);
-  if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * M * C, st);
-  // channel chunk: largest power-of-two multiple of 4 (<= 64, dividing C, not straddling a k-NN group) whose
-  // [M][CW] fp32 image fits the LDS budget, shrunk until the grid has ~2 workgroups per CU
+  // channel chunk: largest power of two (4..64) dividing C and c whose [M][CW] fp32 image fits the LDS budget, shrunk
+  // until the grid has ~2 workgroups per CU
   int CW = 64;
   while (CW > 4 && ((size_t)M * CW * 4 > (size_t)MR_LDS_BUDGET || C % CW || c % CW)) CW >>= 1;
   while (CW > 8 && (long)(C / CW) * B < 512) CW >>= 1;
   if ((size_t)M * CW * 4 <= (size_t)MR_LDS_BUDGET && C % CW == 0 && c % CW == 0 && B <= 65535) {
     const size_t lds = (size_t)M * CW * 4;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mr_bwd_tm_scatter_kernel, dim3(C / CW, B), dim3(256), lds, st, gin, nn_idx, argmax,
-                       gsrc ? gsrc : gx, B, G, c, N, M, k, mode, CW);
-  } else {
+    if (gsrc) {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((mr_bwd_tm_scatter_kernel<false>), dim3(C / CW, B), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,
+                         B, G, c, N, M, k, mode, CW);
+    } else {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((mr_bwd_tm_scatter_kernel<true>), dim3(C / CW, B), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,
+                         B, G, c, N, M, k, mode, CW);
+    }
+  } else {                           // destination image too large for LDS: elementwise seed + fp32 global atomics
+    hipLaunchKernelGGL(mr_bwd_tm_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, gx, C, T, mode);
+    if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * M * C, st);
     hipLaunchKernelGGL(mr_bwd_tm_scatter_atomic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, nn_idx,
                        argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode);
   }
