@@ -74,58 +74,65 @@ __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------ column statistics
-// part[q][blk][0][c] = sum_r y[q][r][c], part[q][blk][1][c] = sum_r y^2 over this block's row range.
-// Thread layout: CGT = min(C/4, 256) column groups (float4) x RL = 256/CGT row lanes; q = blockIdx.y selects
-// one of `nb` stacked (R, C) matrices (the 4 groups of the grouped projection).
-struct StatsGeom { int C4, CGT, RL; };
-__device__ __forceinline__ StatsGeom stats_geom(int C) {
-  StatsGeom g; g.C4 = C >> 2; g.CGT = min(g.C4, 256); g.RL = 256 / g.CGT; return g;
+// part[q][chunk][0][c] = sum_r y[q][r][c], part[q][chunk][1][c] = sum_r y^2 over the chunk's row range.
+// 2-D decomposition: a workgroup owns one 64-channel column tile (16 float4 groups) x one row chunk, its 256
+// threads are 16 column groups x 16 row lanes; grid = (row chunks, column tiles, nb) where q = blockIdx.z selects
+// one of `nb` stacked (R, C) matrices (the 4 groups of the grouped projection).  Wide-and-short matrices (the
+// label path's (B*L, 4C)) therefore still fill the chip, and the number of partial rows the second stage has
+// to walk stays <= 256.
+constexpr int ST_CG = 16;                           // float4 column groups per tile (64 channels)
+constexpr int ST_RL = 16;                           // row lanes
+
+__device__ __forceinline__ void stats_block_reduce(float (*red)[ST_RL][4 * ST_CG], const float4& s, const float4& sq,
+                                                   int cg, int rl, float* __restrict__ part, int C, int tile) {
+  *reinterpret_cast<float4*>(&red[0][rl][4 * cg]) = s;
+  *reinterpret_cast<float4*>(&red[1][rl][4 * cg]) = sq;
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 8 * ST_CG) {
+    const int which = t >> 6, col = t & 63;
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < ST_RL; ++l) acc += red[which][l][col];
+    const int ch = tile * 4 * ST_CG + col;
+    if (ch < C) part[(size_t)which * C + ch] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, float* __restrict__ part,
                                                         int R, int C, int rows_per_block) {
-  extern __shared__ float red[];                    // [RL][2][C]
-  const StatsGeom gm = stats_geom(C);
+  __shared__ float red[2][ST_RL][4 * ST_CG];
   const int tid = threadIdx.x;
-  const int cg = tid % gm.CGT, rl = tid / gm.CGT;
-  const int q = blockIdx.y;
+  const int cg = tid & (ST_CG - 1), rl = tid >> 4;
+  const int cgi = blockIdx.y * ST_CG + cg;
+  const int q = blockIdx.z;
   y += (size_t)q * R * C;
   part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(R, r0 + rows_per_block);
-  if (rl < gm.RL) {
-    for (int cgi = cg; cgi < gm.C4; cgi += gm.CGT) {
-      float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
-      const float* p = y + (size_t)4 * cgi;
-      int r = r0 + rl;
-      for (; r + 3 * gm.RL < r1; r += 4 * gm.RL) {        // 4 independent loads in flight
-        const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)r * C);
-        const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(r + gm.RL) * C);
-        const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(r + 2 * gm.RL) * C);
-        const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(r + 3 * gm.RL) * C);
-        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
-        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
-        sq.x += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
-        sq.y += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
-        sq.z += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
-        sq.w += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
-      }
-      for (; r < r1; r += gm.RL) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)r * C);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
-      }
-      float* rr = red + (size_t)rl * 2 * C;
-      *reinterpret_cast<float4*>(rr + 4 * cgi) = s;
-      *reinterpret_cast<float4*>(rr + C + 4 * cgi) = sq;
+  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+  if (cgi < (C >> 2)) {
+    const float* p = y + (size_t)4 * cgi;
+    int r = r0 + rl;
+    for (; r + 3 * ST_RL < r1; r += 4 * ST_RL) {        // 4 independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)r * C);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(r + ST_RL) * C);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(r + 2 * ST_RL) * C);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(r + 3 * ST_RL) * C);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+      sq.x += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
+      sq.y += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
+      sq.z += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
+      sq.w += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
+    }
+    for (; r < r1; r += ST_RL) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)r * C);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
     }
   }
-  __syncthreads();
-  for (int i = tid; i < 2 * C; i += 256) {
-    float acc = 0.f;
-    for (int l = 0; l < gm.RL; ++l) acc += red[(size_t)l * 2 * C + i];
-    part[i] = acc;
-  }
+  stats_block_reduce(red, s, sq, cg, rl, part, C, blockIdx.y);
 }
 
 // Same two-stage scheme for the backward statistics: sum dz and sum dz*yhat, dz = dout * act'(a*y + c),
@@ -136,66 +143,99 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ part, int R, int C, int rows_per_block,
                                                            int ldg, size_t g_bstride, float* __restrict__ dz_out) {
-  extern __shared__ float red[];
-  const StatsGeom gm = stats_geom(C);
+  __shared__ float red[2][ST_RL][4 * ST_CG];
   const int tid = threadIdx.x;
-  const int cg = tid % gm.CGT, rl = tid / gm.CGT;
-  const int q = blockIdx.y;
+  const int cg = tid & (ST_CG - 1), rl = tid >> 4;
+  const int cgi = blockIdx.y * ST_CG + cg;
+  const int q = blockIdx.z;
   y += (size_t)q * R * C; dout += (size_t)q * g_bstride;
   if (dz_out) dz_out += (size_t)q * R * C;
   a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C;
   part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(R, r0 + rows_per_block);
-  if (rl < gm.RL) {
-    for (int cgi = cg; cgi < gm.C4; cgi += gm.CGT) {
-      const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cgi);
-      const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cgi);
-      const float4 m4 = *reinterpret_cast<const float4*>(mean + 4 * cgi);
-      const float4 i4 = *reinterpret_cast<const float4*>(invstd + 4 * cgi);
-      float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+  if (cgi < (C >> 2)) {
+    const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cgi);
+    const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cgi);
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + 4 * cgi);
+    const float4 i4 = *reinterpret_cast<const float4*>(invstd + 4 * cgi);
 #pragma unroll 4
-      for (int r = r0 + rl; r < r1; r += gm.RL) {
-        const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)r * ldg + 4 * cgi);
-        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
-        float4 dz = g;
-        if (ACT == 1) {
-          dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
-          dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
-          *reinterpret_cast<float4*>(dz_out + (size_t)r * C + 4 * cgi) = dz;
-        }
-        s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
-        sq.x += dz.x * ((v.x - m4.x) * i4.x); sq.y += dz.y * ((v.y - m4.y) * i4.y);
-        sq.z += dz.z * ((v.z - m4.z) * i4.z); sq.w += dz.w * ((v.w - m4.w) * i4.w);
+    for (int r = r0 + rl; r < r1; r += ST_RL) {
+      const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)r * ldg + 4 * cgi);
+      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
+      float4 dz = g;
+      if (ACT == 1) {
+        dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
+        dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
+        *reinterpret_cast<float4*>(dz_out + (size_t)r * C + 4 * cgi) = dz;
       }
-      float* rr = red + (size_t)rl * 2 * C;
-      *reinterpret_cast<float4*>(rr + 4 * cgi) = s;
-      *reinterpret_cast<float4*>(rr + C + 4 * cgi) = sq;
+      s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
+      sq.x += dz.x * ((v.x - m4.x) * i4.x); sq.y += dz.y * ((v.y - m4.y) * i4.y);
+      sq.z += dz.z * ((v.z - m4.z) * i4.z); sq.w += dz.w * ((v.w - m4.w) * i4.w);
     }
   }
-  __syncthreads();
-  for (int i = tid; i < 2 * C; i += 256) {
-    float acc = 0.f;
-    for (int l = 0; l < gm.RL; ++l) acc += red[(size_t)l * 2 * C + i];
-    part[i] = acc;
-  }
+  stats_block_reduce(red, s, sq, cg, rl, part, C, blockIdx.y);
 }
 
-// sums[q][0][c], sums[q][1][c] = fixed-order (deterministic) double-precision reduction of the block partials.
-// 64 columns x 4 partial-lanes per workgroup; each lane sums every 4th partial with 8 loads in flight, the 4
+// sums[q][0][c], sums[q][1][c] = fixed-order (deterministic) double-precision reduction of the chunk partials.
+// 32 columns x 8 partial-lanes per workgroup; each lane sums every 8th partial with 8 loads in flight, the 8
 // lane sums are combined in a fixed order.  Optionally also scatters the two halves to out0/out1 ([nb][C]),
 // which is how the BN backward gets dbeta / dgamma.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ sums,
                                                               int nblk, int C2, float* __restrict__ out0,
                                                               float* __restrict__ out1) {
-  __shared__ double lane_sum[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int ln = threadIdx.x >> 6;
+  __shared__ double lane_sum[8][32];
+  const int t = threadIdx.x & 31;
+  const int col = blockIdx.x * 32 + t;
+  const int ln = threadIdx.x >> 5;
   const int q = blockIdx.y;
   double acc = 0.0;
   if (col < C2) {
     const float* p = part + (size_t)q * nblk * C2 + col;
     int b = ln;
+    for (; b + 56 < nblk; b += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + 8 * u) * C2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < nblk; b += 8) acc += (double)p[(size_t)b * C2];
+  }
+  lane_sum[ln][t] = acc;
+  __syncthreads();
+  if (ln == 0 && col < C2) {
+    double tot = lane_sum[0][t];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) tot += lane_sum[l][t];
+    const float r = (float)tot;
+    sums[(size_t)q * C2 + col] = r;
+    const int C = C2 >> 1;
+    if (out0) { if (col < C) out0[(size_t)q * C + col] = r; else out1[(size_t)q * C + col - C] = r; }
+  }
+}
+
+// Forward statistics: fixed-order reduction of the partials (sum and sum-of-squares of 32 channels per
+// workgroup, 4 lanes each) fused with the BN parameter computation of bn_finalize_kernel below.
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int nblk,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float* __restrict__ a,
+                                                              float* __restrict__ cs, float* __restrict__ mean,
+                                                              float* __restrict__ invstd, int R, int C, float momentum, float eps,
+                                                              long long* __restrict__ num_batches_tracked) {
+  __shared__ double lane_sum[8][32];
+  if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  const int t = threadIdx.x & 31;
+  const int ch = blockIdx.x * 32 + t;
+  const int ln = threadIdx.x >> 5;                 // lanes 0-3: sum (every 4th partial); lanes 4-7: sum of squares
+  const int q = blockIdx.y;
+  const int C2 = 2 * C;
+  double acc = 0.0;
+  if (ch < C) {
+    const float* p = part + (size_t)q * nblk * C2 + (ln >> 2) * C + ch;
+    int b = ln & 3;
     for (; b + 28 < nblk; b += 32) {
       float v[8];
 #pragma unroll
@@ -205,50 +245,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
     for (; b < nblk; b += 4) acc += (double)p[(size_t)b * C2];
   }
-  lane_sum[ln][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (ln == 0 && col < C2) {
-    const int t = threadIdx.x;
-    const float r = (float)(((lane_sum[0][t] + lane_sum[1][t]) + lane_sum[2][t]) + lane_sum[3][t]);
-    sums[(size_t)q * C2 + col] = r;
-    const int C = C2 >> 1;
-    if (out0) { if (col < C) out0[(size_t)q * C + col] = r; else out1[(size_t)q * C + col - C] = r; }
-  }
-}
-
-// Forward statistics: fixed-order reduction of the partials (sum and sum-of-squares of 64 channels per
-// workgroup, 2 lanes each) fused with the BN parameter computation of bn_finalize_kernel below.
-__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int nblk,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ bias, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var, float* __restrict__ a,
-                                                              float* __restrict__ cs, float* __restrict__ mean,
-                                                              float* __restrict__ invstd, int R, int C, float momentum, float eps,
-                                                              long long* __restrict__ num_batches_tracked) {
-  __shared__ double lane_sum[4][64];
-  if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-  const int t = threadIdx.x & 63;
-  const int ch = blockIdx.x * 64 + t;
-  const int ln = threadIdx.x >> 6;                 // lanes 0,1: sum (even / odd partials); lanes 2,3: sum of squares
-  const int q = blockIdx.y;
-  const int C2 = 2 * C;
-  double acc = 0.0;
-  if (ch < C) {
-    const float* p = part + (size_t)q * nblk * C2 + (ln >> 1) * C + ch;
-    int b = ln & 1;
-    for (; b + 14 < nblk; b += 16) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + 2 * u) * C2];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; b < nblk; b += 2) acc += (double)p[(size_t)b * C2];
-  }
   lane_sum[ln][t] = acc;
   __syncthreads();
   if (ln != 0 || ch >= C) return;
-  const double S = lane_sum[0][t] + lane_sum[1][t], Q = lane_sum[2][t] + lane_sum[3][t];
+  const double S = (lane_sum[0][t] + lane_sum[1][t]) + (lane_sum[2][t] + lane_sum[3][t]);
+  const double Q = (lane_sum[4][t] + lane_sum[5][t]) + (lane_sum[6][t] + lane_sum[7][t]);
   const size_t o = (size_t)q * C + ch;
   const double m = S / R;
   double var = Q / R - m * m;
@@ -383,25 +384,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
 
 using namespace gkg;
 
-static int stats_blocks(int R, int nb, int* rows_per_block) {
-  int nblk = (R + 31) / 32;                  // >= 32 rows per block
-  const int cap = nb > 1 ? 128 : 256;
+static int stats_tiles(int C) { return ((C >> 2) + ST_CG - 1) / ST_CG; }
+
+// Row chunks: enough workgroups (chunks x column tiles x nb) for ~3 per CU, at least ST_RL rows each, and at
+// most 128 (256 for narrow matrices) partial rows for the second stage to reduce.
+static int stats_blocks(int R, int C, int nb, int* rows_per_block) {
+  const int cols = stats_tiles(C) * nb;
+  int nblk = (768 + cols - 1) / cols;
+  const int cap = cols >= 4 ? 128 : 256;
   if (nblk > cap) nblk = cap;
+  const int by_rows = (R + ST_RL - 1) / ST_RL;
+  if (nblk > by_rows) nblk = by_rows;
   if (nblk < 1) nblk = 1;
   *rows_per_block = (R + nblk - 1) / nblk;
   return (R + *rows_per_block - 1) / *rows_per_block;
 }
 
 static bool bad_c(int C) { return C <= 0 || (C & 3) != 0 || C > 4096; }
-static size_t stats_lds(int C) {
-  const int C4 = C >> 2, CGT = C4 < 256 ? C4 : 256, RL = 256 / CGT;
-  return (size_t)RL * 2 * C * sizeof(float);
-}
 
 extern "C" size_t gkg_bn_workspace_bytes(int R, int C, int nb) {
   if (R <= 0 || bad_c(C) || nb <= 0) return 0;
   int rpb;
-  const int nblk = stats_blocks(R, nb, &rpb);
+  const int nblk = stats_blocks(R, C, nb, &rpb);
   return (size_t)nb * (nblk + 1) * 2 * C * sizeof(float);
 }
 
@@ -433,14 +437,14 @@ extern "C" int gkg_bn_train_stats(const float* y, const float* gamma, const floa
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_train_stats: need R > 0, C % 4 == 0, C <= 4096, 1 <= nb <= 64");
   if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_train_stats: running stats come in pairs");
   int rpb;
-  const int nblk = stats_blocks(R, nb, &rpb);
+  const int nblk = stats_blocks(R, C, nb, &rpb);
   if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float))
     return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_train_stats: workspace too small (gkg_bn_workspace_bytes)");
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   float* sums = part + (size_t)nb * nblk * 2 * C;
-  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, nb), dim3(256), stats_lds(C), st, y, part, R, C, rpb);
-  hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, st, part, nblk, gamma, beta, bias,
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, y, part, R, C, rpb);
+  hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, nb), dim3(256), 0, st, part, nblk, gamma, beta, bias,
                      running_mean, running_var, a, c, mean, invstd, R, C, momentum, eps, num_batches_tracked);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_train_stats");
@@ -477,18 +481,17 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd: bad sizes");
   int rpb;
-  const int nblk = stats_blocks(R, nb, &rpb);
+  const int nblk = stats_blocks(R, C, nb, &rpb);
   if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float)) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   float* sums = part + (size_t)nb * nblk * 2 * C;
-  const size_t lds = stats_lds(C);
   // With an activation the statistics pass also stores dz = dout*act'(z) into `dy`; the apply pass then runs in
   // place on it, so erf/exp are evaluated once per element in the whole backward.
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dy);
-  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, nb), dim3(256), lds, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dy);
+  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
   // dbeta[q] = sum dz ; dgamma[q] = sum dz*yhat
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 31) / 32, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
   if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dy, y, a, c, mean, invstd, sums, dy, total4, C, R, C, (size_t)R * C);

@@ -74,6 +74,34 @@ def to_token_major(x):
     return _ToTokenMajor.apply(x)
 
 
+class _BlockEntry(torch.autograd.Function):
+    """x (B, C, *spatial) -> (x_tm (B*N, C), x): a block's token-major input and its residual branch leave ONE
+    autograd node, so the backward receives both incoming gradients together and adds them inside the layout
+    kernel (instead of a separate layout pass followed by autograd's elementwise accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C = x.shape[:2]
+        N = x[0, 0].numel()
+        out = torch.empty((B * N, C), dtype=_F32, device=x.device)
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _stream()), "gkg_nchw_to_tm")
+        ctx.shape = tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_tm, g_res):
+        if g_tm is None:
+            return g_res
+        B, C = ctx.shape[:2]
+        N = g_tm.shape[0] // B
+        res = None if g_res is None else g_res.contiguous()
+        out = torch.empty(ctx.shape, dtype=_F32, device=g_tm.device)
+        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g_tm.contiguous()), None, None, _ptr(res), _ptr(out), B, C, N,
+                                                     _stream()), "gkg_tm_affine_to_nchw")
+        return out
+
+
 # ----------------------------------------------------------------------------------------------- BN helpers
 def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
     """Returns (a, c, mean, invstd) for out = a*Y + c; updates running statistics in train mode."""
@@ -306,8 +334,7 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     B, C, H, W = x.shape
     N = H * W
     gc = mod.graph_conv
-    x = x.float().contiguous()
-    xt = to_token_major(x)                                          # (T, C)
+    xt, x = _BlockEntry.apply(x.float().contiguous())              # (T, C) and the residual branch
     x1 = _lin(xt, mod.fc1)                                          # fc1 + BN
     x1b = x1.view(B, N, C)
     yb = None
@@ -359,7 +386,6 @@ def ffn_supported(mod, x) -> bool:
 
 def ffn_forward(mod, x):
     """reference gkgnet.py:66-72 on token-major activations: two library GEMMs + the BN/GELU/residual kernels."""
-    x = x.float().contiguous()
-    xt = to_token_major(x)
+    xt, x = _BlockEntry.apply(x.float().contiguous())
     h = _lin(xt, mod.fc1, act=1)
     return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape))
