@@ -176,6 +176,25 @@ def main():
             graph.replay()
         bucket.all_reduce()
 
+    if graph is not None and world > 1:
+        # Multi-rank guard (untimed): replay + collective must actually beat eager launches + collective on this
+        # node's runtime; if it does not (the ranks decide together), fall back to eager launches.
+        def timed(fn, n=4):
+            fn()
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / n
+        t_cmp = torch.tensor([timed(step), timed(eager_step)], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t_cmp, op=torch.distributed.ReduceOp.MAX)
+        if t_cmp[0].item() > t_cmp[1].item():
+            print(f"[bench] hipGraph replay slower than eager launches under this process group "
+                  f"({1e3 * t_cmp[0].item():.2f} vs {1e3 * t_cmp[1].item():.2f} ms/step); running eagerly", file=sys.stderr)
+            graph = None
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -20,11 +20,15 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GKG_DIST_BACKEND") == "gloo" and torch.cuda.is_available():
+        local %= torch.cuda.device_count()             # ranks may share a device in the single-GPU exercise
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GKG_DIST_BACKEND=gloo lets a multi-rank run share ONE GPU (RCCL refuses duplicate devices): used to
+            # exercise the N>1 control flow on a single-GPU box; production is RCCL.
+            backend = os.environ.get("GKG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
