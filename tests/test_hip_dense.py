@@ -17,7 +17,9 @@ def _bn(C):
 
 
 @pytest.mark.parametrize("R,cin,cout,act,with_res", [(1000, 64, 32, 0, False), (777, 32, 64, 1, True),
-                                                     (2560, 320, 1280, 1, False), (2560, 1280, 320, 0, True)])
+                                                     (2560, 320, 1280, 1, False), (2560, 1280, 320, 0, True),
+                                                     (10368, 320, 320, 0, False), (4100, 36, 40, 1, True),
+                                                     (19, 16, 8, 1, False)])
 def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res):
     from gkgnet_amd import fused
     torch.manual_seed(0)
