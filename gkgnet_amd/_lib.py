@@ -10,7 +10,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16 = 0, 1
 KNN_NORMALIZE = 1
 
@@ -54,11 +54,11 @@ def load():
     lib.gkg_knn_fwd_tm.restype = I
     lib.gkg_knn_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V, Z, V]
     lib.gkg_mr_fwd_tm.restype = I
-    lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 7 + [V]
+    lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [V]
     lib.gkg_mr_bwd_tm.restype = I
     lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 7 + [V]
     lib.gkg_nchw_to_tm.restype = I
-    lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, V]
+    lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, I, V]
     lib.gkg_tm_affine_to_nchw.restype = I
     lib.gkg_tm_affine_to_nchw.argtypes = [V] * 5 + [I, I, I, V]
     lib.gkg_bn_workspace_bytes.restype = Z
@@ -68,7 +68,7 @@ def load():
     lib.gkg_bn_eval_affine.restype = I
     lib.gkg_bn_eval_affine.argtypes = [V] * 7 + [I, F, V]
     lib.gkg_affine_act.restype = I
-    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, V]
+    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, I, V]
     lib.gkg_bn_bwd.restype = I
     lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_prof_enable.restype = None

@@ -17,6 +17,15 @@ __device__ __forceinline__ void stf(uint16_t* p, float v) {
   *p = __builtin_bit_cast(uint16_t, b);
 }
 
+// 4 consecutive features: one 16-byte (fp32) or 8-byte (bf16, round-to-nearest-even) store.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+}
+__device__ __forceinline__ void stf4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stf4(uint16_t* p, const float4& v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+
 }  // namespace gkg
 
 // Records the message for gkg_last_error_string() and returns `code`.

@@ -25,7 +25,8 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 
 // ------------------------------------------------------------------------------------------ layout
 // (B, C, N) channel-major -> (B*N, C) token-major through a padded 32x32 LDS tile (coalesced both sides).
-__global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict__ x, float* __restrict__ out,
+template <typename OutT>
+__global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict__ x, OutT* __restrict__ out,
                                                          int C, int N) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, ch = c0 + tx;
-    if (ch < C && n < N) out[((size_t)b * N + n) * C + ch] = tile[tx][ty + 8 * i];
+    if (ch < C && n < N) stf(out + ((size_t)b * N + n) * C + ch, tile[tx][ty + 8 * i]);
   }
 }
 
@@ -316,10 +317,10 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
 // ------------------------------------------------------------------------------------------ apply
 // out[r][c] = act(a[c]*y[r][c] + cs[c]) (+ res[r][c]); out may have a different row pitch / column offset
 // (ldo, used to write the grouped conv's output straight into the next layer's (T, 2C) input).
-template <int ACT>
+template <int ACT, typename OutT>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ y, const float* __restrict__ a,
                                                          const float* __restrict__ cs, const float* __restrict__ res,
-                                                         float* __restrict__ out, size_t total4, int C, int ldo,
+                                                         OutT* __restrict__ out, size_t total4, int C, int ldo,
                                                          size_t o_bstride) {
   const int C4 = C >> 2;
   const int q = blockIdx.y;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       const float4 rv = *reinterpret_cast<const float4*>(res + 4 * i);
       o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
-    *reinterpret_cast<float4*>(out + r * (size_t)ldo + 4 * cg) = o;
+    stf4(out + r * (size_t)ldo + 4 * cg, o);
   }
 }
 
@@ -409,11 +410,13 @@ extern "C" size_t gkg_bn_workspace_bytes(int R, int C, int nb) {
   return (size_t)nb * (nblk + 1) * 2 * C * sizeof(float);
 }
 
-extern "C" int gkg_nchw_to_tm(const float* x, float* out, int B, int C, int N, void* stream) {
+extern "C" int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype, void* stream) {
   if (!x || !out) return gkg_fail(GKG_ERR_NULL, "gkg_nchw_to_tm: null pointer");
   if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_nchw_to_tm: bad sizes");
+  if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_nchw_to_tm: out_dtype is GKG_F32 or GKG_BF16");
   dim3 grid((N + 31) / 32, (C + 31) / 32, B);
-  hipLaunchKernelGGL(nchw_to_tm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, N);
+  if (out_dtype == GKG_BF16) hipLaunchKernelGGL(nchw_to_tm_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)out, C, N);
+  else hipLaunchKernelGGL(nchw_to_tm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)out, C, N);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "nchw_to_tm_kernel");
 }
@@ -460,15 +463,25 @@ extern "C" int gkg_bn_eval_affine(const float* gamma, const float* beta, const f
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_eval_affine_kernel");
 }
 
-extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, float* out, int R, int C,
-                              int nb, int ldo, size_t out_bstride, int act, void* stream) {
+extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
+                              int nb, int ldo, size_t out_bstride, int act, int out_dtype, void* stream) {
   if (!y || !a || !c || !out) return gkg_fail(GKG_ERR_NULL, "gkg_affine_act: null pointer");
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldo < C || (ldo & 3) || (out_bstride & 3) || (act != 0 && act != 1))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: bad sizes");
+  if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_affine_act: out_dtype is GKG_F32 or GKG_BF16");
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1>), dim3(blocks, nb), dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, total4, C, ldo, out_bstride);
-  else hipLaunchKernelGGL((affine_act_kernel<0>), dim3(blocks, nb), dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, total4, C, ldo, out_bstride);
+  const dim3 grid(blocks, nb);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == GKG_BF16) {
+    uint16_t* o = (uint16_t*)out;
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
+    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
+  } else {
+    float* o = (float*)out;
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");
 }

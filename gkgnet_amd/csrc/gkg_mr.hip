@@ -217,10 +217,11 @@ __global__ __launch_bounds__(256) void negate_kernel(const float* __restrict__ g
 //   mode 0: m (B,N,C) token-major.
 //   mode 1: the grouped 1x1 projection's input directly, U[q][t][2i] = x[t][q*C/4+i], U[q][t][2i+1] = m[...]
 //           (reference interleave torch_vertex.py:57-61 + Conv2d(groups=4) channel split torch_nn.py:61).
-template <int KS, int QP>   // KS: compile-time k (all k index loads and row gathers issued up front);
+template <int KS, int QP, typename OutT = float>   // KS: compile-time k (all k index loads and row gathers issued up front);
                             // QP: channel quads per thread (share one index row; QP*4 channels stay inside a group)
+                            // OutT: element type of `out` (float, or uint16_t = bf16 for the grouped GEMM's operand)
 __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
-                                                        const int64_t* __restrict__ nn_idx, float* __restrict__ out,
+                                                        const int64_t* __restrict__ nn_idx, OutT* __restrict__ out,
                                                         uint8_t* __restrict__ argmax, int B, int G, int c, int N, int M,
                                                         int k_rt, int mode) {
   const int k = KS > 0 ? KS : k_rt;
@@ -270,13 +271,13 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
     const int chq = ch + 4 * q;
     if (argmax) *reinterpret_cast<uint32_t*>(argmax + t * C + chq) = arg[q];
     if (mode == 0) {
-      *reinterpret_cast<float4*>(out + t * C + chq) = best[q];
+      stf4(out + t * C + chq, best[q]);
     } else {
       const int Cq = C >> 2;                      // original channels per conv group
       const int qc = chq / Cq, il = chq - qc * Cq;   // 4 channels never straddle a conv group (C % 16 == 0)
-      float* o = out + ((size_t)qc * T + t) * (size_t)(2 * Cq) + 2 * il;
-      *reinterpret_cast<float4*>(o) = make_float4(xi[q].x, best[q].x, xi[q].y, best[q].y);
-      *reinterpret_cast<float4*>(o + 4) = make_float4(xi[q].z, best[q].z, xi[q].w, best[q].w);
+      OutT* o = out + ((size_t)qc * T + t) * (size_t)(2 * Cq) + 2 * il;
+      stf4(o, make_float4(xi[q].x, best[q].x, xi[q].y, best[q].y));
+      stf4(o + 4, make_float4(xi[q].z, best[q].z, xi[q].w, best[q].w));
     }
   }
 }
@@ -506,12 +507,13 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
 }
 
 // ------------------------------------------------------------------------------------------ token-major entry points
-extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, float* out, uint8_t* argmax,
-                             int B, int G, int c, int N, int M, int k, int mode, void* stream) {
+extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out, uint8_t* argmax,
+                             int B, int G, int c, int N, int M, int k, int mode, int out_dtype, void* stream) {
   if (!x || !nn_idx || !out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_fwd_tm: x, nn_idx and out must be non-null");
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: bad sizes (c % 4 == 0, k <= 255)");
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode is 0 or 1");
   if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode 1 needs C % 16 == 0");
+  if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: out_dtype is GKG_F32 or GKG_BF16");
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
   GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
   const size_t total = (size_t)B * N * (G * c / 4);
@@ -519,8 +521,15 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   // wants more threads in flight, not fewer index loads
   const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1>), grid, dim3(256), 0, st, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
-  else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1>), grid, dim3(256), 0, st, x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode);
+  if (out_dtype == GKG_BF16) {
+    uint16_t* o = (uint16_t*)out;
+    if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
+    else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
+  } else {
+    float* o = (float*)out;
+    if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
+    else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
 }

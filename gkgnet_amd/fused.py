@@ -45,6 +45,38 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+def lowp_inference() -> bool:
+    """bf16 autocast with gradients off: intermediates that only feed a projection GEMM (the block's token-major
+    input, the aggregated [x, m] operand, FFN hidden activations) are written as bf16 by the producing kernel, and the
+    GEMMs return fp32 directly (``out_dtype``) — no stand-alone cast kernels, half the bytes on those tensors."""
+    return (not torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+_W16 = {}           # id(weight) -> (version, data_ptr, bf16 copy): eval-time weights are cast once
+
+
+def _w16(w: torch.Tensor) -> torch.Tensor:
+    ent = _W16.get(id(w))
+    if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
+        if len(_W16) > 4096:
+            _W16.clear()
+        ent = _W16[id(w)] = (w._version, w.data_ptr(), w.detach().to(torch.bfloat16))
+    return ent[2]
+
+
+def _mm_t(x, W):
+    """x (R, cin) @ W (cout, cin)^T -> fp32 (R, cout).  bf16 ``x``: bf16 operands, fp32 accumulate AND fp32 result."""
+    if x.dtype == torch.bfloat16:
+        return torch.mm(x, _w16(W).t(), out_dtype=_F32)
+    Y = torch.mm(x, W.t())               # under autocast: bf16 operands, fp32 accumulate
+    return Y if Y.dtype == _F32 else Y.float()
+
+
+def _tm_dtype(lowp: bool):
+    return (torch.bfloat16, _lib.BF16) if lowp else (_F32, _lib.F32)
+
+
 # ----------------------------------------------------------------------------------------------- layout
 class _ToTokenMajor(torch.autograd.Function):
     """(B, C, *spatial) -> (B*N, C)."""
@@ -55,7 +87,7 @@ class _ToTokenMajor(torch.autograd.Function):
         N = x[0, 0].numel()
         x = x.contiguous()
         out = torch.empty((B * N, C), dtype=_F32, device=x.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _stream()), "gkg_nchw_to_tm")
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _lib.F32, _stream()), "gkg_nchw_to_tm")
         ctx.shape = tuple(x.shape)
         return out
 
@@ -80,11 +112,12 @@ class _BlockEntry(torch.autograd.Function):
     kernel (instead of a separate layout pass followed by autograd's elementwise accumulation)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, lowp=False):
         B, C = x.shape[:2]
         N = x[0, 0].numel()
-        out = torch.empty((B * N, C), dtype=_F32, device=x.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _stream()), "gkg_nchw_to_tm")
+        dt, code = _tm_dtype(lowp)
+        out = torch.empty((B * N, C), dtype=dt, device=x.device)
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, code, _stream()), "gkg_nchw_to_tm")
         ctx.shape = tuple(x.shape)
         ctx.set_materialize_grads(False)
         return out, x.view_as(x)
@@ -92,14 +125,14 @@ class _BlockEntry(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_tm, g_res):
         if g_tm is None:
-            return g_res
+            return g_res, None
         B, C = ctx.shape[:2]
         N = g_tm.shape[0] // B
         res = None if g_res is None else g_res.contiguous()
         out = torch.empty(ctx.shape, dtype=_F32, device=g_tm.device)
         _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g_tm.contiguous()), None, None, _ptr(res), _ptr(out), B, C, N,
                                                      _stream()), "gkg_tm_affine_to_nchw")
-        return out
+        return out, None
 
 
 # ----------------------------------------------------------------------------------------------- BN helpers
@@ -133,20 +166,19 @@ class _LinearBNAct(torch.autograd.Function):
     residual) in (B, C, N) layout — the block's last layer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False):
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
         W = weight.view(cout, cin)
-        Y = torch.mm(x, W.t())              # under autocast: bf16 operands, fp32 accumulate
-        if Y.dtype != _F32:
-            Y = Y.float()
+        Y = _mm_t(x, W)
         a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
         if nchw is None:
-            out = torch.empty((R, cout), dtype=_F32, device=x.device)
+            dt, code = _tm_dtype(out_lowp)
+            out = torch.empty((R, cout), dtype=dt, device=x.device)
             res = None if residual is None else residual.contiguous()
             _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
-                                          _stream()), "gkg_affine_act")
+                                          code, _stream()), "gkg_affine_act")
         else:
             assert act == 0
             B = nchw[0]
@@ -168,8 +200,8 @@ class _LinearBNAct(torch.autograd.Function):
         dres = dout if has_res else None
         if nchw is not None:
             g = torch.empty((R, cout), dtype=_F32, device=dout.device)
-            _lib.check(lib.gkg_nchw_to_tm(_ptr(dout.contiguous()), _ptr(g), nchw[0], cout, R // nchw[0], _stream()),
-                       "gkg_nchw_to_tm")
+            _lib.check(lib.gkg_nchw_to_tm(_ptr(dout.contiguous()), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32,
+                                          _stream()), "gkg_nchw_to_tm")
         else:
             g = dout.contiguous()
         if mean is None:
@@ -186,7 +218,7 @@ class _LinearBNAct(torch.autograd.Function):
         W = weight.view(cout, cin)
         dx = torch.mm(dY, W)
         dW = _wgrad(dY, x).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -194,19 +226,23 @@ class _GroupedLinearBNAct(torch.autograd.Function):
     U (4, R, ci) group-major -> out (R, 4*co) token-major (column q*co + j)."""
 
     @staticmethod
-    def forward(ctx, U, weight, bias, gamma, beta, bn, act):
+    def forward(ctx, U, weight, bias, gamma, beta, bn, act, out_lowp=False):
         lib = _lib.load()
         nb, R, ci = U.shape
         cout = weight.shape[0]
         co = cout // nb
         Wg = weight.view(nb, co, ci)
-        Y = torch.bmm(U, Wg.transpose(1, 2))                           # (nb, R, co)
-        if Y.dtype != _F32:
-            Y = Y.float()
+        if U.dtype == torch.bfloat16:
+            Y = torch.bmm(U, _w16(weight).view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
+        else:
+            Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
+            if Y.dtype != _F32:
+                Y = Y.float()
         a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
-        out = torch.empty((R, cout), dtype=_F32, device=U.device)
+        dt, code = _tm_dtype(out_lowp)
+        out = torch.empty((R, cout), dtype=dt, device=U.device)
         _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
-                                      _stream()), "gkg_affine_act")
+                                      code, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         return out
@@ -232,7 +268,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         Wg = weight.view(nb, co, ci)
         dU = torch.bmm(dY, Wg)
         dW = torch.bmm(dY.transpose(1, 2), U).view_as(weight)
-        return dU, dW, None, dgamma, dbeta, None, None      # dbias == 0 exactly (see _LinearBNAct)
+        return dU, dW, None, dgamma, dbeta, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 
 # ----------------------------------------------------------------------------------------------- graph ops
@@ -258,17 +294,18 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
 
 class _MaxRelativeTM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, src, nn_idx, G, mode):
+    def forward(ctx, x, src, nn_idx, G, mode, out_lowp=False):
         lib = _lib.load()
         B, N, C = x.shape
         M = N if src is None else src.shape[1]
         k = nn_idx.shape[2]
         T = B * N
-        out = torch.empty((4, T, C // 2) if mode == 1 else (B, N, C), dtype=_F32, device=x.device)
+        dt, code = _tm_dtype(out_lowp)
+        out = torch.empty((4, T, C // 2) if mode == 1 else (B, N, C), dtype=dt, device=x.device)
         need = any(ctx.needs_input_grad[:2])
         arg = torch.empty((B, N, C), dtype=torch.uint8, device=x.device) if need else None
         _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
-                                     _stream()), "gkg_mr_fwd_tm")
+                                     code, _stream()), "gkg_mr_fwd_tm")
         ctx.save_for_backward(nn_idx, arg)
         ctx.meta = (B, G, C, N, M, k, mode, src is not None)
         return out
@@ -283,7 +320,7 @@ class _MaxRelativeTM(torch.autograd.Function):
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode,
                                      _stream()), "gkg_mr_bwd_tm")
-        return gx, gsrc, None, None, None
+        return gx, gsrc, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------- block drivers
@@ -324,9 +361,9 @@ def fused_supported(mod, x, groups: int) -> bool:
     return ENABLED
 
 
-def _lin(x, seq, act=0, residual=None, nchw=None):
+def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False):
     conv, bn = seq[0], seq[1]
-    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw)
+    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp)
 
 
 def grapher_forward(mod, x, relative_pos, groups: int):
@@ -334,7 +371,8 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     B, C, H, W = x.shape
     N = H * W
     gc = mod.graph_conv
-    xt, x = _BlockEntry.apply(x.float().contiguous())              # (T, C) and the residual branch
+    lp = lowp_inference()
+    xt, x = _BlockEntry.apply(x.float().contiguous(), lp)          # (T, C) and the residual branch
     x1 = _lin(xt, mod.fc1)                                          # fc1 + BN
     x1b = x1.view(B, N, C)
     yb = None
@@ -342,9 +380,9 @@ def grapher_forward(mod, x, relative_pos, groups: int):
         pooled = F.avg_pool2d(x1.view(B, H, W, C).permute(0, 3, 1, 2), gc.r, gc.r)
         yb = pooled.permute(0, 2, 3, 1).reshape(B, -1, C)
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
-    U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1)           # (4, T, C/2) interleaved [x, m]
+    U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1, lp)       # (4, T, C/2) interleaved [x, m]
     nn_ = gc.gconv.nn
-    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1)   # (T, 2C)
+    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp)   # (T, 2C)
     out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W))          # fc2 + BN + residual, back to NCHW
     return out, edge
 
@@ -358,11 +396,12 @@ def grapher_label_forward(mod, e, features, groups: int):
     x1 = _lin(e2, mod.fc1)
     x1b = x1.view(B, L, C)
     edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
-    U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1)
+    lp = lowp_inference()
+    U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1, lp)
     nn_ = gc.gconv.nn
-    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1)
+    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp)
     h2 = _lin(a2, mod.fc2, residual=e2)
-    f1 = _lin(h2, mod.ffn.fc1, act=1)
+    f1 = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp)
     out = _lin(f1, mod.ffn.fc2, residual=h2)
     return out.view(B, L, C), edge
 
@@ -386,6 +425,7 @@ def ffn_supported(mod, x) -> bool:
 
 def ffn_forward(mod, x):
     """reference gkgnet.py:66-72 on token-major activations: two library GEMMs + the BN/GELU/residual kernels."""
-    xt, x = _BlockEntry.apply(x.float().contiguous())
-    h = _lin(xt, mod.fc1, act=1)
+    lp = lowp_inference()
+    xt, x = _BlockEntry.apply(x.float().contiguous(), lp)
+    h = _lin(xt, mod.fc1, act=1, out_lowp=lp)
     return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape))

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 1
+#define GKG_ABI_VERSION 2
 
 /* dtype codes */
 #define GKG_F32 0
@@ -114,8 +114,8 @@ int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void
 int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
-int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, float* out, uint8_t* argmax,
-                  int B, int G, int c, int N, int M, int k, int mode, void* stream);
+int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out /* out_dtype elements */,
+                  uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, void* stream);
 int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
                   int B, int G, int c, int N, int M, int k, int mode, void* stream);
 
@@ -125,7 +125,8 @@ int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax
  * caller in the vendor library on token-major (rows = tokens) fp32 matrices.  `nb` stacks nb independent
  * (R, C) matrices (the 4 groups of the grouped projection) with parameters laid out [nb][C].
  */
-int gkg_nchw_to_tm(const float* x, float* out, int B, int C, int N, void* stream);          /* (B,C,N) -> (B*N,C) */
+/* (B,C,N) fp32 -> (B*N,C) in out_dtype (GKG_F32, or GKG_BF16 when the result only feeds a bf16 GEMM) */
+int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype, void* stream);
 /* out(B,C,N) = a[ch]*y[t][ch] + c[ch] + res(B,C,N); a/c and res optional (NULL) */
 int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
                           int B, int C, int N, void* stream);
@@ -140,9 +141,10 @@ int gkg_bn_train_stats(const float* y, const float* gamma, const float* beta, co
 /* Eval mode: a = gamma/sqrt(rv+eps), c = beta + a*(bias - rm) */
 int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias, const float* running_mean,
                        const float* running_var, float* a, float* c, int C, float eps, void* stream);
-/* out = act(a*y + c) (+ res); act 0 = identity, 1 = GELU(erf).  out[q] has row pitch ldo and batch stride out_bstride */
-int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, float* out, int R, int C,
-                   int nb, int ldo, size_t out_bstride, int act, void* stream);
+/* out = act(a*y + c) (+ res); act 0 = identity, 1 = GELU(erf).  out[q] has row pitch ldo and batch stride out_bstride
+ * (both in elements of out_dtype: GKG_F32, or GKG_BF16 = round-to-nearest-even of the fp32 result) */
+int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
+                   int nb, int ldo, size_t out_bstride, int act, int out_dtype, void* stream);
 /* Backward of out = act(BN_train(y)): dy, dgamma, dbeta from dout (row pitch ldg, batch stride dout_bstride). */
 int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,

@@ -113,3 +113,38 @@ def test_layout_round_trip_and_token_major_graph_ops():
     for q in range(4):
         assert torch.equal(U[q][:, 0::2], xtm.reshape(B * N, C)[:, q * Cq:(q + 1) * Cq])
         assert torch.equal(U[q][:, 1::2], m_tm.reshape(B * N, C)[:, q * Cq:(q + 1) * Cq])
+
+
+def test_bf16_outputs_are_the_rounded_fp32_outputs():
+    """Inference under bf16 autocast writes GEMM-only intermediates as bf16 from the producing kernel: each must equal
+    the fp32 result rounded to nearest-even, bit for bit (layout kernel, BN-apply(+GELU), aggregation operand)."""
+    from gkgnet_amd import fused
+    torch.manual_seed(3)
+    B, C, H, G, k = 3, 64, 10, 4, 9
+    N = H * H
+    x = torch.randn(B, C, H, H, device="cuda")
+    with torch.no_grad():
+        t32, _ = fused._BlockEntry.apply(x, False)
+        t16, _ = fused._BlockEntry.apply(x, True)
+        assert t16.dtype == torch.bfloat16 and torch.equal(t16, t32.to(torch.bfloat16))
+        assert torch.equal(t32.view(B, N, C), x.flatten(2).transpose(1, 2))
+        # BN(eval)+GELU apply
+        conv = torch.nn.Conv2d(C, 2 * C, 1).cuda()
+        bn = _bn(2 * C).eval()
+        o32 = fused._LinearBNAct.apply(t32, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 1, None, False)
+        o16 = fused._LinearBNAct.apply(t32, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 1, None, True)
+        assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.to(torch.bfloat16))
+        ref = F.gelu(bn(conv(x))).flatten(2).transpose(1, 2).reshape(B * N, 2 * C)
+        assert torch.allclose(o32, ref, atol=2e-5, rtol=1e-4)
+        # aggregation operand U (4, T, C/2) = interleaved [x, max-relative]
+        xb = t32.view(B, N, C)
+        edge = fused.knn_graph_tm(xb, None, None, k, 1, G)
+        for kk in (9, 5):                                     # specialised k = 9 and the generic-k kernel
+            idx = edge[0][..., :kk].contiguous()
+            u32 = fused._MaxRelativeTM.apply(xb, None, idx, G, 1, False)
+            u16 = fused._MaxRelativeTM.apply(xb, None, idx, G, 1, True)
+            assert u16.dtype == torch.bfloat16 and torch.equal(u16, u32.to(torch.bfloat16))
+        # bf16 operands with fp32 result: same GEMM as an fp32 product of the rounded operands (fp32 accumulation)
+        y = fused._mm_t(t16, conv.weight.view(2 * C, C))
+        want = t16.float() @ conv.weight.view(2 * C, C).to(torch.bfloat16).float().t()
+        assert y.dtype == torch.float32 and torch.allclose(y, want, atol=1e-3, rtol=1e-3)

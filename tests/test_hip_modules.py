@@ -164,6 +164,37 @@ def test_autocast_bf16_fused_vs_composable():
     assert (out_f.float() - out_c.float()).abs().mean().item() < 3e-2 * scale
 
 
+def test_autocast_bf16_label_module_and_ffn_inference():
+    """Inference under bf16 autocast (bf16 GEMM-only intermediates written by the producing kernels, fp32 results
+    straight from the GEMMs): GrapherLabel and the backbone FFN stay close to their fp32 outputs, and the fused and
+    composable paths pick (almost) the same label graph."""
+    from gkgnet_amd import fused
+    from gkgnet_amd.backbone import FFN
+    meta, a = load_fixture("f5_label_g2")
+    mod = make_label(meta)
+    mod.load_state_dict(state_from(a))
+    mod.cuda().eval()
+    e, feat = _t(a["e"]), _t(a["feat"])
+    with torch.no_grad():
+        ref, idx_ref = mod(e, feat)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert fused.lowp_inference()
+            out, idx = mod(e, feat)
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().mean().item() < 2e-2 * scale
+    assert (idx == idx_ref).float().mean().item() > 0.9
+    torch.manual_seed(0)
+    ffn = FFN(64, 256, act="gelu").cuda().eval()
+    x = torch.randn(2, 64, 12, 12, device="cuda")
+    with torch.no_grad():
+        r32 = ffn(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            r16 = ffn(x)
+    assert r16.dtype == torch.float32
+    assert (r16 - r32).abs().max().item() < 5e-2 * r32.abs().max().item()
+
+
 def test_cfg2_full_size_grapher_and_label_vs_oracle():
     """BASELINE config 2 at FULL size (B=32, C=320, 18x18, k=9, G=4, +80 label tokens): fused fwd+bwd on the GPU against
     the CPU oracle with the same weights and inputs.
