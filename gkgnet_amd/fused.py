@@ -53,22 +53,22 @@ def lowp_inference() -> bool:
             and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
-_W16 = {}           # id(weight) -> (version, data_ptr, bf16 copy): eval-time weights are cast once
-
-
-def _w16(w: torch.Tensor) -> torch.Tensor:
-    ent = _W16.get(id(w))
+def _w16_of(conv) -> torch.Tensor:
+    """bf16 copy of a projection's weight, cached ON the module (inference: cast once, not per call) and refreshed
+    whenever the parameter is updated in place or replaced."""
+    w = conv.weight
+    ent = getattr(conv, "_gkg_w16", None)
     if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
-        if len(_W16) > 4096:
-            _W16.clear()
-        ent = _W16[id(w)] = (w._version, w.data_ptr(), w.detach().to(torch.bfloat16))
+        ent = (w._version, w.data_ptr(), w.detach().to(torch.bfloat16))
+        conv._gkg_w16 = ent
     return ent[2]
 
 
-def _mm_t(x, W):
+def _mm_t(x, W, W16=None):
     """x (R, cin) @ W (cout, cin)^T -> fp32 (R, cout).  bf16 ``x``: bf16 operands, fp32 accumulate AND fp32 result."""
     if x.dtype == torch.bfloat16:
-        return torch.mm(x, _w16(W).t(), out_dtype=_F32)
+        Wb = W.to(torch.bfloat16) if W16 is None else W16.view(W.shape)
+        return torch.mm(x, Wb.t(), out_dtype=_F32)
     Y = torch.mm(x, W.t())               # under autocast: bf16 operands, fp32 accumulate
     return Y if Y.dtype == _F32 else Y.float()
 
@@ -166,12 +166,12 @@ class _LinearBNAct(torch.autograd.Function):
     residual) in (B, C, N) layout — the block's last layer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None):
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
         W = weight.view(cout, cin)
-        Y = _mm_t(x, W)
+        Y = _mm_t(x, W, w16)
         a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
         if nchw is None:
             dt, code = _tm_dtype(out_lowp)
@@ -218,7 +218,7 @@ class _LinearBNAct(torch.autograd.Function):
         W = weight.view(cout, cin)
         dx = torch.mm(dY, W)
         dW = _wgrad(dY, x).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -226,14 +226,15 @@ class _GroupedLinearBNAct(torch.autograd.Function):
     U (4, R, ci) group-major -> out (R, 4*co) token-major (column q*co + j)."""
 
     @staticmethod
-    def forward(ctx, U, weight, bias, gamma, beta, bn, act, out_lowp=False):
+    def forward(ctx, U, weight, bias, gamma, beta, bn, act, out_lowp=False, w16=None):
         lib = _lib.load()
         nb, R, ci = U.shape
         cout = weight.shape[0]
         co = cout // nb
         Wg = weight.view(nb, co, ci)
         if U.dtype == torch.bfloat16:
-            Y = torch.bmm(U, _w16(weight).view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
+            Wb = weight.to(torch.bfloat16) if w16 is None else w16
+            Y = torch.bmm(U, Wb.view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
         else:
             Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
             if Y.dtype != _F32:
@@ -268,7 +269,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         Wg = weight.view(nb, co, ci)
         dU = torch.bmm(dY, Wg)
         dW = torch.bmm(dY.transpose(1, 2), U).view_as(weight)
-        return dU, dW, None, dgamma, dbeta, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
+        return dU, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 
 # ----------------------------------------------------------------------------------------------- graph ops
@@ -363,7 +364,8 @@ def fused_supported(mod, x, groups: int) -> bool:
 
 def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False):
     conv, bn = seq[0], seq[1]
-    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp)
+    w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
+    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16)
 
 
 def grapher_forward(mod, x, relative_pos, groups: int):
@@ -382,7 +384,8 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
     U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1, lp)       # (4, T, C/2) interleaved [x, m]
     nn_ = gc.gconv.nn
-    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp)   # (T, 2C)
+    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
+                                   _w16_of(nn_[0]) if lp else None)   # (T, 2C)
     out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W))          # fc2 + BN + residual, back to NCHW
     return out, edge
 
@@ -399,7 +402,8 @@ def grapher_label_forward(mod, e, features, groups: int):
     lp = lowp_inference()
     U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1, lp)
     nn_ = gc.gconv.nn
-    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp)
+    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
+                                   _w16_of(nn_[0]) if lp else None)
     h2 = _lin(a2, mod.fc2, residual=e2)
     f1 = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp)
     out = _lin(f1, mod.ffn.fc2, residual=h2)

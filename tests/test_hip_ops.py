@@ -222,3 +222,35 @@ def test_non_finite_inputs_do_not_crash_or_leave_the_index_range():
     m.sum().backward()
     torch.cuda.synchronize()
     assert torch.isfinite(m).all() and torch.isfinite(x.grad).all()
+
+
+def test_exact_ties_decide_membership_and_order():
+    """Inputs built to tie EXACTLY (keys duplicated three times; small-integer features without normalisation) for long
+    and short lists: 'equal distance -> smaller key index first' must decide both which neighbours enter the top
+    k*d and their order (hence which survive the dilation), bit for bit like the C oracle."""
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    rng = np.random.RandomState(77)
+    # (BG, c, N, M, self, k, d, relpos, kind)
+    cases = [(2, 12, 90, 150, False, 9, 2, False, "dup"), (1, 16, 130, 130, True, 12, 2, True, "dup"),
+             (2, 40, 200, 1200, False, 9, 1, False, "dup"), (3, 20, 70, 70, True, 3, 3, True, "dup"),
+             (2, 8, 70, 200, False, 6, 3, False, "int"), (1, 4, 64, 64, True, 18, 1, False, "int"),
+             (1, 3, 33, 500, False, 32, 2, False, "int")]
+    for BG, c, N, M, self_graph, k, d, use_rp, kind in cases:
+        normalize = kind != "int"
+        if kind == "int":
+            x = rng.randint(-2, 3, size=(BG, c, N)).astype(np.float32)
+            y = None if self_graph else rng.randint(-2, 3, size=(BG, c, M)).astype(np.float32)
+        else:
+            x = rng.standard_normal((BG, c, N)).astype(np.float32)
+            y = None if self_graph else rng.standard_normal((BG, c, M)).astype(np.float32)
+            t = x if self_graph else y
+            T = t.shape[2] // 3
+            t[:, :, T:2 * T] = t[:, :, :T]
+            t[:, :, 2 * T:3 * T] = t[:, :, :T]
+        rp = (np.round(-rng.random_sample((N, M)) * 4) / 4).astype(np.float32) if use_rp else None   # coarse: ties survive
+        tag = (BG, c, N, M, self_graph, k, d, use_rp, kind)
+        want_idx, want_center = O.knn(x, y, rp, k, d, normalize=normalize)
+        got = ops.knn_graph(_dev(x), _dev(y), None if rp is None else _dev(rp).unsqueeze(0), k, d, normalize).cpu().numpy()
+        assert np.array_equal(got[0], want_idx), tag
+        assert np.array_equal(got[1], want_center), tag
