@@ -17,7 +17,8 @@ KNN_NORMALIZE = 1
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
            "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
-           "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd")
+           "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
+           "gkg_bn_bwd_sums", "gkg_bn_bwd_apply")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
 
 _lib = None
@@ -71,6 +72,14 @@ def load():
     lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, I, V]
     lib.gkg_bn_bwd.restype = I
     lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
+    lib.gkg_bn_stats_sums.restype = I
+    lib.gkg_bn_stats_sums.argtypes = [V, V, I, I, I, V, Z, V]
+    lib.gkg_bn_finalize.restype = I
+    lib.gkg_bn_finalize.argtypes = [V] * 11 + [I, I, F, F, V, V]
+    lib.gkg_bn_bwd_sums.restype = I
+    lib.gkg_bn_bwd_sums.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V]
+    lib.gkg_bn_bwd_apply.restype = I
+    lib.gkg_bn_bwd_apply.argtypes = [V] * 9 + [I, I, I, I, Z, I, V]
     lib.gkg_prof_enable.restype = None
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None

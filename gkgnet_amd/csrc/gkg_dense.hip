@@ -277,9 +277,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
                                    const float* __restrict__ beta, const float* __restrict__ bias,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ a, float* __restrict__ cs, float* __restrict__ mean,
-                                   float* __restrict__ invstd, int R, int C, float momentum, float eps) {
+                                   float* __restrict__ invstd, const float* __restrict__ count, int C, float momentum,
+                                   float eps, long long* __restrict__ num_batches_tracked) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (num_batches_tracked && ch == 0 && blockIdx.y == 0) *num_batches_tracked += 1;
   if (ch >= C) return;
+  const double R = (double)count[0];               // rows over ALL ranks (device scalar: it rode the all-reduce)
   const int q = blockIdx.y;
   sums += (size_t)q * 2 * C; gamma += (size_t)q * C; beta += (size_t)q * C; a += (size_t)q * C; cs += (size_t)q * C;
   mean += (size_t)q * C; invstd += (size_t)q * C;
@@ -297,7 +300,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
   if (running_mean) {
     const float b = bias ? bias[ch] : 0.f;
     running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * ((float)m + b);
-    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    const double unb = R > 1.0 ? var * R / (R - 1.0) : var;
     running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
   }
 }
@@ -350,9 +353,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
                                                            const float* __restrict__ a, const float* __restrict__ cs,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ sums, float* dy,
-                                                           size_t total4, int C, int R, int ldg, size_t g_bstride) {
+                                                           size_t total4, int C, int R, int ldg, size_t g_bstride,
+                                                           const float* __restrict__ count) {
   const int C4 = C >> 2;
-  const float invR = 1.0f / (float)R;
+  const float invR = 1.0f / (count ? count[0] : (float)R);   // count: rows over all ranks (SyncBN)
   const int q = blockIdx.y;
   y += (size_t)q * total4 * 4; dy += (size_t)q * total4 * 4; dout += (size_t)q * g_bstride;
   a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C; sums += (size_t)q * 2 * C;
@@ -507,8 +511,78 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 31) / 32, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dy, y, a, c, mean, invstd, sums, dy, total4, C, R, C, (size_t)R * C);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dy, y, a, c, mean, invstd, sums, dy, total4, C, R, C, (size_t)R * C, (const float*)nullptr);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, (const float*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd");
+}
+
+// ------------------------------------------------------------------------------------------ cross-rank (SyncBN) halves
+// The same passes split where the reference's SyncBatchNorm exchanges statistics: the caller all-reduces `sums`
+// (and the row count) over the ranks between the two calls.
+extern "C" int gkg_bn_stats_sums(const float* y, float* sums, int R, int C, int nb, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!y || !sums || !workspace) return gkg_fail(GKG_ERR_NULL, "gkg_bn_stats_sums: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_stats_sums: bad sizes");
+  int rpb;
+  const int nblk = stats_blocks(R, C, nb, &rpb);
+  if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float))
+    return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_stats_sums: workspace too small (gkg_bn_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, y, part, R, C, rpb);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 31) / 32, nb), dim3(256), 0, st, part, sums, nblk, 2 * C,
+                     (float*)nullptr, (float*)nullptr);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_stats_sums");
+}
+
+extern "C" int gkg_bn_finalize(const float* sums, const float* count, const float* gamma, const float* beta,
+                               const float* bias, float* running_mean, float* running_var, float* a, float* c,
+                               float* mean, float* invstd, int C, int nb, float momentum, float eps,
+                               long long* num_batches_tracked, void* stream) {
+  if (!sums || !count || !gamma || !beta || !a || !c || !mean || !invstd) return gkg_fail(GKG_ERR_NULL, "gkg_bn_finalize: null pointer");
+  if (bad_c(C) || nb <= 0 || nb > 64) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_finalize: bad sizes");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_finalize: running stats come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta,
+                     bias, running_mean, running_var, a, c, mean, invstd, count, C, momentum, eps, num_batches_tracked);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_finalize_kernel");
+}
+
+extern "C" int gkg_bn_bwd_sums(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                               const float* invstd, float* dy, float* sums, float* dgamma, float* dbeta, int R, int C,
+                               int nb, int ldg, size_t dout_bstride, int act, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !dy || !sums || !dgamma || !dbeta || !workspace)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_sums: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_sums: bad sizes");
+  int rpb;
+  const int nblk = stats_blocks(R, C, nb, &rpb);
+  if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float)) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_bwd_sums: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dy);
+  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
+  // the LOCAL sums are the parameter gradients (the data-parallel gradient exchange averages them later)
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 31) / 32, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_sums");
+}
+
+extern "C" int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                                const float* invstd, const float* sums, const float* count, float* dy, int R, int C,
+                                int nb, int ldg, size_t dout_bstride, int act, void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !sums || !count || !dy) return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_apply: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_apply: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total4 = (size_t)R * (C >> 2);
+  const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  // act == 1: gkg_bn_bwd_sums parked dz = dout*act'(z) in dy; apply in place
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dy, y, a, c, mean, invstd, sums, dy, total4, C, R, C, (size_t)R * C, count);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, count);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_apply_kernel");
 }

@@ -136,8 +136,20 @@ class _BlockEntry(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------- BN helpers
+def _sync_group(bn):
+    """The process group this BN exchanges its batch statistics over (SyncBatchNorm in training under an
+    initialised multi-rank group: the reference's DDP semantics), or None for local statistics."""
+    if not (isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
 def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
-    """Returns (a, c, mean, invstd) for out = a*Y + c; updates running statistics in train mode."""
+    """Returns (a, c, mean, invstd, sync) for out = a*Y + c; updates running statistics in train mode.
+    ``sync`` is None (local statistics) or (group, count): the statistics were summed over the ranks of ``group``
+    (one all-reduce of the column sums, sums of squares and the row count) and ``count`` is the device scalar
+    holding the total number of rows — the backward needs both."""
     dev = Y.device
     a = torch.empty(nb * C, dtype=_F32, device=dev)
     c = torch.empty_like(a)
@@ -146,19 +158,51 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
         invstd = torch.empty_like(a)
         ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), dev)
         track = bn.training and bn.track_running_stats
-        _lib.check(lib.gkg_bn_train_stats(_ptr(Y), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
-                                          _ptr(bn.running_mean) if track else None,
-                                          _ptr(bn.running_var) if track else None,
-                                          _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), R, C, nb,
-                                          float(bn.momentum), float(bn.eps),
-                                          _ptr(bn.num_batches_tracked) if track else None,
-                                          _ptr(ws), ws.numel(), _stream()),
-                   "gkg_bn_train_stats")
-        return a, c, mean, invstd
+        rm = _ptr(bn.running_mean) if track else None
+        rv = _ptr(bn.running_var) if track else None
+        nbt = _ptr(bn.num_batches_tracked) if track else None
+        group = _sync_group(bn)
+        if group is None:
+            _lib.check(lib.gkg_bn_train_stats(_ptr(Y), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias), rm, rv,
+                                              _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), R, C, nb,
+                                              float(bn.momentum), float(bn.eps), nbt, _ptr(ws), ws.numel(), _stream()),
+                       "gkg_bn_train_stats")
+            return a, c, mean, invstd, None
+        buf = torch.empty(nb * 2 * C + 1, dtype=_F32, device=dev)              # [sums | row count]
+        _lib.check(lib.gkg_bn_stats_sums(_ptr(Y), _ptr(buf), R, C, nb, _ptr(ws), ws.numel(), _stream()),
+                   "gkg_bn_stats_sums")
+        count = buf[-1:]
+        count.fill_(float(R))
+        dist.all_reduce(buf, group=group)
+        _lib.check(lib.gkg_bn_finalize(_ptr(buf), _ptr(count), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias), rm, rv,
+                                       _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), C, nb, float(bn.momentum),
+                                       float(bn.eps), nbt, _stream()), "gkg_bn_finalize")
+        return a, c, mean, invstd, (group, count)
     _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
                                       _ptr(bn.running_var), _ptr(a), _ptr(c), nb * C, float(bn.eps), _stream()),
                "gkg_bn_eval_affine")
-    return a, c, None, None
+    return a, c, None, None, None
+
+
+def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync):
+    """dY, dgamma, dbeta of out = act(BN_train(Y)) from the upstream gradient g; with ``sync`` the two column sums the
+    input gradient needs are all-reduced over the ranks (dgamma/dbeta stay local, like torch's SyncBatchNorm: the
+    data-parallel gradient exchange averages them)."""
+    ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), Y.device)
+    if sync is None:
+        _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
+                                  _ptr(dgamma), _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(ws), ws.numel(),
+                                  _stream()), "gkg_bn_bwd")
+        return
+    group, count = sync
+    sums = torch.empty(nb * 2 * C, dtype=_F32, device=Y.device)
+    _lib.check(lib.gkg_bn_bwd_sums(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(sums),
+                                   _ptr(dgamma), _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(ws), ws.numel(),
+                                   _stream()), "gkg_bn_bwd_sums")
+    dist.all_reduce(sums, group=group)
+    _lib.check(lib.gkg_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(sums),
+                                    _ptr(count), _ptr(dY), R, C, nb, ldg, g_bstride, act, _stream()),
+               "gkg_bn_bwd_apply")
 
 
 class _LinearBNAct(torch.autograd.Function):
@@ -172,7 +216,7 @@ class _LinearBNAct(torch.autograd.Function):
         cout = weight.shape[0]
         W = weight.view(cout, cin)
         Y = _mm_t(x, W, w16)
-        a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
+        a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
         if nchw is None:
             dt, code = _tm_dtype(out_lowp)
             out = torch.empty((R, cout), dtype=dt, device=x.device)
@@ -188,6 +232,7 @@ class _LinearBNAct(torch.autograd.Function):
                                                  _stream()), "gkg_tm_affine_to_nchw")
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, nchw, residual is not None, bias is not None)
+        ctx.sync = sync
         return out
 
     @staticmethod
@@ -209,10 +254,7 @@ class _LinearBNAct(torch.autograd.Function):
         dY = torch.empty_like(Y)
         dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
         dbeta = torch.empty_like(dgamma)
-        ws = _ws(lib.gkg_bn_workspace_bytes(R, cout, 1), Y.device)
-        _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
-                                  _ptr(dgamma), _ptr(dbeta), R, cout, 1, cout, 0, act, _ptr(ws), ws.numel(),
-                                  _stream()), "gkg_bn_bwd")
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
         # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean): not materialised
         dbias = None
         W = weight.view(cout, cin)
@@ -239,13 +281,14 @@ class _GroupedLinearBNAct(torch.autograd.Function):
             Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
             if Y.dtype != _F32:
                 Y = Y.float()
-        a, c, mean, invstd = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
+        a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((R, cout), dtype=dt, device=U.device)
         _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
                                       code, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
+        ctx.sync = sync
         return out
 
     @staticmethod
@@ -262,10 +305,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         dY = torch.empty_like(Y)
         dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
         dbeta = torch.empty_like(dgamma)
-        ws = _ws(lib.gkg_bn_workspace_bytes(R, co, nb), Y.device)
-        _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
-                                  _ptr(dgamma), _ptr(dbeta), R, co, nb, cout, co, act, _ptr(ws), ws.numel(),
-                                  _stream()), "gkg_bn_bwd")
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync)
         Wg = weight.view(nb, co, ci)
         dU = torch.bmm(dY, Wg)
         dW = torch.bmm(dY.transpose(1, 2), U).view_as(weight)
@@ -328,10 +368,7 @@ class _MaxRelativeTM(torch.autograd.Function):
 def _bn_ok(bn) -> bool:
     if not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) or not bn.affine or bn.momentum is None:
         return False
-    if isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and dist.is_available() and dist.is_initialized() \
-            and dist.get_world_size() > 1:
-        return False            # cross-rank statistics: composable path (torch SyncBatchNorm collectives)
-    return True
+    return True                 # SyncBatchNorm across ranks: the statistics are all-reduced inside the fused path
 
 
 def fused_supported(mod, x, groups: int) -> bool:

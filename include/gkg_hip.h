@@ -150,6 +150,24 @@ int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                size_t dout_bstride, int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Cross-rank batch statistics (the reference's SyncBatchNorm under DDP, torch_nn.py:37 / mmcv build_norm_layer):
+ * gkg_bn_train_stats and gkg_bn_bwd split where the ranks exchange statistics.  Forward: gkg_bn_stats_sums ->
+ * caller all-reduces `sums` [nb][2][C] (column sum, sum of squares) and the row count over the ranks ->
+ * gkg_bn_finalize with the device scalar `count` (total rows).  Backward: gkg_bn_bwd_sums (also writes the LOCAL
+ * dgamma/dbeta, like torch's batch_norm_backward_reduce, and parks dz in dy when act == 1) -> all-reduce `sums`
+ * [nb][2][C] (sum dz, sum dz*yhat) -> gkg_bn_bwd_apply with the same `count`. */
+int gkg_bn_stats_sums(const float* y, float* sums, int R, int C, int nb, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int gkg_bn_finalize(const float* sums, const float* count, const float* gamma, const float* beta, const float* bias,
+                    float* running_mean, float* running_var, float* a, float* c, float* mean, float* invstd, int C,
+                    int nb, float momentum, float eps, long long* num_batches_tracked, void* stream);
+int gkg_bn_bwd_sums(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                    const float* invstd, float* dy, float* sums, float* dgamma, float* dbeta, int R, int C, int nb,
+                    int ldg, size_t dout_bstride, int act, void* workspace, size_t workspace_bytes, void* stream);
+int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                     const float* invstd, const float* sums, const float* count, float* dy, int R, int C, int nb,
+                     int ldg, size_t dout_bstride, int act, void* stream);
+
 /*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).
  * When enabled, every kernel launch made by this library is bracketed by hipEventRecord on the SAME

@@ -1,0 +1,86 @@
+"""Cross-rank batch statistics inside the fused block (the reference's SyncBatchNorm under DDP):
+two ranks, each with half of the batch, must reproduce the single-process full-batch result — outputs of their own
+half, input gradients of their own half, parameter gradients summed over the ranks, and the running statistics.
+The ranks share the one GPU of the test box and talk over gloo (RCCL refuses two ranks on one device); the code path
+in the product is the same `dist.all_reduce` either way."""
+import os
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(norm_type):
+    from gkgnet_amd import layers
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    layers.norm_cfg["type"] = norm_type
+    torch.manual_seed(0)
+    B, C, H, G, k, L = 8, 64, 10, 4, 9, 12
+    g = Grapher(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=True, use_multi_group=True,
+                num_group=G).cuda().train()
+    gl = GrapherLabel(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, num_nodes=L, use_multi_group=True,
+                      num_group=G).cuda().train()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, H, H, generator=gen).cuda()
+    e = torch.randn(B, L, C, generator=gen).cuda()
+    cx = torch.randn(B, C, H, H, generator=gen).cuda()
+    ce = torch.randn(B, L, C, generator=gen).cuda()
+    return g, gl, x, e, cx, ce
+
+
+def _run(g, gl, x, e, cx, ce):
+    xg, eg = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    out = g(xg)
+    e2, _ = gl(eg, out)
+    torch.autograd.backward([out, e2], [cx, ce])
+    grads = {n: p.grad.clone() for mod, tag in ((g, "g."), (gl, "l.")) for n, p in
+             ((tag + n_, p_) for n_, p_ in mod.named_parameters()) if p.grad is not None}
+    bufs = {tag + n_: b.clone() for mod, tag in ((g, "g."), (gl, "l.")) for n_, b in mod.named_buffers()
+            if "running" in n_ or "num_batches" in n_}
+    return out.detach(), e2.detach(), xg.grad, eg.grad, grads, bufs
+
+
+def _worker(rank, world, store_path, result_path):
+    import torch.distributed as dist
+    from gkgnet_amd import fused, layers
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", store=dist.FileStore(store_path, world), rank=rank, world_size=world)
+    try:
+        # single-process reference: full batch, local statistics (plain BN), same fused kernels
+        ref = _run(*_build("BN"))
+        # two ranks, half a batch each, SyncBatchNorm: statistics exchanged inside the fused path
+        g, gl, x, e, cx, ce = _build("SyncBN")
+        assert isinstance(g.fc1[1], torch.nn.SyncBatchNorm) and fused._sync_group(g.fc1[1]) is not None
+        calls = []
+        real = fused.grapher_forward
+        fused.grapher_forward = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        B = x.shape[0]
+        sl = slice(rank * B // world, (rank + 1) * B // world)
+        got = _run(g, gl, x[sl], e[sl], cx[sl], ce[sl])
+        fused.grapher_forward = real
+        assert calls, "SyncBatchNorm across ranks was expected to stay on the fused path"
+        tol = dict(atol=2e-4, rtol=1e-3)
+        for name, a_, b_ in zip(("out", "labels", "dx", "de"), got[:4], ref[:4]):
+            assert torch.allclose(a_, b_[sl], **tol), (name, float((a_ - b_[sl]).abs().max()))
+        for n_, gr in got[4].items():                      # parameter gradients add up over the ranks
+            tot = gr.clone()
+            dist.all_reduce(tot)
+            assert torch.allclose(tot, ref[4][n_], atol=2e-3, rtol=2e-3), (n_, float((tot - ref[4][n_]).abs().max()))
+        for n_, b_ in got[5].items():                      # running statistics are the global-batch ones on every rank
+            assert torch.allclose(b_.float(), ref[5][n_].float(), atol=1e-5, rtol=1e-4), n_
+        with open(result_path + f".{rank}", "w") as fh:
+            fh.write("ok")
+    finally:
+        layers.norm_cfg["type"] = "BN"
+        dist.destroy_process_group()
+
+
+def test_fused_block_syncbn_two_ranks_equals_full_batch():
+    import torch.multiprocessing as mp
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        store, res = os.path.join(d, "store"), os.path.join(d, "res")
+        mp.spawn(_worker, args=(world, store, res), nprocs=world, join=True)
+        assert all(os.path.exists(res + f".{r}") for r in range(world))
