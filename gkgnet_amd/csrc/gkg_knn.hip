@@ -176,6 +176,24 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   const int n0 = (jj % nqt) * QT;
   const int N = a.N, M = a.M, cpad = a.cpad;
 
+  // ---- first key batch of this wave's first tile and the lane's |x|^2: issued before the query staging so their
+  //      L2/HBM round trip overlaps it (every workgroup of the launch runs this prologue at the same time)
+  const int lane_n = n0 + lane;
+  const int nc = lane_n < N ? lane_n : N - 1;
+  const int kk = lane >> 5;       // which k of the k-pair this lane feeds
+  const int l31 = lane & 31;
+  const float* yp = a.yh + (size_t)bg * cpad * M;
+  const int t_begin = split * a.tiles_per_split;
+  float an[KU];
+  {
+    const int t0 = t_begin + w;
+    const int mk0 = min(t0 * KT + l31, M - 1);
+    const float* y0 = yp + (size_t)kk * M + mk0;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) an[u] = y0[(size_t)(2 * u) * M];
+  }
+  const float sqx = a.sqx[(size_t)bg * N + nc];
+
   // ---- stage the query tile scaled by -2 (exact): xs[ch][64] = -2 * xh (zero for n >= N).
   //      All loads of a pass are issued before the first LDS store.
   {
@@ -215,13 +233,8 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   }
   __syncthreads();
 
-  const int n = n0 + lane;
-  const int nc = n < N ? n : N - 1;
-  const float sqx = a.sqx[(size_t)bg * N + nc];
+  const int n = lane_n;
   const float* sqy = a.sqy + (size_t)bg * M;
-  const float* yp = a.yh + (size_t)bg * cpad * M;
-  const int kk = lane >> 5;       // which k of the k-pair this lane feeds
-  const int l31 = lane & 31;
 
   const bool two_blocks = n0 + 32 < N;   // wave-uniform
 
@@ -229,20 +242,11 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   top.init();
 
   const int ktiles = (M + KT - 1) / KT;
-  const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, ktiles);
   const int CP = cpad / 2;          // k-pairs; cpad % 8 == 0 -> CP % 4 == 0
 
-  // The first key batch of a tile is loaded during the PREVIOUS tile's last MFMA batch (before its selection phase),
-  // so no tile starts with an exposed L2 round trip.
-  float an[KU];
-  {
-    const int t0 = t_begin + w;
-    const int mk0 = min(t0 * KT + l31, M - 1);
-    const float* y0 = yp + (size_t)kk * M + mk0;
-#pragma unroll
-    for (int u = 0; u < KU; ++u) an[u] = y0[(size_t)(2 * u) * M];
-  }
+  // The first key batch of every later tile is loaded during the PREVIOUS tile's last MFMA batch (before its selection
+  // phase), so no tile starts with an exposed L2 round trip.
   for (int t = t_begin + w; t < t_end; t += NW) {
     const int m0 = t * KT;
     const int mk = min(m0 + l31, M - 1);
