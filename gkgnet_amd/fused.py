@@ -372,8 +372,9 @@ def _bn_ok(bn) -> bool:
 
 
 def fused_supported(mod, x, groups: int) -> bool:
-    """Fused path preconditions: fp32 CUDA input, 'mr' aggregation with GELU+BN, channel counts that keep
-    float4 / group boundaries aligned, local batch statistics, inactive DropPath."""
+    """Fused path preconditions: fp32 CUDA input (any dtype under autocast), 'mr' aggregation with GELU+BN, channel
+    counts that keep float4 / group boundaries aligned, inactive DropPath.  BatchNorm and SyncBatchNorm (statistics
+    all-reduced inside the path) are both handled."""
     from .graph import MRConv2d
     gc = mod.graph_conv
     C = mod.channels
