@@ -107,29 +107,63 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(const T* __restrict__ t,
 }
 
 // ------------------------------------------------------------------------------------------ top-KD list
-// Sorted ascending (v[0] smallest).  Candidates of one lane arrive in increasing key index, so the strict
-// '<' keeps the smaller index first among equal distances (the documented tie rule).
+// Sorted ascending.  A list entry is ONE fp64 key that orders exactly like the pair (distance, key index): the fp32
+// distance converted to fp64 (exact; leaves the low 29 mantissa bits zero) with the index stored in those bits —
+// complemented for negative distances, where a larger mantissa means a smaller value — so "equal distance -> smaller
+// index first" is the plain fp64 '<'.  The sorted insert is then a v_min_f64 + v_max_f64 per slot (fp64 vector ops
+// issue at the fp32 rate on CDNA3/4) instead of compare + v_med3 + two selects per slot: 2 instead of 4 vector
+// instructions per slot, and the index never has to be moved separately.
+//   An fp64 infinity or NaN cannot carry index bits (inf | bits is a NaN), and does not need to: v_min_f64 /
+// v_max_f64 return the non-NaN operand, so a candidate whose distance is +inf or NaN (non-finite inputs only) leaves
+// the list untouched, exactly like the strict '<' of a scalar insert.  Keys past M are masked with a large FINITE
+// |y|^2 (MASKED_SQ) instead of +inf; they can only surface when fewer than k*d real candidates exist at all, and the
+// output stage keeps indices in range for that case.  (A distance is never -0.0: |x|^2 >= +0 heads the sum.)
+constexpr uint32_t IDX_BITS = 0x1fffffffu;          // 29 bits: key index < 2^29
+constexpr float MASKED_SQ = 3.0e38f;
+
+__device__ __forceinline__ double pack_key(float d, int m) {
+  // low 29 bits: m for d >= 0, IDX_BITS - m (== IDX_BITS ^ m) for d < 0
+  const uint32_t flip = (uint32_t)(__float_as_int(d) >> 31) & IDX_BITS;
+  return __longlong_as_double(__double_as_longlong((double)d) + (long long)(flip ^ (uint32_t)m));
+}
+__device__ __forceinline__ float key_dist(double k) {
+  return (float)__longlong_as_double(__double_as_longlong(k) & ~(long long)IDX_BITS);
+}
+__device__ __forceinline__ int key_index(double k) {
+  const long long b = __double_as_longlong(k);
+  if ((b & 0x7fffffffffffffffLL) == 0x7ff0000000000000LL) return 0x7fffffff;      // empty slot (+inf)
+  const uint32_t lo = (uint32_t)b & IDX_BITS;
+  return (int)(b < 0 ? IDX_BITS - lo : lo);
+}
+
+// Raw v_min_f64 / v_max_f64: the builtin forms are preceded by a canonicalising v_max_f64 x,x per operand (sNaN
+// quieting under IEEE mode) — a third of the insert for nothing, the keys are never NaN.
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int KD>
 struct TopList {
-  float v[KD];
-  int id[KD];
+  double key[KD];
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int j = 0; j < KD; ++j) { v[j] = INFINITY; id[j] = 0x7fffffff; }
+    for (int j = 0; j < KD; ++j) key[j] = (double)INFINITY;
   }
-  // Sorted insert; a no-op for lanes with d >= v[KD-1], skipped when no lane of the wave improves.
+  // Sorted insert; a no-op for lanes whose candidate does not beat their KD-th entry, skipped when no lane of the
+  // wave improves.
   __device__ __forceinline__ void insert(float d, int m) {
-    if (__builtin_amdgcn_ballot_w64(d < v[KD - 1]) == 0ull) return;
-    bool lt_j = d < v[KD - 1];
+    const double k = pack_key(d, m);
+    if (__builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
 #pragma unroll
-    for (int j = KD - 1; j >= 1; --j) {
-      const bool lt_jm1 = d < v[j - 1];
-      v[j] = __builtin_amdgcn_fmed3f(v[j - 1], d, v[j]);
-      id[j] = lt_jm1 ? id[j - 1] : (lt_j ? m : id[j]);
-      lt_j = lt_jm1;
-    }
-    v[0] = lt_j ? d : v[0];
-    id[0] = lt_j ? m : id[0];
+    for (int j = KD - 1; j >= 1; --j) key[j] = max_f64(key[j - 1], min_f64(key[j], k));
+    key[0] = min_f64(key[0], k);
   }
 };
 
@@ -252,9 +286,9 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     const int mk = min(m0 + l31, M - 1);
     const int mk_next = min((t + NW < t_end ? t + NW : t) * KT + l31, M - 1);
     // ---- side inputs of this tile, issued first so their latency hides under the contraction:
-    //      |y|^2 of key m0+l31 (broadcast per candidate with v_readlane; +inf masks keys past M) and the
+    //      |y|^2 of key m0+l31 (broadcast per candidate with v_readlane; MASKED_SQ sends keys past M to the end of every list) and the
     //      positional bias of this lane's query row
-    const float sy32 = (m0 + l31 < M) ? sqy[mk] : INFINITY;
+    const float sy32 = (m0 + l31 < M) ? sqy[mk] : MASKED_SQ;
     float rp[KT];
     if (HAS_RP) {
       const float* rpp = a.relpos + (size_t)nc * M + m0;
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     // ---- lane l needs all 32 keys of ITS query: v_permlane32_swap exchanges the 32-lane halves of the two
     //      accumulators (vdst.hi <-> src.lo); afterwards lo = key rows (r&3)+8(r>>2), hi = those + 4.
     //      dist = ((|x|^2 + (-2 x.y)) + |y|^2) + relpos in the reference's order; |y|^2 comes through the
-    //      scalar cache (the key row is wave-uniform) and is +inf for keys past M, which also masks them.
+    //      scalar cache (the key row is wave-uniform) and is MASKED_SQ for keys past M, which also masks them.
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float lo[4], hi[4];
@@ -343,8 +377,8 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   int* li = reinterpret_cast<int*>(smem + NW * KD * 64);
 #pragma unroll
   for (int j = 0; j < KD; ++j) {
-    lv[(w * KD + j) * 64 + lane] = top.v[j];
-    li[(w * KD + j) * 64 + lane] = top.id[j];
+    lv[(w * KD + j) * 64 + lane] = key_dist(top.key[j]);
+    li[(w * KD + j) * 64 + lane] = key_index(top.key[j]);
   }
   __syncthreads();
   if (w != 0) return;
@@ -389,7 +423,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
 // so ranks 0,d,2d,.. < kd are written straight to their output slot — no serial merge.
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i,
                                                         int64_t* __restrict__ nn_idx, int64_t* __restrict__ center,
-                                                        int S, int BG, int N, int k, int dilation, int kd) {
+                                                        int S, int BG, int N, int M, int k, int dilation, int kd) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;        // (s, q, p) flattened as s*nq*kd + q*kd + p
   const size_t nq = (size_t)BG * N;
   const size_t stride = nq * kd;                                   // between splits
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   if (rank < kd && rank % dilation == 0) {
     const int outj = rank / dilation;
     if (outj < k) {
-      nn_idx[q * k + outj] = id;
+      nn_idx[q * k + outj] = id < M ? id : 0;       // masked tail keys can only rank here on non-finite inputs
       if (center) center[q * k + outj] = (int64_t)(q % N);
     }
   }
@@ -597,7 +631,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     // ranks that no finite candidate claims (non-finite inputs only) must still hold a valid index
     (void)hipMemsetAsync(nn_idx, 0, sizeof(int64_t) * (size_t)BG * N * k, st);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
-                       nn_idx, center, p.S, BG, N, k, dilation, p.kd);
+                       nn_idx, center, p.S, BG, N, M, k, dilation, p.kd);
     e = hipGetLastError();
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_merge_kernel");
   }
