@@ -14,8 +14,8 @@
 //                            reference's native channel-major layout: a lane reads y[ch][m0+lane]) and the
 //                            64 staged queries as two B operands from LDS.  The two 32x32 accumulators are
 //                            exchanged with v_permlane32_swap so that lane l owns query n0+l and all 32
-//                            key distances of the tile; each lane keeps a sorted top-KD list (value via
-//                            v_med3_f32, index via v_cndmask) in registers.  The 4 per-wave lists of a
+//                            key distances of the tile; each lane keeps a sorted top-KD list of fp64
+//                            (distance, index) keys in registers (v_min_f64 + v_max_f64 per slot).  The 4 per-wave lists of a
 //                            query are merged through LDS; ranks 0,d,2d,.. go out as int64.
 //   3. knn_merge_kernel    : only when the keys were split over several workgroups (few queries, many
 //                            keys — the label graph): merges the S partial lists of each query.
@@ -187,7 +187,7 @@ struct KnnArgs {
 // waves of one SIMD do NOT overlap (they share the fp32 datapath) — every vector instruction spent on the
 // selection adds to the matrix time, so the per-candidate work is kept minimal: 3 adds for the distance
 // (the -2 is folded into the staged queries, |y|^2 is broadcast with v_readlane and doubles as the
-// out-of-range mask) and a 4-instruction-per-slot sorted insert.  A sparse variant (per-lane clz walk over a
+// out-of-range mask), 4 to pack the (distance, index) key and a 2-instruction-per-slot sorted insert.  A sparse variant (per-lane clz walk over a
 // "beats my k-th best" mask with the distances parked in LDS) was measured 1.5-1.7x SLOWER: per-wave lists
 // see only a quarter of the keys, so some lane of 64 passes for almost every candidate and the divergent
 // loop serialises on LDS latency.
