@@ -161,8 +161,19 @@ struct TopList {
   __device__ __forceinline__ void insert(float d, int m) {
     const double k = pack_key(d, m);
     if (__builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
+    // new key[j] = max(old key[j-1], min(old key[j], k)), from the top slot down.  Four slots at a time, the mins
+    // first and then the maxes, so that no v_max_f64 issues right behind the v_min_f64 it depends on.
+    constexpr int U = 4;
 #pragma unroll
-    for (int j = KD - 1; j >= 1; --j) key[j] = max_f64(key[j - 1], min_f64(key[j], k));
+    for (int j0 = KD - 1; j0 >= 1; j0 -= U) {
+      double t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 - u >= 1) t[u] = min_f64(key[j0 - u], k);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 - u >= 1) key[j0 - u] = max_f64(key[j0 - u - 1], t[u]);
+    }
     key[0] = min_f64(key[0], k);
   }
 };
