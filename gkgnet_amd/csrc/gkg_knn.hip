@@ -158,9 +158,12 @@ struct TopList {
   }
   // Sorted insert; a no-op for lanes whose candidate does not beat their KD-th entry, skipped when no lane of the
   // wave improves.
+  template <bool GUARD>
   __device__ __forceinline__ void insert(float d, int m) {
     const double k = pack_key(d, m);
-    if (__builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
+    // GUARD: skip the insert when no lane of the wave improves.  Pays once a wave has streamed a few hundred keys per
+    // query (late candidates rarely enter a list); before that it is a compare + branch per candidate for nothing.
+    if (GUARD && __builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
     // new key[j] = max(old key[j-1], min(old key[j], k)), from the top slot down.  Four slots at a time, the mins
     // first and then the maxes, so that no v_max_f64 issues right behind the v_min_f64 it depends on.
     constexpr int U = 4;
@@ -202,7 +205,7 @@ struct KnnArgs {
 // "beats my k-th best" mask with the distances parked in LDS) was measured 1.5-1.7x SLOWER: per-wave lists
 // see only a quarter of the keys, so some lane of 64 passes for almost every candidate and the divergent
 // loop serialises on LDS latency.
-template <int KD, bool HAS_RP, int KU>
+template <int KD, bool HAS_RP, int KU, bool GUARD = true>
 __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_tile_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
@@ -237,7 +240,16 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
 #pragma unroll
     for (int u = 0; u < KU; ++u) an[u] = y0[(size_t)(2 * u) * M];
   }
-  const float sqx = a.sqx[(size_t)bg * N + nc];
+
+  // The last k-pair of every contraction adds |x|^2 and |y|^2 on the matrix pipe: keys feed (1, |y|^2), queries
+  // (|x|^2, 1), so acc = fma(|y|^2, 1, fma(1, |x|^2, acc)) — bit for bit ((|x|^2 + (-2 x.y)) + |y|^2), the contract's
+  // order — and each candidate saves two vector adds and a v_readlane (the vector pipe is the contended one).
+  // Used by the deep-batch instantiations (KU == 8: channel counts that are multiples of 16); measured a few per cent
+  // slower on the KU == 4 ones (c = 200 at 36x36), which keep the three vector adds.
+  constexpr bool FOLD = KU == 8;
+  const float qtail0 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + l31, N - 1)];
+  const float qtail1 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + 32 + l31, N - 1)];
+  const float sqx = FOLD ? 0.0f : a.sqx[(size_t)bg * N + nc];
 
   // ---- stage the query tile scaled by -2 (exact): xs[ch][64] = -2 * xh (zero for n >= N).
   //      All loads of a pass are issued before the first LDS store.
@@ -339,6 +351,11 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, acc1, 0, 0, 0);
           }
         }
+        if (FOLD) {
+          const float atail = kk ? sy32 : 1.0f;                // k-pair (1, |y|^2) x (|x|^2, 1)
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(atail, qtail0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(atail, qtail1, acc1, 0, 0, 0);
+        }
       } else {                                    // tail query tile with <= 32 queries: one query block only
         for (int s = 0; s < CP; s += KU) {
           const bool last = s + KU >= CP;
@@ -352,12 +369,14 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
           for (int u = 0; u < KU; ++u)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], xsp[(2 * (s + u)) * QT], acc0, 0, 0, 0);
         }
+        if (FOLD) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kk ? sy32 : 1.0f, qtail0, acc0, 0, 0, 0);
       }
     }
     // ---- lane l needs all 32 keys of ITS query: v_permlane32_swap exchanges the 32-lane halves of the two
     //      accumulators (vdst.hi <-> src.lo); afterwards lo = key rows (r&3)+8(r>>2), hi = those + 4.
-    //      dist = ((|x|^2 + (-2 x.y)) + |y|^2) + relpos in the reference's order; |y|^2 comes through the
-    //      scalar cache (the key row is wave-uniform) and is MASKED_SQ for keys past M, which also masks them.
+    //      dist = ((|x|^2 + (-2 x.y)) + |y|^2) + relpos in the reference's order; with FOLD the first two adds happened
+    //      in the contraction's last k-pair, otherwise |y|^2 is broadcast per candidate with v_readlane; it is
+    //      MASKED_SQ for keys past M, which also masks them.
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float lo[4], hi[4];
@@ -373,10 +392,13 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int row = 8 * g + 4 * hh + j;                              // increasing key order (tie rule)
-          const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-          float dist = (sqx + (hh ? hi[j] : lo[j])) + sy;
+          float dist = hh ? hi[j] : lo[j];
+          if (!FOLD) {                                                   // FOLD: both adds already happened on the matrix pipe
+            const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
+            dist = (sqx + dist) + sy;
+          }
           if (HAS_RP) dist = dist + rp[row];
-          top.insert(dist, m0 + row);
+          top.template insert<GUARD>(dist, m0 + row);
         }
       }
     }
@@ -543,13 +565,24 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
   return p.total;
 }
 
-template <int KD, bool HAS_RP, int KU>
+template <int KD, bool HAS_RP, int KU, bool GUARD = true>
 static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
+}
+
+// Short key streams (< 10 key tiles per wave: the 18x18 stage, label graphs over it): insert without the ballot guard.
+// Only for the 9-entry list: with 18 or 27 entries the insert is expensive enough that skipping it wins again
+// (measured: k*d = 27 at 18x18 is 19 % slower without the guard).
+template <int KD>
+static hipError_t launch_tile_short(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
+  const bool deep = (a.cpad % 16) == 0;
+  if (a.relpos) return deep ? launch_tile_v<KD, true, 8, false>(a, grid, lds, st) : launch_tile_v<KD, true, 4, false>(a, grid, lds, st);
+  return deep ? launch_tile_v<KD, false, 8, false>(a, grid, lds, st) : launch_tile_v<KD, false, 4, false>(a, grid, lds, st);
 }
 
 template <int KD>
@@ -623,6 +656,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
   size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
   size_t lds = lds_q > lds_m ? lds_q : lds_m;
+  const bool short_stream = p.tps < 10 * NW;
+  if (short_stream && p.KD == 9) {
+    e = launch_tile_short<9>(a, grid, lds, st);
+  } else
   switch (p.KD) {
     case 9: e = launch_tile<9>(a, grid, lds, st); break;
     case 12: e = launch_tile<12>(a, grid, lds, st); break;
