@@ -533,6 +533,7 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   if (p->KD < 0) return GKG_ERR_UNSUPPORTED;
   if ((size_t)p->cpad * QT * sizeof(float) > 150 * 1024) return GKG_ERR_UNSUPPORTED;   // c <= 600
   if (BG > 65535) return GKG_ERR_UNSUPPORTED;           // token_prep uses grid.y = BG
+  if ((long)M + KT > (long)IDX_BITS) return GKG_ERR_UNSUPPORTED;   // key indices live in 29 bits of the list keys
   p->S = pick_splits(BG, N, M);
   const int ktiles = (M + KT - 1) / KT;
   p->tps = (ktiles + p->S - 1) / p->S;
