@@ -44,12 +44,21 @@ struct PrepStrides { int G; size_t sb, sg, sc, sn; };
 // (token-major input: float4 loads of the contiguous channel run), (2) run both chains out of LDS, (3) store
 // the normalised copy coalesced along the token axis.  PT (tokens per workgroup) shrinks with c so the column
 // block always fits: PT * c * 4 B <= 48 KB.
+// One launch prepares the queries AND (bipartite graphs) the keys: workgroups blockIdx.x >= nbx1 take the second
+// tensor — for the short label-branch problems a second dependent launch costs as much as the work itself.
+struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; };
+
 template <typename T, bool NORM, int PT>
-__global__ __launch_bounds__(PT) void token_prep_kernel(const T* __restrict__ t, float* __restrict__ th,
-                                                        float* __restrict__ sq, int c, int cpad, int Tn,
-                                                        PrepStrides ps) {
+__global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
   extern __shared__ float col[];          // [c][PT]
-  const int n = blockIdx.x * PT + threadIdx.x;
+  const bool second = (int)blockIdx.x >= nbx1;
+  const PrepSet& S = second ? s2 : s1;
+  const T* __restrict__ t = static_cast<const T*>(S.t);
+  float* __restrict__ th = S.th;
+  float* __restrict__ sq = S.sq;
+  const int Tn = S.Tn;
+  const PrepStrides ps = S.ps;
+  const int n = ((int)blockIdx.x - (second ? nbx1 : 0)) * PT + threadIdx.x;
   const int bg = blockIdx.y;
   if (n >= Tn) return;
   // element (bg = b*G + g, ch, n) of the input lives at  b*sb + g*sg + ch*sc + n*sn
@@ -595,21 +604,22 @@ static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream
 }
 
 template <typename T, int PT>
-static void launch_prep_pt(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
-                           hipStream_t st, PrepStrides ps) {
-  dim3 grid((Tn + PT - 1) / PT, BG);
+static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
+  const int nbx1 = (s1.Tn + PT - 1) / PT;
+  const int nbx2 = s2 ? (s2->Tn + PT - 1) / PT : 0;
+  dim3 grid(nbx1 + nbx2, BG);
   const size_t lds = (size_t)c * PT * sizeof(float);
-  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, (const T*)t, th, sq, c, cpad, Tn, ps);
-  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, (const T*)t, th, sq, c, cpad, Tn, ps);
+  const PrepSet second = s2 ? *s2 : s1;
+  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
+  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
 }
 
 template <typename T>
-static hipError_t launch_prep(const void* t, float* th, float* sq, int BG, int c, int cpad, int Tn, bool norm,
-                              hipStream_t st, PrepStrides ps) {
+static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
-  if (c <= 192) launch_prep_pt<T, 64>(t, th, sq, BG, c, cpad, Tn, norm, st, ps);          // <= 48 KB column block
-  else if (c <= 384) launch_prep_pt<T, 32>(t, th, sq, BG, c, cpad, Tn, norm, st, ps);
-  else launch_prep_pt<T, 16>(t, th, sq, BG, c, cpad, Tn, norm, st, ps);                    // c <= 600 (plan limit)
+  if (c <= 192) launch_prep_pt<T, 64>(s1, s2, BG, c, cpad, norm, st);          // <= 48 KB column block
+  else if (c <= 384) launch_prep_pt<T, 32>(s1, s2, BG, c, cpad, norm, st);
+  else launch_prep_pt<T, 16>(s1, s2, BG, c, cpad, norm, st);                    // c <= 600 (plan limit)
   return hipGetLastError();
 }
 
@@ -638,14 +648,11 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     else { ps.G = 1; ps.sb = (size_t)c * Tn; ps.sg = 0; ps.sc = Tn; ps.sn = 1; }
     return ps;
   };
-  if (dtype == GKG_F32) e = launch_prep<float>(x, xh, sqx, BG, c, p.cpad, N, norm, st, strides(N));
-  else e = launch_prep<uint16_t>(x, xh, sqx, BG, c, p.cpad, N, norm, st, strides(N));
-  if (e != hipSuccess) return gkg_fail_hip(e, "token_prep(x)");
-  if (y) {
-    if (dtype == GKG_F32) e = launch_prep<float>(y, yh, sqy, BG, c, p.cpad, M, norm, st, strides(M));
-    else e = launch_prep<uint16_t>(y, yh, sqy, BG, c, p.cpad, M, norm, st, strides(M));
-    if (e != hipSuccess) return gkg_fail_hip(e, "token_prep(y)");
-  }
+  const PrepSet sx{x, xh, sqx, N, strides(N)};
+  const PrepSet sy{y, yh, sqy, M, strides(M)};
+  if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
+  else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
+  if (e != hipSuccess) return gkg_fail_hip(e, "token_prep");
   KnnArgs a;
   a.xh = xh; a.yh = yh; a.sqx = sqx; a.sqy = sqy; a.relpos = relpos;
   a.nn_idx = nn_idx; a.center = center;
