@@ -17,6 +17,7 @@ hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabe
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -34,6 +35,8 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dW (Cout, Cin) = dY^T (Cout x R) @ x (R x Cin).  The output is tiny and the contraction long (R = B*N),
     so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials."""
     R = x.shape[0]
+    if R < 4096:                 # short contractions (the label branch): the partial-sum kernel costs more than it saves
+        return torch.mm(dY.t(), x)
     for S in (8, 6, 4, 3, 2):
         if R % S == 0 and R // S >= 1024:
             part = torch.bmm(dY.view(S, R // S, -1).transpose(1, 2), x.view(S, R // S, -1))
