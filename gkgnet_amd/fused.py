@@ -17,7 +17,6 @@ hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabe
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
