@@ -43,6 +43,18 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return torch.mm(dY.t(), x)
 
 
+def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
+    """Grouped projection: dW[q] (co, ci) = dY[q]^T @ U[q] for the nb groups; long contractions are split like
+    ``_wgrad`` (nb*S batched GEMMs + one partial sum)."""
+    nb, R, co = dY.shape
+    ci = U.shape[2]
+    S = 4
+    if R >= 4096 and R % S == 0:
+        part = torch.bmm(dY.reshape(nb * S, R // S, co).transpose(1, 2), U.reshape(nb * S, R // S, ci))
+        return part.view(nb, S, co, ci).sum(1)
+    return torch.bmm(dY.transpose(1, 2), U)
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -310,7 +322,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync)
         Wg = weight.view(nb, co, ci)
         dU = torch.bmm(dY, Wg)
-        dW = torch.bmm(dY.transpose(1, 2), U).view_as(weight)
+        dW = _wgrad_grouped(dY, U).view_as(weight)
         return dU, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 
