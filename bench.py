@@ -114,7 +114,7 @@ def main():
         tunable.enable(True)
         tunable.tuning_enable(True)
         tunable.set_max_tuning_duration(30)
-        tunable.set_max_tuning_iterations(20)
+        tunable.set_max_tuning_iterations(40)
         tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_rank{rank}.csv"))
     torch.manual_seed(0)
     grapher, label = build_modules(w, dev)
