@@ -5,7 +5,7 @@
 // materialising the (BG,N,M) distance matrix.
 //
 // Pipeline (all on the caller's stream):
-//   1. token_prep_kernel   : per token, ordered-fma L2 norm over the group's channels, normalised fp32
+//   1. token_prep_kernel   : (one launch for queries and keys) per token, ordered-fma L2 norm over the group's channels, normalised fp32
 //                            copy th (BG,cpad,T) (cpad = c rounded up to a multiple of 8, zero padded) + |th|^2.
 //   2. knn_tile_kernel<KD> : one workgroup = 64 queries of one (b,g) problem x one key split; its 4 waves
 //                            take key tiles of 32 round-robin.  Per key tile a wave runs the contraction on
