@@ -17,8 +17,6 @@ hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabe
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
