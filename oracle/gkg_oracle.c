@@ -14,7 +14,9 @@
  * with the near-tie protocol, and the HIP kernels must match THIS file exactly (indices, m, argmax).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
- * Build: make -C oracle   (gcc -O2 -ffp-contract=off; fmaf must be a true fused multiply-add).
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; fmaf must be a true fused multiply-add).
+ * OpenMP only spreads independent queries / (problem, channel) rows over threads: every output element is
+ * still computed by one thread in the scalar order above, so results do not depend on the thread count.
  */
 #include <math.h>
 #include <stdint.h>
@@ -46,10 +48,16 @@ static void token_prep(const float* t, float* th, float* sq, int c, int T, unsig
 /* Full distance row for query n of one (bg) problem. */
 static void dist_row(const float* xh, const float* yh, const float* sqx, const float* sqy,
                      const float* relpos, int c, int N, int M, int n, float* out) {
+  /* channel-outer loop: out[m] carries key m's ordered fmaf chain over ch = 0..c-1 (same arithmetic as a
+     per-key inner loop, contiguous reads of yh) */
+  for (int m = 0; m < M; ++m) out[m] = 0.0f;
+  for (int ch = 0; ch < c; ++ch) {
+    const float xv = xh[(size_t)ch * N + n];
+    const float* yr = yh + (size_t)ch * M;
+    for (int m = 0; m < M; ++m) out[m] = fmaf(yr[m], xv, out[m]);
+  }
   for (int m = 0; m < M; ++m) {
-    float acc = 0.0f;
-    for (int ch = 0; ch < c; ++ch) acc = fmaf(yh[(size_t)ch * M + m], xh[(size_t)ch * N + n], acc);
-    float d = (sqx[n] + (-2.0f * acc)) + sqy[m];
+    float d = (sqx[n] + (-2.0f * out[m])) + sqy[m];
     if (relpos) d = d + relpos[(size_t)n * M + m];
     out[m] = d;
   }
@@ -67,32 +75,37 @@ int oracle_knn_fwd(const float* x, const float* y, const float* relpos, int64_t*
   float* yh = y ? (float*)malloc(sizeof(float) * (size_t)c * M) : xh;
   float* sqx = (float*)malloc(sizeof(float) * N);
   float* sqy = y ? (float*)malloc(sizeof(float) * M) : sqx;
-  float* row = (float*)malloc(sizeof(float) * M);
-  float* bv = (float*)malloc(sizeof(float) * kd);
-  int* bi = (int*)malloc(sizeof(int) * kd);
   for (int bg = 0; bg < BG; ++bg) {
     token_prep(x + (size_t)bg * c * N, xh, sqx, c, N, flags);
     if (y) token_prep(y + (size_t)bg * c * M, yh, sqy, c, M, flags);
-    for (int n = 0; n < N; ++n) {
-      dist_row(xh, yh, sqx, sqy, relpos, c, N, M, n, row);
-      if (dist_out) memcpy(dist_out + ((size_t)bg * N + n) * M, row, sizeof(float) * M);
-      /* stable insertion of keys in increasing m: strict '<' keeps the smaller index first on ties */
-      int cnt = 0;
-      for (int m = 0; m < M; ++m) {
-        float d = row[m];
-        if (cnt == kd && !(d < bv[kd - 1])) continue;
-        int p = cnt < kd ? cnt : kd - 1;
-        while (p > 0 && d < bv[p - 1]) { bv[p] = bv[p - 1]; bi[p] = bi[p - 1]; --p; }
-        bv[p] = d; bi[p] = m;
-        if (cnt < kd) ++cnt;
+    /* queries are independent: OpenMP over n with thread-private scratch (results do not depend on the thread count) */
+#pragma omp parallel
+    {
+      float* row = (float*)malloc(sizeof(float) * M);
+      float* bv = (float*)malloc(sizeof(float) * kd);
+      int* bi = (int*)malloc(sizeof(int) * kd);
+#pragma omp for schedule(static)
+      for (int n = 0; n < N; ++n) {
+        dist_row(xh, yh, sqx, sqy, relpos, c, N, M, n, row);
+        if (dist_out) memcpy(dist_out + ((size_t)bg * N + n) * M, row, sizeof(float) * M);
+        /* stable insertion of keys in increasing m: strict '<' keeps the smaller index first on ties */
+        int cnt = 0;
+        for (int m = 0; m < M; ++m) {
+          float d = row[m];
+          if (cnt == kd && !(d < bv[kd - 1])) continue;
+          int p = cnt < kd ? cnt : kd - 1;
+          while (p > 0 && d < bv[p - 1]) { bv[p] = bv[p - 1]; bi[p] = bi[p - 1]; --p; }
+          bv[p] = d; bi[p] = m;
+          if (cnt < kd) ++cnt;
+        }
+        for (int j = 0; j < k; ++j) {
+          nn_idx[((size_t)bg * N + n) * k + j] = bi[j * dilation];
+          if (center) center[((size_t)bg * N + n) * k + j] = n;
+        }
       }
-      for (int j = 0; j < k; ++j) {
-        nn_idx[((size_t)bg * N + n) * k + j] = bi[j * dilation];
-        if (center) center[((size_t)bg * N + n) * k + j] = n;
-      }
+      free(bi); free(bv); free(row);
     }
   }
-  free(bi); free(bv); free(row);
   if (y) { free(sqy); free(yh); }
   free(sqx); free(xh);
   return 0;
@@ -102,6 +115,7 @@ int oracle_mr_fwd(const float* x, const float* src, const int64_t* nn_idx, float
                   int BG, int c, int N, int M, int k) {
   if (!x || !nn_idx || !m_out) return -1;
   if (!src) { src = x; if (M != N) return -2; }
+#pragma omp parallel for collapse(2) schedule(static)
   for (int bg = 0; bg < BG; ++bg)
     for (int ch = 0; ch < c; ++ch) {
       const float* xr = x + ((size_t)bg * c + ch) * N;
@@ -125,6 +139,7 @@ int oracle_mr_bwd(const float* g, const int64_t* nn_idx, const uint8_t* argmax, 
                   int BG, int c, int N, int M, int k) {
   if (!g || !nn_idx || !argmax || !gx) return -1;
   if (!gsrc && M != N) return -2;
+#pragma omp parallel for collapse(2) schedule(static)
   for (int bg = 0; bg < BG; ++bg)
     for (int ch = 0; ch < c; ++ch) {
       const size_t ro = ((size_t)bg * c + ch) * N;

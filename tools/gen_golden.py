@@ -361,8 +361,126 @@ def head_case(ref, name):
                     "losses/asymmetric_loss.py:9-71; losses/label_smooth_loss.py:122-175"), **arrays)
 
 
+# ----------------------------------------------------------------------------- autocast (bf16) cases
+def autocast_case(ref, name, *, C, k, d, hw, G, L, B=2, seed=0):
+    """F14: the reference's Grapher -> GrapherLabel chain evaluated under torch.autocast('cpu', bfloat16) (eval mode,
+    no_grad: BASELINE configs 3/5 are bf16 inference) next to the same chain in fp32.  Under autocast the reference runs
+    its 1x1 convolutions AND the pairwise-distance matmul in bf16, so its own graph differs from the fp32 one; the
+    fixture stores both runs so that the product's mixed-precision path (bf16 GEMM operands, fp32 accumulation, fp32
+    k-NN) is held to: at least as close to the fp32 reference as the reference's own autocast run is."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    n = hw * hw
+    g = ref.vig.Grapher(C, k, d, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=True,
+                        use_multi_group=True, num_group=G)
+    gl = ref.vig.GrapherLabel(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0,
+                              relative_pos=False, num_nodes=L, use_multi_group=True, num_group=G)
+    randomize_norm_(g, gen)
+    randomize_norm_(gl, gen)
+    x = torch.randn(B, C, hw, hw, generator=gen)
+    e = torch.randn(B, L, C, generator=gen)
+    g.eval(); gl.eval()
+    cap = {}
+    h = g.graph_conv.register_forward_hook(lambda m, i, o: cap.update(edge=o[1].detach().clone()))
+
+    def run():
+        out = g(x)
+        e2, idx = gl(e, out.float())
+        return out.float(), e2.float(), cap["edge"].clone(), idx.clone()
+
+    with torch.no_grad():
+        out32, e32, edge32, idx32 = run()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out_ac, e_ac, edge_ac, idx_ac = run()
+    h.remove()
+    arrays = dict(x=x.numpy(), e=e.numpy(), out_fp32=out32.numpy(), labels_fp32=e32.numpy(),
+                  edge_fp32=edge32.numpy().astype(np.int32), idx_fp32=idx32.numpy().astype(np.int32),
+                  out_autocast=out_ac.numpy(), labels_autocast=e_ac.numpy(),
+                  edge_autocast=edge_ac.numpy().astype(np.int32), idx_autocast=idx_ac.numpy().astype(np.int32))
+    arrays.update({"g/" + k_: v for k_, v in np_state(g).items()})
+    arrays.update({"gl/" + k_: v for k_, v in np_state(gl).items()})
+    meta = dict(kind="autocast", C=C, k=k, dilation=d, hw=hw, n=n, G=G, L=L, B=B,
+                ref="torch_vertex.py:278-403 under torch.autocast('cpu', torch.bfloat16), eval, no_grad")
+    save(name, meta, **arrays)
+
+
+# ----------------------------------------------------------------------------- train-step case
+def paramwise_groups(modules, weight_decay):
+    """The reference's paramwise_cfg (configs/gkgnet/gkgnet_coco_576.py:110-117: norm_decay_mult=0, bias_decay_mult=0)
+    as mmcv's DefaultOptimizerConstructor applies it: every parameter of a norm layer and every 'bias' decays with 0."""
+    decay, no_decay = [], []
+    for mod in modules:
+        for m in mod.modules():
+            is_norm = isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.LayerNorm, torch.nn.GroupNorm))
+            for pn, p in m.named_parameters(recurse=False):
+                if p.requires_grad:
+                    (no_decay if (is_norm or pn == "bias") else decay).append(p)
+    return [dict(params=decay, weight_decay=weight_decay), dict(params=no_decay, weight_decay=0.0)]
+
+
+def train_step_case(ref, name, steps=2):
+    """F15 (SURVEY §8 f2 / BASELINE config 4 at a tiny size): the reference's GKGNet backbone + LabelQueryHead in train
+    mode, loss = smoothed BCE + 10 x ASL (heads/label_query_head.py:70-85), AdamW lr 1e-4 wd 0.05 with the paramwise
+    config, grad-clip 5.0 (gkgnet_coco_576.py:110-126).  Stores per-step loss / pre-clip gradient norm and a few
+    parameters after `steps` updates.  Weights: keyed_fill_ (both sides regenerate them)."""
+    torch.manual_seed(0)
+    kw = dict(choice="t", k=4, k_label_gcn=4, n_classes=8, size=128, drop_path=0.0)
+    net = ref.gkgnet.GKGNet(**kw)
+    sd = net.state_dict()
+    with torch.no_grad():
+        keyed_fill_(sd, seed=15)
+    net.load_state_dict(sd)
+    head = ref.head.LabelQueryHead(num_classes=8, in_channels=384, softmax=False,
+                                   loss=dict(type="AsymmetricLoss", gamma_pos=0.0, gamma_neg=2.0, clip=0.05), topk=(1, 1))
+    hsd = head.state_dict()
+    with torch.no_grad():
+        keyed_fill_(hsd, seed=16)
+    head.load_state_dict(hsd)
+    net.train(); head.train()
+    gen = torch.Generator().manual_seed(150)
+    B = 4
+    img = torch.randn(B, 3, 128, 128, generator=gen).to(torch.bfloat16).float()     # bf16-representable: stored as 16 bits
+    gt = (torch.rand(B, 8, generator=gen) < 0.3).float()
+    params = [p for p in list(net.parameters()) + list(head.parameters()) if p.requires_grad]
+    opt = torch.optim.AdamW(paramwise_groups([net, head], 0.05), lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    watch = ["backbone.0.0.fc1.0.weight", "backbone.0.0.graph_conv.gconv.nn.0.weight", "backbone.7.0.fc2.0.weight",
+             "backbone.13.0.fc1.1.weight", "gcn_label.0.0.ffn.fc1.0.weight", "gcn_label.3.0.graph_conv.gconv.nn.1.bias",
+             "label_lt.weight", "backbone.4.0.fc2.1.weight", "pos_embed"]
+    named = dict(net.named_parameters())
+    before = {k_: named[k_].detach().clone() for k_ in watch}
+    hbefore = head.fc1.weight.detach().clone()
+    losses, bces, asys, norms = [], [], [], []
+    grads0 = {}
+    for it in range(steps):
+        opt.zero_grad(set_to_none=True)
+        out = head.forward_train(net(img), gt)
+        loss = out["bce_loss"] + out["asy_loss"]
+        loss.backward()
+        if it == 0:
+            grads0 = {k_: named[k_].grad.detach().clone() for k_ in watch}
+        norms.append(float(torch.nn.utils.clip_grad_norm_(params, 5.0)))
+        opt.step()
+        losses.append(float(loss)); bces.append(float(out["bce_loss"])); asys.append(float(out["asy_loss"]))
+    arrays = dict(img_bf16=img.to(torch.bfloat16).view(torch.int16).numpy(), gt=gt.numpy(), loss=np.array(losses), bce_loss=np.array(bces),
+                  asy_loss=np.array(asys), grad_norm=np.array(norms), head_fc1_delta=(head.fc1.weight.detach() - hbefore).numpy())
+    for k_ in watch:
+        arrays["delta/" + k_] = (named[k_].detach() - before[k_]).numpy()
+        arrays["grad0/" + k_] = grads0[k_].numpy()
+    meta = dict(kind="train_step", ctor=kw, head=dict(num_classes=8, in_channels=384), B=B, steps=steps, lr=1e-4,
+                weight_decay=0.05, grad_clip=5.0, watch=watch,
+                ref="gkgnet.py:150-284; heads/label_query_head.py:70-85; configs/gkgnet/gkgnet_coco_576.py:110-126")
+    save(name, meta, **arrays)
+
+
 def main():
     ref = load_reference(with_backbone=True, with_head=True)
+    only = set(sys.argv[1:])
+    if only:
+        if 'f14' in only:
+            autocast_case(ref, 'f14_autocast_bf16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=14)
+        if 'f15' in only:
+            train_step_case(ref, 'f15_train_step')
+        return
     grapher_case(ref, "f1_grapher_cfg1", C=64, k=9, d=1, r=1, hw=14, G=1, multi=False)
     grapher_case(ref, "f2_grapher_g4", C=64, k=9, d=1, r=1, hw=8, G=4, multi=True, seed=2)
     grapher_case(ref, "f3_grapher_dil3", C=64, k=9, d=3, r=1, hw=12, G=2, multi=True, seed=3)
@@ -381,6 +499,8 @@ def main():
     relpos_case(ref, "f9_relpos", [(64, 196, 1), (80, 144, 1), (32, 256, 2), (32, 256, 4)])
     backbone_case(ref, "f10_backbone_tiny")
     head_case(ref, "f12_head_loss")
+    autocast_case(ref, 'f14_autocast_bf16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=14)
+    train_step_case(ref, 'f15_train_step')
     map_case("f13_map")
 
 
