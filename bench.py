@@ -226,6 +226,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
 
+    from gkgnet_amd import fused
+    lib_desc = "vendor-library GEMMs (TunableOp-selected)" if not args.no_tune else "vendor-library GEMMs (default heuristic)"
+    gemm_desc = {"all": "own fp32-MFMA kernels (csrc/gkg_gemm.hip): forward with BN-statistics epilogue, dgrad/wgrad with BN-backward prologue",
+                 "fwd": "forward projections: own fp32-MFMA kernels with BN-statistics epilogue (csrc/gkg_gemm.hip); dgrad/wgrad: " + lib_desc,
+                 "none": lib_desc}[fused.OWN_GEMM]
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
@@ -272,7 +277,7 @@ def main():
                                HW=f"{H}x{H}", k=w["k"], dilation=w["d"], label_tokens=L, bn="sync" if
                                layers.norm_cfg["type"] == "SyncBN" else "local", parallelism=f"dp{world}",
                                launch="hipGraph replay of fwd+bwd+grad-pack" if graph is not None else "eager",
-                               gemm="library GEMMs, TunableOp-selected" if not args.no_tune else "library GEMMs, default heuristic",
+                               gemm=gemm_desc,
                                grad_allreduce="one flat RCCL all-reduce per step" if world > 1 else "none (1 GPU)"),
                    roofline=roof, hip_kernels=kernels)
         if world == 1 and not args.no_cpu_baseline:

@@ -10,15 +10,17 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16 = 0, 1
 KNN_NORMALIZE = 1
+LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
            "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
-           "gkg_bn_bwd_sums", "gkg_bn_bwd_apply")
+           "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
+           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
 
 _lib = None
@@ -80,6 +82,18 @@ def load():
     lib.gkg_bn_bwd_sums.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_bwd_apply.restype = I
     lib.gkg_bn_bwd_apply.argtypes = [V] * 9 + [I, I, I, I, Z, I, V]
+    lib.gkg_linear_workspace_bytes.restype = Z
+    lib.gkg_linear_workspace_bytes.argtypes = [I, I, I, I]
+    lib.gkg_linear_counters.restype = I
+    lib.gkg_linear_counters.argtypes = []
+    lib.gkg_linear_bn_fwd.restype = I
+    lib.gkg_linear_stats_doubles.restype = I
+    lib.gkg_linear_stats_doubles.argtypes = []
+    lib.gkg_linear_bn_fwd.argtypes = [V, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V]
+    lib.gkg_bn_bwd_coef.restype = I
+    lib.gkg_bn_bwd_coef.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V, Z, V]
+    lib.gkg_linear_bn_bwd.restype = I
+    lib.gkg_linear_bn_bwd.argtypes = [V, I, Z, V, V, V, V, V, V, I, I, I, I, C.c_uint, V, Z, V, V]
     lib.gkg_prof_enable.restype = None
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None

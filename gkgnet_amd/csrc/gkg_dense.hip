@@ -100,6 +100,11 @@ __device__ __forceinline__ void stats_block_reduce(float (*red)[ST_RL][4 * ST_CG
   }
 }
 
+// SHIFT: sums are taken of (y - y[row 0]) instead of y: any sample of the column is within a few standard deviations of
+// its mean, so the second moment no longer cancels catastrophically when |mean| >> std (E[y^2] - E[y]^2 in fp32 loses
+// ~1e-7 * mean^2 / var of the variance); reduce_finalize_kernel adds the shift back.  The cross-rank (SyncBN) form keeps
+// plain sums: its partial sums travel through an all-reduce and every rank would shift by a different row.
+template <bool SHIFT>
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, float* __restrict__ part,
                                                         int R, int C, int rows_per_block) {
   __shared__ float red[2][ST_RL][4 * ST_CG];
@@ -114,12 +119,18 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
   if (cgi < (C >> 2)) {
     const float* p = y + (size_t)4 * cgi;
+    const float4 sh = SHIFT ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](int row) {
+      float4 v = *reinterpret_cast<const float4*>(p + (size_t)row * C);
+      if (SHIFT) { v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w; }
+      return v;
+    };
     int r = r0 + rl;
     for (; r + 3 * ST_RL < r1; r += 4 * ST_RL) {        // 4 independent loads in flight
-      const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)r * C);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(r + ST_RL) * C);
-      const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(r + 2 * ST_RL) * C);
-      const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(r + 3 * ST_RL) * C);
+      const float4 v0 = ld(r);
+      const float4 v1 = ld(r + ST_RL);
+      const float4 v2 = ld(r + 2 * ST_RL);
+      const float4 v3 = ld(r + 3 * ST_RL);
       s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
       s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
       sq.x += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
       sq.w += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
     }
     for (; r < r1; r += ST_RL) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)r * C);
+      const float4 v = ld(r);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
     }
@@ -225,7 +236,8 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
                                                               float* __restrict__ running_var, float* __restrict__ a,
                                                               float* __restrict__ cs, float* __restrict__ mean,
                                                               float* __restrict__ invstd, int R, int C, float momentum, float eps,
-                                                              long long* __restrict__ num_batches_tracked) {
+                                                              long long* __restrict__ num_batches_tracked,
+                                                              const float* __restrict__ y_shift_row /* y: row 0 is the shift */) {
   __shared__ double lane_sum[8][32];
   if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   const int t = threadIdx.x & 31;
@@ -252,13 +264,14 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   const double S = (lane_sum[0][t] + lane_sum[1][t]) + (lane_sum[2][t] + lane_sum[3][t]);
   const double Q = (lane_sum[4][t] + lane_sum[5][t]) + (lane_sum[6][t] + lane_sum[7][t]);
   const size_t o = (size_t)q * C + ch;
-  const double m = S / R;
-  double var = Q / R - m * m;
+  const double ms = S / R;                         // mean of the shifted values
+  double var = Q / R - ms * ms;
   if (var < 0.0) var = 0.0;
+  const double m = ms + (y_shift_row ? (double)y_shift_row[(size_t)q * R * C + ch] : 0.0);
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float av = gamma[o] * is;
   a[o] = av;
-  cs[o] = beta[o] - av * (float)m;
+  cs[o] = (float)((double)beta[o] - (double)av * m);
   mean[o] = (float)m;
   invstd[o] = is;
   if (running_mean) {
@@ -385,6 +398,55 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
   }
 }
 
+// ------------------------------------------------------------------------------------------ BN backward coefficients
+// From the chunk partials of (sum dz, sum dz*yhat) (bn_bwd_stats_kernel in gkg_dense.hip): dbeta, dgamma and the
+// coefficients of  dy = alpha*dz + beta*y + gamma  with
+//   dy = a*(dz - S1/R - yhat*S2/R),  yhat = (y - mean)*invstd   =>  alpha = a,  beta = -a*invstd*S2/R,
+//   gamma = -a*S1/R + a*invstd*mean*S2/R
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ part, int nblk, int C,
+                                                          const float* __restrict__ a, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, float invR,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ coef, float* __restrict__ zero_buf,
+                                                          size_t zero_floats) {
+  __shared__ double lane_sum[8][32];
+  if (zero_buf) {                                  // side job: clear the caller's accumulator (the following wgrad's dW)
+    const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+    for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_floats; i += nthreads) zero_buf[i] = 0.f;
+  }
+  const int t = threadIdx.x & 31, ln = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + t;
+  const int q = blockIdx.y;
+  const int C2 = 2 * C;
+  double acc = 0.0;                                 // lanes 0-3: sum dz (every 4th partial); lanes 4-7: sum dz*yhat
+  if (ch < C) {
+    const float* p = part + (size_t)q * nblk * C2 + (ln >> 2) * C + ch;
+    int b = ln & 3;
+    for (; b + 28 < nblk; b += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + 4 * u) * C2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < nblk; b += 4) acc += (double)p[(size_t)b * C2];
+  }
+  lane_sum[ln][t] = acc;
+  __syncthreads();
+  if (ln != 0 || ch >= C) return;
+  const double S1 = (lane_sum[0][t] + lane_sum[1][t]) + (lane_sum[2][t] + lane_sum[3][t]);
+  const double S2 = (lane_sum[4][t] + lane_sum[5][t]) + (lane_sum[6][t] + lane_sum[7][t]);
+  const size_t o = (size_t)q * C + ch;
+  dbeta[o] = (float)S1;
+  dgamma[o] = (float)S2;
+  const float av = a[o], is = invstd[o], mu = mean[o];
+  const float s1 = (float)S1 * invR, s2 = (float)S2 * invR;
+  float* cf = coef + (size_t)q * 3 * C;
+  cf[ch] = av;
+  cf[C + ch] = -av * is * s2;
+  cf[2 * C + ch] = av * (is * mu * s2 - s1);
+}
+
 }  // namespace gkg
 
 using namespace gkg;
@@ -450,9 +512,9 @@ extern "C" int gkg_bn_train_stats(const float* y, const float* gamma, const floa
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   float* sums = part + (size_t)nb * nblk * 2 * C;
-  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, y, part, R, C, rpb);
+  hipLaunchKernelGGL(col_stats_kernel<true>, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, y, part, R, C, rpb);
   hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, nb), dim3(256), 0, st, part, nblk, gamma, beta, bias,
-                     running_mean, running_var, a, c, mean, invstd, R, C, momentum, eps, num_batches_tracked);
+                     running_mean, running_var, a, c, mean, invstd, R, C, momentum, eps, num_batches_tracked, y);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_train_stats");
 }
@@ -530,7 +592,7 @@ extern "C" int gkg_bn_stats_sums(const float* y, float* sums, int R, int C, int 
     return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_stats_sums: workspace too small (gkg_bn_workspace_bytes)");
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, y, part, R, C, rpb);
+  hipLaunchKernelGGL(col_stats_kernel<false>, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, y, part, R, C, rpb);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 31) / 32, nb), dim3(256), 0, st, part, sums, nblk, 2 * C,
                      (float*)nullptr, (float*)nullptr);
   hipError_t e = hipGetLastError();
@@ -585,4 +647,30 @@ extern "C" int gkg_bn_bwd_apply(const float* dout, const float* y, const float* 
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, count);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_apply_kernel");
+}
+
+// ------------------------------------------------------------------------------------------ backward, fused-GEMM form
+// First half of the BN backward for the projection kernels of gkg_gemm.hip: statistics pass (parks dz = dout*act'(z) in
+// `dz` when act == 1) + ONE finalize kernel that writes dbeta, dgamma and the (alpha, beta, gamma) coefficients of
+// dy = alpha*dz + beta*y + gamma.  The apply pass does not exist any more: gkg_linear_bn_bwd applies the coefficients
+// while it stages dz / y tiles for the dgrad and wgrad products.
+extern "C" int gkg_bn_bwd_coef(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                               const float* invstd, float* dz, float* dgamma, float* dbeta, float* coef, int R, int C,
+                               int nb, int ldg, size_t dout_bstride, int act, float* zero_buf, size_t zero_floats,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace || (act == 1 && !dz))
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_coef: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_coef: bad sizes");
+  int rpb;
+  const int nblk = stats_blocks(R, C, nb, &rpb);
+  if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float)) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_bwd_coef: workspace too small (gkg_bn_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dz);
+  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32, nb), dim3(256), 0, st, part, nblk, C, a, mean, invstd,
+                     1.0f / (float)R, dgamma, dbeta, coef, zero_buf, zero_floats);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_coef");
 }

@@ -476,6 +476,9 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   const int p = (int)(rem - q * kd);
   const float v = part_v[e];
   const int id = part_i[e];
+  // the centre plane does not depend on the distances: split 0's threads write it for every output slot, so ranks that
+  // no finite candidate claims (non-finite inputs only) still carry a defined centre index
+  if (center && s == 0 && p < k) center[q * k + p] = (int64_t)(q % N);
   if (id == 0x7fffffff) return;                                    // padding of a short list
   int rank = p;
   for (int s2 = 0; s2 < S && rank < kd; ++s2) {
@@ -495,7 +498,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     const int outj = rank / dilation;
     if (outj < k) {
       nn_idx[q * k + outj] = id < M ? id : 0;       // masked tail keys can only rank here on non-finite inputs
-      if (center) center[q * k + outj] = (int64_t)(q % N);
     }
   }
 }

@@ -22,6 +22,10 @@ constexpr int MR_LDS_BUDGET = 96 * 1024;   // bytes of LDS for source rows / acc
 // corrupted index tensor from becoming an out-of-bounds access.
 __device__ __forceinline__ int clamp_idx(int64_t v, int M) { return (int)(v < 0 ? 0 : (v >= M ? M - 1 : v)); }
 
+// torch.max semantics for the running maximum (reference torch_vertex.py:54): a NaN candidate replaces a non-NaN best and
+// then stays (first NaN wins, like the first-max tie rule), so a diverging run surfaces NaN instead of hiding it.
+__device__ __forceinline__ bool takes(float v, float best) { return v > best || (v != v && best == best); }
+
 // ------------------------------------------------------------------------------------------ forward
 // These kernels move ~1 flop per byte and, at the sizes of this path, every operand is L2/MALL resident:
 // they are bound by memory *latency*, so each thread issues all of its independent loads before the
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
       for (int u = 0; u < MR_CB; ++u) {
         const float v = rows[(size_t)min(cb + u, nch - 1) * M + id] - xi[u];
-        if (v > best[u]) { best[u] = v; arg[u] = j; }
+        if (takes(v, best[u])) { best[u] = v; arg[u] = j; }
       }
     }
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void mr_fwd_gather_kernel(const T* __restrict_
     int arg = 0;
     for (int j = 1; j < k; ++j) {
       const float v = ldf(r + clamp_idx(ip[j], M)) - xi;
-      if (v > best) { best = v; arg = j; }
+      if (takes(v, best)) { best = v; arg = j; }
     }
     stf(m_out + o, best);
     if (argmax) argmax[o] = (uint8_t)arg;
@@ -242,10 +246,10 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
   auto upd = [&](int q, const float4& v, int j) {
     const float d0 = v.x - xi[q].x, d1 = v.y - xi[q].y, d2 = v.z - xi[q].z, d3 = v.w - xi[q].w;
     if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); return; }
-    if (d0 > best[q].x) { best[q].x = d0; arg[q] = (arg[q] & 0xffffff00u) | (uint32_t)j; }
-    if (d1 > best[q].y) { best[q].y = d1; arg[q] = (arg[q] & 0xffff00ffu) | ((uint32_t)j << 8); }
-    if (d2 > best[q].z) { best[q].z = d2; arg[q] = (arg[q] & 0xff00ffffu) | ((uint32_t)j << 16); }
-    if (d3 > best[q].w) { best[q].w = d3; arg[q] = (arg[q] & 0x00ffffffu) | ((uint32_t)j << 24); }
+    if (takes(d0, best[q].x)) { best[q].x = d0; arg[q] = (arg[q] & 0xffffff00u) | (uint32_t)j; }
+    if (takes(d1, best[q].y)) { best[q].y = d1; arg[q] = (arg[q] & 0xffff00ffu) | ((uint32_t)j << 8); }
+    if (takes(d2, best[q].z)) { best[q].z = d2; arg[q] = (arg[q] & 0xff00ffffu) | ((uint32_t)j << 16); }
+    if (takes(d3, best[q].w)) { best[q].w = d3; arg[q] = (arg[q] & 0x00ffffffu) | ((uint32_t)j << 24); }
   };
   if (KS > 0) {
     int id[KS > 0 ? KS : 1];

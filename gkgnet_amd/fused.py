@@ -17,6 +17,8 @@ hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabe
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -26,6 +28,13 @@ from .ops import _ptr, _stream
 
 _F32 = torch.float32
 ENABLED = True          # set False to force the composable (per-op) path, e.g. in A/B tests
+# Which projections run on the library's own fp32 matrix-core kernels (csrc/gkg_gemm.hip) instead of the vendor GEMM
+# library + separate BN passes: "fwd" (default), "all" (forward, dgrad and wgrad), "none".  Measured at cfg2 on MI355X:
+# the forward kernel with the BN statistics in its epilogue beats vendor GEMM + statistics passes on every layer; the
+# dgrad / wgrad kernels with the BN backward-apply prologue are 20-40 % behind the vendor kernels + apply pass at these
+# shapes (parity at the 41 472-token stages), so the backward keeps the vendor GEMMs unless asked otherwise.
+OWN_GEMM = os.environ.get("GKG_OWN_GEMM", "fwd")
+DETERMINISTIC = False   # True: ordered (run-to-run bit-identical) reduction of the split weight-gradient products
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -55,6 +64,96 @@ def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_COUNTERS = {}
+
+
+def _counters(device) -> torch.Tensor:
+    """Zero-initialised arrival counters of the projection kernels' last-arriver reductions (every kernel leaves them
+    zero).  One buffer per device, allocated on first use — outside any hipGraph capture, because the warm-up steps
+    that precede a capture run eagerly."""
+    key = (device.type, device.index)
+    t = _COUNTERS.get(key)
+    if t is None:
+        t = torch.zeros(_lib.load().gkg_linear_counters(), dtype=torch.int32, device=device)
+        _COUNTERS[key] = t
+    return t
+
+
+_STATS = {}
+
+
+def _stats_scratch(device) -> torch.Tensor:
+    """fp64 column-sum scratch of the projection kernels' BN-statistics epilogue: zero on entry, re-zeroed by the
+    finalize kernel of every call, so ONE buffer per device serves all layers (stream-ordered)."""
+    key = (device.type, device.index)
+    t = _STATS.get(key)
+    if t is None:
+        t = torch.zeros(_lib.load().gkg_linear_stats_doubles(), dtype=torch.float64, device=device)
+        _STATS[key] = t
+    return t
+
+
+def _own_gemm(x, weight, bn) -> bool:
+    """fp32 operands outside autocast and batch statistics local to this rank: the projection runs on the library's own
+    fp32 matrix-core kernels with the BN passes fused in (csrc/gkg_gemm.hip).  bf16 autocast and cross-rank SyncBN keep
+    the vendor-GEMM + separate-pass form."""
+    return (OWN_GEMM in ("fwd", "all") and x.dtype == _F32 and weight.dtype == _F32
+            and not torch.is_autocast_enabled() and _sync_group(bn) is None)
+
+
+def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb):
+    """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue)."""
+    dev = x.device
+    Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
+    a = torch.empty(nb * cout, dtype=_F32, device=dev)
+    c = torch.empty_like(a)
+    train = bn.training or not bn.track_running_stats
+    if train:
+        mean = torch.empty_like(a)
+        invstd = torch.empty_like(a)
+        track = bn.training and bn.track_running_stats
+        _lib.check(lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 1, _ptr(bn.weight), _ptr(bn.bias),
+                                         _ptr(bias), _ptr(bn.running_mean) if track else None,
+                                         _ptr(bn.running_var) if track else None,
+                                         _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
+                                         _ptr(invstd), float(bn.momentum), float(bn.eps), _ptr(_stats_scratch(dev)),
+                                         _stream()), "gkg_linear_bn_fwd")
+        return Y, a, c, mean, invstd
+    _lib.check(lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 0, None, None, None, None, None, None,
+                                     None, None, None, None, 0.0, 0.0, None, _stream()), "gkg_linear_bn_fwd")
+    _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
+                                      _ptr(bn.running_var), _ptr(a), _ptr(c), nb * cout, float(bn.eps), _stream()),
+               "gkg_bn_eval_affine")
+    return Y, a, c, None, None
+
+
+def _linear_bwd_own(lib, g, ldg, g_bstride, Y, a, c, mean, invstd, x, W, R, cin, cout, nb, act, need_dx):
+    """dx, dW, dgamma, dbeta of out = act(BN_train(x W^T)): statistics pass (+ dz parked for GELU) -> coefficients ->
+    dgrad / wgrad kernels that apply the BN backward while staging their operand tiles."""
+    dev = Y.device
+    dgamma = torch.empty(nb * cout, dtype=_F32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    coef = torch.empty(nb * 3 * cout, dtype=_F32, device=dev)
+    dz = torch.empty_like(Y) if act == 1 else None
+    dW = torch.empty((nb * cout, cin), dtype=_F32, device=dev)
+    ws = _ws(lib.gkg_bn_workspace_bytes(R, cout, nb), dev)
+    # the coefficient kernel also clears dW, the accumulator of the split weight-gradient product that follows
+    _lib.check(lib.gkg_bn_bwd_coef(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
+                                   _ptr(dbeta), _ptr(coef), R, cout, nb, ldg, g_bstride, act,
+                                   None if DETERMINISTIC else _ptr(dW), dW.numel(), _ptr(ws), ws.numel(), _stream()),
+               "gkg_bn_bwd_coef")
+    dzp = dz if act == 1 else g
+    dx = torch.empty((nb, R, cin) if nb > 1 else (R, cin), dtype=_F32, device=dev) if need_dx else None
+    if DETERMINISTIC:
+        flags, ws2, ctr = _lib.LINEAR_DETERMINISTIC, _ws(lib.gkg_linear_workspace_bytes(R, cin, cout, nb), dev), _counters(dev)
+    else:
+        flags, ws2, ctr = _lib.LINEAR_DW_ZEROED, None, None
+    _lib.check(lib.gkg_linear_bn_bwd(_ptr(dzp), cout, R * cout, _ptr(Y), _ptr(coef), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW),
+                                     R, cin, cout, nb, flags, _ptr(ws2), 0 if ws2 is None else ws2.numel(), _ptr(ctr),
+                                     _stream()), "gkg_linear_bn_bwd")
+    return dx, dW, dgamma, dbeta
 
 
 def lowp_inference() -> bool:
@@ -227,8 +326,14 @@ class _LinearBNAct(torch.autograd.Function):
         R, cin = x.shape
         cout = weight.shape[0]
         W = weight.view(cout, cin)
-        Y = _mm_t(x, W, w16)
-        a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
+        own = _own_gemm(x, weight, bn)
+        if own:
+            x = x.contiguous()
+            Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1)
+            sync = None
+        else:
+            Y = _mm_t(x, W, w16)
+            a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
         if nchw is None:
             dt, code = _tm_dtype(out_lowp)
             out = torch.empty((R, cout), dtype=dt, device=x.device)
@@ -245,6 +350,7 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, nchw, residual is not None, bias is not None)
         ctx.sync = sync
+        ctx.own = own and OWN_GEMM == "all"
         return out
 
     @staticmethod
@@ -257,18 +363,24 @@ class _LinearBNAct(torch.autograd.Function):
         dres = dout if has_res else None
         if nchw is not None:
             g = torch.empty((R, cout), dtype=_F32, device=dout.device)
-            _lib.check(lib.gkg_nchw_to_tm(_ptr(dout.contiguous()), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32,
+            dout_c = dout.contiguous()           # named: the copy must outlive the launch that reads it
+            _lib.check(lib.gkg_nchw_to_tm(_ptr(dout_c), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32,
                                           _stream()), "gkg_nchw_to_tm")
         else:
             g = dout.contiguous()
         if mean is None:
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
+        # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean): not materialised
+        dbias = None
+        if ctx.own:
+            dx, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, R * cout, Y, a, c, mean, invstd, x,
+                                                    weight.view(cout, cin), R, cin, cout, 1, act,
+                                                    ctx.needs_input_grad[0])
+            return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None
         dY = torch.empty_like(Y)
         dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
         dbeta = torch.empty_like(dgamma)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
-        # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean): not materialised
-        dbias = None
         W = weight.view(cout, cin)
         dx = torch.mm(dY, W)
         dW = _wgrad(dY, x).view_as(weight)
@@ -286,14 +398,20 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         cout = weight.shape[0]
         co = cout // nb
         Wg = weight.view(nb, co, ci)
-        if U.dtype == torch.bfloat16:
+        own = _own_gemm(U, weight, bn) and act == 1
+        if own:
+            U = U.contiguous()
+            Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb)
+            sync = None
+        elif U.dtype == torch.bfloat16:
             Wb = weight.to(torch.bfloat16) if w16 is None else w16
             Y = torch.bmm(U, Wb.view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
         else:
             Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
             if Y.dtype != _F32:
                 Y = Y.float()
-        a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
+        if not own:
+            a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((R, cout), dtype=dt, device=U.device)
         _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
@@ -301,6 +419,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         ctx.sync = sync
+        ctx.own = own and OWN_GEMM == "all"
         return out
 
     @staticmethod
@@ -314,6 +433,10 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         g = dout.contiguous()
         if mean is None:
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
+        if ctx.own:
+            dU, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, co, Y, a, c, mean, invstd, U, weight.view(nb, co, ci),
+                                                    R, ci, co, nb, act, ctx.needs_input_grad[0])
+            return dU, dW.view_as(weight), None, dgamma, dbeta, None, None, None, None
         dY = torch.empty_like(Y)
         dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
         dbeta = torch.empty_like(dgamma)

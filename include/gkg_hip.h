@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 2
+#define GKG_ABI_VERSION 3
 
 /* dtype codes */
 #define GKG_F32 0
@@ -167,6 +167,45 @@ int gkg_bn_bwd_sums(const float* dout, const float* y, const float* a, const flo
 int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                      const float* invstd, const float* sums, const float* count, float* dy, int R, int C, int nb,
                      int ldg, size_t dout_bstride, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The dense 1x1 projections themselves (reference torch_vertex.py:290-306 fc1 / fc2 = Conv2d(1x1) + BN,
+ * torch_nn.py:57-69 BasicConv = Conv2d(1x1, groups=4) + BN + GELU on the interleaved [x, m] channels,
+ * torch_vertex.py:334-360 FFNLabel) as fp32 matrix-core kernels with the batch-norm passes fused in
+ * (csrc/gkg_gemm.hip).  Token-major fp32: x (nb, R, cin), w (nb, cout, cin), y (nb, R, cout); nb = 4 stacks the groups of
+ * the grouped projection.
+ *   gkg_linear_bn_fwd  y = x w^T.  train != 0: the train-mode BN statistics of y are taken in the kernel's epilogue (per
+ *                      tile centred mean / M2 from the accumulator registers, accumulated into fp64 column sums with
+ *                      atomics) and a small finalize kernel writes scale a, shift c (out = a*y + c; the conv bias is
+ *                      folded: it cancels in the output and is added to running_mean), saved mean / invstd and updates the
+ *                      running statistics.  `stats`: gkg_linear_stats_doubles() doubles, zero on entry, zeroed again
+ *                      before the call's work completes (one buffer can serve every layer on a stream).
+ *                      `counters` (backward): gkg_linear_counters() zero-initialised unsigned ints, left zero by every call.
+ *   gkg_bn_bwd_coef    first half of the BN backward: dz = dout*act'(a*y+c) (stored to `dz` when act == 1, else dz is
+ *                      dout itself), dbeta = sum dz, dgamma = sum dz*yhat, and coef [nb][3][C] = (alpha, beta, gamma) with
+ *                      dy = alpha*dz + beta*y + gamma  (== a*(dz - mean(dz) - yhat*mean(dz*yhat))).
+ *   gkg_linear_bn_bwd  dx = dy w and dw = dy^T x with dy formed from (dz, y, coef) while the operand tiles are staged —
+ *                      dy is never written.  dw's token contraction is split over workgroups which add their partial tiles
+ *                      into dw with fp32 hardware atomics (dw is cleared first unless GKG_LINEAR_DW_ZEROED says the caller
+ *                      did); with GKG_LINEAR_DETERMINISTIC the partial tiles go to `workspace` instead and the
+ *                      last-arriving split of an output tile adds them in split order.  dx or dw may be NULL.
+ */
+#define GKG_LINEAR_DW_ZEROED 1u     /* dw is already zero (e.g. cleared by gkg_bn_bwd_coef's zero_buf) */
+#define GKG_LINEAR_DETERMINISTIC 2u /* ordered split reduction through `workspace` + `counters` */
+size_t gkg_linear_workspace_bytes(int R, int cin, int cout, int nb);
+int gkg_linear_counters(void);
+int gkg_linear_stats_doubles(void);
+int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R, int cin, int cout, int nb, int train,
+                      const float* gamma, const float* beta, const float* bias, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean, float* bn_invstd,
+                      float momentum, float eps, double* stats, void* stream);
+int gkg_bn_bwd_coef(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                    const float* invstd, float* dz, float* dgamma, float* dbeta, float* coef, int R, int C, int nb,
+                    int ldg, size_t dout_bstride, int act, float* zero_buf /* optional: cleared by the same launches */,
+                    size_t zero_floats, void* workspace, size_t workspace_bytes, void* stream);
+int gkg_linear_bn_bwd(const float* dz, int ldg, size_t g_bstride, const float* y, const float* coef, const float* x,
+                      const float* w, float* dx, float* dw, int R, int cin, int cout, int nb, unsigned flags,
+                      void* workspace, size_t workspace_bytes, unsigned* counters, void* stream);
 
 /*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).

@@ -126,7 +126,7 @@ int oracle_mr_fwd(const float* x, const float* src, const int64_t* nn_idx, float
         int arg = 0;
         for (int j = 1; j < k; ++j) {
           float v = sr[id[j]] - xr[n];
-          if (v > best) { best = v; arg = j; }
+          if (v > best || (v != v && best == best)) { best = v; arg = j; }   /* torch.max: NaN propagates, first NaN wins */
         }
         m_out[((size_t)bg * c + ch) * N + n] = best;
         if (argmax) argmax[((size_t)bg * c + ch) * N + n] = (uint8_t)arg;

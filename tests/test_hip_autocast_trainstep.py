@@ -1,0 +1,189 @@
+"""GPU parity of (i) the bf16-autocast inference path (BASELINE configs 3 and 5) and (ii) a complete training step
+(BASELINE config 4 at a tiny size) against fixtures produced by the reference itself (tools/gen_golden.py F14, F15)."""
+import numpy as np
+import pytest
+import torch
+
+from util import keyed_fill_, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.array(a)).cuda()
+
+
+def _set_agreement(a, b):
+    """mean fraction of each query's neighbour SET shared by the two graphs"""
+    a = np.sort(a.reshape(-1, a.shape[-1]), -1)
+    b = np.sort(b.reshape(-1, b.shape[-1]), -1)
+    return float(np.mean([(np.isin(x, y)).mean() for x, y in zip(a, b)]))
+
+
+def test_autocast_bf16_against_reference_autocast_fixture():
+    """F14: Grapher -> GrapherLabel under torch.autocast(bf16), eval, no_grad.
+
+    What "parity" means under bf16: the reference's own autocast run (bf16 convolutions AND a bf16 distance matmul)
+    deviates from its fp32 run by  err_ref = mean|ref_autocast - ref_fp32|  and keeps only ~85 % of the fp32
+    neighbour sets.  The product's mixed-precision path (bf16 GEMM operands, fp32 accumulation, activations, BN and
+    k-NN in fp32) must be AT LEAST AS FAITHFUL to the reference's fp32 result as the reference's own autocast run:
+        mean|prod - ref_fp32| <= 1.0 * err_ref        graph agreement with fp32 >= the reference's own
+    and must stay within a stated distance of the reference's autocast output itself:
+        mean|prod - ref_autocast| <= 1.5 * err_ref,   max|prod - ref_autocast| <= 0.35 * scale."""
+    from gkgnet_amd import fused
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    meta, a = load_fixture("f14_autocast_bf16")
+    C, k, d, G, L, n = meta["C"], meta["k"], meta["dilation"], meta["G"], meta["L"], meta["n"]
+    g = Grapher(C, k, d, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=True,
+                use_multi_group=True, num_group=G)
+    gl = GrapherLabel(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=False,
+                      num_nodes=L, use_multi_group=True, num_group=G)
+    g.load_state_dict({k_[len("g/sd/"):]: torch.from_numpy(np.array(v)) for k_, v in a.items() if k_.startswith("g/sd/")})
+    gl.load_state_dict({k_[len("gl/sd/"):]: torch.from_numpy(np.array(v)) for k_, v in a.items() if k_.startswith("gl/sd/")})
+    g.cuda().eval(); gl.cuda().eval()
+    x, e = _t(a["x"]), _t(a["e"])
+    cap = {}
+    real = fused.knn_graph_tm
+
+    def rec(*args, **kw):
+        edge = real(*args, **kw)
+        cap.setdefault("edges", []).append(edge.cpu().numpy())
+        return edge
+    fused.knn_graph_tm = rec
+    try:
+        with torch.no_grad():
+            out32 = g(x)
+            e32, idx32 = gl(e, out32)
+            n32 = len(cap["edges"])
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert fused.lowp_inference()
+                out = g(x)
+                e2, idx = gl(e, out)
+    finally:
+        fused.knn_graph_tm = real
+    assert n32 == 2 and len(cap["edges"]) == 4, "both blocks must take the fused token-major path"
+    assert out.dtype == torch.float32 and e2.dtype == torch.float32
+    # fp32 run of the product vs the fp32 reference: the usual 1e-3 bar (sanity that the fixture is wired right)
+    assert torch.allclose(out32, _t(a["out_fp32"]), atol=1e-3, rtol=1e-3)
+    assert torch.allclose(e32, _t(a["labels_fp32"]), atol=1e-3, rtol=1e-3)
+    for got, ref32, refac in ((out, a["out_fp32"], a["out_autocast"]), (e2, a["labels_fp32"], a["labels_autocast"])):
+        got = got.cpu().numpy()
+        err_ref = np.abs(refac - ref32).mean()
+        scale = np.abs(ref32).max()
+        assert np.abs(got - ref32).mean() <= 1.0 * err_ref, (np.abs(got - ref32).mean(), err_ref)
+        assert np.abs(got - refac).mean() <= 1.5 * err_ref, (np.abs(got - refac).mean(), err_ref)
+        assert np.abs(got - refac).max() <= 0.35 * scale
+    # graphs: neighbour-set agreement with the fp32 reference graph at least the reference-autocast's own
+    edge_ac_prod = cap["edges"][2][0]
+    ref_self = _set_agreement(a["edge_autocast"][0], a["edge_fp32"][0])
+    assert _set_agreement(edge_ac_prod, a["edge_fp32"][0]) >= ref_self
+    ref_lab = _set_agreement(a["idx_autocast"], a["idx_fp32"])
+    assert _set_agreement(idx.cpu().numpy(), a["idx_fp32"]) >= ref_lab - 0.02
+
+
+def _build(meta):
+    from gkgnet_amd.backbone import GKGNet
+    from gkgnet_amd.head import LabelQueryHead
+    net = GKGNet(**meta["ctor"])
+    with torch.no_grad():
+        keyed_fill_(net.state_dict(), seed=15)
+    head = LabelQueryHead(meta["head"]["num_classes"], meta["head"]["in_channels"], softmax=False,
+                          loss=dict(type="AsymmetricLoss", gamma_pos=0.0, gamma_neg=2.0, clip=0.05), topk=(1, 1))
+    with torch.no_grad():
+        keyed_fill_(head.state_dict(), seed=16)
+    return net, head
+
+
+def _run_steps(meta, a, forced):
+    """Runs meta['steps'] training steps; with `forced` the product's k-NN calls return the reference's recorded graphs
+    (fixture graph/NN, call order) instead of computing them.  Returns per-step records + parameter deltas."""
+    from gkgnet_amd import fused
+    from gkgnet_amd.head import build_optimizer
+    net, head = _build(meta)
+    net.cuda().train(); head.cuda().train()
+    img = torch.from_numpy(a["img_bf16"]).view(torch.bfloat16).float().cuda()
+    gt = _t(a["gt"])
+    params = [p for p in list(net.parameters()) + list(head.parameters()) if p.requires_grad]
+    opt = build_optimizer([net, head], lr=meta["lr"], weight_decay=meta["weight_decay"])
+    named = dict(net.named_parameters())
+    before = {k: named[k].detach().clone() for k in meta["watch"]}
+    hbefore = head.fc1.weight.detach().clone()
+    rec = dict(loss=[], bce=[], asy=[], norm=[], grads0={}, graphs=[])
+    real = fused.knn_graph_tm
+    calls = [0]
+
+    def knn(x, y, rp, k, d, G):
+        gi = calls[0]
+        calls[0] += 1
+        if forced:
+            nn_idx = torch.from_numpy(a[f"graph/{gi:02d}"].astype(np.int64)).cuda()
+            center = torch.arange(nn_idx.shape[1], device="cuda").view(1, -1, 1).expand_as(nn_idx)
+            return torch.stack([nn_idx, center])
+        edge = real(x, y, rp, k, d, G)
+        rec["graphs"].append(edge[0].cpu().numpy())
+        return edge
+    fused.knn_graph_tm = knn
+    try:
+        for it in range(meta["steps"]):
+            opt.zero_grad(set_to_none=True)
+            out = head.forward_train(net(img), gt)
+            loss = out["bce_loss"] + out["asy_loss"]
+            loss.backward()
+            if it == 0:
+                rec["grads0"] = {k: named[k].grad.detach().flatten().double().cpu() for k in meta["watch"]}
+            rec["norm"].append(float(torch.nn.utils.clip_grad_norm_(params, meta["grad_clip"])))
+            opt.step()
+            rec["loss"].append(float(loss.detach())); rec["bce"].append(float(out["bce_loss"].detach()))
+            rec["asy"].append(float(out["asy_loss"].detach()))
+    finally:
+        fused.knn_graph_tm = real
+    assert calls[0] == 16 * meta["steps"], "all 16 graph layers must run on the fused token-major path"
+    rec["delta"] = {k: (named[k].detach() - before[k]).cpu().numpy() for k in meta["watch"]}
+    rec["head_delta"] = (head.fc1.weight.detach() - hbefore).cpu().numpy()
+    return rec
+
+
+def _rel(x, ref):
+    return abs(x - ref) / abs(ref)
+
+
+def test_train_step_on_reference_graphs():
+    """F15, graphs forced: two complete training steps of GKGNet('t', 128 px) + LabelQueryHead — forward on the HIP path,
+    smoothed BCE + 10 x ASL, backward, grad-clip 5.0, AdamW with the paramwise config — run on the graphs the REFERENCE
+    built (the k-NN operator itself is pinned bit-exactly elsewhere).  With the only discontinuous element fixed,
+    everything must follow the reference closely:
+      losses of both steps 1e-3 relative; pre-clip gradient norms 5e-3; first-step gradients cosine >= 0.9999;
+      parameter deltas after 2 AdamW steps: >= 99 % of the elements within 0.1 * lr of the reference's delta
+      (AdamW's first steps move every element by ~lr * sign(g); only elements with |g| ~ 0 can differ)."""
+    meta, a = load_fixture("f15_train_step")
+    r = _run_steps(meta, a, forced=True)
+    for i in range(meta["steps"]):
+        assert _rel(r["loss"][i], a["loss"][i]) <= 1e-3, (i, r["loss"], a["loss"])
+        assert _rel(r["bce"][i], a["bce_loss"][i]) <= 1e-3 and _rel(r["asy"][i], a["asy_loss"][i]) <= 1e-3
+        assert _rel(r["norm"][i], a["grad_norm"][i]) <= 5e-3, (i, r["norm"], a["grad_norm"])
+    for k in meta["watch"]:
+        g_, r_ = r["grads0"][k], torch.from_numpy(a["grad0/" + k]).flatten().double()
+        cos = float((g_ * r_).sum() / (g_.norm() * r_.norm() + 1e-30))
+        assert cos >= 0.9999, (k, cos)
+        ok = np.abs(r["delta"][k] - a["delta/" + k]) <= 0.1 * meta["lr"]
+        assert ok.mean() >= 0.99, (k, float(ok.mean()))
+    ok = np.abs(r["head_delta"] - a["head_fc1_delta"]) <= 0.1 * meta["lr"]
+    assert ok.mean() >= 0.99
+
+
+def test_train_step_free_running():
+    """F15 with the product's own graphs.  A 16-layer k-NN network amplifies fp32 near-tie neighbour flips (one flipped
+    neighbour of a label token moves that class score by O(1)), so the end-to-end numbers are looser than on forced
+    graphs: first-step loss within 2 %, gradient norm within 5 %; the first layer's graph (identical inputs up to fp32
+    rounding) agrees with the reference's at >= 99.9 % of the neighbour slots and the first 8 graph layers (stages 1-2 and
+    the first blocks of stage 3) at >= 99 %; behind them the upstream flips compound (measured 0.91 -> 0.25 over the last
+    7 layers, whose 8x8 / 4x4 token maps keep 12 of 64 / 16 keys), which is why the forced-graph test exists.  (The second step is not compared free-running:
+    AdamW's first update moves all 6 M parameters by lr*sign(g), after which the two runs' graphs differ in many slots
+    and the loss — 80 -> 21 in the reference — is no longer a like-for-like number; the forced-graph test covers it.)"""
+    meta, a = load_fixture("f15_train_step")
+    r = _run_steps(meta, a, forced=False)
+    assert _rel(r["loss"][0], a["loss"][0]) <= 2e-2, (r["loss"], a["loss"])
+    assert _rel(r["norm"][0], a["grad_norm"][0]) <= 5e-2, (r["norm"], a["grad_norm"])
+    agree = [float((r["graphs"][gi] == a[f"graph/{gi:02d}"]).mean()) for gi in range(16)]
+    assert agree[0] >= 0.999 and min(agree[:8]) >= 0.99, " ".join(f"{v:.3f}" for v in agree)
+    print("graph agreement per layer:", " ".join(f"{v:.3f}" for v in agree))

@@ -7,6 +7,19 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["none", "fwd", "all", "all-deterministic"])
+def gemm_mode(request):
+    """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("none"), with the
+    own forward kernel (BN statistics in the epilogue, the default) and with own forward + dgrad + wgrad kernels (BN
+    backward-apply as operand prologue; atomic or ordered split reduction)."""
+    from gkgnet_amd import fused
+    old = (fused.OWN_GEMM, fused.DETERMINISTIC)
+    fused.OWN_GEMM = request.param.split("-")[0]
+    fused.DETERMINISTIC = request.param.endswith("deterministic")
+    yield request.param
+    fused.OWN_GEMM, fused.DETERMINISTIC = old
+
+
 def _bn(C):
     torch.manual_seed(C)
     bn = torch.nn.BatchNorm2d(C).cuda().train()
@@ -20,7 +33,7 @@ def _bn(C):
                                                      (2560, 320, 1280, 1, False), (2560, 1280, 320, 0, True),
                                                      (10368, 320, 320, 0, False), (4100, 36, 40, 1, True),
                                                      (19, 16, 8, 1, False)])
-def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res):
+def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res, gemm_mode):
     from gkgnet_amd import fused
     torch.manual_seed(0)
     x = torch.randn(R, cin, device="cuda", requires_grad=True)
@@ -62,7 +75,7 @@ def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res):
     assert int(bn.num_batches_tracked) == 1
 
 
-def test_grouped_linear_matches_grouped_conv():
+def test_grouped_linear_matches_grouped_conv(gemm_mode):
     """_GroupedLinearBNAct on the interleaved group-major input == Conv2d(groups=4)+BN+GELU on (B,2C,N,1)."""
     from gkgnet_amd import fused
     torch.manual_seed(1)
@@ -148,3 +161,55 @@ def test_bf16_outputs_are_the_rounded_fp32_outputs():
         y = fused._mm_t(t16, conv.weight.view(2 * C, C))
         want = t16.float() @ conv.weight.view(2 * C, C).to(torch.bfloat16).float().t()
         assert y.dtype == torch.float32 and torch.allclose(y, want, atol=1e-3, rtol=1e-3)
+
+
+def test_deterministic_weight_gradient_is_bit_reproducible():
+    """fused.DETERMINISTIC: the split weight-gradient product adds its partial tiles in split order -> two runs agree bit
+    for bit (the default atomic accumulation only agrees to rounding)."""
+    from gkgnet_amd import fused
+    old = (fused.OWN_GEMM, fused.DETERMINISTIC)
+    fused.OWN_GEMM, fused.DETERMINISTIC = "all", True
+    try:
+        torch.manual_seed(4)
+        x = torch.randn(5000, 96, device="cuda")
+        conv = torch.nn.Conv2d(96, 160, 1).cuda()
+        bn = _bn(160)
+        g = torch.randn(5000, 160, device="cuda")
+        grads = []
+        for _ in range(2):
+            conv.weight.grad = None
+            out = fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 1, None)
+            out.backward(g)
+            grads.append(conv.weight.grad.clone())
+        assert torch.equal(grads[0], grads[1])
+    finally:
+        fused.OWN_GEMM, fused.DETERMINISTIC = old
+
+
+@pytest.mark.parametrize("mode", ["none", "fwd"])
+def test_bn_statistics_survive_a_large_channel_offset(mode):
+    """Train-mode BN variance when |mean| >> std (y = 100 + 0.01*noise per channel): E[y^2] - E[y]^2 in fp32 would lose
+    the variance entirely (1e-7 * 1e4 / 1e-4 = 10x its value); the statistics are taken centred (own GEMM epilogue: per
+    tile mean / M2 from registers, fp64 merge) or shifted by a sample row (stand-alone pass), so invstd stays within
+    1e-3 of the fp64 value."""
+    from gkgnet_amd import fused
+    old = fused.OWN_GEMM
+    fused.OWN_GEMM = mode
+    try:
+        torch.manual_seed(5)
+        R, cin, cout = 6000, 32, 64
+        x = torch.cat([torch.ones(R, 4, device="cuda"), 0.01 * torch.randn(R, cin - 4, device="cuda")], 1)
+        conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+        with torch.no_grad():
+            conv.weight[:, :4] = 25.0                      # y = 100 + O(0.01)
+        bn = _bn(cout)
+        with torch.no_grad():
+            bn.weight.fill_(1.0); bn.bias.zero_()
+        out = fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 0, None)
+        y = (x.double() @ conv.weight.view(cout, cin).double().t())
+        want = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+        assert float(y.detach().mean().abs()) > 50 and float(y.detach().std(0).mean()) < 0.1
+        # the fp32 product itself rounds y to ~6e-6 absolute, i.e. ~1e-3 of its 5e-3 standard deviation
+        assert torch.allclose(out.detach().double(), want, atol=2e-2, rtol=1e-2), float((out.detach().double() - want).abs().max())
+    finally:
+        fused.OWN_GEMM = old

@@ -451,6 +451,11 @@ def train_step_case(ref, name, steps=2):
     hbefore = head.fc1.weight.detach().clone()
     losses, bces, asys, norms = [], [], [], []
     grads0 = {}
+    # the graphs the reference builds, in call order (16 DenseDilatedKnnGraph modules per forward): lets the product
+    # be run ON THE SAME GRAPHS, which removes the only chaotic element (fp32 near-tie neighbour flips) from the comparison
+    graphs = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: graphs.append(o.detach()[0].clone()))
+             for m in net.modules() if isinstance(m, ref.torch_edge.DenseDilatedKnnGraph)]
     for it in range(steps):
         opt.zero_grad(set_to_none=True)
         out = head.forward_train(net(img), gt)
@@ -461,8 +466,13 @@ def train_step_case(ref, name, steps=2):
         norms.append(float(torch.nn.utils.clip_grad_norm_(params, 5.0)))
         opt.step()
         losses.append(float(loss)); bces.append(float(out["bce_loss"])); asys.append(float(out["asy_loss"]))
+    for h_ in hooks:
+        h_.remove()
+    assert len(graphs) == 16 * steps
     arrays = dict(img_bf16=img.to(torch.bfloat16).view(torch.int16).numpy(), gt=gt.numpy(), loss=np.array(losses), bce_loss=np.array(bces),
                   asy_loss=np.array(asys), grad_norm=np.array(norms), head_fc1_delta=(head.fc1.weight.detach() - hbefore).numpy())
+    for gi, gr in enumerate(graphs):
+        arrays[f"graph/{gi:02d}"] = gr.numpy().astype(np.int16)
     for k_ in watch:
         arrays["delta/" + k_] = (named[k_].detach() - before[k_]).numpy()
         arrays["grad0/" + k_] = grads0[k_].numpy()
