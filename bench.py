@@ -230,6 +230,7 @@ def main():
     lib_desc = "vendor-library GEMMs (TunableOp-selected)" if not args.no_tune else "vendor-library GEMMs (default heuristic)"
     gemm_desc = {"all": "own fp32-MFMA kernels (csrc/gkg_gemm.hip): forward with BN-statistics epilogue, dgrad/wgrad with BN-backward prologue",
                  "fwd": "forward projections: own fp32-MFMA kernels with BN-statistics epilogue (csrc/gkg_gemm.hip); dgrad/wgrad: " + lib_desc,
+                 "auto": "own fp32-MFMA forward kernels with BN-statistics epilogue (csrc/gkg_gemm.hip) where measured faster (R <= 4096 or R >= 32768: here the label branch); otherwise " + lib_desc,
                  "none": lib_desc}[fused.OWN_GEMM]
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps

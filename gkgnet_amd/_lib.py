@@ -20,7 +20,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
            "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
-           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd")
+           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
+           "gkg_bn_apply_train", "gkg_bn_bwd_train")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
 
 _lib = None
@@ -94,6 +95,16 @@ def load():
     lib.gkg_bn_bwd_coef.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V, Z, V]
     lib.gkg_linear_bn_bwd.restype = I
     lib.gkg_linear_bn_bwd.argtypes = [V, I, Z, V, V, V, V, V, V, I, I, I, I, C.c_uint, V, Z, V, V]
+    lib.gkg_bn_scratch_doubles.restype = I
+    lib.gkg_bn_scratch_doubles.argtypes = []
+    lib.gkg_bn_counters.restype = I
+    lib.gkg_bn_counters.argtypes = []
+    lib.gkg_bn_stats_accum.restype = I
+    lib.gkg_bn_stats_accum.argtypes = [V, I, I, I, V, V]
+    lib.gkg_bn_apply_train.restype = I
+    lib.gkg_bn_apply_train.argtypes = [V, V, I] + [V] * 12 + [I, I, I, I, Z, I, I, I, F, F, V, V]
+    lib.gkg_bn_bwd_train.restype = I
+    lib.gkg_bn_bwd_train.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, V, V, Z, V]
     lib.gkg_prof_enable.restype = None
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None

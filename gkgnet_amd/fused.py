@@ -33,7 +33,17 @@ ENABLED = True          # set False to force the composable (per-op) path, e.g. 
 # the forward kernel with the BN statistics in its epilogue beats vendor GEMM + statistics passes on every layer; the
 # dgrad / wgrad kernels with the BN backward-apply prologue are 20-40 % behind the vendor kernels + apply pass at these
 # shapes (parity at the 41 472-token stages), so the backward keeps the vendor GEMMs unless asked otherwise.
-OWN_GEMM = os.environ.get("GKG_OWN_GEMM", "fwd")
+# "auto" = "fwd" restricted to the row counts where the own forward kernel measured faster than vendor GEMM + statistics
+# passes end to end (tools/bench_gemm.py, MI355X): R <= 4096 (label branch: 11 + 5 vs 10-14 + 9.5 us per layer) and
+# R >= 32768 (stage-3/4 of GKGNet-576: 150 vs 186 + 10 us at 41 472 x 400 x 400); in between (cfg2's 10 368 rows) the
+# vendor kernels' finer macro-tiles win by ~3 us per layer.
+OWN_GEMM = os.environ.get("GKG_OWN_GEMM", "auto")
+# Two-kernel train-mode BN (fp64-atomic statistics, coefficients derived inline by the consumer, csrc/gkg_dense.hip) vs
+# the three-kernel form (two-stage ordered sums -> finalize -> apply).  Measured at cfg2: the two-kernel form is SLOWER
+# (1.148 vs 1.021 ms/step): every consumer workgroup then starts with a dependent read of freshly atomically-written
+# sums (served from HBM, not L2) and ends on a ticket round trip, which costs the short workgroups of these kernels more
+# than the removed launch saves (apply 4.4 -> 14 us, backward apply 6.6 -> 13 us).  Kept selectable and tested; off.
+BN_TWO_KERNEL = os.environ.get("GKG_BN_TWO_KERNEL", "0") != "0"
 DETERMINISTIC = False   # True: ordered (run-to-run bit-identical) reduction of the split weight-gradient products
 
 
@@ -95,21 +105,62 @@ def _stats_scratch(device) -> torch.Tensor:
     return t
 
 
+def _bn2(bn, Y) -> bool:
+    """Two-kernel train-mode BN (fp64-atomic statistics + inline finalize): batch statistics local to this rank."""
+    return (BN_TWO_KERNEL and Y.dtype == _F32 and (bn.training or not bn.track_running_stats)
+            and _sync_group(bn) is None)
+
+
+def _bn2_apply(lib, Y, bn, bias, shifted, res, out, R, C, nb, ldo, obs, act, code, nchw_B):
+    """Consumer half: out = act(BN(Y)) (+ res); returns the saved (a, c, mean, invstd)."""
+    dev = Y.device
+    a = torch.empty(nb * C, dtype=_F32, device=dev)
+    c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    track = bn.training and bn.track_running_stats
+    _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(_stats_scratch(dev)), shifted, _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                      _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                      _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
+                                      _ptr(invstd), _ptr(res), _ptr(out), R, C, nb, ldo, obs, act, code, nchw_B,
+                                      float(bn.momentum), float(bn.eps), _bn_counters(dev).data_ptr(), _stream()),
+               "gkg_bn_apply_train")
+    return a, c, mean, invstd
+
+
+def _bn_counters(device) -> torch.Tensor:
+    """Ticket counters of the two-kernel BN consumers (zero between launches), one buffer per device."""
+    key = ("bn", device.type, device.index)
+    t = _COUNTERS.get(key)
+    if t is None:
+        t = torch.zeros(_lib.load().gkg_bn_counters(), dtype=torch.int32, device=device)
+        _COUNTERS[key] = t
+    return t
+
+
 def _own_gemm(x, weight, bn) -> bool:
     """fp32 operands outside autocast and batch statistics local to this rank: the projection runs on the library's own
     fp32 matrix-core kernels with the BN passes fused in (csrc/gkg_gemm.hip).  bf16 autocast and cross-rank SyncBN keep
     the vendor-GEMM + separate-pass form."""
-    return (OWN_GEMM in ("fwd", "all") and x.dtype == _F32 and weight.dtype == _F32
-            and not torch.is_autocast_enabled() and _sync_group(bn) is None)
+    if OWN_GEMM == "auto":
+        R = x.shape[-2]
+        if 4096 < R < 32768:
+            return False
+    elif OWN_GEMM not in ("fwd", "all"):
+        return False
+    return (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None)
 
 
-def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb):
+def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False):
     """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue)."""
     dev = x.device
     Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
     a = torch.empty(nb * cout, dtype=_F32, device=dev)
     c = torch.empty_like(a)
     train = bn.training or not bn.track_running_stats
+    if train and stats_only:
+        _lib.check(lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, None, None, None, None, None, None,
+                                         None, None, None, None, 0.0, 0.0, _ptr(_stats_scratch(dev)), _stream()),
+                   "gkg_linear_bn_fwd")
+        return Y, None, None, None, None
     if train:
         mean = torch.empty_like(a)
         invstd = torch.empty_like(a)
@@ -138,12 +189,18 @@ def _linear_bwd_own(lib, g, ldg, g_bstride, Y, a, c, mean, invstd, x, W, R, cin,
     coef = torch.empty(nb * 3 * cout, dtype=_F32, device=dev)
     dz = torch.empty_like(Y) if act == 1 else None
     dW = torch.empty((nb * cout, cin), dtype=_F32, device=dev)
-    ws = _ws(lib.gkg_bn_workspace_bytes(R, cout, nb), dev)
     # the coefficient kernel also clears dW, the accumulator of the split weight-gradient product that follows
-    _lib.check(lib.gkg_bn_bwd_coef(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
+    if BN_TWO_KERNEL:
+        _lib.check(lib.gkg_bn_bwd_train(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
+                                        _ptr(dbeta), _ptr(coef), R, cout, nb, ldg, g_bstride, act, _ptr(_stats_scratch(dev)),
+                                        _bn_counters(dev).data_ptr(), None if DETERMINISTIC else _ptr(dW), dW.numel(),
+                                        _stream()), "gkg_bn_bwd_train")
+    else:
+      ws = _ws(lib.gkg_bn_workspace_bytes(R, cout, nb), dev)
+      _lib.check(lib.gkg_bn_bwd_coef(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
                                    _ptr(dbeta), _ptr(coef), R, cout, nb, ldg, g_bstride, act,
                                    None if DETERMINISTIC else _ptr(dW), dW.numel(), _ptr(ws), ws.numel(), _stream()),
-               "gkg_bn_bwd_coef")
+                 "gkg_bn_bwd_coef")
     dzp = dz if act == 1 else g
     dx = torch.empty((nb, R, cin) if nb > 1 else (R, cin), dtype=_F32, device=dev) if need_dx else None
     if DETERMINISTIC:
@@ -299,6 +356,12 @@ def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg
     """dY, dgamma, dbeta of out = act(BN_train(Y)) from the upstream gradient g; with ``sync`` the two column sums the
     input gradient needs are all-reduced over the ranks (dgamma/dbeta stay local, like torch's SyncBatchNorm: the
     data-parallel gradient exchange averages them)."""
+    if sync is None and BN_TWO_KERNEL:
+        dev = Y.device
+        _lib.check(lib.gkg_bn_bwd_train(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
+                                        _ptr(dbeta), None, R, C, nb, ldg, g_bstride, act, _ptr(_stats_scratch(dev)),
+                                        _bn_counters(dev).data_ptr(), None, 0, _stream()), "gkg_bn_bwd_train")
+        return
     ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), Y.device)
     if sync is None:
         _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
@@ -327,26 +390,41 @@ class _LinearBNAct(torch.autograd.Function):
         cout = weight.shape[0]
         W = weight.view(cout, cin)
         own = _own_gemm(x, weight, bn)
-        if own:
-            x = x.contiguous()
-            Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1)
-            sync = None
-        else:
-            Y = _mm_t(x, W, w16)
-            a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
+        res = None if residual is None else residual.contiguous()
         if nchw is None:
             dt, code = _tm_dtype(out_lowp)
             out = torch.empty((R, cout), dtype=dt, device=x.device)
-            res = None if residual is None else residual.contiguous()
-            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
-                                          code, _stream()), "gkg_affine_act")
         else:
             assert act == 0
-            B = nchw[0]
+            dt, code = _F32, _lib.F32
             out = torch.empty(nchw, dtype=_F32, device=x.device)
-            res = None if residual is None else residual.contiguous()
-            _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), B, cout, R // B,
-                                                 _stream()), "gkg_tm_affine_to_nchw")
+        if own:
+            x = x.contiguous()
+        two = _bn2(bn, x if own else torch.empty(0, dtype=_F32))
+        sync = None
+        if own and two:                               # projection kernel (statistics in its epilogue) -> apply: 2 kernels
+            Y = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, stats_only=True)[0]
+            a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 0, res, out, R, cout, 1, cout, 0, act, code,
+                                            0 if nchw is None else nchw[0])
+        else:
+            if own:
+                Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1)
+            else:
+                Y = _mm_t(x, W, w16)
+                if two:                               # vendor GEMM -> statistics (atomics) -> apply (inline finalize)
+                    _lib.check(lib.gkg_bn_stats_accum(_ptr(Y), R, cout, 1, _ptr(_stats_scratch(Y.device)), _stream()),
+                               "gkg_bn_stats_accum")
+                    a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 1, res, out, R, cout, 1, cout, 0, act, code,
+                                                    0 if nchw is None else nchw[0])
+                else:
+                    a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
+            if own or not two:
+                if nchw is None:
+                    _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
+                                                  code, _stream()), "gkg_affine_act")
+                else:
+                    _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), nchw[0], cout,
+                                                         R // nchw[0], _stream()), "gkg_tm_affine_to_nchw")
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, nchw, residual is not None, bias is not None)
         ctx.sync = sync
@@ -399,23 +477,34 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         co = cout // nb
         Wg = weight.view(nb, co, ci)
         own = _own_gemm(U, weight, bn) and act == 1
-        if own:
-            U = U.contiguous()
-            Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb)
-            sync = None
-        elif U.dtype == torch.bfloat16:
-            Wb = weight.to(torch.bfloat16) if w16 is None else w16
-            Y = torch.bmm(U, Wb.view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
-        else:
-            Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
-            if Y.dtype != _F32:
-                Y = Y.float()
-        if not own:
-            a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((R, cout), dtype=dt, device=U.device)
-        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
-                                      code, _stream()), "gkg_affine_act")
+        sync = None
+        two = _bn2(bn, U if own else torch.empty(0, dtype=_F32))
+        if own:
+            U = U.contiguous()
+            if two:
+                Y = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, stats_only=True)[0]
+                a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 0, None, out, R, co, nb, cout, co, act, code, 0)
+            else:
+                Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb)
+        else:
+            if U.dtype == torch.bfloat16:
+                Wb = weight.to(torch.bfloat16) if w16 is None else w16
+                Y = torch.bmm(U, Wb.view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
+            else:
+                Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
+                if Y.dtype != _F32:
+                    Y = Y.float()
+            if two:
+                _lib.check(lib.gkg_bn_stats_accum(_ptr(Y), R, co, nb, _ptr(_stats_scratch(Y.device)), _stream()),
+                           "gkg_bn_stats_accum")
+                a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 1, None, out, R, co, nb, cout, co, act, code, 0)
+            else:
+                a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
+        if not two:
+            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
+                                          code, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         ctx.sync = sync

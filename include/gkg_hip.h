@@ -180,6 +180,7 @@ int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const fl
  *                      folded: it cancels in the output and is added to running_mean), saved mean / invstd and updates the
  *                      running statistics.  `stats`: gkg_linear_stats_doubles() doubles, zero on entry, zeroed again
  *                      before the call's work completes (one buffer can serve every layer on a stream).
+ *                      train == 2: statistics only — the exact fp64 sums stay in `stats` for gkg_bn_apply_train (shifted = 0).
  *                      `counters` (backward): gkg_linear_counters() zero-initialised unsigned ints, left zero by every call.
  *   gkg_bn_bwd_coef    first half of the BN backward: dz = dout*act'(a*y+c) (stored to `dz` when act == 1, else dz is
  *                      dout itself), dbeta = sum dz, dgamma = sum dz*yhat, and coef [nb][3][C] = (alpha, beta, gamma) with
@@ -206,6 +207,32 @@ int gkg_bn_bwd_coef(const float* dout, const float* y, const float* a, const flo
 int gkg_linear_bn_bwd(const float* dz, int ldg, size_t g_bstride, const float* y, const float* coef, const float* x,
                       const float* w, float* dx, float* dw, int R, int cin, int cout, int nb, unsigned flags,
                       void* workspace, size_t workspace_bytes, unsigned* counters, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Two-kernel train-mode BN (the form the fused block uses when batch statistics are local to the rank): a producer
+ * accumulates column sums into ONE fp64 scratch [nb][2][C] with atomics, the consumer derives the coefficients inline.
+ * `scratch`: gkg_bn_scratch_doubles() doubles, zero on entry of the producer, zeroed again by the consumer (its last
+ * workgroup); `counter`: gkg_bn_counters() zero-initialised unsigneds the consumer leaves zero.  One scratch / counter per device
+ * serves every layer on a stream and survives hipGraph replay.
+ *   gkg_bn_stats_accum   producer: sums of (y - y[row 0]) and squares  (shifted = 1 for the consumer).  The projection
+ *                        kernel gkg_linear_bn_fwd(train = 2) is the other producer (exact fp64 sums, shifted = 0).
+ *   gkg_bn_apply_train   consumer: out = act(BN(y)) (+ res), writes a / c / mean / invstd for the backward and updates
+ *                        the running statistics (conv bias folded).  nchw_B > 0: out and res are (B, C, R/B) channel-major.
+ *   gkg_bn_bwd_train     both halves of the backward: statistics of dz = dout*act'(z) -> dy (act == 1: in place on the
+ *                        parked dz), dgamma, dbeta; with `coef` != NULL the (alpha, beta, gamma) coefficients for
+ *                        gkg_linear_bn_bwd are written instead of dy (act == 1 still parks dz in dy) and `zero_buf` is cleared.
+ */
+int gkg_bn_scratch_doubles(void);
+int gkg_bn_counters(void);   /* `counter` arguments below: this many zero-initialised unsigned ints */
+int gkg_bn_stats_accum(const float* y, int R, int C, int nb, double* scratch, void* stream);
+int gkg_bn_apply_train(const float* y, double* scratch, int shifted, const float* gamma, const float* beta, const float* bias,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
+                       float* mean, float* invstd, const float* res, void* out, int R, int C, int nb, int ldo,
+                       size_t out_bstride, int act, int out_dtype, int nchw_B, float momentum, float eps, unsigned* counter,
+                       void* stream);
+int gkg_bn_bwd_train(const float* dout, const float* y, const float* a, const float* c, const float* mean, const float* invstd,
+                     float* dy, float* dgamma, float* dbeta, float* coef, int R, int C, int nb, int ldg, size_t dout_bstride,
+                     int act, double* scratch, unsigned* counter, float* zero_buf, size_t zero_floats, void* stream);
 
 /*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).

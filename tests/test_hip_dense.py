@@ -7,17 +7,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["none", "fwd", "all", "all-deterministic"])
+@pytest.fixture(params=["none", "none-bn3", "fwd", "fwd-bn3", "all", "all-deterministic"])
 def gemm_mode(request):
     """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("none"), with the
     own forward kernel (BN statistics in the epilogue, the default) and with own forward + dgrad + wgrad kernels (BN
     backward-apply as operand prologue; atomic or ordered split reduction)."""
     from gkgnet_amd import fused
-    old = (fused.OWN_GEMM, fused.DETERMINISTIC)
+    old = (fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL)
     fused.OWN_GEMM = request.param.split("-")[0]
     fused.DETERMINISTIC = request.param.endswith("deterministic")
+    fused.BN_TWO_KERNEL = not request.param.endswith("bn3")      # "-bn3": three-kernel BN (two-stage ordered sums)
     yield request.param
-    fused.OWN_GEMM, fused.DETERMINISTIC = old
+    fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL = old
 
 
 def _bn(C):
