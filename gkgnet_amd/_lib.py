@@ -10,8 +10,8 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
 
-ABI_VERSION = 3
-F32, BF16 = 0, 1
+ABI_VERSION = 4
+F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 
@@ -62,9 +62,9 @@ def load():
     lib.gkg_mr_bwd_tm.restype = I
     lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 7 + [V]
     lib.gkg_nchw_to_tm.restype = I
-    lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, I, V]
+    lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, I, V, V]
     lib.gkg_tm_affine_to_nchw.restype = I
-    lib.gkg_tm_affine_to_nchw.argtypes = [V] * 5 + [I, I, I, V]
+    lib.gkg_tm_affine_to_nchw.argtypes = [V] * 5 + [I, I, I, V, V]
     lib.gkg_bn_workspace_bytes.restype = Z
     lib.gkg_bn_workspace_bytes.argtypes = [I, I, I]
     lib.gkg_bn_train_stats.restype = I
@@ -72,7 +72,7 @@ def load():
     lib.gkg_bn_eval_affine.restype = I
     lib.gkg_bn_eval_affine.argtypes = [V] * 7 + [I, F, V]
     lib.gkg_affine_act.restype = I
-    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, I, V]
+    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, I, V, I, V]
     lib.gkg_bn_bwd.restype = I
     lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_stats_sums.restype = I

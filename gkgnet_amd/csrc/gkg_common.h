@@ -10,7 +10,9 @@ namespace gkg {
 // Feature element load/store: fp32 as is, bf16 carried as raw uint16_t (widening is exact).
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const uint16_t* p) { return __uint_as_float(((uint32_t)*p) << 16); }
+__device__ __forceinline__ float ldf(const _Float16* p) { return (float)*p; }            // fp16: widening is exact
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(_Float16* p, float v) { *p = (_Float16)v; }           // round-to-nearest-even
 __device__ __forceinline__ void stf(uint16_t* p, float v) {
   // round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
   const __bf16 b = (__bf16)v;

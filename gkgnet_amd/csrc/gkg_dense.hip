@@ -27,7 +27,7 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 // (B, C, N) channel-major -> (B*N, C) token-major through a padded 32x32 LDS tile (coalesced both sides).
 template <typename OutT>
 __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict__ x, OutT* __restrict__ out,
-                                                         int C, int N) {
+                                                         int C, int N, const float* __restrict__ img_scale) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
@@ -36,18 +36,20 @@ __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict
     const int ch = c0 + ty + 8 * i, n = n0 + tx;
     tile[ty + 8 * i][tx] = (ch < C && n < N) ? x[((size_t)b * C + ch) * N + n] : 0.f;
   }
+  const float sc = img_scale ? img_scale[b] : 1.0f;       // stochastic depth: per-image keep / (1 - p) factor
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, ch = c0 + tx;
-    if (ch < C && n < N) stf(out + ((size_t)b * N + n) * C + ch, tile[tx][ty + 8 * i]);
+    if (ch < C && n < N) stf(out + ((size_t)b * N + n) * C + ch, img_scale ? tile[tx][ty + 8 * i] * sc : tile[tx][ty + 8 * i]);
   }
 }
 
 // out(B,C,N) = act(a[ch]*y_tm[t][ch] + c[ch]) + res(B,C,N)     (a/c/res optional)
 __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ a,
                                                                 const float* __restrict__ cs, const float* __restrict__ res,
-                                                                float* __restrict__ out, int C, int N) {
+                                                                float* __restrict__ out, int C, int N,
+                                                                const float* __restrict__ img_scale) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __r
     if (ch < C && n < N) {
       const size_t o = ((size_t)b * C + ch) * N + n;
       float v = tile[tx][ty + 8 * i];
+      if (img_scale) v *= img_scale[b];             // DropPath (reference torch_vertex.py:332): branch * mask / keep
       if (res) v += res[o];
       out[o] = v;
     }
@@ -337,7 +340,8 @@ template <int ACT, typename OutT>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ y, const float* __restrict__ a,
                                                          const float* __restrict__ cs, const float* __restrict__ res,
                                                          OutT* __restrict__ out, size_t total4, int C, int ldo,
-                                                         size_t o_bstride) {
+                                                         size_t o_bstride, const float* __restrict__ row_scale,
+                                                         int rows_per_scale) {
   const int C4 = C >> 2;
   const int q = blockIdx.y;
   y += (size_t)q * total4 * 4; a += (size_t)q * C; cs += (size_t)q * C; out += (size_t)q * o_bstride;
@@ -352,6 +356,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     o.x = __builtin_fmaf(a4.x, v.x, c4.x); o.y = __builtin_fmaf(a4.y, v.y, c4.y);
     o.z = __builtin_fmaf(a4.z, v.z, c4.z); o.w = __builtin_fmaf(a4.w, v.w, c4.w);
     if (ACT == 1) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
+    if (row_scale) {                                // DropPath: one factor per image = rows_per_scale consecutive rows
+      const float sc = row_scale[r / rows_per_scale];
+      o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
+    }
     if (res) {
       const float4 rv = *reinterpret_cast<const float4*>(res + 4 * i);
       o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
@@ -476,23 +484,24 @@ extern "C" size_t gkg_bn_workspace_bytes(int R, int C, int nb) {
   return (size_t)nb * (nblk + 1) * 2 * C * sizeof(float);
 }
 
-extern "C" int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype, void* stream) {
+extern "C" int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype, const float* img_scale,
+                              void* stream) {
   if (!x || !out) return gkg_fail(GKG_ERR_NULL, "gkg_nchw_to_tm: null pointer");
   if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_nchw_to_tm: bad sizes");
   if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_nchw_to_tm: out_dtype is GKG_F32 or GKG_BF16");
   dim3 grid((N + 31) / 32, (C + 31) / 32, B);
-  if (out_dtype == GKG_BF16) hipLaunchKernelGGL(nchw_to_tm_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)out, C, N);
-  else hipLaunchKernelGGL(nchw_to_tm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)out, C, N);
+  if (out_dtype == GKG_BF16) hipLaunchKernelGGL(nchw_to_tm_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)out, C, N, img_scale);
+  else hipLaunchKernelGGL(nchw_to_tm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)out, C, N, img_scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "nchw_to_tm_kernel");
 }
 
 extern "C" int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
-                                     int B, int C, int N, void* stream) {
+                                     int B, int C, int N, const float* img_scale, void* stream) {
   if (!y || !out || ((a == nullptr) != (c == nullptr))) return gkg_fail(GKG_ERR_NULL, "gkg_tm_affine_to_nchw: null pointer");
   if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_tm_affine_to_nchw: bad sizes");
   dim3 grid((N + 31) / 32, (C + 31) / 32, B);
-  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, C, N);
+  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, C, N, img_scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "tm_affine_to_nchw_kernel");
 }
@@ -530,7 +539,9 @@ extern "C" int gkg_bn_eval_affine(const float* gamma, const float* beta, const f
 }
 
 extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
-                              int nb, int ldo, size_t out_bstride, int act, int out_dtype, void* stream) {
+                              int nb, int ldo, size_t out_bstride, int act, int out_dtype, const float* row_scale,
+                              int rows_per_scale, void* stream) {
+  if (row_scale && rows_per_scale <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: rows_per_scale must be positive");
   if (!y || !a || !c || !out) return gkg_fail(GKG_ERR_NULL, "gkg_affine_act: null pointer");
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldo < C || (ldo & 3) || (out_bstride & 3) || (act != 0 && act != 1))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: bad sizes");
@@ -541,12 +552,12 @@ extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, co
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
-    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
+    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
   } else {
     float* o = (float*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
-    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");

@@ -168,8 +168,9 @@ struct TopList {
   // Sorted insert; a no-op for lanes whose candidate does not beat their KD-th entry, skipped when no lane of the
   // wave improves.
   template <bool GUARD>
-  __device__ __forceinline__ void insert(float d, int m) {
-    const double k = pack_key(d, m);
+  __device__ __forceinline__ void insert(float d, int m) { insert_key<GUARD>(pack_key(d, m)); }
+  template <bool GUARD>
+  __device__ __forceinline__ void insert_key(const double k) {
     // GUARD: skip the insert when no lane of the wave improves.  Pays once a wave has streamed a few hundred keys per
     // query (late candidates rarely enter a list); before that it is a compare + branch per candidate for nothing.
     if (GUARD && __builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
@@ -214,7 +215,17 @@ struct KnnArgs {
 // "beats my k-th best" mask with the distances parked in LDS) was measured 1.5-1.7x SLOWER: per-wave lists
 // see only a quarter of the keys, so some lane of 64 passes for almost every candidate and the divergent
 // loop serialises on LDS latency.
-template <int KD, bool HAS_RP, int KU, bool GUARD = true>
+// BUF > 0 — buffered selection.  The sorted insert costs 2*KD+6 vector instructions per candidate and lane, and on gfx950
+// those are paid in matrix time (fp32 MFMA and fp32 VALU do not overlap).  Once a list has seen a few dozen keys almost
+// every candidate fails against its KD-th entry, but per-lane divergence rules out skipping: some lane of 64 passes for
+// almost every candidate.  So a candidate is only TESTED against the lane's (possibly stale) KD-th distance — one compare —
+// and, when it passes, APPENDED raw (distance, index: 8 bytes) to a per-lane LDS buffer of BUF entries; the sorted inserts
+// run in wave-uniform flushes: when some lane's buffer could overflow within the next 8 candidates (and at the end of the
+// stream) every lane inserts its buffered entries, i.e. max-over-lanes(count) insert steps, and refreshes its threshold.
+// A stale threshold only admits MORE candidates than necessary; the insert itself re-decides with the full (distance,
+// index) key, so the result is bit-identical to the direct form (ties included: keys arrive in increasing index order
+// within a wave, so a later candidate equal to the KD-th entry never displaces it — the strict '<' is exact).
+template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0>
 __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_tile_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
@@ -306,6 +317,21 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
 
   TopList<KD> top;
   top.init();
+  // buffered selection state: the buffer lives behind the staged queries, [BUF][256] x {distance, index}
+  float2* cbuf = reinterpret_cast<float2*>(smem + (size_t)cpad * QT) + tid;
+  int bcnt = 0;
+  float thr = INFINITY;
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < BUF; ++i) {                 // forward branches only: a back edge makes the allocator duplicate the list
+      if (__builtin_amdgcn_ballot_w64(i < bcnt) == 0ull) break;
+      const float2 e = cbuf[i * 256];
+      const double k = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+      top.template insert_key<false>(k);
+    }
+    bcnt = 0;
+    thr = key_dist(top.key[KD - 1]);               // +inf while the list is not full
+  };
 
   const int ktiles = (M + KT - 1) / KT;
   const int t_end = min(t_begin + a.tiles_per_split, ktiles);
@@ -407,9 +433,18 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
             dist = (sqx + dist) + sy;
           }
           if (HAS_RP) dist = dist + rp[row];
-          top.template insert<GUARD>(dist, m0 + row);
+          if (BUF > 0) {
+            if (dist < thr) {                       // NaN fails, like the insert's strict '<'
+              cbuf[bcnt * 256] = make_float2(dist, __int_as_float(m0 + row));
+              ++bcnt;
+            }
+          } else {
+            top.template insert<GUARD>(dist, m0 + row);
+          }
         }
       }
+      // room for the next 8 candidates?  (the stream's last group flushes unconditionally)
+      if (BUF > 0 && ((g == 3 && t + NW >= t_end) || __builtin_amdgcn_ballot_w64(bcnt > BUF - 8) != 0ull)) flush();
     }
   }
 
@@ -577,12 +612,18 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
   return p.total;
 }
 
-template <int KD, bool HAS_RP, int KU, bool GUARD = true>
+constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 bytes each: 32 KB per workgroup)
+
+template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0>
 static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (BUF > 0) {
+    const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 256 * sizeof(float2);
+    if (lds < need) lds = need;
+  }
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -603,6 +644,15 @@ static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream
   const bool deep = (a.cpad % 16) == 0;      // 8 k-pairs per register batch when the channel count allows
   if (a.relpos) return deep ? launch_tile_v<KD, true, 8>(a, grid, lds, st) : launch_tile_v<KD, true, 4>(a, grid, lds, st);
   return deep ? launch_tile_v<KD, false, 8>(a, grid, lds, st) : launch_tile_v<KD, false, 4>(a, grid, lds, st);
+}
+
+// long key streams per wave and / or long lists: buffered selection (see the kernel's comment)
+template <int KD>
+static hipError_t launch_tile_buffered(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
+  const bool deep = (a.cpad % 16) == 0;
+  if (a.relpos) return deep ? launch_tile_v<KD, true, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, true, 4, false, KNN_BUF>(a, grid, lds, st);
+  return deep ? launch_tile_v<KD, false, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, false, 4, false, KNN_BUF>(a, grid, lds, st);
 }
 
 template <typename T, int PT>
@@ -629,7 +679,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
                         int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                         void* workspace, size_t workspace_bytes, void* stream, int G_tm) {
   if (!x || !nn_idx || !workspace) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
-  if (dtype != GKG_F32 && dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32 or GKG_BF16");
+  if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32, GKG_BF16 or GKG_F16");
   KnnPlan p;
   int rc = make_plan(BG, c, N, M, k, dilation, y != nullptr, &p);
   if (rc == GKG_ERR_SHAPE) return gkg_fail(rc, "gkg_knn_fwd: bad sizes (need >0, k*dilation <= M, M == N for the self graph)");
@@ -653,6 +703,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   const PrepSet sx{x, xh, sqx, N, strides(N)};
   const PrepSet sy{y, yh, sqy, M, strides(M)};
   if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
+  else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   if (e != hipSuccess) return gkg_fail_hip(e, "token_prep");
   KnnArgs a;
@@ -667,7 +718,31 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
   size_t lds = lds_q > lds_m ? lds_q : lds_m;
   const bool short_stream = p.tps < 10 * NW;
-  if (short_stream && p.KD == 9) {
+  // Selection mode.  Buffered selection (see the kernel) wins where the per-candidate insert dominates and its 32 KB
+  // buffer does not cost occupancy — measured on MI355X (tools/bench_ops.py, direct -> buffered): pvig_m@768 k=18
+  // stage 1 (c=12, kd=18) 15.97 -> 10.61 ms, stage 2 4.46 -> 3.13 ms, stage 3 (c=48, kd=36) 2.59 -> 1.55 ms; pvig_s@576
+  // stage 1 2.52 -> 2.42 ms, stage 2 0.96 -> 0.89 ms, label graph over 20 736 keys 250 -> 214 us; it LOSES with wide groups
+  // (c=200: query tile 51 KB + buffer -> one workgroup per CU, 607 -> 876 us) and on short streams with 9-entry lists
+  // (cfg2 label graph 24.6 -> 31.5 us).  GKG_KNN_SELECT=direct|buffered overrides the rule (measurement / tests).
+  const char* sel = getenv("GKG_KNN_SELECT");
+  const int force = !sel ? 0 : (sel[0] == 'b' ? 2 : (sel[0] == 'd' ? 1 : 0));
+  const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 <= 150 * 1024;
+  const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
+  const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));
+  if (buffered) {
+    switch (p.KD) {
+      case 9: e = launch_tile_buffered<9>(a, grid, lds, st); break;
+      case 12: e = launch_tile_buffered<12>(a, grid, lds, st); break;
+      case 16: e = launch_tile_buffered<16>(a, grid, lds, st); break;
+      case 18: e = launch_tile_buffered<18>(a, grid, lds, st); break;
+      case 24: e = launch_tile_buffered<24>(a, grid, lds, st); break;
+      case 27: e = launch_tile_buffered<27>(a, grid, lds, st); break;
+      case 32: e = launch_tile_buffered<32>(a, grid, lds, st); break;
+      case 36: e = launch_tile_buffered<36>(a, grid, lds, st); break;
+      case 48: e = launch_tile_buffered<48>(a, grid, lds, st); break;
+      default: e = launch_tile_buffered<64>(a, grid, lds, st); break;
+    }
+  } else if (short_stream && p.KD == 9) {
     e = launch_tile_short<9>(a, grid, lds, st);
   } else
   switch (p.KD) {

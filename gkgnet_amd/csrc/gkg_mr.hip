@@ -442,7 +442,7 @@ extern "C" int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx,
   if (!x || !nn_idx || !m_out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_fwd: x, nn_idx and m_out must be non-null");
   if (BG <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd: bad sizes (k <= 255)");
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd: self graph needs M == N"); src = x; }
-  if (dtype != GKG_F32 && dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd: dtype");
+  if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd: dtype");
   if (BG > 65535) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd: BG <= 65535");
   const int extra = k * 256 * 4;
   // channels per workgroup: as many source rows as fit, but keep enough workgroups to fill the chip
@@ -451,6 +451,7 @@ extern "C" int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx,
     GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
     dim3 grid((N + 255) / 256, c < 64 ? c : 64, BG);
     if (dtype == GKG_F32) hipLaunchKernelGGL((mr_fwd_gather_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)src, nn_idx, (float*)m_out, argmax, c, N, M, k);
+    else if (dtype == GKG_F16) hipLaunchKernelGGL((mr_fwd_gather_kernel<_Float16>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)src, nn_idx, (_Float16*)m_out, argmax, c, N, M, k);
     else hipLaunchKernelGGL((mr_fwd_gather_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)src, nn_idx, (uint16_t*)m_out, argmax, c, N, M, k);
     hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? 0 : gkg_fail_hip(e2, "mr_fwd_gather_kernel");
@@ -458,6 +459,7 @@ extern "C" int gkg_mr_fwd(const void* x, const void* src, const int64_t* nn_idx,
   const long ntiles = (N + 255) / 256;
   while (CH > 4 && ntiles * ((c + CH - 1) / CH) * BG < 1024) CH = (CH + 1) / 2;
   hipError_t e = dtype == GKG_F32 ? mr_fwd_launch<float>(x, src, nn_idx, m_out, argmax, BG, c, N, M, k, CH, (hipStream_t)stream)
+               : dtype == GKG_F16 ? mr_fwd_launch<_Float16>(x, src, nn_idx, m_out, argmax, BG, c, N, M, k, CH, (hipStream_t)stream)
                                   : mr_fwd_launch<uint16_t>(x, src, nn_idx, m_out, argmax, BG, c, N, M, k, CH, (hipStream_t)stream);
   if (e != hipSuccess) return gkg_fail_hip(e, "mr_fwd_kernel");
   return 0;
@@ -486,7 +488,7 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
   if (!g || !nn_idx || !argmax || !gx) return gkg_fail(GKG_ERR_NULL, "gkg_mr_bwd: g, nn_idx, argmax and gx must be non-null");
   if (BG <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd: bad sizes (k <= 255)");
   if (!gsrc && M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd: self graph needs M == N");
-  if (dtype != GKG_F32 && dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd: dtype");
+  if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd: dtype");
   if (BG > 65535) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd: BG <= 65535");
   const int extra = k * 256 * 4;
   int CH = pick_ch(c, M, extra);
@@ -505,6 +507,7 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
   }
   while (CH > 2 && (long)((c + CH - 1) / CH) * BG < 1024) CH = (CH + 1) / 2;
   hipError_t e = dtype == GKG_F32 ? mr_bwd_launch<float>(g, nn_idx, argmax, gx, gsrc, BG, c, N, M, k, CH, (hipStream_t)stream)
+               : dtype == GKG_F16 ? mr_bwd_launch<_Float16>(g, nn_idx, argmax, gx, gsrc, BG, c, N, M, k, CH, (hipStream_t)stream)
                                   : mr_bwd_launch<uint16_t>(g, nn_idx, argmax, gx, gsrc, BG, c, N, M, k, CH, (hipStream_t)stream);
   if (e != hipSuccess) return gkg_fail_hip(e, "mr_bwd_kernel");
   return 0;

@@ -255,7 +255,7 @@ class _ToTokenMajor(torch.autograd.Function):
         N = x[0, 0].numel()
         x = x.contiguous()
         out = torch.empty((B * N, C), dtype=_F32, device=x.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _lib.F32, _stream()), "gkg_nchw_to_tm")
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _lib.F32, None, _stream()), "gkg_nchw_to_tm")
         ctx.shape = tuple(x.shape)
         return out
 
@@ -265,7 +265,7 @@ class _ToTokenMajor(torch.autograd.Function):
         N = g.shape[0] // B
         g = g.contiguous()
         out = torch.empty(ctx.shape, dtype=_F32, device=g.device)
-        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g), None, None, None, _ptr(out), B, C, N, _stream()),
+        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g), None, None, None, _ptr(out), B, C, N, None, _stream()),
                    "gkg_tm_affine_to_nchw")
         return out
 
@@ -285,7 +285,7 @@ class _BlockEntry(torch.autograd.Function):
         N = x[0, 0].numel()
         dt, code = _tm_dtype(lowp)
         out = torch.empty((B * N, C), dtype=dt, device=x.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, code, _stream()), "gkg_nchw_to_tm")
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, code, None, _stream()), "gkg_nchw_to_tm")
         ctx.shape = tuple(x.shape)
         ctx.set_materialize_grads(False)
         return out, x.view_as(x)
@@ -298,7 +298,8 @@ class _BlockEntry(torch.autograd.Function):
         N = g_tm.shape[0] // B
         res = None if g_res is None else g_res.contiguous()
         out = torch.empty(ctx.shape, dtype=_F32, device=g_tm.device)
-        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g_tm.contiguous()), None, None, _ptr(res), _ptr(out), B, C, N,
+        g_tm = g_tm.contiguous()                 # named: the copy must outlive the launch that reads it
+        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g_tm), None, None, _ptr(res), _ptr(out), B, C, N, None,
                                                      _stream()), "gkg_tm_affine_to_nchw")
         return out, None
 
@@ -384,7 +385,8 @@ class _LinearBNAct(torch.autograd.Function):
     residual) in (B, C, N) layout — the block's last layer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None, scale=None,
+                rows_per_scale=0):
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
@@ -400,7 +402,7 @@ class _LinearBNAct(torch.autograd.Function):
             out = torch.empty(nchw, dtype=_F32, device=x.device)
         if own:
             x = x.contiguous()
-        two = _bn2(bn, x if own else torch.empty(0, dtype=_F32))
+        two = scale is None and _bn2(bn, x if own else torch.empty(0, dtype=_F32))
         sync = None
         if own and two:                               # projection kernel (statistics in its epilogue) -> apply: 2 kernels
             Y = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, stats_only=True)[0]
@@ -421,12 +423,13 @@ class _LinearBNAct(torch.autograd.Function):
             if own or not two:
                 if nchw is None:
                     _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
-                                                  code, _stream()), "gkg_affine_act")
+                                                  code, _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act")
                 else:
                     _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), nchw[0], cout,
-                                                         R // nchw[0], _stream()), "gkg_tm_affine_to_nchw")
+                                                         R // nchw[0], _ptr(scale), _stream()), "gkg_tm_affine_to_nchw")
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, nchw, residual is not None, bias is not None)
+        ctx.scale = (scale, rows_per_scale)
         ctx.sync = sync
         ctx.own = own and OWN_GEMM == "all"
         return out
@@ -443,7 +446,9 @@ class _LinearBNAct(torch.autograd.Function):
             g = torch.empty((R, cout), dtype=_F32, device=dout.device)
             dout_c = dout.contiguous()           # named: the copy must outlive the launch that reads it
             _lib.check(lib.gkg_nchw_to_tm(_ptr(dout_c), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32,
-                                          _stream()), "gkg_nchw_to_tm")
+                                          _ptr(ctx.scale[0]), _stream()), "gkg_nchw_to_tm")      # DropPath: g * mask / keep
+        elif ctx.scale[0] is not None:
+            g = (dout.view(-1, ctx.scale[1], cout) * ctx.scale[0].view(-1, 1, 1)).view(R, cout)
         else:
             g = dout.contiguous()
         if mean is None:
@@ -454,7 +459,7 @@ class _LinearBNAct(torch.autograd.Function):
             dx, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, R * cout, Y, a, c, mean, invstd, x,
                                                     weight.view(cout, cin), R, cin, cout, 1, act,
                                                     ctx.needs_input_grad[0])
-            return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None
+            return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
         dY = torch.empty_like(Y)
         dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
         dbeta = torch.empty_like(dgamma)
@@ -462,7 +467,7 @@ class _LinearBNAct(torch.autograd.Function):
         W = weight.view(cout, cin)
         dx = torch.mm(dY, W)
         dW = _wgrad(dY, x).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -504,7 +509,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
                 a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
         if not two:
             _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
-                                          code, _stream()), "gkg_affine_act")
+                                          code, None, 0, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         ctx.sync = sync
@@ -604,13 +609,11 @@ def fused_supported(mod, x, groups: int) -> bool:
     C = mod.channels
     # fp32 activations; under autocast (mixed precision) bf16 inputs are accepted too: the block then keeps its
     # activations in fp32 and only the projection GEMMs run on bf16 operands (fp32 accumulation)
-    if not x.is_cuda or not (x.dtype == _F32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled())):
+    if not x.is_cuda or not (x.dtype == _F32 or (x.dtype in (torch.bfloat16, torch.float16) and torch.is_autocast_enabled())):
         return False
     if not isinstance(gc.gconv, MRConv2d) or len(gc.gconv.nn) != 3 or not isinstance(gc.gconv.nn[2], torch.nn.GELU):
         return False
     if C % 16 or (C // groups) % 4 or getattr(gc.dilated_knn_graph, "stochastic", False):
-        return False
-    if isinstance(mod.drop_path, torch.nn.Identity) is False and mod.training and mod.drop_path.drop_prob > 0:
         return False
     bns = [mod.fc1[1], gc.gconv.nn[1], mod.fc2[1]]
     if hasattr(mod, "ffn"):
@@ -624,10 +627,17 @@ def fused_supported(mod, x, groups: int) -> bool:
     return ENABLED
 
 
-def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False):
+def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0):
+    """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
+    output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402)."""
     conv, bn = seq[0], seq[1]
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
-    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16)
+    return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
+                              rows_per_scale)
+
+
+def _drop_scale(drop_path, batch, device):
+    return drop_path.sample_scale(batch, device) if hasattr(drop_path, "sample_scale") else None
 
 
 def grapher_forward(mod, x, relative_pos, groups: int):
@@ -648,7 +658,8 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     nn_ = gc.gconv.nn
     a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
                                    _w16_of(nn_[0]) if lp else None)   # (T, 2C)
-    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W))          # fc2 + BN + residual, back to NCHW
+    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W),          # fc2 + BN (+ DropPath) + residual, back to NCHW
+               scale=_drop_scale(mod.drop_path, B, x.device))
     return out, edge
 
 
@@ -666,9 +677,9 @@ def grapher_label_forward(mod, e, features, groups: int):
     nn_ = gc.gconv.nn
     a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
                                    _w16_of(nn_[0]) if lp else None)
-    h2 = _lin(a2, mod.fc2, residual=e2)
+    h2 = _lin(a2, mod.fc2, residual=e2, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
     f1 = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp)
-    out = _lin(f1, mod.ffn.fc2, residual=h2)
+    out = _lin(f1, mod.ffn.fc2, residual=h2, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)
     return out.view(B, L, C), edge
 
 
@@ -676,13 +687,11 @@ def ffn_supported(mod, x) -> bool:
     """Fused path for the backbone's FFN block (1x1 conv + BN + GELU -> 1x1 conv + BN -> + residual)."""
     if not (ENABLED and x.is_cuda and x.dim() == 4):
         return False
-    if not (x.dtype == _F32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled())):
+    if not (x.dtype == _F32 or (x.dtype in (torch.bfloat16, torch.float16) and torch.is_autocast_enabled())):
         return False
     if not isinstance(mod.act, torch.nn.GELU) or not (_bn_ok(mod.fc1[1]) and _bn_ok(mod.fc2[1])):
         return False
     if any(conv.weight.shape[0] % 4 or conv.weight.shape[1] % 4 for conv in (mod.fc1[0], mod.fc2[0])):
-        return False
-    if not isinstance(mod.drop_path, torch.nn.Identity) and mod.training and mod.drop_path.drop_prob > 0:
         return False
     if torch.is_grad_enabled() and not mod.training and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
         return False
@@ -694,4 +703,4 @@ def ffn_forward(mod, x):
     lp = lowp_inference()
     xt, x = _BlockEntry.apply(x.float().contiguous(), lp)
     h = _lin(xt, mod.fc1, act=1, out_lowp=lp)
-    return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape))
+    return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape), scale=_drop_scale(mod.drop_path, x.shape[0], x.device))

@@ -96,7 +96,7 @@ class GrapherLabel(nn.Module):
     def forward(self, x, features):
         B, C = features.shape[:2]
         groups = self.graph_conv.num_head
-        if fused.fused_supported(self, x, groups) and features.is_cuda and features.dtype in (torch.float32, torch.bfloat16):
+        if fused.fused_supported(self, x, groups) and features.is_cuda and features.dtype in (torch.float32, torch.bfloat16, torch.float16):
             out, edge = fused.grapher_label_forward(self, x, features, groups)
             from .graph import DyGraphLabel
             return out, (edge if isinstance(self.graph_conv, DyGraphLabel) else edge[0])

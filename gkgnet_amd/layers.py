@@ -122,12 +122,22 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
 
-    def forward(self, x):
-        if self.drop_prob == 0.0 or not self.training:
-            return x
+    def active(self) -> bool:
+        return self.drop_prob > 0.0 and self.training
+
+    def sample_scale(self, batch: int, device, dtype=torch.float32):
+        """Per-image factor mask / keep (mask ~ Bernoulli(keep)), shape (batch,); None when inactive.  The fused block
+        folds it into its last BN-apply kernel; ``forward`` draws from the same place, so both paths consume the RNG alike."""
+        if not self.active():
+            return None
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x * mask / keep
+        return torch.empty(batch, device=device, dtype=dtype).bernoulli_(keep) / keep
+
+    def forward(self, x):
+        s = self.sample_scale(x.shape[0], x.device, x.dtype)
+        if s is None:
+            return x
+        return x * s.view((x.shape[0],) + (1,) * (x.dim() - 1))
 
     def extra_repr(self):
         return f"p={self.drop_prob}"

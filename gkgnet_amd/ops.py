@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
 def _need_cuda(*ts):
     for t in ts:
@@ -49,7 +49,7 @@ def knn_graph(x: torch.Tensor, y: Optional[torch.Tensor] = None, relative_pos: O
     xq = _tokens(x.detach())
     yk = None if y is None else _tokens(y.detach())
     if xq.dtype not in _DT:
-        raise _lib.GkgError(f"unsupported dtype {xq.dtype} (fp32 / bf16)")
+        raise _lib.GkgError(f"unsupported dtype {xq.dtype} (fp32 / bf16 / fp16)")
     if yk is not None and (yk.dtype != xq.dtype or yk.shape[:2] != xq.shape[:2]):
         raise _lib.GkgError("y must match x in dtype, batch*groups and channels")
     BG, c, N = xq.shape
@@ -110,7 +110,7 @@ def max_relative(x: torch.Tensor, nn_idx: torch.Tensor, y: Optional[torch.Tensor
     xs = _tokens(x)
     ys = None if y is None else _tokens(y)
     if xs.dtype not in _DT:
-        raise _lib.GkgError(f"unsupported dtype {xs.dtype} (fp32 / bf16)")
+        raise _lib.GkgError(f"unsupported dtype {xs.dtype} (fp32 / bf16 / fp16)")
     if ys is not None and ys.dtype != xs.dtype:
         raise _lib.GkgError("y must match x in dtype")
     idx = nn_idx.contiguous()

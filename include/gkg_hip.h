@@ -20,8 +20,8 @@
  *     string (thread-local).  Workspace, when needed, is passed in by the caller.
  *   - Return value: 0 on success; >0 a hipError_t from a launch; <0 an argument error
  *     (GKG_ERR_*).  Nothing throws or exits.
- *   - dtype: element type of the feature tensors x / y / src / g / outputs.  Distances are always
- *     accumulated in fp32 (SURVEY.md §5 AMP row).
+ *   - dtype: element type of the feature tensors x / y / src / g / outputs (GKG_F32, GKG_BF16, GKG_F16).  Distances are
+ *     always accumulated in fp32 (SURVEY.md §5 AMP row).
  *
  * Arithmetic contract of gkg_knn_fwd (restated bit-for-bit by oracle/gkg_oracle.c):
  *     s      = fma-chain_{ch} t[ch]^2            den = max(sqrt(s), 1e-12)       (GKG_KNN_NORMALIZE)
@@ -41,11 +41,12 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 3
+#define GKG_ABI_VERSION 4
 
 /* dtype codes */
 #define GKG_F32 0
 #define GKG_BF16 1
+#define GKG_F16 2 /* the reference trains under fp16 AMP (configs/gkgnet/gkgnet_coco_576.py:146): inputs widened exactly */
 
 /* gkg_knn_fwd flags */
 #define GKG_KNN_NORMALIZE 1u /* L2-normalise tokens over the group's channels first (torch_edge.py:167-173) */
@@ -125,11 +126,13 @@ int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax
  * caller in the vendor library on token-major (rows = tokens) fp32 matrices.  `nb` stacks nb independent
  * (R, C) matrices (the 4 groups of the grouped projection) with parameters laid out [nb][C].
  */
-/* (B,C,N) fp32 -> (B*N,C) in out_dtype (GKG_F32, or GKG_BF16 when the result only feeds a bf16 GEMM) */
-int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype, void* stream);
-/* out(B,C,N) = a[ch]*y[t][ch] + c[ch] + res(B,C,N); a/c and res optional (NULL) */
+/* (B,C,N) fp32 -> (B*N,C) in out_dtype (GKG_F32, or GKG_BF16 when the result only feeds a bf16 GEMM); img_scale (B) or
+ * NULL multiplies image b (the backward of a stochastic-depth branch) */
+int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype, const float* img_scale, void* stream);
+/* out(B,C,N) = (a[ch]*y[t][ch] + c[ch]) * img_scale[b] + res(B,C,N); a/c, img_scale and res optional (NULL).
+ * img_scale is the reference's DropPath (torch_vertex.py:332, timm): per-image Bernoulli keep mask / keep probability. */
 int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
-                          int B, int C, int N, void* stream);
+                          int B, int C, int N, const float* img_scale, void* stream);
 size_t gkg_bn_workspace_bytes(int R, int C, int nb);
 /* Train-mode batch statistics of y (R,C) (conv bias NOT included in y; it is folded: it cancels in the output and
  * is added to running_mean).  Writes scale a, shift c (out = a*y + c), saved mean / invstd; updates running stats
@@ -141,10 +144,12 @@ int gkg_bn_train_stats(const float* y, const float* gamma, const float* beta, co
 /* Eval mode: a = gamma/sqrt(rv+eps), c = beta + a*(bias - rm) */
 int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias, const float* running_mean,
                        const float* running_var, float* a, float* c, int C, float eps, void* stream);
-/* out = act(a*y + c) (+ res); act 0 = identity, 1 = GELU(erf).  out[q] has row pitch ldo and batch stride out_bstride
- * (both in elements of out_dtype: GKG_F32, or GKG_BF16 = round-to-nearest-even of the fp32 result) */
+/* out = act(a*y + c) * row_scale[r / rows_per_scale] (+ res); act 0 = identity, 1 = GELU(erf); row_scale optional (NULL).
+ * out[q] has row pitch ldo and batch stride out_bstride (both in elements of out_dtype: GKG_F32, or GKG_BF16 =
+ * round-to-nearest-even of the fp32 result) */
 int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
-                   int nb, int ldo, size_t out_bstride, int act, int out_dtype, void* stream);
+                   int nb, int ldo, size_t out_bstride, int act, int out_dtype, const float* row_scale, int rows_per_scale,
+                   void* stream);
 /* Backward of out = act(BN_train(y)): dy, dgamma, dbeta from dout (row pitch ldg, batch stride dout_bstride). */
 int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,

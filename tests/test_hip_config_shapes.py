@@ -58,8 +58,24 @@ def _dev(a, dtype=torch.float32):
     return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
+@pytest.fixture(params=["auto", "direct", "buffered"])
+def knn_select(request):
+    """The k-NN kernel's selection mode: the library's own rule, or one mode forced (GKG_KNN_SELECT is read per call)."""
+    import os
+    old = os.environ.get("GKG_KNN_SELECT")
+    if request.param == "auto":
+        os.environ.pop("GKG_KNN_SELECT", None)
+    else:
+        os.environ["GKG_KNN_SELECT"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("GKG_KNN_SELECT", None)
+    else:
+        os.environ["GKG_KNN_SELECT"] = old
+
+
 @pytest.mark.parametrize("name", sorted(SHAPES))
-def test_layer_shape_bit_exact_vs_c_oracle(name):
+def test_layer_shape_bit_exact_vs_c_oracle(name, knn_select):
     from gkgnet_amd import fused, ops
     from oracle import c_oracle as O
     BG = 2

@@ -288,3 +288,67 @@ def test_cfg2_full_size_grapher_and_label_vs_oracle():
     assert close(got[0], own[0]) > 0.9995 and (got[0] - own[0]).abs().median().item() < 1e-5
     assert close(got[1], own[1]) > 0.99
     assert ((got[3] - own[3]).norm() / own[3].norm()).item() < 2e-2
+
+
+def _droppath_block(kind):
+    from gkgnet_amd.backbone import FFN
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    torch.manual_seed(21)
+    if kind == "grapher":
+        return Grapher(64, 9, 2, "mr", "gelu", "batch", True, False, 0.2, 1, n=100, drop_path=0.4, relative_pos=True,
+                       use_multi_group=True, num_group=2)
+    if kind == "label":
+        return GrapherLabel(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=100, drop_path=0.4, num_nodes=20,
+                            use_multi_group=True, num_group=2)
+    return FFN(64, 256, act="gelu", drop_path=0.4)
+
+
+@pytest.mark.parametrize("kind", ["grapher", "label", "ffn"])
+def test_fused_path_covers_active_droppath(kind):
+    """The reference's real training config runs stochastic depth (configs/gkgnet/gkgnet_coco_576.py:15 drop_path=0.1;
+    gkgnet.py:181,235-237; torch_vertex.py:332): the fused block folds the per-image keep / (1 - p) factor into its last
+    BN-apply kernel (and into the layout kernel of the backward).  Same RNG state -> same mask -> the fused and the
+    composable per-op paths must agree, forward and backward."""
+    from gkgnet_amd import fused
+    mod = _droppath_block(kind).cuda().train()
+    B = 6
+    x = torch.randn(B, 64, 10, 10, device="cuda")
+    e = torch.randn(B, 20, 64, device="cuda")
+    outs = []
+    calls = {"n": 0}
+    real = (fused.grapher_forward, fused.grapher_label_forward, fused.ffn_forward)
+
+    def counting(fn):
+        def w(*a, **k):
+            calls["n"] += 1
+            return fn(*a, **k)
+        return w
+    fused.grapher_forward, fused.grapher_label_forward, fused.ffn_forward = map(counting, real)
+    try:
+        for enabled in (True, False):
+            fused.ENABLED = enabled
+            mod.zero_grad(set_to_none=True)
+            torch.manual_seed(1234)                                   # identical Bernoulli draws on both paths
+            xg, eg = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+            if kind == "label":
+                out = mod(eg, xg)[0]
+            else:
+                out = mod(xg)
+            out.square().sum().backward()
+            outs.append((out.detach(), xg.grad.clone(), None if kind != "label" else eg.grad.clone(),
+                         {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}))
+    finally:
+        fused.ENABLED = True
+        fused.grapher_forward, fused.grapher_label_forward, fused.ffn_forward = real
+    assert calls["n"] == 1, "the fused path must run with DropPath active (and only when enabled)"
+    (o1, dx1, de1, g1), (o2, dx2, de2, g2) = outs
+    # some images really were dropped: their branch contributes nothing, the block returns its input
+    res = e if kind == "label" else x
+    assert any(torch.equal(o1[b], res[b]) for b in range(B)) or kind == "label"
+    assert torch.allclose(o1, o2, atol=1e-3, rtol=1e-3)
+    assert torch.allclose(dx1, dx2, atol=2e-3, rtol=2e-3)
+    if de1 is not None:
+        assert torch.allclose(de1, de2, atol=2e-3, rtol=2e-3)
+    for n in g2:
+        if n in g1:
+            assert torch.allclose(g1[n], g2[n], atol=5e-3, rtol=5e-3), n

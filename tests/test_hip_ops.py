@@ -150,10 +150,46 @@ def test_errors_are_loud():
     with pytest.raises(_lib.GkgError):
         ops.knn_graph(torch.zeros(1, 4, 8, device="cuda"), None, None, 9, 1)  # k > M
     with pytest.raises(_lib.GkgError):
-        ops.knn_graph(torch.zeros(1, 4, 8, device="cuda", dtype=torch.float16), None, None, 3, 1)
+        ops.knn_graph(torch.zeros(1, 4, 8, device="cuda", dtype=torch.float64), None, None, 3, 1)
 
 
-def test_fuzz_random_shapes_bit_exact():
+def test_fp16_inputs_match_fp32_math_on_rounded_values():
+    """fp16 I/O (the reference trains under fp16 AMP, configs/gkgnet/gkgnet_coco_576.py:146): features are widened
+    exactly and distances accumulated in fp32 -> the same graph / aggregation as fp32 math on the fp16-rounded values,
+    bit for bit against the C oracle; the backward within fp16 rounding."""
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    for seed, (BG, c, N, M, k, d) in enumerate([(2, 40, 96, 150, 9, 1), (3, 24, 130, None, 6, 2), (1, 16, 80, 3000, 9, 1)]):
+        x, y, _ = _rand_case(90 + seed, BG, c, N, M, False)
+        xh = torch.from_numpy(x).to(torch.float16)
+        yh = None if y is None else torch.from_numpy(y).to(torch.float16)
+        xo = xh.float().numpy()
+        yo = None if yh is None else yh.float().numpy()
+        want_idx, want_center = O.knn(xo, yo, None, k, d)
+        edge = ops.knn_graph(xh.cuda(), None if yh is None else yh.cuda(), None, k, d).cpu().numpy()
+        assert np.array_equal(edge[0], want_idx) and np.array_equal(edge[1], want_center)
+        want_m, want_arg = O.mr_fwd(xo, yo, want_idx)
+        xg = xh.cuda().requires_grad_(True)
+        yg = None if yh is None else yh.cuda().requires_grad_(True)
+        m = ops.max_relative(xg, torch.from_numpy(want_idx).cuda(), yg)
+        assert m.dtype == torch.float16
+        assert np.array_equal(m.detach().float().cpu().numpy(), torch.from_numpy(want_m).to(torch.float16).float().numpy())
+        if M is None or M < 2000:               # (the > 24k-key fallback scatters with fp32 atomics: fp32 tensors only)
+            g = torch.from_numpy(np.random.RandomState(7).standard_normal(want_m.shape).astype(np.float32)).to(torch.float16)
+            m.backward(g.cuda())
+            gx, gs = O.mr_bwd(g.float().numpy(), want_idx, want_arg, M)
+            assert np.allclose(xg.grad.float().cpu().numpy(), gx, atol=2e-2, rtol=2e-3)
+            if M is not None:
+                assert np.allclose(yg.grad.float().cpu().numpy(), gs, atol=2e-2, rtol=2e-3)
+
+
+@pytest.mark.parametrize("select", ["direct", "buffered"])
+def test_fuzz_random_shapes_bit_exact(select, monkeypatch):
+    monkeypatch.setenv("GKG_KNN_SELECT", select)
+    _fuzz_random_shapes()
+
+
+def _fuzz_random_shapes():
     """60 random (BG, c, N, M, k, d, relpos, dtype) problems incl. ragged sizes (c not a multiple of 8, N/M not multiples
     of the 64/32 tiles, k*d up to 64, self and bipartite graphs): graph, aggregation and argmax bit-exact vs the C
     oracle, backward within rounding."""
@@ -230,7 +266,13 @@ def test_non_finite_inputs_do_not_crash_or_leave_the_index_range():
     assert torch.isfinite(m).all() and torch.isfinite(x.grad).all()
 
 
-def test_exact_ties_decide_membership_and_order():
+@pytest.mark.parametrize("select", ["direct", "buffered"])
+def test_exact_ties_decide_membership_and_order(select, monkeypatch):
+    monkeypatch.setenv("GKG_KNN_SELECT", select)
+    _exact_ties()
+
+
+def _exact_ties():
     """Inputs built to tie EXACTLY (keys duplicated three times; small-integer features without normalisation) for long
     and short lists: 'equal distance -> smaller key index first' must decide both which neighbours enter the top
     k*d and their order (hence which survive the dilation), bit for bit like the C oracle."""

@@ -21,6 +21,13 @@ SHAPES = {   # name: (BG, c, N, M(None=self), k, d, relpos_C)
     "stage1": (64, 40, 20736, 1296, 9, 1, "rand"),
     "stage1_norp": (64, 40, 20736, 1296, 9, 1, None),
     "label_stage1": (64, 40, 80, 20736, 9, 1, None),
+    "stage3_d3": (64, 200, 1296, None, 9, 3, 400),
+    # pvig_m @ 768, B = 16, G = 8 (BASELINE config 5)
+    "m1": (128, 12, 36864, 2304, 18, 1, "rand"),
+    "m2": (128, 24, 9216, 2304, 18, 1, "rand"),
+    "m3": (128, 48, 2304, None, 18, 2, "rand"),
+    "m4": (128, 96, 576, None, 18, 2, "rand"),
+    "m1_label": (128, 12, 80, 36864, 18, 1, None),
 }
 
 def run(name, iters=20):

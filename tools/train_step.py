@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-tune", action="store_true")
+    ap.add_argument("--drop-path", type=float, default=0.1, help="stochastic depth rate (reference config: 0.1)")
     args = ap.parse_args()
     os.environ.setdefault("GKG_RELPOS_DEVICE", "cuda")
     from gkgnet_amd import layers, parallel
@@ -35,7 +36,7 @@ def main():
         tunable.set_max_tuning_duration(30); tunable.set_max_tuning_iterations(10)
         tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_train_rank{rank}.csv"))
     torch.manual_seed(0)
-    net = GKGNet(choice=args.choice, n_classes=args.classes, size=args.size, drop_path=0.0).to(dev).train()
+    net = GKGNet(choice=args.choice, n_classes=args.classes, size=args.size, drop_path=args.drop_path).to(dev).train()
     head = LabelQueryHead(args.classes, GKGNet.arch_settings[args.choice]["channels"][-1]).to(dev).train()
     parallel.broadcast_parameters(net); parallel.broadcast_parameters(head)
     params = [p for p in list(net.parameters()) + list(head.parameters()) if p.requires_grad]
