@@ -511,6 +511,7 @@ def main():
     head_case(ref, "f12_head_loss")
     autocast_case(ref, 'f14_autocast_bf16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=14)
     train_step_case(ref, 'f15_train_step')
+    coco_case('f16_coco')
     map_case("f13_map")
 
 
@@ -532,5 +533,78 @@ def map_case(name="f13_map"):
     save(name, dict(kind="map", ref="core/evaluation/mean_ap.py:6-74"), pred=pred, target=target,
          mAP=np.float64(m.mAP(pred, target)), ap=np.array(aps))
 
+def coco_case(name="f16_coco"):
+    """F16: the reference's COCO dataset class — its pickled-annotation reader and get_coco_metrics —
+    run on a synthetic annotation file and random scores.  mmcls/datasets/coco.py is imported by path with stand-ins for
+    the packages its module header pulls in (mmcv, the mmcls dataset registry / base class, pipelines); scikit-learn,
+    which get_coco_metrics calls, is the real one."""
+    import importlib.util
+    import pickle
+    import tempfile
+    import types
+    root = os.environ.get("GKG_REFERENCE_ROOT", "/root/reference")
+
+    def mod(name_, **attrs):
+        m = types.ModuleType(name_)
+        m.__dict__.update(attrs)
+        sys.modules[name_] = m
+        return m
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    class _Base:                                              # stands in for MultiLabelDataset (abstract plumbing only)
+        def get_gt_labels(self):
+            return np.array([d["gt_label"] for d in self.data_infos])
+    saved = {k_: sys.modules.get(k_) for k_ in ("mmcv", "mmcls", "mmcls.datasets", "mmcls.datasets.builder",
+                                                "mmcls.datasets.multi_label", "mmcls.core", "mmcls.core.evaluation",
+                                                "mmcls.models", "mmcls.models.losses", "mmcls.datasets.pipelines", "easydict")}
+    mod("mmcv")
+    for pk in ("mmcls", "mmcls.datasets", "mmcls.core", "mmcls.models"):
+        m = mod(pk); m.__path__ = []
+    mod("mmcls.datasets.builder", DATASETS=_Reg())
+    mod("mmcls.datasets.multi_label", MultiLabelDataset=_Base)
+    mod("mmcls.core.evaluation", precision_recall_f1=None, support=None)
+    mod("mmcls.models.losses", accuracy=None)
+    mod("mmcls.datasets.pipelines", Compose=None)
+    mod("easydict", EasyDict=dict)
+    spec = importlib.util.spec_from_file_location("mmcls.datasets.coco", os.path.join(root, "mmcls/datasets/coco.py"))
+    ref_coco = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_coco)
+    rng = np.random.RandomState(16)
+    N, C = 60, 80
+    records = [dict(file_name=f"COCO_val2014_{i:012d}.jpg", objects=(rng.rand(C) < 0.06).astype(np.float32), area=None)
+               for i in range(N)]
+    for r in records[:3]:
+        r["objects"][0] = 1.0
+    with tempfile.TemporaryDirectory() as td:
+        ann = os.path.join(td, "val_test.data")
+        with open(ann, "wb") as fh:
+            pickle.dump(records, fh)
+        ds = object.__new__(ref_coco.COCO)
+        ds.ann_file, ds.data_prefix = ann, "../0data/coco/val2014"
+        ds.data_infos = ds.load_annotations()
+        ann_bytes = np.frombuffer(open(ann, "rb").read(), dtype=np.uint8)
+    gt = ds.get_gt_labels()
+    preds = (rng.rand(N, C) ** 3).astype(np.float32)
+    preds[gt == 1] = np.clip(preds[gt == 1] + 0.45, 0, 1)         # an informative classifier: positives score higher
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        met = ref_coco.get_coco_metrics(gt, preds, threshold=0.5)
+    for k_, v in saved.items():
+        if v is None:
+            sys.modules.pop(k_, None)
+        else:
+            sys.modules[k_] = v
+    meta = dict(kind="coco", N=N, C=C, data_prefix=ds.data_prefix, filenames=[d["img_info"]["filename"] for d in ds.data_infos],
+                metrics={k_: float(v) for k_, v in met.items()}, ref="mmcls/datasets/coco.py:65-176,261-285")
+    save(name, meta, ann_file_bytes=ann_bytes, gt=gt.astype(np.int8), preds=preds)
+
+
 if __name__ == "__main__":
-    main()
+    if "f16" in sys.argv[1:]:
+        coco_case()
+    else:
+        main()

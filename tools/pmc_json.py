@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 counter_collection.csv files (one directory per --pmc pass) into one JSON: per gkg:: kernel
+instantiation the mean counter values over the second half of its dispatches (steady state), plus the HBM-side bytes
+per launch derived as the MI355X guide prescribes:
+    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads and
+    is uncalibrated for other widths -> calibrated here on nchw_to_tm_kernel, whose reads (one dword per lane, a known
+    byte count: B*C*N*4) use the same access width as the graph kernels' operand loads.
+    python tools/pmc_json.py <dir> [<dir> ...]"""
+import collections, csv, glob, json, subprocess, sys
+
+
+def load(d):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"]
+            if "gkg::" not in name:
+                continue
+            key = name.split("gkg::", 1)[1].split("(")[0]
+            out[key + f" grid={r.get('Grid_Size', '?')}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    acc = collections.defaultdict(dict)
+    for d in sys.argv[1:]:
+        for k, cs in load(d).items():
+            for c, v in cs.items():
+                v = v[len(v) // 2:]
+                acc[k][c] = round(sum(v) / len(v), 1)
+                acc[k]["dispatches"] = len(v)
+    try:
+        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = "unknown (gpurun snapshot has no .git; see the commit that adds this file)"
+    res = {"note": __doc__.strip().split("\n\n")[0], "commit": commit, "kernels": acc}
+    # calibration on the layout kernel of the Grapher entry: reads B*C*N*4 = 13 271 040 bytes at cfg2
+    cal = [v for k, v in acc.items() if k.startswith("nchw_to_tm_kernel") and "FETCH_SIZE" in v]
+    if cal:
+        known = 32 * 320 * 324 * 4
+        fs = max(c["FETCH_SIZE"] for c in cal) * 1024
+        res["calibration"] = {"kernel": "nchw_to_tm_kernel<float> (Grapher entry, cfg2)", "known_read_bytes": known,
+                              "FETCH_SIZE_bytes": fs, "factor": round(fs / known, 4)}
+        f = fs / known
+        for k, v in acc.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                v["hbm_bytes_per_launch"] = round(v["FETCH_SIZE"] * 1024 / f + v["WRITE_SIZE"] * 1024)
+    tiles = {k: v for k, v in acc.items() if k.startswith("knn_tile_kernel") and "hbm_bytes_per_launch" in v}
+    if tiles:
+        res["knn_tile_per_step_traffic_bytes"] = sum(v["hbm_bytes_per_launch"] for v in tiles.values())
+        res["knn_tile_launches_per_step"] = len(tiles)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
