@@ -108,8 +108,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     layers.norm_cfg["type"] = "SyncBN" if (args.sync_bn and world > 1) else "BN"
-    if args.sync_bn and world > 1:
-        args.no_graph = True      # the statistics all-reduces sit inside the step: launched eagerly, not captured
+    # --sync-bn: the statistics all-reduces sit inside the step.  Capturing them into the hipGraph is attempted like
+    # everything else (RCCL collectives are capturable); if capture fails, or replay loses the untimed vote against eager
+    # launches below, the step runs eagerly.
     w = WORKLOADS[args.workload]
     B, C, H, L = args.batch, w["C"], w["H"], w["L"]
 

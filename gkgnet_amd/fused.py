@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .ops import _ptr, _stream
+from .parallel import grad_view
 
 _F32 = torch.float32
 ENABLED = True          # set False to force the composable (per-op) path, e.g. in A/B tests
@@ -47,29 +48,33 @@ BN_TWO_KERNEL = os.environ.get("GKG_BN_TWO_KERNEL", "0") != "0"
 DETERMINISTIC = False   # True: ordered (run-to-run bit-identical) reduction of the split weight-gradient products
 
 
-def _wgrad(dY: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
     """dW (Cout, Cin) = dY^T (Cout x R) @ x (R x Cin).  The output is tiny and the contraction long (R = B*N),
-    so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials."""
+    so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials.
+    ``out``: the parameter's slot in the gradient bucket (written in place, see parallel.grad_view)."""
     R = x.shape[0]
-    if R < 4096:                 # short contractions (the label branch): the partial-sum kernel costs more than it saves
-        return torch.mm(dY.t(), x)
-    for S in (8, 6, 4, 3, 2):
-        if R % S == 0 and R // S >= 1024:
-            part = torch.bmm(dY.view(S, R // S, -1).transpose(1, 2), x.view(S, R // S, -1))
-            return part.sum(0)
-    return torch.mm(dY.t(), x)
+    if out is not None and out.dtype != dY.dtype:
+        out = None
+    if R >= 4096:                # short contractions (the label branch): the partial-sum kernel costs more than it saves
+        for S in (8, 6, 4, 3, 2):
+            if R % S == 0 and R // S >= 1024:
+                part = torch.bmm(dY.view(S, R // S, -1).transpose(1, 2), x.view(S, R // S, -1))
+                return part.sum(0) if out is None else torch.sum(part, 0, out=out)
+    return torch.mm(dY.t(), x) if out is None else torch.mm(dY.t(), x, out=out)
 
 
-def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
+def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None) -> torch.Tensor:
     """Grouped projection: dW[q] (co, ci) = dY[q]^T @ U[q] for the nb groups; long contractions are split like
     ``_wgrad`` (nb*S batched GEMMs + one partial sum)."""
     nb, R, co = dY.shape
     ci = U.shape[2]
     S = 4
+    if out is not None and out.dtype != dY.dtype:
+        out = None
     if R >= 4096 and R % S == 0:
         part = torch.bmm(dY.reshape(nb * S, R // S, co).transpose(1, 2), U.reshape(nb * S, R // S, ci))
-        return part.view(nb, S, co, ci).sum(1)
-    return torch.bmm(dY.transpose(1, 2), U)
+        return part.view(nb, S, co, ci).sum(1) if out is None else torch.sum(part.view(nb, S, co, ci), 1, out=out)
+    return torch.bmm(dY.transpose(1, 2), U) if out is None else torch.bmm(dY.transpose(1, 2), U, out=out)
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -149,6 +154,24 @@ def _own_gemm(x, weight, bn) -> bool:
     return (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None)
 
 
+def _grad_outs(gparams, wshape, nch, dev):
+    """Output tensors for (dW, dgamma, dbeta): the parameters' slots in the gradient bucket when they have one and the
+    step is not accumulating (parallel.grad_view), else fresh tensors."""
+    w = g = b = None
+    if gparams is not None:
+        wp, gp, bp = gparams
+        w = grad_view(wp, wshape) if wp.dtype == _F32 else None
+        g = grad_view(gp, (nch,)) if gp.dtype == _F32 else None
+        b = grad_view(bp, (nch,)) if bp.dtype == _F32 else None
+    if w is None:
+        w = torch.empty(wshape, dtype=_F32, device=dev)
+    if g is None:
+        g = torch.empty(nch, dtype=_F32, device=dev)
+    if b is None:
+        b = torch.empty(nch, dtype=_F32, device=dev)
+    return w, g, b
+
+
 def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False):
     """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue)."""
     dev = x.device
@@ -180,15 +203,13 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False):
     return Y, a, c, None, None
 
 
-def _linear_bwd_own(lib, g, ldg, g_bstride, Y, a, c, mean, invstd, x, W, R, cin, cout, nb, act, need_dx):
+def _linear_bwd_own(lib, g, ldg, g_bstride, Y, a, c, mean, invstd, x, W, R, cin, cout, nb, act, need_dx, gparams=None):
     """dx, dW, dgamma, dbeta of out = act(BN_train(x W^T)): statistics pass (+ dz parked for GELU) -> coefficients ->
     dgrad / wgrad kernels that apply the BN backward while staging their operand tiles."""
     dev = Y.device
-    dgamma = torch.empty(nb * cout, dtype=_F32, device=dev)
-    dbeta = torch.empty_like(dgamma)
+    dW, dgamma, dbeta = _grad_outs(gparams, (nb * cout, cin), nb * cout, dev)
     coef = torch.empty(nb * 3 * cout, dtype=_F32, device=dev)
     dz = torch.empty_like(Y) if act == 1 else None
-    dW = torch.empty((nb * cout, cin), dtype=_F32, device=dev)
     # the coefficient kernel also clears dW, the accumulator of the split weight-gradient product that follows
     if BN_TWO_KERNEL:
         _lib.check(lib.gkg_bn_bwd_train(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
@@ -430,6 +451,7 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, nchw, residual is not None, bias is not None)
         ctx.scale = (scale, rows_per_scale)
+        ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.own = own and OWN_GEMM == "all"
         return out
@@ -458,15 +480,14 @@ class _LinearBNAct(torch.autograd.Function):
         if ctx.own:
             dx, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, R * cout, Y, a, c, mean, invstd, x,
                                                     weight.view(cout, cin), R, cin, cout, 1, act,
-                                                    ctx.needs_input_grad[0])
+                                                    ctx.needs_input_grad[0], ctx.gparams)
             return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
         dY = torch.empty_like(Y)
-        dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
-        dbeta = torch.empty_like(dgamma)
+        dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (cout, cin), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
         W = weight.view(cout, cin)
         dx = torch.mm(dY, W)
-        dW = _wgrad(dY, x).view_as(weight)
+        dW = _wgrad(dY, x, dWv).view_as(weight)
         return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
@@ -512,6 +533,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
                                           code, None, 0, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
+        ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.own = own and OWN_GEMM == "all"
         return out
@@ -529,15 +551,14 @@ class _GroupedLinearBNAct(torch.autograd.Function):
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
         if ctx.own:
             dU, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, co, Y, a, c, mean, invstd, U, weight.view(nb, co, ci),
-                                                    R, ci, co, nb, act, ctx.needs_input_grad[0])
+                                                    R, ci, co, nb, act, ctx.needs_input_grad[0], ctx.gparams)
             return dU, dW.view_as(weight), None, dgamma, dbeta, None, None, None, None
         dY = torch.empty_like(Y)
-        dgamma = torch.empty(cout, dtype=_F32, device=Y.device)
-        dbeta = torch.empty_like(dgamma)
+        dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (nb, co, ci), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync)
         Wg = weight.view(nb, co, ci)
         dU = torch.bmm(dY, Wg)
-        dW = _wgrad_grouped(dY, U).view_as(weight)
+        dW = _wgrad_grouped(dY, U, dWv).view_as(weight)
         return dU, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 

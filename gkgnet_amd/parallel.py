@@ -36,9 +36,20 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
 
 
 class GradBucket:
-    """Flat gradient storage for a set of parameters + one all-reduce(avg) per step."""
+    """Flat gradient storage for a set of parameters + the gradient all-reduce(avg) of the step.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    * ``p.grad`` are views into ONE contiguous buffer.  The fused blocks' backward kernels write weight / BN-parameter
+      gradients STRAIGHT into those views (``grad_view``: the autograd engine then adopts the returned view as
+      ``p.grad`` without a copy), so :meth:`pack` only moves what ordinary autograd produced elsewhere (stem /
+      downsample convolutions, embeddings, the head) — at GKGNet-576 a few MB instead of the 138 MB re-pack.
+    * The buffer is cut into ``bucket_bytes`` chunks at parameter boundaries, in REVERSE parameter order (the order the
+      backward finishes them).  :meth:`all_reduce` reduces everything at once (what a hipGraph-replayed step uses);
+      :meth:`install_overlap_hooks` starts each chunk's all-reduce from a post-accumulate hook as soon as its last
+      gradient exists, on the collective stream RCCL picks — the reference's DDP-reducer behaviour
+      (mmcls/apis/train.py:117-125) — and :meth:`wait` joins them.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -46,10 +57,34 @@ class GradBucket:
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
         self._zeros = None
+        self._offset = {}
+        # layout: reverse parameter order, so that a chunk completes while the backward is still running
         o = 0
-        for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self.chunks = []                        # (start, end, [params])
+        cur_start, cur_params = 0, []
+        per = max(1, bucket_bytes // self.flat.element_size())
+        for p in reversed(self.params):
+            self._offset[p] = o
+            p._gkg_bucket = (self.flat, o)
+            cur_params.append(p)
             o += p.numel()
+            if o - cur_start >= per:
+                self.chunks.append((cur_start, o, cur_params))
+                cur_start, cur_params = o, []
+        if cur_params:
+            self.chunks.append((cur_start, o, cur_params))
+        self._point_grads()
+        self._pending = []
+        self._hooks = []
+        self._ready = {}
+
+    def _view(self, p):
+        o = self._offset[p]
+        return self.flat[o:o + p.numel()].view_as(p)
+
+    def _point_grads(self):
+        for p in self.params:
+            p.grad = self._view(p)
 
     def zero(self):
         self.flat.zero_()
@@ -60,24 +95,99 @@ class GradBucket:
         for p in self.params:
             p.grad = None
 
+    def _resident(self, p) -> bool:
+        g = p.grad
+        return g is not None and g.data_ptr() == self.flat.data_ptr() + self._offset[p] * self.flat.element_size() \
+            and g.is_contiguous()
+
     def pack(self):
-        """Gather the freshly produced ``p.grad`` tensors into the flat bucket with one batched copy and
-        re-point ``p.grad`` at the bucket views."""
-        if self._zeros is None:          # parameters whose gradient is identically zero come back as None
-            self._zeros = torch.zeros(max(p.numel() for p in self.params), device=self.flat.device, dtype=self.flat.dtype)
-        grads = [(p.grad.reshape(-1) if p.grad is not None else self._zeros[:p.numel()]) for p in self.params]
-        torch.cat(grads, out=self.flat)
-        o = 0
+        """Bring every gradient into the flat bucket: gradients the fused kernels already wrote in place are left alone,
+        the others are copied with one batched copy; parameters without a gradient get zeros.  Re-points ``p.grad`` at
+        the bucket views."""
+        src, dst = [], []
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
+            if self._resident(p):
+                continue
+            v = self._view(p)
+            if p.grad is None:
+                v.zero_()
+            else:
+                src.append(p.grad.reshape(p.shape))
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        self._point_grads()
 
     def all_reduce(self, async_op: bool = False):
-        """Average over ranks.  No-op in a single process."""
+        """Average over ranks with ONE collective over the whole buffer.  No-op in a single process."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         self.flat.div_(dist.get_world_size())
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    # ---- overlapped form (eager training loops)
+    def install_overlap_hooks(self):
+        """After this call a backward pass all-reduces each chunk as soon as all of its gradients exist.  Use
+        ``release()`` before the backward and ``wait()`` after it (instead of ``pack()`` + ``all_reduce()``)."""
+        if self._hooks:
+            return
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        for ci, (start, end, plist) in enumerate(self.chunks):
+            for p in plist:
+                def hook(param, ci=ci, start=start, end=end, plist=plist, world=world):
+                    self._ready[ci] = self._ready.get(ci, 0) + 1
+                    if self._ready[ci] < len(plist):
+                        return
+                    self._ready[ci] = 0
+                    for q in plist:                                  # gradients not written in place: copy this chunk now
+                        if not self._resident(q):
+                            v = self._view(q)
+                            if q.grad is None:
+                                v.zero_()
+                            else:
+                                v.copy_(q.grad.reshape(q.shape))
+                            q.grad = v
+                    if world > 1:
+                        chunk = self.flat[start:end]
+                        chunk.div_(world)
+                        self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+
+    def wait(self):
+        """Join the chunk all-reduces started during the backward; parameters that received no gradient at all (unused
+        this step) are zero-filled and their chunks reduced now, so every rank issues the same collectives."""
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        for ci, (start, end, plist) in enumerate(self.chunks):
+            if self._ready.get(ci, 0) != 0:                           # incomplete chunk: some parameter had no gradient
+                self._ready[ci] = 0
+                for q in plist:
+                    if not self._resident(q):
+                        v = self._view(q)
+                        if q.grad is None:
+                            v.zero_()
+                        else:
+                            v.copy_(q.grad.reshape(q.shape))
+                        q.grad = v
+                if world > 1:
+                    chunk = self.flat[start:end]
+                    chunk.div_(world)
+                    self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        self._point_grads()
+
+
+def grad_view(p: torch.nn.Parameter, shape=None):
+    """A fresh view of ``p``'s slot in its gradient bucket (None when ``p`` is not bucketed or its ``.grad`` is currently
+    attached, i.e. the step accumulates): backward kernels write the gradient there and return the view, which autograd
+    adopts as ``p.grad`` — no separate gradient tensor, no re-pack."""
+    b = getattr(p, "_gkg_bucket", None)
+    if b is None or p.grad is not None:
+        return None
+    flat, o = b
+    v = flat[o:o + p.numel()]
+    return v.view(p.shape if shape is None else shape)
 
 
 def shard_batch(global_batch: int, rank: int, world: int) -> range:

@@ -42,11 +42,11 @@ def _run(g, gl, x, e, cx, ce):
     return out.detach(), e2.detach(), xg.grad, eg.grad, grads, bufs
 
 
-def _worker(rank, world, store_path, result_path):
+def _worker(rank, world, store_path, result_path, backend="gloo"):
     import torch.distributed as dist
     from gkgnet_amd import fused, layers
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", store=dist.FileStore(store_path, world), rank=rank, world_size=world)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)      # RCCL: one device per rank; gloo: the ranks share GPU 0
+    dist.init_process_group(backend, store=dist.FileStore(store_path, world), rank=rank, world_size=world)
     try:
         # single-process reference: full batch, local statistics (plain BN), same fused kernels
         ref = _run(*_build("BN"))
@@ -77,10 +77,14 @@ def _worker(rank, world, store_path, result_path):
         dist.destroy_process_group()
 
 
-def test_fused_block_syncbn_two_ranks_equals_full_batch():
+def run_two_ranks(backend="gloo"):
     import torch.multiprocessing as mp
     world = 2
     with tempfile.TemporaryDirectory() as d:
         store, res = os.path.join(d, "store"), os.path.join(d, "res")
-        mp.spawn(_worker, args=(world, store, res), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, store, res, backend), nprocs=world, join=True)
         assert all(os.path.exists(res + f".{r}") for r in range(world))
+
+
+def test_fused_block_syncbn_two_ranks_equals_full_batch():
+    run_two_ranks("gloo")

@@ -1,4 +1,5 @@
-"""world_size-2 gloo test of the data-parallel plumbing (flat gradient bucket + single all-reduce)."""
+"""world_size-2 gloo tests of the data-parallel plumbing: flat gradient bucket with one all-reduce, and the chunked form
+whose all-reduces start from post-accumulate hooks during the backward (the reference's DDP reducer, apis/train.py:117-125)."""
 import os
 import socket
 
@@ -15,39 +16,56 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _net():
+    return torch.nn.Sequential(torch.nn.Conv2d(4, 6, 1), torch.nn.BatchNorm2d(6), torch.nn.Conv2d(6, 2, 1),
+                               torch.nn.BatchNorm2d(2), torch.nn.Conv2d(2, 3, 1))
+
+
+def _worker(rank, world, port, out, mode, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from gkgnet_amd.parallel import GradBucket, broadcast_parameters, init_distributed, shard_batch
-    init_distributed("gloo")
+    init_distributed(backend)
+    dev = torch.device("cuda", rank) if backend == "nccl" else torch.device("cpu")
     torch.manual_seed(100 + rank)                       # ranks start different ...
-    net = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 1), torch.nn.BatchNorm2d(6), torch.nn.Conv2d(6, 2, 1))
+    net = _net().to(dev)
     broadcast_parameters(net)                           # ... and are made identical
-    bucket = GradBucket(net.parameters())
+    unused = torch.nn.Parameter(torch.ones(5, device=dev))          # a parameter the loss never touches
+    bucket = GradBucket(list(net.parameters()) + [unused], bucket_bytes=64)     # tiny chunks: several collectives
+    assert len(bucket.chunks) > 2
     g = torch.Generator().manual_seed(0)
-    data = torch.randn(6, 4, 3, 3, generator=g)         # global batch, same on both ranks
+    data = torch.randn(6, 4, 3, 3, generator=g).to(dev)  # global batch, same on both ranks
     mine = data[list(shard_batch(6, rank, world))]
-    bucket.release()
-    net(mine).square().sum().backward()
-    bucket.pack()
-    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
-    bucket.all_reduce()
-    out[rank] = (bucket.flat.clone(), [p.detach().clone() for p in net.parameters()])
+    for step in range(2):                               # two steps: hooks / views must survive re-use
+        bucket.release()
+        if mode == "overlap":
+            bucket.install_overlap_hooks()
+            net(mine).square().sum().backward()
+            bucket.wait()
+        else:
+            net(mine).square().sum().backward()
+            bucket.pack()
+            bucket.all_reduce()
+        lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)
+        assert float(unused.grad.abs().sum()) == 0.0
+    out[rank] = ([p.grad.detach().cpu().clone() for p in net.parameters()], [p.detach().cpu().clone() for p in net.parameters()])
     dist.destroy_process_group()
 
 
-def test_flat_bucket_allreduce_matches_manual_average():
+def _run(mode, backend="gloo"):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    f0, p0 = out[0]
-    f1, p1 = out[1]
-    assert torch.equal(f0, f1)                          # identical averaged gradients everywhere
+    mp.spawn(_worker, args=(world, _free_port(), out, mode, backend), nprocs=world, join=True)
+    g0, p0 = out[0]
+    g1, p1 = out[1]
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)                        # identical averaged gradients everywhere
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
     # manual reference: average of the two per-shard gradients
-    net = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 1), torch.nn.BatchNorm2d(6), torch.nn.Conv2d(6, 2, 1))
+    net = _net()
     with torch.no_grad():
         for p, v in zip(net.parameters(), p0):
             p.copy_(v)
@@ -57,8 +75,48 @@ def test_flat_bucket_allreduce_matches_manual_average():
     for sl in (slice(0, 3), slice(3, 6)):
         net.zero_grad()
         net(data[sl]).square().sum().backward()
-        grads.append(torch.cat([p.grad.flatten() for p in net.parameters()]))
-    assert torch.allclose(f0, (grads[0] + grads[1]) / 2, atol=1e-6)
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for got, a, b in zip(g0, grads[0], grads[1]):
+        assert torch.allclose(got, (a + b) / 2, atol=1e-6)
+
+
+def test_flat_bucket_allreduce_matches_manual_average():
+    _run("flat")
+
+
+def test_overlapped_chunk_allreduce_matches_manual_average():
+    _run("overlap")
+
+
+def test_grad_view_is_adopted_without_copy():
+    """A backward that returns ``grad_view(p)`` (what the fused blocks do for weight / BN gradients) leaves ``p.grad``
+    aliasing the bucket: pack() has nothing to move for it."""
+    from gkgnet_amd.parallel import GradBucket, grad_view
+
+    class WriteInPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            out = grad_view(w)
+            assert out is not None
+            torch.mm(g.t(), x, out=out)
+            return g @ w, out
+    w = torch.nn.Parameter(torch.randn(3, 4))
+    other = torch.nn.Parameter(torch.randn(2))
+    bucket = GradBucket([w, other])
+    x = torch.randn(5, 4)
+    bucket.release()
+    (WriteInPlace.apply(x, w).sum() + other.sum()).backward()
+    assert bucket._resident(w) and not bucket._resident(other)
+    want = torch.ones(5, 3).t() @ x
+    bucket.pack()
+    assert bucket._resident(other) and torch.allclose(w.grad, want) and torch.equal(other.grad, torch.ones(2))
+    assert grad_view(w) is None                         # grads attached: an accumulating step must not write in place
 
 
 def test_shard_batch_partitions():

@@ -46,14 +46,15 @@ def main():
     img = torch.randn(args.batch, 3, args.size, args.size, generator=gen).to(dev)
     tgt = (torch.rand(args.batch, args.classes, generator=gen) < 0.04).float().to(dev)
 
+    bucket.install_overlap_hooks()       # chunk all-reduces start during the backward (the reference's DDP reducer)
+
     def step():
         bucket.release()
         feats = net(img)
         losses = head.forward_train(feats, tgt)
         loss = losses["bce_loss"] + losses["asy_loss"]
         loss.backward()
-        bucket.pack()
-        bucket.all_reduce()
+        bucket.wait()
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
         return loss
