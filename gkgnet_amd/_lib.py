@@ -14,6 +14,7 @@ ABI_VERSION = 4
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
+MR_DETERMINISTIC = 1
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
            "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
@@ -60,7 +61,7 @@ def load():
     lib.gkg_mr_fwd_tm.restype = I
     lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [V]
     lib.gkg_mr_bwd_tm.restype = I
-    lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 7 + [V]
+    lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 7 + [C.c_uint, V]
     lib.gkg_nchw_to_tm.restype = I
     lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, I, V, V]
     lib.gkg_tm_affine_to_nchw.restype = I

@@ -381,6 +381,88 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
   }
 }
 
+// Deterministic scatter (GKG_MR_DETERMINISTIC): the LDS-atomic kernel above adds the fan-in of a key in whatever order
+// its lanes arrive, so gsrc differs in the last bit from run to run (like the reference's CUDA index_put_(accumulate)).
+// Here a workgroup owns ONE channel quad of one image; each of its TL threads sweeps its own residue class of queries
+// (n = tl, tl + TL, ...) in ascending order into a PRIVATE copy of the destination rows ([TL][M] float4 in LDS, plain
+// read-modify-write, no atomics); the copies are then added in thread order.  Every sum has a fixed order -> results
+// are bit-identical from run to run.
+template <bool SELF>
+__global__ __launch_bounds__(64) void mr_bwd_tm_det_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                           const uint8_t* __restrict__ argmax, float* __restrict__ gx,
+                                                           float* __restrict__ gsrc, int B, int G, int c, int N, int M,
+                                                           int k, int mode, int TL) {
+  extern __shared__ float acc[];                  // [TL][M][4]
+  const int C = G * c;
+  const int b = blockIdx.y;
+  const int ch = 4 * blockIdx.x;
+  const int tl = threadIdx.x;
+  const size_t T = (size_t)B * N;
+  const int g = ch / c;
+  const int km = k - 1;
+  for (int i = tl; i < TL * M; i += 64) *reinterpret_cast<float4*>(acc + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  if (tl < TL) {
+    float* mine = acc + (size_t)tl * M * 4;
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+      const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+      float4 direct, gm;
+      load_grad(gin, T, t, C, ch, mode, direct, gm);
+      if (!SELF)
+        *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+      const int j0 = clamp_idx(ip[min((int)(am & 0xff), km)], M), j1 = clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M),
+                j2 = clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M), j3 = clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M);
+      mine[4 * j0 + 0] += gm.x;
+      mine[4 * j1 + 1] += gm.y;
+      mine[4 * j2 + 2] += gm.z;
+      mine[4 * j3 + 3] += gm.w;
+    }
+  }
+  __syncthreads();
+  float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch;
+  for (int m = tl; m < M; m += 64) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SELF) {                                    // centre term of the self graph: direct - gm of the token itself
+      float4 direct, gm;
+      load_grad(gin, T, (size_t)b * N + m, C, ch, mode, direct, gm);
+      s = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+    }
+    for (int t2 = 0; t2 < TL; ++t2) {
+      const float4 v = *reinterpret_cast<const float4*>(acc + ((size_t)t2 * M + m) * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(db + (size_t)m * C) = s;
+  }
+}
+
+// Deterministic fallback for destination images too large for LDS (label graphs over > 9 600 keys: few queries): one
+// thread per (image, channel quad) walks its queries in order and read-modify-writes the pre-seeded global rows.
+__global__ __launch_bounds__(64) void mr_bwd_tm_det_global_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                                  const uint8_t* __restrict__ argmax, float* __restrict__ dst,
+                                                                  int B, int G, int c, int N, int M, int k, int mode) {
+  const int C = G * c, C4 = C >> 2;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= B * C4) return;
+  const int b = i / C4, ch = 4 * (i - b * C4);
+  const size_t T = (size_t)B * N;
+  const int g = ch / c;
+  const int km = k - 1;
+  float* db = dst + (size_t)b * M * C + ch;
+  for (int n = 0; n < N; ++n) {
+    const size_t t = (size_t)b * N + n;
+    const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+    const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+    float4 direct, gm;
+    load_grad(gin, T, t, C, ch, mode, direct, gm);
+    db[(size_t)clamp_idx(ip[min((int)(am & 0xff), km)], M) * C + 0] += gm.x;
+    db[(size_t)clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M) * C + 1] += gm.y;
+    db[(size_t)clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M) * C + 2] += gm.z;
+    db[(size_t)clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M) * C + 3] += gm.w;
+  }
+}
+
 // Fallback when a destination image does not fit in LDS even for a 4-channel chunk: fp32 global atomics.
 __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
                                                                        const uint8_t* __restrict__ argmax, float* __restrict__ dst,
@@ -542,7 +624,7 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
 }
 
 extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
-                             int B, int G, int c, int N, int M, int k, int mode, void* stream) {
+                             int B, int G, int c, int N, int M, int k, int mode, unsigned flags, void* stream) {
   if (!gin || !nn_idx || !argmax || !gx) return gkg_fail(GKG_ERR_NULL, "gkg_mr_bwd_tm: gin, nn_idx, argmax and gx must be non-null");
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: bad sizes");
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode is 0 or 1");
@@ -553,6 +635,28 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   const int C = G * c;
   const size_t T = (size_t)B * N;
   const size_t total = T * (C / 4);
+  if (flags & GKG_MR_DETERMINISTIC) {
+    if (B > 65535) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd_tm: B <= 65535");
+    long TL = (long)(144 * 1024) / ((long)M * 16);
+    if (TL > 64) TL = 64;
+    if (TL >= 1) {
+      const size_t lds = (size_t)TL * M * 16;
+      if (gsrc) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_det_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((mr_bwd_tm_det_kernel<false>), dim3(C / 4, B), dim3(64), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, mode, (int)TL);
+      } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_det_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((mr_bwd_tm_det_kernel<true>), dim3(C / 4, B), dim3(64), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, mode, (int)TL);
+      }
+    } else {                         // seed (gx = direct - gm; gsrc = 0), then the ordered global walk
+      hipLaunchKernelGGL(mr_bwd_tm_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, gx, C, T, mode);
+      if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * M * C, st);
+      hipLaunchKernelGGL(mr_bwd_tm_det_global_kernel, dim3((unsigned)((B * (C / 4) + 63) / 64)), dim3(64), 0, st, gin, nn_idx,
+                         argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode);
+    }
+    hipError_t ed = hipGetLastError();
+    return ed == hipSuccess ? 0 : gkg_fail_hip(ed, "mr_bwd_tm (deterministic)");
+  }
   // channel chunk: largest power of two (4..64) dividing C and c whose [M][CW] fp32 image fits the LDS budget, shrunk
   // until the grid has ~2 workgroups per CU
   int CW = 64;

@@ -45,7 +45,9 @@ OWN_GEMM = os.environ.get("GKG_OWN_GEMM", "auto")
 # sums (served from HBM, not L2) and ends on a ticket round trip, which costs the short workgroups of these kernels more
 # than the removed launch saves (apply 4.4 -> 14 us, backward apply 6.6 -> 13 us).  Kept selectable and tested; off.
 BN_TWO_KERNEL = os.environ.get("GKG_BN_TWO_KERNEL", "0") != "0"
-DETERMINISTIC = False   # True: ordered (run-to-run bit-identical) reduction of the split weight-gradient products
+# True: run-to-run bit-identical backward — ordered reduction of the split weight-gradient products (own-GEMM path) and
+# fixed-order neighbour-gradient scatter (gkg_mr_bwd_tm); the defaults use fp32 atomics.
+DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
@@ -610,7 +612,7 @@ class _MaxRelativeTM(torch.autograd.Function):
         gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode,
-                                     _stream()), "gkg_mr_bwd_tm")
+                                     _lib.MR_DETERMINISTIC if DETERMINISTIC else 0, _stream()), "gkg_mr_bwd_tm")
         return gx, gsrc, None, None, None, None
 
 

@@ -111,14 +111,17 @@ int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void
  *                    argmax (B,N,C) u8
  *   gkg_mr_bwd_tm  : mode 0: gin = g (B,N,C); mode 1: gin = dU (4,B*N,C/2) (even columns = gradient reaching x
  *                    directly, odd columns = gradient of m).  gx (B,N,C) and gsrc (B,M,C)|NULL fully overwritten.
+ *                    Default: LDS atomics (fan-in summed in arrival order: last-bit run-to-run differences);
+ *                    flags & GKG_MR_DETERMINISTIC: per-thread private accumulators added in a fixed order.
  */
 int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
 int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out /* out_dtype elements */,
                   uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, void* stream);
+#define GKG_MR_DETERMINISTIC 1u /* fixed summation order in the scatter: bit-identical results from run to run */
 int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
-                  int B, int G, int c, int N, int M, int k, int mode, void* stream);
+                  int B, int G, int c, int N, int M, int k, int mode, unsigned flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bandwidth kernels between the dense 1x1 projections (Conv2d 1x1 + SyncBN [+ GELU], reference

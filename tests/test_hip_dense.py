@@ -214,3 +214,36 @@ def test_bn_statistics_survive_a_large_channel_offset(mode):
         assert torch.allclose(out.detach().double(), want, atol=2e-2, rtol=1e-2), float((out.detach().double() - want).abs().max())
     finally:
         fused.OWN_GEMM = old
+
+
+def test_deterministic_scatter_is_bit_reproducible_and_correct():
+    """fused.DETERMINISTIC: the neighbour-gradient scatter of the max-relative backward adds each key's fan-in in a fixed
+    order -> bit-identical from run to run, and equal (to rounding) to the default LDS-atomic kernel; self and bipartite
+    graphs, the interleaved (mode 1) and plain (mode 0) gradient layouts, and the > 9 600-key global fallback."""
+    from gkgnet_amd import fused
+    torch.manual_seed(6)
+    old = fused.DETERMINISTIC
+    try:
+        for (B, N, M, C, G, k, mode) in [(3, 200, None, 64, 4, 9, 1), (2, 80, 324, 64, 2, 9, 1), (2, 150, None, 32, 2, 5, 0),
+                                         (1, 40, 12000, 16, 2, 9, 0)]:
+            Mk = N if M is None else M
+            x = torch.randn(B, N, C, device="cuda")
+            src = None if M is None else torch.randn(B, Mk, C, device="cuda")
+            # heavy fan-in: all queries choose among the first 7 keys
+            idx = torch.randint(0, 7, (B * G, N, k), device="cuda")
+            g = torch.randn((4, B * N, C // 2) if mode == 1 else (B, N, C), device="cuda")
+            outs = {}
+            for det in (True, True, False):
+                fused.DETERMINISTIC = det
+                xg = x.clone().requires_grad_(True)
+                sg = None if src is None else src.clone().requires_grad_(True)
+                fused._MaxRelativeTM.apply(xg, sg, idx, G, mode).backward(g)
+                outs.setdefault(det, []).append((xg.grad.clone(), None if sg is None else sg.grad.clone()))
+            (a1, s1), (a2, s2) = outs[True]
+            assert torch.equal(a1, a2) and (s1 is None or torch.equal(s1, s2))
+            b1, t1 = outs[False][0]
+            assert torch.allclose(a1, b1, atol=1e-4, rtol=1e-4)
+            if s1 is not None:
+                assert torch.allclose(s1, t1, atol=1e-4, rtol=1e-4)
+    finally:
+        fused.DETERMINISTIC = old
