@@ -59,9 +59,9 @@ def load():
     lib.gkg_knn_fwd_tm.restype = I
     lib.gkg_knn_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V, Z, V]
     lib.gkg_mr_fwd_tm.restype = I
-    lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [V]
+    lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 9 + [V]
     lib.gkg_mr_bwd_tm.restype = I
-    lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 7 + [C.c_uint, V]
+    lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V]
     lib.gkg_nchw_to_tm.restype = I
     lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, I, V, V]
     lib.gkg_tm_affine_to_nchw.restype = I

@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256) void negate_kernel(const float* __restrict__ g
 //   mode 0: m (B,N,C) token-major.
 //   mode 1: the grouped 1x1 projection's input directly, U[q][t][2i] = x[t][q*C/4+i], U[q][t][2i+1] = m[...]
 //           (reference interleave torch_vertex.py:57-61 + Conv2d(groups=4) channel split torch_nn.py:61).
-template <int KS, int QP, typename OutT = float>   // KS: compile-time k (all k index loads and row gathers issued up front);
+// AK — what `argmax` holds for the backward: 0 = the winning SLOT j (u8, the C-ABI's documented form), 1 = the winning
+// neighbour's ROW INDEX itself (u16; needs M <= 65536).  With the row stored the backward scatters straight from it: no
+// index-row lookup, i.e. one dependent global round trip less per query and no 72-byte index rows to fetch.
+template <int KS, int QP, typename OutT = float, int AK = 0>   // KS: compile-time k (all k index loads and row gathers issued up front);
                             // QP: channel quads per thread (share one index row; QP*4 channels stay inside a group)
                             // OutT: element type of `out` (float, or uint16_t = bf16 for the grouped GEMM's operand)
 __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
@@ -230,22 +233,39 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
                                                         int k_rt, int mode) {
   const int k = KS > 0 ? KS : k_rt;
   const int C = G * c, CT = C / (4 * QP);                         // thread-columns per token
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // (t, column)
   const size_t T = (size_t)B * N;
-  if (i >= T * CT) return;
-  const size_t t = i / CT;
-  const int ch = 4 * QP * (int)(i - t * CT);
-  const int b = (int)(t / N), n = (int)(t - (size_t)b * N);
+  // XCD-aware map: a token's k neighbours are rows of ITS image, so all workgroups of one image get linear ids that are
+  // congruent mod 8 — one XCD, one L2 — and adjacent in dispatch order: the image's rows (N*C*4 bytes: 415 KB at cfg2)
+  // are fetched into that L2 once and every gather after the first hits it.  With the plain linear map the k-fold
+  // re-reads were spread over all 8 L2s (measured FETCH_SIZE 40 MB per launch against 13 MB of source rows).
+  const int bpi = (N * CT + 255) / 256;                          // workgroups per image
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, seq = lin >> 3;
+  const int b = (seq / bpi) * 8 + xcd;
+  if (b >= B) return;                                            // grid padded to a multiple of 8 images
+  const int jt = (seq - (seq / bpi) * bpi) * 256 + (int)threadIdx.x;
+  if (jt >= N * CT) return;
+  const int n = jt / CT;
+  const int ch = 4 * QP * (jt - n * CT);
+  const size_t t = (size_t)b * N + n;
   const int g = ch / c;
   const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
   const float* sb = src + (size_t)b * M * C + ch;
   float4 xi[QP], best[QP];
   uint32_t arg[QP];
+  int ai[QP][4];                                                  // AK == 1: winning row index per channel
 #pragma unroll
   for (int q = 0; q < QP; ++q) { xi[q] = *reinterpret_cast<const float4*>(x + t * C + ch + 4 * q); arg[q] = 0; }
-  auto upd = [&](int q, const float4& v, int j) {
+  auto upd = [&](int q, const float4& v, int j, int row) {
     const float d0 = v.x - xi[q].x, d1 = v.y - xi[q].y, d2 = v.z - xi[q].z, d3 = v.w - xi[q].w;
-    if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); return; }
+    if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); ai[q][0] = ai[q][1] = ai[q][2] = ai[q][3] = row; return; }
+    if (AK == 1) {
+      if (takes(d0, best[q].x)) { best[q].x = d0; ai[q][0] = row; }
+      if (takes(d1, best[q].y)) { best[q].y = d1; ai[q][1] = row; }
+      if (takes(d2, best[q].z)) { best[q].z = d2; ai[q][2] = row; }
+      if (takes(d3, best[q].w)) { best[q].w = d3; ai[q][3] = row; }
+      return;
+    }
     if (takes(d0, best[q].x)) { best[q].x = d0; arg[q] = (arg[q] & 0xffffff00u) | (uint32_t)j; }
     if (takes(d1, best[q].y)) { best[q].y = d1; arg[q] = (arg[q] & 0xffff00ffu) | ((uint32_t)j << 8); }
     if (takes(d2, best[q].z)) { best[q].z = d2; arg[q] = (arg[q] & 0xff00ffffu) | ((uint32_t)j << 16); }
@@ -261,19 +281,24 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C + 4 * q);
 #pragma unroll
-      for (int j = 0; j < KS; ++j) upd(q, v[j], j);
+      for (int j = 0; j < KS; ++j) upd(q, v[j], j, id[j]);
     }
   } else {
     for (int j = 0; j < k; ++j) {
-      const size_t row = (size_t)clamp_idx(ip[j], M) * C;
+      const int rid = clamp_idx(ip[j], M);
+      const size_t row = (size_t)rid * C;
 #pragma unroll
-      for (int q = 0; q < QP; ++q) upd(q, *reinterpret_cast<const float4*>(sb + row + 4 * q), j);
+      for (int q = 0; q < QP; ++q) upd(q, *reinterpret_cast<const float4*>(sb + row + 4 * q), j, rid);
     }
   }
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
     const int chq = ch + 4 * q;
-    if (argmax) *reinterpret_cast<uint32_t*>(argmax + t * C + chq) = arg[q];
+    if (argmax) {
+      if (AK == 1) *reinterpret_cast<uint2*>(argmax + 2 * (t * C + chq)) =
+          make_uint2((uint32_t)ai[q][0] | ((uint32_t)ai[q][1] << 16), (uint32_t)ai[q][2] | ((uint32_t)ai[q][3] << 16));
+      else *reinterpret_cast<uint32_t*>(argmax + t * C + chq) = arg[q];
+    }
     if (mode == 0) {
       stf4(out + t * C + chq, best[q]);
     } else {
@@ -328,20 +353,44 @@ __device__ __forceinline__ void load_grad(const float* __restrict__ gin, size_t 
   }
 }
 
+// destination rows of the 4 channels of one thread: from the winning slots + the index row (AK == 0) or directly (AK == 1)
+__device__ __forceinline__ void mr_targets(const uint8_t* __restrict__ argmax, int ak, size_t elem, const int64_t* __restrict__ ip,
+                                           int k, int M, int (&j)[4]) {
+  if (ak == 1) {
+    const uint2 v = *reinterpret_cast<const uint2*>(argmax + 2 * elem);
+    j[0] = min((int)(v.x & 0xffff), M - 1); j[1] = min((int)(v.x >> 16), M - 1);
+    j[2] = min((int)(v.y & 0xffff), M - 1); j[3] = min((int)(v.y >> 16), M - 1);
+  } else {
+    const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + elem);
+    const int km = k - 1;
+    j[0] = clamp_idx(ip[min((int)(am & 0xff), km)], M); j[1] = clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M);
+    j[2] = clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M); j[3] = clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M);
+  }
+}
+
 template <bool SELF>
 __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
                                                                 const uint8_t* __restrict__ argmax, float* __restrict__ gx,
                                                                 float* __restrict__ gsrc, int B, int G, int c, int N, int M,
-                                                                int k, int mode, int CW) {
+                                                                int k, int mode, int CW, int ak) {
   extern __shared__ float acc[];                  // [M][CW]
   const int C = G * c;
-  const int b = blockIdx.y;
-  const int ch0 = blockIdx.x * CW;
+  // XCD-aware map (see mr_fwd_tm_kernel): the C/CW channel-chunk workgroups of one image read interleaved pieces of the
+  // same gradient rows and index rows -> same XCD, adjacent in dispatch order
+  const int nchunk = C / CW;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, seq = lin >> 3;
+  const int b = (seq / nchunk) * 8 + xcd;
+  if (b >= B) return;
+  const int ch0 = (seq - (seq / nchunk) * nchunk) * CW;
   const int cw4 = CW >> 2;                        // quads per row chunk
   const int tid = threadIdx.x;
   const int qd = tid % cw4, tl = tid / cw4, TL = 256 / cw4;
   const size_t T = (size_t)B * N;
   const int ch = ch0 + 4 * qd;
+  // phase 1: seed the LDS image (self graph: a token's own "direct - gm"; bipartite graph: zeros).  Seeding with the same
+  // LDS atomics as the scatter, to read every gradient row once instead of twice, was measured SLOWER (31.8 -> 40 us at
+  // cfg2): the second read hits L2, the four extra atomics per row do not come free.
   if (tl < TL) {
     for (int m = tl; m < M; m += TL) {
       float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -354,23 +403,22 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
     }
   }
   __syncthreads();
+  // phase 2: sweep the queries; the destination rows come straight from the saved row indices (arg kind 1)
   if (tl < TL) {
     const int g = ch / c;
-    const int km = k - 1;
     for (int n = tl; n < N; n += TL) {
       const size_t t = (size_t)b * N + n;
       const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
-      const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+      int j[4];
+      mr_targets(argmax, ak, t * C + ch, ip, k, M, j);
       float4 direct, gm;
       load_grad(gin, T, t, C, ch, mode, direct, gm);
       if (!SELF)
         *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
-      const int j0 = clamp_idx(ip[min((int)(am & 0xff), km)], M), j1 = clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M),
-                j2 = clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M), j3 = clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M);
-      atomicAdd(acc + (size_t)j0 * CW + 4 * qd + 0, gm.x);
-      atomicAdd(acc + (size_t)j1 * CW + 4 * qd + 1, gm.y);
-      atomicAdd(acc + (size_t)j2 * CW + 4 * qd + 2, gm.z);
-      atomicAdd(acc + (size_t)j3 * CW + 4 * qd + 3, gm.w);
+      atomicAdd(acc + (size_t)j[0] * CW + 4 * qd + 0, gm.x);
+      atomicAdd(acc + (size_t)j[1] * CW + 4 * qd + 1, gm.y);
+      atomicAdd(acc + (size_t)j[2] * CW + 4 * qd + 2, gm.z);
+      atomicAdd(acc + (size_t)j[3] * CW + 4 * qd + 3, gm.w);
     }
   }
   __syncthreads();
@@ -391,7 +439,7 @@ template <bool SELF>
 __global__ __launch_bounds__(64) void mr_bwd_tm_det_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
                                                            const uint8_t* __restrict__ argmax, float* __restrict__ gx,
                                                            float* __restrict__ gsrc, int B, int G, int c, int N, int M,
-                                                           int k, int mode, int TL) {
+                                                           int k, int mode, int TL, int ak) {
   extern __shared__ float acc[];                  // [TL][M][4]
   const int C = G * c;
   const int b = blockIdx.y;
@@ -399,7 +447,6 @@ __global__ __launch_bounds__(64) void mr_bwd_tm_det_kernel(const float* __restri
   const int tl = threadIdx.x;
   const size_t T = (size_t)B * N;
   const int g = ch / c;
-  const int km = k - 1;
   for (int i = tl; i < TL * M; i += 64) *reinterpret_cast<float4*>(acc + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   if (tl < TL) {
@@ -407,17 +454,16 @@ __global__ __launch_bounds__(64) void mr_bwd_tm_det_kernel(const float* __restri
     for (int n = tl; n < N; n += TL) {
       const size_t t = (size_t)b * N + n;
       const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
-      const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+      int j[4];
+      mr_targets(argmax, ak, t * C + ch, ip, k, M, j);
       float4 direct, gm;
       load_grad(gin, T, t, C, ch, mode, direct, gm);
       if (!SELF)
         *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
-      const int j0 = clamp_idx(ip[min((int)(am & 0xff), km)], M), j1 = clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M),
-                j2 = clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M), j3 = clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M);
-      mine[4 * j0 + 0] += gm.x;
-      mine[4 * j1 + 1] += gm.y;
-      mine[4 * j2 + 2] += gm.z;
-      mine[4 * j3 + 3] += gm.w;
+      mine[4 * j[0] + 0] += gm.x;
+      mine[4 * j[1] + 1] += gm.y;
+      mine[4 * j[2] + 2] += gm.z;
+      mine[4 * j[3] + 3] += gm.w;
     }
   }
   __syncthreads();
@@ -441,32 +487,32 @@ __global__ __launch_bounds__(64) void mr_bwd_tm_det_kernel(const float* __restri
 // thread per (image, channel quad) walks its queries in order and read-modify-writes the pre-seeded global rows.
 __global__ __launch_bounds__(64) void mr_bwd_tm_det_global_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
                                                                   const uint8_t* __restrict__ argmax, float* __restrict__ dst,
-                                                                  int B, int G, int c, int N, int M, int k, int mode) {
+                                                                  int B, int G, int c, int N, int M, int k, int mode, int ak) {
   const int C = G * c, C4 = C >> 2;
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= B * C4) return;
   const int b = i / C4, ch = 4 * (i - b * C4);
   const size_t T = (size_t)B * N;
   const int g = ch / c;
-  const int km = k - 1;
   float* db = dst + (size_t)b * M * C + ch;
   for (int n = 0; n < N; ++n) {
     const size_t t = (size_t)b * N + n;
     const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
-    const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+    int j[4];
+    mr_targets(argmax, ak, t * C + ch, ip, k, M, j);
     float4 direct, gm;
     load_grad(gin, T, t, C, ch, mode, direct, gm);
-    db[(size_t)clamp_idx(ip[min((int)(am & 0xff), km)], M) * C + 0] += gm.x;
-    db[(size_t)clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M) * C + 1] += gm.y;
-    db[(size_t)clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M) * C + 2] += gm.z;
-    db[(size_t)clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M) * C + 3] += gm.w;
+    db[(size_t)j[0] * C + 0] += gm.x;
+    db[(size_t)j[1] * C + 1] += gm.y;
+    db[(size_t)j[2] * C + 2] += gm.z;
+    db[(size_t)j[3] * C + 3] += gm.w;
   }
 }
 
 // Fallback when a destination image does not fit in LDS even for a 4-channel chunk: fp32 global atomics.
 __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
                                                                        const uint8_t* __restrict__ argmax, float* __restrict__ dst,
-                                                                       int B, int G, int c, int N, int M, int k, int mode) {
+                                                                       int B, int G, int c, int N, int M, int k, int mode, int ak) {
   const int C = G * c, C4 = C >> 2;
   const size_t T = (size_t)B * N;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -476,7 +522,8 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const flo
   const int b = (int)(t / N), n = (int)(t - (size_t)b * N);
   const int g = ch / c;
   const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
-  const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + t * C + ch);
+  int j[4];
+  mr_targets(argmax, ak, t * C + ch, ip, k, M, j);
   float4 gm;
   if (mode == 0) {
     gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
@@ -488,11 +535,10 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const flo
     gm = make_float4(u0.y, u0.w, u1.y, u1.w);
   }
   float* db = dst + (size_t)b * M * C + ch;
-  const int km = k - 1;
-  atomicAdd(db + (size_t)clamp_idx(ip[min((int)(am & 0xff), km)], M) * C + 0, gm.x);
-  atomicAdd(db + (size_t)clamp_idx(ip[min((int)((am >> 8) & 0xff), km)], M) * C + 1, gm.y);
-  atomicAdd(db + (size_t)clamp_idx(ip[min((int)((am >> 16) & 0xff), km)], M) * C + 2, gm.z);
-  atomicAdd(db + (size_t)clamp_idx(ip[min((int)((am >> 24) & 0xff), km)], M) * C + 3, gm.w);
+  atomicAdd(db + (size_t)j[0] * C + 0, gm.x);
+  atomicAdd(db + (size_t)j[1] * C + 1, gm.y);
+  atomicAdd(db + (size_t)j[2] * C + 2, gm.z);
+  atomicAdd(db + (size_t)j[3] * C + 3, gm.w);
 }
 
 }  // namespace gkg
@@ -597,7 +643,9 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
 
 // ------------------------------------------------------------------------------------------ token-major entry points
 extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out, uint8_t* argmax,
-                             int B, int G, int c, int N, int M, int k, int mode, int out_dtype, void* stream) {
+                             int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
+  if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: arg_kind is 0 (u8 slot) or 1 (u16 row index)");
+  if (arg_kind == 1 && M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: arg_kind 1 needs M <= 65536");
   if (!x || !nn_idx || !out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_fwd_tm: x, nn_idx and out must be non-null");
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: bad sizes (c % 4 == 0, k <= 255)");
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode is 0 or 1");
@@ -605,26 +653,28 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: out_dtype is GKG_F32 or GKG_BF16");
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
   GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
-  const size_t total = (size_t)B * N * (G * c / 4);
   // one channel quad per thread: two quads per thread (shared index row) measured 20 % slower at cfg2 — the kernel
   // wants more threads in flight, not fewer index loads
-  const dim3 grid((unsigned)((total + 255) / 256));
+  const long bpi = ((long)N * (G * c / 4) + 255) / 256;
+  if (bpi * (((long)B + 7) / 8) * 8 > 0x7fffffffL) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: problem too large for one launch");
+  const dim3 grid((unsigned)(bpi * ((B + 7) / 8) * 8));
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
-    else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
+    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
   } else {
     float* o = (float*)out;
-    if (k == 9) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
-    else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode);
+    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
 }
 
 extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
-                             int B, int G, int c, int N, int M, int k, int mode, unsigned flags, void* stream) {
+                             int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream) {
+  if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: arg_kind is 0 or 1");
   if (!gin || !nn_idx || !argmax || !gx) return gkg_fail(GKG_ERR_NULL, "gkg_mr_bwd_tm: gin, nn_idx, argmax and gx must be non-null");
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: bad sizes");
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode is 0 or 1");
@@ -643,16 +693,16 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
       const size_t lds = (size_t)TL * M * 16;
       if (gsrc) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_det_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((mr_bwd_tm_det_kernel<false>), dim3(C / 4, B), dim3(64), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, mode, (int)TL);
+        hipLaunchKernelGGL((mr_bwd_tm_det_kernel<false>), dim3(C / 4, B), dim3(64), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, mode, (int)TL, arg_kind);
       } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_det_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((mr_bwd_tm_det_kernel<true>), dim3(C / 4, B), dim3(64), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, mode, (int)TL);
+        hipLaunchKernelGGL((mr_bwd_tm_det_kernel<true>), dim3(C / 4, B), dim3(64), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, mode, (int)TL, arg_kind);
       }
     } else {                         // seed (gx = direct - gm; gsrc = 0), then the ordered global walk
       hipLaunchKernelGGL(mr_bwd_tm_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, gx, C, T, mode);
       if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * M * C, st);
       hipLaunchKernelGGL(mr_bwd_tm_det_global_kernel, dim3((unsigned)((B * (C / 4) + 63) / 64)), dim3(64), 0, st, gin, nn_idx,
-                         argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode);
+                         argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode, arg_kind);
     }
     hipError_t ed = hipGetLastError();
     return ed == hipSuccess ? 0 : gkg_fail_hip(ed, "mr_bwd_tm (deterministic)");
@@ -662,24 +712,24 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   int CW = 64;
   while (CW > 4 && ((size_t)M * CW * 4 > (size_t)MR_LDS_BUDGET || C % CW || c % CW)) CW >>= 1;
   while (CW > 8 && (long)(C / CW) * B < 512) CW >>= 1;
-  if ((size_t)M * CW * 4 <= (size_t)MR_LDS_BUDGET && C % CW == 0 && c % CW == 0 && B <= 65535) {
+  if ((size_t)M * CW * 4 <= (size_t)MR_LDS_BUDGET && C % CW == 0 && c % CW == 0 && (long)(C / CW) * (B + 7) < 0x7fffffffL) {
     const size_t lds = (size_t)M * CW * 4;
     if (gsrc) {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((mr_bwd_tm_scatter_kernel<false>), dim3(C / CW, B), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,
-                         B, G, c, N, M, k, mode, CW);
+      hipLaunchKernelGGL((mr_bwd_tm_scatter_kernel<false>), dim3((C / CW) * ((B + 7) / 8) * 8), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,
+                         B, G, c, N, M, k, mode, CW, arg_kind);
     } else {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((mr_bwd_tm_scatter_kernel<true>), dim3(C / CW, B), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,
-                         B, G, c, N, M, k, mode, CW);
+      hipLaunchKernelGGL((mr_bwd_tm_scatter_kernel<true>), dim3((C / CW) * ((B + 7) / 8) * 8), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,
+                         B, G, c, N, M, k, mode, CW, arg_kind);
     }
   } else {                           // destination image too large for LDS: elementwise seed + fp32 global atomics
     hipLaunchKernelGGL(mr_bwd_tm_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, gx, C, T, mode);
     if (gsrc) (void)hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * M * C, st);
     hipLaunchKernelGGL(mr_bwd_tm_scatter_atomic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gin, nn_idx,
-                       argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode);
+                       argmax, gsrc ? gsrc : gx, B, G, c, N, M, k, mode, arg_kind);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_bwd_tm");

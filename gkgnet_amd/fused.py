@@ -572,6 +572,7 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
     B, N, C = x.shape
     c = C // G
     M = N if y is None else y.shape[1]
+    flags = _lib.KNN_NORMALIZE
     rp = None
     if relative_pos is not None:
         rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
@@ -580,7 +581,7 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
     edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device=x.device)
     ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
     rc = lib.gkg_knn_fwd_tm(_ptr(x), _ptr(y), _ptr(rp), edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k,
-                            dilation, _lib.F32, _lib.KNN_NORMALIZE, _ptr(ws), ws.numel(), _stream())
+                            dilation, _lib.F32, flags, _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "gkg_knn_fwd_tm")
     return edge
 
@@ -596,22 +597,23 @@ class _MaxRelativeTM(torch.autograd.Function):
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((4, T, C // 2) if mode == 1 else (B, N, C), dtype=dt, device=x.device)
         need = any(ctx.needs_input_grad[:2])
-        arg = torch.empty((B, N, C), dtype=torch.uint8, device=x.device) if need else None
+        ak = 1 if M <= 65536 else 0              # the winning neighbour's row index (u16) instead of its slot (u8)
+        arg = torch.empty((B, N, C), dtype=torch.int16 if ak else torch.uint8, device=x.device) if need else None
         _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
-                                     code, _stream()), "gkg_mr_fwd_tm")
+                                     code, ak, _stream()), "gkg_mr_fwd_tm")
         ctx.save_for_backward(nn_idx, arg)
-        ctx.meta = (B, G, C, N, M, k, mode, src is not None)
+        ctx.meta = (B, G, C, N, M, k, mode, src is not None, ak)
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         nn_idx, arg = ctx.saved_tensors
-        B, G, C, N, M, k, mode, has_src = ctx.meta
+        B, G, C, N, M, k, mode, has_src, ak = ctx.meta
         g = g.contiguous()
         gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
-        _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode,
+        _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode, ak,
                                      _lib.MR_DETERMINISTIC if DETERMINISTIC else 0, _stream()), "gkg_mr_bwd_tm")
         return gx, gsrc, None, None, None, None
 

@@ -117,11 +117,14 @@ int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void
 int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* arg_kind: what `argmax` holds — 0: (B,N,C) u8, the winning slot j (as gkg_mr_fwd); 1: (B,N,C) u16, the winning
+ * neighbour's row index itself (M <= 65536), which lets the backward scatter without looking the index row up again. */
 int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out /* out_dtype elements */,
-                  uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, void* stream);
+                  uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind,
+                  void* stream);
 #define GKG_MR_DETERMINISTIC 1u /* fixed summation order in the scatter: bit-identical results from run to run */
 int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
-                  int B, int G, int c, int N, int M, int k, int mode, unsigned flags, void* stream);
+                  int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bandwidth kernels between the dense 1x1 projections (Conv2d 1x1 + SyncBN [+ GELU], reference
