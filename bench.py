@@ -239,6 +239,11 @@ def main():
                  "fwd": "forward projections: own fp32-MFMA kernels with BN-statistics epilogue (csrc/gkg_gemm.hip); dgrad/wgrad: " + lib_desc,
                  "auto": "own fp32-MFMA forward kernels with BN-statistics epilogue (csrc/gkg_gemm.hip) where measured faster (R <= 4096 or R >= 32768: here the label branch); otherwise " + lib_desc,
                  "none": lib_desc}[fused.OWN_GEMM]
+    if fused.GEMM_MATH in ("x6", "x6all") and fused.OWN_GEMM != "none":
+        gemm_desc = ("fp32 projections; " + ("every" if fused.GEMM_MATH == "x6all" else "the long (R >= 8192) and wide-output")
+                     + " forward / input-gradient GEMMs on the bf16 matrix cores with an exact 3-way operand split, 6 cross "
+                     "products, fp32 accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 below the fp32-MFMA kernel's); the rest: "
+                     + gemm_desc)
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed

@@ -10,7 +10,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
@@ -21,7 +21,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
            "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
-           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
+           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
+           "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
            "gkg_bn_apply_train", "gkg_bn_bwd_train")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
 
@@ -96,6 +97,20 @@ def load():
     lib.gkg_bn_bwd_coef.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V, Z, V]
     lib.gkg_linear_bn_bwd.restype = I
     lib.gkg_linear_bn_bwd.argtypes = [V, I, Z, V, V, V, V, V, V, I, I, I, I, C.c_uint, V, Z, V, V]
+    lib.gkg_stream_capture_id.restype = C.c_ulonglong
+    lib.gkg_stream_capture_id.argtypes = [V]
+    lib.gkg_x6_planes_bytes.restype = Z
+    lib.gkg_x6_planes_bytes.argtypes = [I, I, I, I]
+    lib.gkg_x6_prep_desc_bytes.restype = I
+    lib.gkg_x6_prep_desc_bytes.argtypes = []
+    lib.gkg_x6_prep_desc_fill.restype = C.c_longlong
+    lib.gkg_x6_prep_desc_fill.argtypes = [V, I, V, V, V, I, I, I, C.c_longlong]
+    lib.gkg_x6_prep_weights.restype = I
+    lib.gkg_x6_prep_weights.argtypes = [V, I, C.c_longlong, V]
+    lib.gkg_linear_bn_fwd_x6.restype = I
+    lib.gkg_linear_bn_fwd_x6.argtypes = [V, I, Z, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V]
+    lib.gkg_linear_dgrad_x6.restype = I
+    lib.gkg_linear_dgrad_x6.argtypes = [V, I, Z, V, V, I, I, I, I, V]
     lib.gkg_bn_scratch_doubles.restype = I
     lib.gkg_bn_scratch_doubles.argtypes = []
     lib.gkg_bn_counters.restype = I

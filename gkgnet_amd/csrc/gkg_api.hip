@@ -18,6 +18,15 @@ int gkg_fail_hip(hipError_t e, const char* where) {
 
 extern "C" int gkg_version(void) { return GKG_ABI_VERSION; }
 
+// Identifier of the graph capture `stream` is recording into (0: not capturing).  Lets host-side caches that must emit a
+// refresh kernel once per captured step (the x6 weight planes) tell one capture from the next.
+extern "C" unsigned long long gkg_stream_capture_id(void* stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return st == hipStreamCaptureStatusActive ? (id ? id : 1ull) : 0ull;
+}
+
 extern "C" const char* gkg_last_error_string(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------ profiling

@@ -484,6 +484,14 @@ __global__ __launch_bounds__(256) void bn_sums_finalize_kernel(double* __restric
   }
 }
 
+hipError_t launch_bn_sums_finalize(double* stats, int R, int cout, int nb, const float* gamma, const float* beta,
+                                   const float* bias, float* running_mean, float* running_var, float* bn_a, float* bn_c,
+                                   float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st) {
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3((cout + 255) / 256, nb), dim3(256), 0, st, stats, R, cout, gamma, beta,
+                     bias, running_mean, running_var, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, nbt);
+  return hipGetLastError();
+}
+
 }  // namespace gkg
 
 using namespace gkg;

@@ -1,0 +1,477 @@
+// gkg_gemm_x6.hip — the Grapher block's dense projections (forward and input-gradient) on the bf16 matrix cores at fp32
+// accuracy: every fp32 operand is split into three bf16 terms, x = hi + mid + lo (exactly: each residual is computed in
+// fp32 and is representable), and six of the nine cross products are kept
+//     a*b ~= ah*bh + [ah*bm + am*bh + am*bm + ah*bl + al*bh]          (dropped: am*bl, al*bm, al*bl <= 2^-24 |a*b|)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, the bracketed corrections in their own accumulator.  Measured against
+// an fp64 evaluation (tools/ubench/gemm_x6_bench.hip, K = 320..1280): max error 5.0e-8 * sum|a b|, mean 4.6e-9 — three
+// to four times SMALLER than the fp32-MFMA kernel of gkg_gemm.hip (1.5e-7 / 1.7e-8) and than any fp32 fma chain of that
+// length; 6 bf16 MFMAs cost 6*32 cycles per 32x32x16 block where the fp32 MFMA costs 8*64.
+//
+// Replaces (reference torch_vertex.py:290-306 fc1 / fc2, :57-62 + torch_nn.py:57-69 BasicConv groups=4, :334-360
+// FFNLabel — the 1x1 convolutions and their input gradients):
+//     forward   Y[m][n]  = sum_k X[m][k]  W[n][k]     (+ train-mode BN column statistics in the epilogue)
+//     dgrad     dX[m][n] = sum_k dY[m][k] W[k][n]
+// Both are C = A * B^T with A a row-major fp32 activation matrix and B a WEIGHT matrix, so the weights are split once per
+// optimiser step by x6_prep_kernel (both orientations, all registered layers, one launch) into
+//     planes[p][k/8][n][8]  bf16      p = hi, mid, lo;  n padded to 128, k padded to 32 (zeros)
+// and only the activation operand is split inside the GEMM.
+//
+// Kernel (256 threads = 4 waves, tile 128 rows x 32*NI columns, K-step 32):
+//   * waves are stacked 4(M) x 1(N): wave w owns rows [32w, 32w+32), so each A element is split by exactly one wave.  Its
+//     rows travel global -> the wave's PRIVATE LDS ring (LDS-DMA, 3 stages, no workgroup barrier on that path) -> registers
+//     (2 ds_read_b128 per 16-deep half step; the ring image is XOR-swizzled on the SOURCE address, conflict-free), where
+//     the 44-instruction split runs in the shadow of the MFMAs (4-5 VALU per MFMA gap: measured free up to ~5,
+//     tools/ubench/mfma_bf16_fill.hip);
+//   * the weight planes are DMA'd as 1-KiB contiguous pieces (64 n x 16 B) into a 2-stage image [p][k/8][n] that every
+//     wave reads conflict-free with ds_read_b128 — no VALU on the B side at all;
+//   * one workgroup barrier per K-step, in the MIDDLE of the step: it certifies stage kt+1 (first read right after it)
+//     and releases stage kt's B image and the wave's oldest A slot for the DMA issued next; counted vmcnt leaves the
+//     newest A stage in flight across it;
+//   * XCD-aware 1-D grid: the column tiles of one 128-row block run back to back on one XCD, so the row block is fetched
+//     from HBM into that L2 once.
+#include "gkg_common.h"
+
+namespace gkg {
+
+typedef float x6_f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 x6_bf16x8;
+typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x6_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X6_NPAD = 128;             // plane rows are padded to this many n (covers NI = 2 and 4 column tiles)
+
+__device__ __forceinline__ unsigned x6_cvt2(float a, float b) {
+  x6_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+
+// two floats -> packed (hi, mid, lo) bf16 pairs; the residuals are exact fp32 differences
+__device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = x6_cvt2(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = x6_cvt2(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = x6_cvt2(s0, s1);
+}
+
+// ---- weight planes ------------------------------------------------------------------------------------------------------
+// One descriptor per registered projection weight w (nb, N, K) row-major (N = cout, K = cin per group):
+//   forward planes  pf: [nb][3][KCf][NPf][8]   B[n][k] = w[n][k]      NPf = roundup(N, 128), KCf = roundup(K, 32) / 8
+//   dgrad planes    pd: [nb][3][KCd][NPd][8]   B[n][k] = w[k][n]      NPd = roundup(K, 128), KCd = roundup(N, 32) / 8
+// A work unit is one (k/8, n) pair = 8 floats in, 3 x 16 B out; unit_begin is the running unit count over descriptors.
+struct X6PrepDesc {
+  const float* w;
+  uint4* pf;
+  uint4* pd;
+  int nb, N, K;
+  int unit_begin;
+};
+
+__global__ __launch_bounds__(256) void x6_prep_kernel(const X6PrepDesc* __restrict__ descs, int ndesc, int total_units) {
+  __shared__ int begin[256];
+  __shared__ int first;
+  const int u0 = blockIdx.x * 256;
+  if ((int)threadIdx.x < ndesc) begin[threadIdx.x] = descs[threadIdx.x].unit_begin;
+  __syncthreads();
+  if (threadIdx.x == 0) {                      // the block's 256 consecutive units start in this descriptor
+    int d0 = 0;
+    while (d0 + 1 < ndesc && begin[d0 + 1] <= u0) ++d0;
+    first = d0;
+  }
+  __syncthreads();
+  const int u = u0 + threadIdx.x;
+  if (u >= total_units) return;
+  int d = first;
+  while (d + 1 < ndesc && begin[d + 1] <= u) ++d;
+  const X6PrepDesc g = descs[d];
+  int v = u - g.unit_begin;
+  const int NPf = (g.N + X6_NPAD - 1) / X6_NPAD * X6_NPAD, KCf = (g.K + 31) / 32 * 4;
+  const int NPd = (g.K + X6_NPAD - 1) / X6_NPAD * X6_NPAD, KCd = (g.N + 31) / 32 * 4;
+  const int fwd_units = g.pf ? g.nb * KCf * NPf : 0;        // an orientation nobody asked for (null planes) has no units
+  const bool dgrad = v >= fwd_units;
+  if (dgrad) v -= fwd_units;
+  const int NP = dgrad ? NPd : NPf, KC = dgrad ? KCd : KCf;
+  const int Nn = dgrad ? g.K : g.N, Kk = dgrad ? g.N : g.K;      // extents of (n, k) in this orientation
+  const int n = v % NP, kc = (v / NP) % KC, z = v / (NP * KC);
+  const float* w = g.w + (size_t)z * g.N * g.K;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kc * 8 + j;
+    f[j] = (n < Nn && k < Kk) ? (dgrad ? w[(size_t)k * g.K + n] : w[(size_t)n * g.K + k]) : 0.f;
+  }
+  uint4 h, m, l;
+  x6_split2(f[0], f[1], h.x, m.x, l.x); x6_split2(f[2], f[3], h.y, m.y, l.y);
+  x6_split2(f[4], f[5], h.z, m.z, l.z); x6_split2(f[6], f[7], h.w, m.w, l.w);
+  uint4* P = (dgrad ? g.pd : g.pf) + (size_t)z * 3 * KC * NP;
+  const size_t plane = (size_t)KC * NP, at = (size_t)kc * NP + n;
+  P[at] = h; P[plane + at] = m; P[2 * plane + at] = l;
+}
+
+// ---- the GEMM -----------------------------------------------------------------------------------------------------------
+struct X6Args {
+  const float* A;  size_t a_bstride;  int lda;          // (nb, M, K) activations, row pitch lda floats (lda % 4 == 0)
+  const uint4* P;  size_t p_bstride;                    // weight planes of this orientation, uint4 units per batch
+  float* C;  size_t c_bstride;  int ldc;
+  int M, N, K;
+  int NP, KC;                                           // plane geometry (padded n, k/8 chunks)
+  int mtiles, ntiles;
+  double* sums;                                         // EPI_BNSTATS: [nb][2][N] fp64, accumulated with atomics
+};
+
+enum { X6_STORE = 0, X6_BNSTATS = 1 };
+
+__device__ __forceinline__ void x6_chan_merge(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+  if (nb <= 0.0) return;
+  const double tot = n + nb;
+  const double delta = mb - mean;
+  mean += delta * (nb / tot);
+  m2 += m2b + delta * delta * (n * nb / tot);
+  n = tot;
+}
+
+// LDS-DMA of one 1-KiB piece: 64 lanes x 16 B from (sbase + voff) to LDS bytes [lds_dst, lds_dst + 1024).  M0 carries the
+// destination and is compiler-reserved: saved and restored inside the statement.  Invisible to the compiler's waitcnt
+// bookkeeping — completion is counted by hand (s_waitcnt vmcnt(N)) before the barrier that precedes the reads.
+__device__ __forceinline__ void x6_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int NI, int EPI>
+__global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
+  constexpr int BM = 128, BN = 32 * NI, BK = 32, SA = 3;
+  constexpr int A_STAGE = 4 * 4096, B_STAGE = 12 * BN * 16, B_BASE = SA * A_STAGE;
+  constexpr int BI = 12 * BN / 64 / 4;                   // B DMA pieces per wave per K-step
+  extern __shared__ uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.y;
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int tn = slot % g.ntiles, tm = (slot / g.ntiles) * 8 + xcd;
+  if (tm >= g.mtiles) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = g.M, N = g.N, K = g.K;
+  const float* A = g.A + (size_t)z * g.a_bstride;
+  const uint4* P = g.P + (size_t)z * g.p_bstride;
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int nk = (K + BK - 1) / BK;
+  const bool ktail = (K & (BK - 1)) != 0;
+
+  // A pieces: LDS slot L = 64 i + lane of the wave's 32 x 128-B image holds chunk (L & 7) ^ ((row >> 1) & 7) of row L >> 3
+  unsigned aoff[4];
+  int achunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int L = 64 * i + lane, row = L >> 3, chunk = (L & 7) ^ ((row >> 1) & 7);
+    const int gr = min(m0 + 32 * w + row, M - 1);        // rows past the end re-read the last row (never stored)
+    aoff[i] = (unsigned)((size_t)gr * g.lda + chunk * 4) * 4u;
+    achunk[i] = chunk;
+  }
+  const size_t plane = (size_t)g.KC * g.NP * 16;
+  unsigned boff[BI], bdst[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int piece = w + 4 * i;
+    const int rowid = piece * 64 / BN, p = rowid >> 2, chunk = rowid & 3, nb = (piece * 64) % BN;
+    boff[i] = (unsigned)(p * plane + ((size_t)chunk * g.NP + n0 + nb + lane) * 16);
+    bdst[i] = piece * 1024;
+  }
+  auto dma_a = [&](int kt) {
+    const char* base = (const char*)A + (size_t)kt * (BK * 4);
+    const unsigned dst = lds0 + (kt % SA) * A_STAGE + w * 4096;
+    const bool last = ktail && kt == nk - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned o = aoff[i];
+      if (last && kt * BK + achunk[i] * 4 >= K) o -= achunk[i] * 16;      // past K: a valid address, masked after the read
+      x6_dma16(base, o, dst + i * 1024);
+    }
+  };
+  auto dma_b = [&](int kt) {
+    const char* base = (const char*)P + (size_t)kt * 4 * g.NP * 16;
+    const unsigned dst = lds0 + B_BASE + (kt & 1) * B_STAGE;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) x6_dma16(base, boff[i], dst + bdst[i]);
+  };
+
+  x6_f32x16 acc[NI], accs[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[j][q] = 0.f; accs[j][q] = 0.f; }
+
+  const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+  int ac[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) { ac[s][0] = r * 128 + (((4 * s + 2 * h) ^ sw) << 4); ac[s][1] = r * 128 + (((4 * s + 2 * h + 1) ^ sw) << 4); }
+
+  float f[8];                        // raw A fragment of the next half step, split in place
+  unsigned sh_[4], sm_[4], sl_[4], t0_[4], t1_[4];
+  x6_bf16x8 a[2][3], b[2][NI][3];
+
+  auto read_raw = [&](int kt, int s) {
+    const char* ab = (const char*)lds + (kt % SA) * A_STAGE + w * 4096;
+    const float4 f0 = *(const float4*)(ab + ac[s][0]);
+    const float4 f1 = *(const float4*)(ab + ac[s][1]);
+    f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
+    if (ktail && kt == nk - 1) {
+      const int kb = kt * BK + 16 * s + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = kb + j < K ? f[j] : 0.f;
+    }
+  };
+  auto read_b = [&](int kt, int s, int buf) {
+    const uint4* bb = lds + (B_BASE + (kt & 1) * B_STAGE) / 16 + r;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[buf][j][p] = __builtin_bit_cast(x6_bf16x8, bb[(p * 4 + 2 * s + h) * BN + j * 32]);
+  };
+  // The split of f[] as 44 single-instruction steps (asm volatile: fixed order, never sunk into another block).  Step i
+  // works on pair i & 3, so consecutive steps are independent.
+  auto op = [&](int i) {
+    const int p = i & 3, o = i >> 2;
+    float& x0 = f[2 * p]; float& x1 = f[2 * p + 1];
+    if (o == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(sh_[p]) : "v"(x0), "v"(x1));
+    if (o == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0_[p]) : "v"(sh_[p]));
+    if (o == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1_[p]) : "v"(sh_[p]));
+    if (o == 3) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(t0_[p]));
+    if (o == 4) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x1) : "v"(t1_[p]));
+    if (o == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(sm_[p]) : "v"(x0), "v"(x1));
+    if (o == 6) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0_[p]) : "v"(sm_[p]));
+    if (o == 7) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1_[p]) : "v"(sm_[p]));
+    if (o == 8) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(t0_[p]));
+    if (o == 9) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x1) : "v"(t1_[p]));
+    if (o == 10) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(sl_[p]) : "v"(x0), "v"(x1));
+  };
+  auto commit = [&](int buf) {
+    a[buf][0] = __builtin_bit_cast(x6_bf16x8, uint4{sh_[0], sh_[1], sh_[2], sh_[3]});
+    a[buf][1] = __builtin_bit_cast(x6_bf16x8, uint4{sm_[0], sm_[1], sm_[2], sm_[3]});
+    a[buf][2] = __builtin_bit_cast(x6_bf16x8, uint4{sl_[0], sl_[1], sl_[2], sl_[3]});
+  };
+  // One half step (16 deep): the MFMAs of buffer `cur`; in their gaps the NEXT half step's (stage nkt, half ns) B fragments
+  // are read and its raw A fragment (read at the top) is split into buffer cur ^ 1.
+  constexpr int SLOTS = 6 * NI, OPS_PER = (44 + SLOTS - 2) / (SLOTS - 1);
+  auto half = [&](int cur, bool has_next, int nkt, int ns) {
+    const uint4* bb = lds + (B_BASE + (nkt & 1) * B_STAGE) / 16 + r;
+    if (has_next) read_raw(nkt, ns);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int si = j * 6 + t;
+        // small terms first, the hi*hi product into its own accumulator
+        if (t == 0) accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], b[cur][j][0], accs[j], 0, 0, 0);
+        if (t == 1) accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[cur][j][2], accs[j], 0, 0, 0);
+        if (t == 2) accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], b[cur][j][1], accs[j], 0, 0, 0);
+        if (t == 3) accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], b[cur][j][0], accs[j], 0, 0, 0);
+        if (t == 4) accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[cur][j][1], accs[j], 0, 0, 0);
+        if (t == 5) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[cur][j][0], acc[j], 0, 0, 0);
+        if (has_next) {
+          if (si < 3 * NI) {
+            const int jj = si / 3, pp = si % 3;
+            b[cur ^ 1][jj][pp] = __builtin_bit_cast(x6_bf16x8, bb[(pp * 4 + 2 * ns + h) * BN + jj * 32]);
+          }
+          if (si >= 1) {
+#pragma unroll
+            for (int o = 0; o < OPS_PER; ++o) { const int i = (si - 1) * OPS_PER + o; if (i < 44) op(i); }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (has_next) commit(cur ^ 1);
+  };
+
+  // ---- pipeline.  DMA issue order per wave: [A0] [B0] [A1] [B1] [A2], then per step after the barrier [B kt+2] [A kt+3]:
+  // at the barrier of step kt the wave needs A kt+1 and B kt+1 and may leave A kt+2 (its newest 4 pieces) in flight.
+  dma_a(0); dma_b(0);
+  if (nk > 1) { dma_a(1); dma_b(1); }
+  if (nk > 2) dma_a(2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + BI) : "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + BI) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_raw(0, 0); read_b(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 44; ++i) op(i);
+  commit(0);
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    half(0, true, kt, 1);                        // s = 0 on buffer 0; fetches and splits (kt, s = 1) into buffer 1
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) dma_b(kt + 2);
+    if (kt + 3 < nk) dma_a(kt + 3);
+    half(1, true, kt + 1, 0);                    // s = 1 on buffer 1; fetches and splits (kt+1, s = 0) into buffer 0
+  }
+  half(0, true, nk - 1, 1);
+  half(1, false, 0, 0);
+
+  // ---- epilogue.  Block j, register q: row 32 w + (q & 3) + 8 (q >> 2) + 4 h, column 32 j + r
+  float* C = g.C + (size_t)z * g.c_bstride;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] += accs[j][q];
+    const int n = n0 + j * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (m < M && n < N) C[(size_t)m * g.ldc + n] = acc[j][q];
+    }
+  }
+  if (EPI != X6_BNSTATS) return;
+
+  // Train-mode BN statistics of the tile's columns (as gkg_gemm.hip's epilogue): per wave (its 32 rows) centred
+  // (mean, M2) from registers, Chan-merged over the four waves in fp64, then ONE fp64 atomic pair per column and tile:
+  // S += n mean, Q += M2 + n mean^2.  No workgroup waits for another.
+  __syncthreads();                                   // every wave is done with the DMA rings
+  float* red = reinterpret_cast<float*>(lds);        // [4 waves][BN][2]
+  const int rbase = m0 + 32 * w;
+  const int cnt = max(0, min(32, M - rbase));
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += rbase + (q & 3) + 8 * (q >> 2) + 4 * h < M ? acc[j][q] : 0.f;
+    s += __shfl_xor(s, 32);
+    const float mean = cnt > 0 ? s / (float)cnt : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float d = acc[j][q] - mean;
+      m2 += rbase + (q & 3) + 8 * (q >> 2) + 4 * h < M ? d * d : 0.f;
+    }
+    m2 += __shfl_xor(m2, 32);
+    if (h == 0) { float* o = red + ((w * BN) + j * 32 + r) * 2; o[0] = mean; o[1] = m2; }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int c = max(0, min(32, M - (m0 + rg * 32)));
+      x6_chan_merge(n, mean, m2, (double)c, (double)red[(rg * BN + tid) * 2], (double)red[(rg * BN + tid) * 2 + 1]);
+    }
+    double* sz = g.sums + (size_t)z * 2 * N + n0 + tid;
+    __hip_atomic_fetch_add(sz, n * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sz + N, m2 + n * mean * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int NI, int EPI>
+static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
+  constexpr int BN = 32 * NI;
+  a.mtiles = (a.M + 127) / 128;
+  a.ntiles = (a.N + BN - 1) / BN;
+  const size_t sh = 3 * 4 * 4096 + 2 * 12 * BN * 16;
+  static bool once = false;
+  if (!once) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_x6_kernel<NI, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return e;
+    once = true;
+  }
+  const int groups = (a.mtiles + 7) / 8;
+  hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
+  return hipGetLastError();
+}
+
+inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
+inline size_t x6_plane_units(int n, int k, int nb) {       // uint4 units of one orientation: B[n][k]
+  return (size_t)nb * 3 * ((k + 31) / 32 * 4) * ((n + X6_NPAD - 1) / X6_NPAD * X6_NPAD);
+}
+
+}  // namespace gkg
+using namespace gkg;
+
+extern "C" size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad) {
+  if (x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0) return 0;
+  return 16 * (dgrad ? x6_plane_units(cin, cout, nb) : x6_plane_units(cout, cin, nb));
+}
+
+extern "C" int gkg_x6_prep_desc_bytes(void) { return (int)sizeof(X6PrepDesc); }
+
+// Fills descriptor `index` of a HOST array laid out as gkg_x6_prep_desc_bytes() per entry (one of the two plane pointers may
+// be null: that orientation is not produced) and returns the unit count after
+// it (pass it as unit_begin of the next entry; the last return value is total_units of gkg_x6_prep_weights).
+extern "C" long long gkg_x6_prep_desc_fill(void* host_descs, int index, const float* w, void* planes_fwd, void* planes_dgrad,
+                                           int cin, int cout, int nb, long long unit_begin) {
+  if (!host_descs || !w || (!planes_fwd && !planes_dgrad) || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || index < 0) return -1;
+  X6PrepDesc* d = reinterpret_cast<X6PrepDesc*>(host_descs) + index;
+  d->w = w; d->pf = (uint4*)planes_fwd; d->pd = (uint4*)planes_dgrad;
+  d->nb = nb; d->N = cout; d->K = cin; d->unit_begin = (int)unit_begin;
+  const long long units = (long long)((planes_fwd ? x6_plane_units(cout, cin, nb) : 0) + (planes_dgrad ? x6_plane_units(cin, cout, nb) : 0)) / 3;
+  if (unit_begin + units > 0x7fffffffLL) return -1;
+  return unit_begin + units;
+}
+
+// One launch splits every described weight into its forward and dgrad planes.  `descs_dev`: the descriptor array copied to
+// the device (it holds device pointers only).
+extern "C" int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long total_units, void* stream) {
+  if (!descs_dev) return gkg_fail(GKG_ERR_NULL, "gkg_x6_prep_weights: null descriptor array");
+  if (ndesc <= 0 || ndesc > 256 || total_units <= 0 || total_units > 0x7fffffffLL) return gkg_fail(GKG_ERR_SHAPE, "gkg_x6_prep_weights: need 1 <= ndesc <= 256 and 0 < total_units < 2^31");
+  hipLaunchKernelGGL(x6_prep_kernel, dim3((unsigned)((total_units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const X6PrepDesc*)descs_dev, ndesc, (int)total_units);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "x6_prep_kernel");
+}
+
+// gkg_linear_bn_fwd with the weights given as forward planes (gkg_x6_prep_weights).  x (nb, R, cin) with row pitch ldx and
+// batch stride x_bstride (floats); y (nb, R, cout) contiguous.  Same `train` modes and outputs as gkg_linear_bn_fwd.
+extern "C" int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
+                                    int cin, int cout, int nb, int train, const float* gamma, const float* beta,
+                                    const float* bias, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
+                                    float* bn_invstd, float momentum, float eps, double* stats, void* stream) {
+  if (!x || !planes_fwd || !y) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: null pointer");
+  if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || nb > 64 || ldx < cin || (ldx & 3) || (x_bstride & 3) ||
+      ((size_t)x & 15))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_bn_fwd_x6: need R > 0, cin % 4 == 0, cout % 4 == 0, 1 <= nb <= 64, 16-byte aligned rows");
+  if ((size_t)R * ldx * 4 > 0xffffffffull) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_bn_fwd_x6: operand larger than 4 GiB per batch");
+  X6Args a{};
+  a.A = x; a.a_bstride = x_bstride; a.lda = ldx;
+  a.NP = (cout + X6_NPAD - 1) / X6_NPAD * X6_NPAD; a.KC = (cin + 31) / 32 * 4;
+  a.P = (const uint4*)planes_fwd; a.p_bstride = (size_t)3 * a.KC * a.NP;
+  a.C = y; a.c_bstride = (size_t)R * cout; a.ldc = cout;
+  a.M = R; a.N = cout; a.K = cin;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (train) {
+    if (!stats) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: training needs the stats scratch");
+    if ((size_t)nb * 2 * cout > (size_t)gkg_linear_stats_doubles()) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_bn_fwd_x6: nb * cout too large for the stats scratch");
+    if (train != 2) {
+      if (!gamma || !beta || !bn_a || !bn_c || !bn_mean || !bn_invstd) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: training needs gamma, beta and the four outputs");
+      if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: running stats come in pairs");
+    }
+    a.sums = stats;
+    e = x6_launch<2, X6_BNSTATS>(a, nb, st);
+    if (e == hipSuccess && train != 2) {
+      e = launch_bn_sums_finalize(stats, R, cout, nb, gamma, beta, bias, running_mean, running_var, bn_a, bn_c, bn_mean,
+                                  bn_invstd, momentum, eps, num_batches_tracked, st);
+    }
+  } else {
+    e = x6_launch<2, X6_STORE>(a, nb, st);
+  }
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (forward)");
+}
+
+// dx (nb, R, cin) = dy (nb, R, cout; row pitch ldg, batch stride g_bstride) * w, the weights given as dgrad planes.
+extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
+                                   int cin, int cout, int nb, void* stream) {
+  if (!dy || !planes_dgrad || !dx) return gkg_fail(GKG_ERR_NULL, "gkg_linear_dgrad_x6: null pointer");
+  if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || nb > 64 || ldg < cout || (ldg & 3) || (g_bstride & 3) ||
+      ((size_t)dy & 15))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6: need R > 0, cin % 4 == 0, cout % 4 == 0, 1 <= nb <= 64, 16-byte aligned rows");
+  if ((size_t)R * ldg * 4 > 0xffffffffull) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_dgrad_x6: operand larger than 4 GiB per batch");
+  X6Args a{};
+  a.A = dy; a.a_bstride = g_bstride; a.lda = ldg;
+  a.NP = (cin + X6_NPAD - 1) / X6_NPAD * X6_NPAD; a.KC = (cout + 31) / 32 * 4;
+  a.P = (const uint4*)planes_dgrad; a.p_bstride = (size_t)3 * a.KC * a.NP;
+  a.C = dx; a.c_bstride = (size_t)R * cin; a.ldc = cin;
+  a.M = R; a.N = cin; a.K = cout;
+  hipError_t e = x6_launch<2, X6_STORE>(a, nb, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad)");
+}

@@ -17,7 +17,9 @@ hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabe
 """
 from __future__ import annotations
 
+import ctypes
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -48,6 +50,133 @@ BN_TWO_KERNEL = os.environ.get("GKG_BN_TWO_KERNEL", "0") != "0"
 # True: run-to-run bit-identical backward — ordered reduction of the split weight-gradient products (own-GEMM path) and
 # fixed-order neighbour-gradient scatter (gkg_mr_bwd_tm); the defaults use fp32 atomics.
 DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
+# Arithmetic of the own projection kernels: "x6" (default) = bf16 matrix cores with every fp32 operand split exactly into
+# three bf16 terms, six cross products, fp32 accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 3-4x below the fp32-MFMA
+# kernel, 1.3-1.4x faster than the vendor fp32 GEMM at cfg2's shapes) for the forward and input-gradient GEMMs of every
+# fp32 projection; "f32" = the fp32-MFMA kernels of csrc/gkg_gemm.hip under the GKG_OWN_GEMM rule above.
+GEMM_MATH = os.environ.get("GKG_GEMM_MATH", "x6")
+
+
+class _WeightPlanes:
+    """bf16 hi / mid / lo planes (forward and dgrad orientation) of every projection weight that went through the x6
+    kernels on one device.  The planes are a function of the parameter values only, so they are refreshed when a
+    parameter's version counter moves (an optimiser step) — ALL registered weights in ONE launch (gkg_x6_prep_weights).
+    Inside a hipGraph capture the host cannot see later in-place updates, so the first projection of each capture emits
+    the refresh unconditionally: a captured training step re-splits the weights once per replay."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}            # id(weight) -> dict
+        self.descs = None            # device copy of the descriptor table
+        self.unit_ends = []
+        self.capture_id = 0
+
+    def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None):
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.GkgError("x6 projection: a weight was first seen inside a hipGraph capture; run one eager "
+                                "warm-up step before capturing")
+        same = (old is not None and old["ref"]() is weight and old["ptr"] == weight.data_ptr()
+                and (old["nb"], old["cout"], old["cin"]) == (nb, cout, cin))
+        e = dict(ref=weakref.ref(weight), nb=nb, cout=cout, cin=cin, ptr=weight.data_ptr(), version=-1,
+                 pf=old["pf"] if same else None, pd=old["pd"] if same else None)
+        if need_f and e["pf"] is None:
+            e["pf"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device=self.device)
+        if need_d and e["pd"] is None:
+            e["pd"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device=self.device)
+        self.entries[id(weight)] = e
+        self.descs = None
+        return e
+
+    def _build_descs(self, lib):
+        live = {k: e for k, e in self.entries.items() if e["ref"]() is not None}
+        self.entries = live
+        size = lib.gkg_x6_prep_desc_bytes()
+        host = ctypes.create_string_buffer(size * max(1, len(live)))
+        units = 0
+        self.unit_ends = []
+        for i, e in enumerate(live.values()):
+            if i % 256 == 0:
+                units = 0                                             # unit numbering restarts with every launch's table
+            units = lib.gkg_x6_prep_desc_fill(host, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"], e["nb"],
+                                              units)
+            if units < 0:
+                raise _lib.GkgError("gkg_x6_prep_desc_fill rejected a weight")
+            self.unit_ends.append(units)
+        self.descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+
+    def refresh(self, lib):
+        """Re-split every registered weight (one launch)."""
+        if self.descs is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GkgError("x6 weight planes: descriptor table is stale inside a capture; run a warm-up step first")
+            self._build_descs(lib)
+        if not self.entries:
+            return
+        n = len(self.entries)
+        size = lib.gkg_x6_prep_desc_bytes()
+        for i0 in range(0, n, 256):                                   # at most 256 descriptors per launch
+            i1 = min(n, i0 + 256)
+            _lib.check(lib.gkg_x6_prep_weights(self.descs.data_ptr() + i0 * size, i1 - i0, self.unit_ends[i1 - 1], _stream()),
+                       "gkg_x6_prep_weights")
+        for e in self.entries.values():
+            w = e["ref"]()
+            e["version"] = -1 if w is None else w._version
+
+    def get(self, lib, weight, nb, cout, cin, need_f=True, need_d=True):
+        e = self.entries.get(id(weight))
+        if (e is None or e["ref"]() is not weight or e["ptr"] != weight.data_ptr()
+                or (e["nb"], e["cout"], e["cin"]) != (nb, cout, cin) or (need_f and e["pf"] is None)
+                or (need_d and e["pd"] is None)):
+            e = self._register(lib, weight, nb, cout, cin, need_f, need_d, e)
+        cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
+        if cap:
+            if cap != self.capture_id:
+                self.capture_id = cap
+                self.refresh(lib)
+        elif e["version"] != weight._version:
+            self.refresh(lib)
+        return e["pf"], e["pd"]
+
+
+_PLANES = {}
+
+
+def _planes(lib, weight, nb, cout, cin, need_f=True, need_d=True):
+    key = (weight.device.type, weight.device.index)
+    reg = _PLANES.get(key)
+    if reg is None:
+        reg = _PLANES[key] = _WeightPlanes(weight.device)
+    return reg.get(lib, weight, nb, cout, cin, need_f, need_d)
+
+
+def refresh_weight_planes(device=None):
+    """Re-split the registered projection weights now (normally automatic: see _WeightPlanes)."""
+    lib = _lib.load()
+    for key, reg in _PLANES.items():
+        if device is None or key == (torch.device(device).type, torch.device(device).index):
+            reg.refresh(lib)
+
+
+def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
+    """This projection GEMM (kind "fwd": y = x W^T, "dgrad": dx = dy W) runs on the x6 kernels.  Eligible: fp32 operands
+    outside autocast, batch statistics local to the rank, 16-byte aligned rows.  GKG_GEMM_MATH=x6 then applies the rule
+    measured inside the cfg2 step on MI355X (tools/prof_graph_steps.py, x6 vs the vendor / fp32-MFMA kernel it replaces):
+    x6 wins on the long un-grouped projections (R >= 8192: fc2 31.6 vs 37.4 us, its dgrad 31.8 vs 36.4, fc1 dgrads 18.4
+    vs 20.6) and on wide outputs (label FFN fc1 320 -> 1280: 20.3 vs 27.5); it loses where a 128-row tile grid leaves the
+    chip under-filled over a long contraction (2560 x 1280 -> 320: 31.8 vs 21.1) and on the grouped K = 160 products
+    (28.5 vs 21.4: five K-steps do not amortise the pipeline fill).  GKG_GEMM_MATH=x6all: every eligible projection."""
+    if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none":
+        return False
+    if not (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None
+            and x.shape[-1] % 4 == 0 and weight.shape[0] % 4 == 0):
+        return False
+    if GEMM_MATH == "x6all":
+        return True
+    R, cin = x.shape[-2], x.shape[-1]
+    cout = weight.shape[0] // nb
+    if nb != 1:
+        return False
+    return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
@@ -174,15 +303,21 @@ def _grad_outs(gparams, wshape, nch, dev):
     return w, g, b
 
 
-def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False):
-    """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue)."""
+def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False, planes=None):
+    """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue); ``planes``: the
+    weight's forward bf16 planes -> gkg_linear_bn_fwd_x6."""
     dev = x.device
+    if planes is not None:
+        def fwd(xp, wp, yp, R_, cin_, cout_, nb_, *rest):
+            return lib.gkg_linear_bn_fwd_x6(xp, cin_, R_ * cin_, _ptr(planes), yp, R_, cin_, cout_, nb_, *rest)
+    else:
+        fwd = lib.gkg_linear_bn_fwd
     Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
     a = torch.empty(nb * cout, dtype=_F32, device=dev)
     c = torch.empty_like(a)
     train = bn.training or not bn.track_running_stats
     if train and stats_only:
-        _lib.check(lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, None, None, None, None, None, None,
+        _lib.check(fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, None, None, None, None, None, None,
                                          None, None, None, None, 0.0, 0.0, _ptr(_stats_scratch(dev)), _stream()),
                    "gkg_linear_bn_fwd")
         return Y, None, None, None, None
@@ -190,14 +325,14 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False):
         mean = torch.empty_like(a)
         invstd = torch.empty_like(a)
         track = bn.training and bn.track_running_stats
-        _lib.check(lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 1, _ptr(bn.weight), _ptr(bn.bias),
+        _lib.check(fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 1, _ptr(bn.weight), _ptr(bn.bias),
                                          _ptr(bias), _ptr(bn.running_mean) if track else None,
                                          _ptr(bn.running_var) if track else None,
                                          _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
                                          _ptr(invstd), float(bn.momentum), float(bn.eps), _ptr(_stats_scratch(dev)),
                                          _stream()), "gkg_linear_bn_fwd")
         return Y, a, c, mean, invstd
-    _lib.check(lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 0, None, None, None, None, None, None,
+    _lib.check(fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 0, None, None, None, None, None, None,
                                      None, None, None, None, 0.0, 0.0, None, _stream()), "gkg_linear_bn_fwd")
     _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
                                       _ptr(bn.running_var), _ptr(a), _ptr(c), nb * cout, float(bn.eps), _stream()),
@@ -414,7 +549,10 @@ class _LinearBNAct(torch.autograd.Function):
         R, cin = x.shape
         cout = weight.shape[0]
         W = weight.view(cout, cin)
-        own = _own_gemm(x, weight, bn)
+        x6f, x6d = _x6(x, weight, bn, 1, "fwd"), _x6(x, weight, bn, 1, "dgrad")
+        own = x6f or _own_gemm(x, weight, bn)
+        pf, pd = _planes(lib, weight, 1, cout, cin, x6f, x6d) if x6f or x6d else (None, None)
+        pf, pd = (pf if x6f else None), (pd if x6d else None)
         res = None if residual is None else residual.contiguous()
         if nchw is None:
             dt, code = _tm_dtype(out_lowp)
@@ -428,12 +566,12 @@ class _LinearBNAct(torch.autograd.Function):
         two = scale is None and _bn2(bn, x if own else torch.empty(0, dtype=_F32))
         sync = None
         if own and two:                               # projection kernel (statistics in its epilogue) -> apply: 2 kernels
-            Y = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, stats_only=True)[0]
+            Y = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, stats_only=True, planes=pf)[0]
             a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 0, res, out, R, cout, 1, cout, 0, act, code,
                                             0 if nchw is None else nchw[0])
         else:
             if own:
-                Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1)
+                Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
             else:
                 Y = _mm_t(x, W, w16)
                 if two:                               # vendor GEMM -> statistics (atomics) -> apply (inline finalize)
@@ -456,6 +594,7 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.own = own and OWN_GEMM == "all"
+        ctx.pd = pd
         return out
 
     @staticmethod
@@ -488,7 +627,14 @@ class _LinearBNAct(torch.autograd.Function):
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (cout, cin), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
         W = weight.view(cout, cin)
-        dx = torch.mm(dY, W)
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif ctx.pd is not None:
+            dx = torch.empty((R, cin), dtype=_F32, device=dY.device)
+            _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), cout, R * cout, _ptr(ctx.pd), _ptr(dx), R, cin, cout, 1, _stream()),
+                       "gkg_linear_dgrad_x6")
+        else:
+            dx = torch.mm(dY, W)
         dW = _wgrad(dY, x, dWv).view_as(weight)
         return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
@@ -504,7 +650,10 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         cout = weight.shape[0]
         co = cout // nb
         Wg = weight.view(nb, co, ci)
-        own = _own_gemm(U, weight, bn) and act == 1
+        x6f, x6d = _x6(U, weight, bn, nb, "fwd") and act == 1, _x6(U, weight, bn, nb, "dgrad")
+        own = x6f or (_own_gemm(U, weight, bn) and act == 1)
+        pf, pd = _planes(lib, weight, nb, co, ci, x6f, x6d) if x6f or x6d else (None, None)
+        pf, pd = (pf if x6f else None), (pd if x6d else None)
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((R, cout), dtype=dt, device=U.device)
         sync = None
@@ -512,10 +661,10 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         if own:
             U = U.contiguous()
             if two:
-                Y = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, stats_only=True)[0]
+                Y = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, stats_only=True, planes=pf)[0]
                 a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 0, None, out, R, co, nb, cout, co, act, code, 0)
             else:
-                Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb)
+                Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, planes=pf)
         else:
             if U.dtype == torch.bfloat16:
                 Wb = weight.to(torch.bfloat16) if w16 is None else w16
@@ -538,6 +687,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.own = own and OWN_GEMM == "all"
+        ctx.pd = pd
         return out
 
     @staticmethod
@@ -559,7 +709,14 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (nb, co, ci), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync)
         Wg = weight.view(nb, co, ci)
-        dU = torch.bmm(dY, Wg)
+        if not ctx.needs_input_grad[0]:
+            dU = None
+        elif ctx.pd is not None:
+            dU = torch.empty((nb, R, ci), dtype=_F32, device=dY.device)
+            _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), co, R * co, _ptr(ctx.pd), _ptr(dU), R, ci, co, nb, _stream()),
+                       "gkg_linear_dgrad_x6")
+        else:
+            dU = torch.bmm(dY, Wg)
         dW = _wgrad_grouped(dY, U, dWv).view_as(weight)
         return dU, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 

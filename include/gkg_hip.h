@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 4
+#define GKG_ABI_VERSION 5
 
 /* dtype codes */
 #define GKG_F32 0
@@ -59,6 +59,8 @@ extern "C" {
 
 /* ABI version of the loaded library (== GKG_ABI_VERSION it was built with). */
 int gkg_version(void);
+/* Identifier of the hipGraph capture `stream` is recording into; 0 when it is not capturing. */
+unsigned long long gkg_stream_capture_id(void* stream);
 
 /* Human-readable description of the last non-zero return on this thread ("" if none). */
 const char* gkg_last_error_string(void);
@@ -218,6 +220,36 @@ int gkg_bn_bwd_coef(const float* dout, const float* y, const float* a, const flo
 int gkg_linear_bn_bwd(const float* dz, int ldg, size_t g_bstride, const float* y, const float* coef, const float* x,
                       const float* w, float* dx, float* dw, int R, int cin, int cout, int nb, unsigned flags,
                       void* workspace, size_t workspace_bytes, unsigned* counters, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The same projections on the bf16 matrix cores at fp32 accuracy (csrc/gkg_gemm_x6.hip): every fp32 operand is split
+ * exactly into three bf16 terms and six of the nine cross products are accumulated in fp32 (error vs fp64 measured 3-4x
+ * BELOW the fp32-MFMA kernels above).  The WEIGHTS are split ahead of time into bf16 "planes", once per optimiser step and
+ * for all layers in one launch; the activations are split inside the GEMM.  Replaces the same reference lines as
+ * gkg_linear_bn_fwd (torch_vertex.py:290-306, torch_nn.py:57-69, torch_vertex.py:334-360) and the input-gradient half of
+ * gkg_linear_bn_bwd; the weight gradient stays with gkg_linear_bn_bwd / the vendor GEMM.
+ *   gkg_x6_planes_bytes     bytes of one orientation's planes of a weight w (nb, cout, cin): dgrad = 0 forward, 1 dgrad
+ *   gkg_x6_prep_desc_bytes  size of one descriptor of the batched split
+ *   gkg_x6_prep_desc_fill   writes descriptor `index` into a HOST array (device pointers inside; one of the two plane
+ *                           pointers may be NULL: that orientation is skipped); returns the running unit count to pass
+ *                           as `unit_begin` of the next descriptor (-1: bad arguments)
+ *   gkg_x6_prep_weights     ONE launch: every described weight -> its forward and dgrad planes.  `descs_dev`: the array
+ *                           copied to device memory; total_units: the last gkg_x6_prep_desc_fill return value
+ *   gkg_linear_bn_fwd_x6    gkg_linear_bn_fwd with `planes_fwd` instead of w; x has row pitch ldx and batch stride
+ *                           x_bstride (floats; a column slice of a wider matrix is allowed); same train modes / outputs
+ *   gkg_linear_dgrad_x6     dx (nb, R, cin) = dy (nb, R, cout; pitch ldg, batch stride g_bstride) w
+ * Rows must be 16-byte aligned (base pointer % 16 == 0, pitches % 4 == 0); each batch of x / dy below 4 GiB. */
+size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad);
+int gkg_x6_prep_desc_bytes(void);
+long long gkg_x6_prep_desc_fill(void* host_descs, int index, const float* w, void* planes_fwd, void* planes_dgrad, int cin,
+                                int cout, int nb, long long unit_begin);
+int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long total_units, void* stream);
+int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R, int cin,
+                         int cout, int nb, int train, const float* gamma, const float* beta, const float* bias,
+                         float* running_mean, float* running_var, long long* num_batches_tracked, float* bn_a, float* bn_c,
+                         float* bn_mean, float* bn_invstd, float momentum, float eps, double* stats, void* stream);
+int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R, int cin,
+                        int cout, int nb, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Two-kernel train-mode BN (the form the fused block uses when batch statistics are local to the rank): a producer

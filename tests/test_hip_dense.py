@@ -7,18 +7,21 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["none", "none-bn3", "fwd", "fwd-bn3", "all", "all-deterministic"])
+@pytest.fixture(params=["none", "none-bn3", "fwd", "fwd-bn3", "all", "all-deterministic", "x6", "x6-bn3", "x6all"])
 def gemm_mode(request):
     """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("none"), with the
-    own forward kernel (BN statistics in the epilogue, the default) and with own forward + dgrad + wgrad kernels (BN
-    backward-apply as operand prologue; atomic or ordered split reduction)."""
+    own fp32-MFMA forward kernel (BN statistics in the epilogue), with own fp32-MFMA forward + dgrad + wgrad kernels (BN
+    backward-apply as operand prologue; atomic or ordered split reduction), and with the split-bf16 ("x6", the default)
+    forward + dgrad kernels — alone and ("x6all") combined with the fp32-MFMA wgrad / dgrad kernels."""
     from gkgnet_amd import fused
-    old = (fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL)
-    fused.OWN_GEMM = request.param.split("-")[0]
+    old = (fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL, fused.GEMM_MATH)
+    mode = request.param.split("-")[0]
+    fused.GEMM_MATH = "x6all" if mode.startswith("x6") else "f32"
+    fused.OWN_GEMM = {"x6": "auto", "x6all": "all"}.get(mode, mode)
     fused.DETERMINISTIC = request.param.endswith("deterministic")
     fused.BN_TWO_KERNEL = not request.param.endswith("bn3")      # "-bn3": three-kernel BN (two-stage ordered sums)
     yield request.param
-    fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL = old
+    fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL, fused.GEMM_MATH = old
 
 
 def _bn(C):

@@ -1,0 +1,168 @@
+"""The split-bf16 ("x6") projection kernels through the C ABI (csrc/gkg_gemm_x6.hip): forward with BN statistics and the
+input gradient, against fp64 evaluations.  The accuracy bar is the fp32 one: the error must not exceed what a plain fp32
+GEMM (torch) makes on the same operands — measured it is 3-4x smaller."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes(lib, w, nb, cout, cin):
+    """Forward / dgrad planes of w (nb, cout, cin) through the batched prep entry points."""
+    pf = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device="cuda")
+    pd = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device="cuda")
+    host = ctypes.create_string_buffer(lib.gkg_x6_prep_desc_bytes())
+    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), pd.data_ptr(), cin, cout, nb, 0)
+    assert units > 0
+    descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).cuda()
+    assert lib.gkg_x6_prep_weights(descs.data_ptr(), 1, units, None) == 0
+    torch.cuda.synchronize()
+    return pf, pd
+
+
+def _rel(a, ref, scale):
+    return float(((a.double() - ref).abs() / scale).max())
+
+
+# (R, cin, cout, nb): cfg2's layers, ragged rows, K not a multiple of 32 (36, 400), N below one tile, grouped (nb = 4)
+SHAPES = [(10368, 320, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1), (10368, 160, 160, 4), (777, 36, 40, 1),
+          (4100, 400, 400, 1), (129, 64, 8, 2), (19, 16, 8, 1), (128, 32, 64, 1)]
+
+
+@pytest.mark.parametrize("R,cin,cout,nb", SHAPES)
+def test_forward_and_dgrad_at_fp32_accuracy(R, cin, cout, nb):
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(R * 7 + cin)
+    x = torch.randn(nb, R, cin, device="cuda", generator=gen) * 2
+    w = torch.randn(nb, cout, cin, device="cuda", generator=gen) * 0.1
+    dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
+    pf, pd = _planes(lib, w, nb, cout, cin)
+    y = torch.full((nb, R, cout), float("nan"), device="cuda")
+    _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 0,
+                                        *([None] * 10), 0.0, 0.0, None, None), "fwd")
+    dx = torch.full((nb, R, cin), float("nan"), device="cuda")
+    _lib.check(lib.gkg_linear_dgrad_x6(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb, None),
+               "dgrad")
+    ref_y = torch.bmm(x.double(), w.double().transpose(1, 2))
+    ref_dx = torch.bmm(dy.double(), w.double())
+    mag_y = torch.bmm(x.double().abs(), w.double().abs().transpose(1, 2)) + 1e-30      # sum |a b|: the fp32 bound's scale
+    mag_dx = torch.bmm(dy.double().abs(), w.double().abs()) + 1e-30
+    e_y, e_dx = _rel(y, ref_y, mag_y), _rel(dx, ref_dx, mag_dx)
+    f_y = _rel(torch.bmm(x, w.transpose(1, 2)), ref_y, mag_y)                         # what plain fp32 makes of it
+    f_dx = _rel(torch.bmm(dy, w), ref_dx, mag_dx)
+    assert e_y <= max(f_y, 1.2e-7) and e_dx <= max(f_dx, 1.2e-7), (e_y, f_y, e_dx, f_dx)
+    assert e_y < 2e-7 and e_dx < 2e-7                                                   # 2^-23 .. 2^-22 of sum |a b|
+
+
+def test_column_slices_and_row_pitch():
+    """x as a column slice of a wider token-major matrix (the grouped projection's operand) and dy with a row pitch."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    R, cin, cout, nb = 900, 32, 48, 4
+    wide = torch.randn(R, nb * cin, device="cuda")                 # group q = columns [q*cin, (q+1)*cin)
+    w = torch.randn(nb, cout, cin, device="cuda") * 0.2
+    pf, pd = _planes(lib, w, nb, cout, cin)
+    y = torch.empty(nb, R, cout, device="cuda")
+    _lib.check(lib.gkg_linear_bn_fwd_x6(wide.data_ptr(), nb * cin, cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 0,
+                                        *([None] * 10), 0.0, 0.0, None, None), "fwd")
+    want = torch.einsum("rqk,qnk->qrn", wide.view(R, nb, cin).double(), w.double())
+    assert torch.allclose(y.double(), want, atol=1e-5, rtol=1e-5)
+    dyw = torch.randn(R, nb * cout, device="cuda")
+    dx = torch.empty(nb, R, cin, device="cuda")
+    _lib.check(lib.gkg_linear_dgrad_x6(dyw.data_ptr(), nb * cout, cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb, None),
+               "dgrad")
+    want = torch.einsum("rqn,qnk->qrk", dyw.view(R, nb, cout).double(), w.double())
+    assert torch.allclose(dx.double(), want, atol=1e-5, rtol=1e-5)
+
+
+def test_train_statistics_epilogue():
+    """train = 1: BN scale / shift / saved statistics / running statistics from the epilogue's fp64 column sums."""
+    from gkgnet_amd import _lib, fused
+    lib = _lib.load()
+    torch.manual_seed(5)
+    R, cin, cout = 3001, 96, 72
+    x = torch.randn(R, cin, device="cuda") + 3.0                     # a large mean against the spread
+    w = torch.randn(cout, cin, device="cuda") * 0.1
+    pf, _ = _planes(lib, w, 1, cout, cin)
+    gamma, beta, bias = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda"), torch.randn(cout, device="cuda")
+    rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    a, c, mean, invstd = (torch.empty(cout, device="cuda") for _ in range(4))
+    y = torch.empty(R, cout, device="cuda")
+    stats = fused._stats_scratch(x.device)
+    _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, 1, 1,
+                                        gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                        nbt.data_ptr(), a.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), 0.1,
+                                        1e-5, stats.data_ptr(), None), "fwd train")
+    yd = x.double() @ w.double().t()
+    m, v = yd.mean(0), yd.var(0, unbiased=False)
+    assert torch.allclose(mean.double(), m, atol=1e-5) and torch.allclose(invstd.double(), (v + 1e-5).rsqrt(), rtol=1e-5)
+    assert torch.allclose(a.double(), gamma.double() * (v + 1e-5).rsqrt(), rtol=1e-5)
+    assert torch.allclose(c.double(), beta.double() - gamma.double() * (v + 1e-5).rsqrt() * m, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(rm.double(), 0.1 * (m + bias.double()), atol=1e-5)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * yd.var(0, unbiased=True), rtol=1e-5)
+    assert int(nbt) == 1 and float(stats.abs().max()) == 0.0          # the scratch is clean again
+
+
+def test_planes_follow_the_parameter(monkeypatch):
+    """The fused layer re-splits its weight after an in-place update (optimiser step) and after the storage is replaced."""
+    from gkgnet_amd import fused
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    torch.manual_seed(9)
+    R, cin, cout = 640, 64, 64
+    conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+    bn = torch.nn.BatchNorm2d(cout).cuda().train()
+    x = torch.randn(R, cin, device="cuda")
+
+    def run():
+        return fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 0, None)
+
+    def want():
+        y = x.double() @ conv.weight.detach().double().view(cout, cin).t()
+        return ((y - y.mean(0)) * (y.var(0, unbiased=False) + bn.eps).rsqrt() * bn.weight.detach().double()
+                + bn.bias.detach().double())
+
+    assert torch.allclose(run().double(), want(), atol=1e-4)
+    with torch.no_grad():
+        conv.weight.mul_(-0.5).add_(0.01)                              # in place: version counter moves
+    assert torch.allclose(run().double(), want(), atol=1e-4)
+    with torch.no_grad():
+        conv.weight.data = torch.randn_like(conv.weight) * 0.1         # new storage
+    assert torch.allclose(run().double(), want(), atol=1e-4)
+
+
+def test_captured_step_resplits_the_weights(monkeypatch):
+    """A hipGraph-captured step sees weight updates made between replays (the capture holds the refresh launch)."""
+    from gkgnet_amd import fused
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    torch.manual_seed(11)
+    R, cin, cout = 512, 32, 32
+    conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+    bn = torch.nn.BatchNorm2d(cout).cuda().train()
+    x = torch.randn(R, cin, device="cuda")
+
+    def step():
+        with torch.no_grad():
+            return fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 0, None)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()                                                     # eager warm-up registers the weight
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn_like(conv.weight) * 0.3)
+    g.replay()
+    torch.cuda.synchronize()
+    y = x.double() @ conv.weight.detach().double().view(cout, cin).t()
+    want = (y - y.mean(0)) * (y.var(0, unbiased=False) + bn.eps).rsqrt() * bn.weight.detach().double() + bn.bias.detach().double()
+    assert torch.allclose(out.double(), want, atol=1e-4)
