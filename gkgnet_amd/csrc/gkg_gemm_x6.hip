@@ -30,6 +30,7 @@
 //   * XCD-aware 1-D grid: the column tiles of one 128-row block run back to back on one XCD, so the row block is fetched
 //     from HBM into that L2 once.
 #include "gkg_common.h"
+#include <stdlib.h>
 
 namespace gkg {
 
@@ -143,7 +144,9 @@ template <int NI, int EPI>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   constexpr int BM = 128, BN = 32 * NI, BK = 32, SA = 3;
   constexpr int A_STAGE = 4 * 4096, B_STAGE = 12 * BN * 16, B_BASE = SA * A_STAGE;
-  constexpr int BI = 12 * BN / 64 / 4;                   // B DMA pieces per wave per K-step
+  constexpr int PIECES = 12 * BN * 16 / 1024;            // 1-KiB pieces of one B stage image
+  constexpr int BI = (PIECES + 3) / 4;                   // ... per wave per K-step (wave w: pieces w, w+4, ...), and the
+  constexpr int BI_MIN = PIECES / 4;                     // fewest any wave issues: what the counted waits may assume
   extern __shared__ uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int z = blockIdx.y;
@@ -169,13 +172,13 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
     achunk[i] = chunk;
   }
   const size_t plane = (size_t)g.KC * g.NP * 16;
-  unsigned boff[BI], bdst[BI];
+  // B pieces: slot s = 64 piece + lane of the stage image [3 planes][4 chunks][BN] holds n = s % BN of row s / BN (a piece
+  // may straddle two rows when BN is not a multiple of 64: the source address is per lane, the destination linear)
+  unsigned boff[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int piece = w + 4 * i;
-    const int rowid = piece * 64 / BN, p = rowid >> 2, chunk = rowid & 3, nb = (piece * 64) % BN;
-    boff[i] = (unsigned)(p * plane + ((size_t)chunk * g.NP + n0 + nb + lane) * 16);
-    bdst[i] = piece * 1024;
+    const int sidx = (w + 4 * i) * 64 + lane, rowid = sidx / BN, n = sidx - rowid * BN, p = rowid >> 2, chunk = rowid & 3;
+    boff[i] = (unsigned)(p * plane + ((size_t)chunk * g.NP + n0 + n) * 16);
   }
   auto dma_a = [&](int kt) {
     const char* base = (const char*)A + (size_t)kt * (BK * 4);
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
     const char* base = (const char*)P + (size_t)kt * 4 * g.NP * 16;
     const unsigned dst = lds0 + B_BASE + (kt & 1) * B_STAGE;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) x6_dma16(base, boff[i], dst + bdst[i]);
+    for (int i = 0; i < BI; ++i)
+      if ((i + 1) * 4 <= PIECES || w + 4 * i < PIECES) x6_dma16(base, boff[i], dst + (w + 4 * i) * 1024);
   };
 
   x6_f32x16 acc[NI], accs[NI];
@@ -290,8 +294,8 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   dma_a(0); dma_b(0);
   if (nk > 1) { dma_a(1); dma_b(1); }
   if (nk > 2) dma_a(2);
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + BI) : "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + BI) : "memory");
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + BI_MIN) : "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + BI_MIN) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_raw(0, 0); read_b(0, 0, 0);
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
 }
 
 template <int NI, int EPI>
-static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
+static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
   constexpr int BN = 32 * NI;
   a.mtiles = (a.M + 127) / 128;
   a.ntiles = (a.N + BN - 1) / BN;
@@ -377,6 +381,22 @@ static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
   const int groups = (a.mtiles + 7) / 8;
   hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
   return hipGetLastError();
+}
+
+// Column-tile width (32 NI).  More columns per wave amortise the 44-instruction A split over more MFMAs (NI = 1 is
+// VALU-bound, NI = 2 about balanced) but leave fewer workgroups: NI = 2, and NI = 1 when that leaves the chip under-filled
+// (few rows: the label branch).  Measured cold-cache per shape with tools/bench_x6.py; NI = 5 (160 columns, one
+// workgroup per CU) was tried and is slower everywhere (cfg2 fc1 25.8 vs 22.9 us).  GKG_X6_NI=1|2 (read per call) forces one.
+template <int EPI>
+static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
+  const int mt = (a.M + 127) / 128;
+  int ni = (long long)mt * ((a.N + 63) / 64) * nb < 160 ? 1 : 2;
+  if (const char* f = getenv("GKG_X6_NI")) {
+    const int v = atoi(f);
+    if (v == 1 || v == 2) ni = v;
+  }
+  if (ni == 1) return x6_launch_ni<1, EPI>(a, nb, st);
+  return x6_launch_ni<2, EPI>(a, nb, st);
 }
 
 inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
@@ -447,13 +467,13 @@ extern "C" int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, c
       if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: running stats come in pairs");
     }
     a.sums = stats;
-    e = x6_launch<2, X6_BNSTATS>(a, nb, st);
+    e = x6_launch<X6_BNSTATS>(a, nb, st);
     if (e == hipSuccess && train != 2) {
       e = launch_bn_sums_finalize(stats, R, cout, nb, gamma, beta, bias, running_mean, running_var, bn_a, bn_c, bn_mean,
                                   bn_invstd, momentum, eps, num_batches_tracked, st);
     }
   } else {
-    e = x6_launch<2, X6_STORE>(a, nb, st);
+    e = x6_launch<X6_STORE>(a, nb, st);
   }
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (forward)");
 }
@@ -472,6 +492,6 @@ extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.P = (const uint4*)planes_dgrad; a.p_bstride = (size_t)3 * a.KC * a.NP;
   a.C = dx; a.c_bstride = (size_t)R * cin; a.ldc = cin;
   a.M = R; a.N = cin; a.K = cout;
-  hipError_t e = x6_launch<2, X6_STORE>(a, nb, (hipStream_t)stream);
+  hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad)");
 }

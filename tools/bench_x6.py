@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-shape timing of the x6 projection kernels (forward store-only / forward + BN statistics / dgrad) for each column
+tile width against the vendor fp32 GEMM (torch.mm / bmm, TunableOp off), with the operands evicted from L2 between
+launches by a 512 MB sweep (in-step conditions).    python tools/bench_x6.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gkgnet_amd import _lib, fused
+
+lib = _lib.load()
+SHAPES = [(10368, 320, 320, 1), (10368, 160, 160, 4), (10368, 640, 320, 1), (10368, 320, 640, 1), (2560, 320, 320, 1),
+          (2560, 160, 160, 4), (2560, 640, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1), (41472, 400, 400, 1),
+          (41472, 800, 400, 1)]
+flush = torch.empty(128 << 20, dtype=torch.float32, device="cuda")
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    tot = 0.0
+    for _ in range(n):
+        flush.add_(1.0)                      # sweep 512 MB through the caches
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize()
+        tot += a.elapsed_time(b)
+    return 1e3 * tot / n
+
+
+def planes(w, nb, cout, cin):
+    pf = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device="cuda")
+    pd = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device="cuda")
+    host = ctypes.create_string_buffer(lib.gkg_x6_prep_desc_bytes())
+    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), pd.data_ptr(), cin, cout, nb, 0)
+    descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).cuda()
+    _lib.check(lib.gkg_x6_prep_weights(descs.data_ptr(), 1, units, None), "prep")
+    return pf, pd
+
+
+for R, cin, cout, nb in SHAPES:
+    x = torch.randn(nb, R, cin, device="cuda"); w = torch.randn(nb, cout, cin, device="cuda") * 0.1
+    dy = torch.randn(nb, R, cout, device="cuda")
+    y = torch.empty(nb, R, cout, device="cuda"); dx = torch.empty(nb, R, cin, device="cuda")
+    pf, pd = planes(w, nb, cout, cin)
+    stats = fused._stats_scratch(x.device)
+    line = f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: vendor fwd {timeit(lambda: torch.bmm(x, w.transpose(1, 2), out=y)):6.1f} dgrad {timeit(lambda: torch.bmm(dy, w, out=dx)):6.1f} |"
+    for ni in ("auto", "1", "2"):
+        if ni == "auto":
+            os.environ.pop("GKG_X6_NI", None)
+        else:
+            os.environ["GKG_X6_NI"] = ni
+        f = timeit(lambda: lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 0,
+                                                    *([None] * 10), 0.0, 0.0, None, None))
+        fs = timeit(lambda: lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
+                                                     *([None] * 10), 0.0, 0.0, stats.data_ptr(), None))
+        stats.zero_()
+        d = timeit(lambda: lib.gkg_linear_dgrad_x6(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb, None))
+        line += f" NI={ni}: fwd {f:5.1f} +stats {fs:5.1f} dgrad {d:5.1f} |"
+    print(line, flush=True)
