@@ -34,7 +34,8 @@ namespace gkg {
 // gkg_gemm.hip: BN scale / shift / saved statistics / running-stat update from the fp64 column sums (re-zeroes them)
 hipError_t launch_bn_sums_finalize(double* stats, int R, int cout, int nb, const float* gamma, const float* beta,
                                    const float* bias, float* running_mean, float* running_var, float* bn_a, float* bn_c,
-                                   float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st);
+                                   float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st,
+                                   int nslots = 1);
 }  // namespace gkg
 
 // Records the message for gkg_last_error_string() and returns `code`.

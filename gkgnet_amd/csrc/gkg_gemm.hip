@@ -458,14 +458,19 @@ __global__ __launch_bounds__(256) void bn_sums_finalize_kernel(double* __restric
                                                                float* __restrict__ running_var, float* __restrict__ a,
                                                                float* __restrict__ cs, float* __restrict__ mean,
                                                                float* __restrict__ invstd, float momentum, float eps,
-                                                               long long* __restrict__ nbt) {
+                                                               long long* __restrict__ nbt, int nslots, int nb) {
   const int ch = blockIdx.x * 256 + threadIdx.x;
   const int q = blockIdx.y;
   if (nbt && ch == 0 && q == 0) *nbt += 1;
   if (ch >= C) return;
-  double* sz = sums + (size_t)q * 2 * C + ch;
-  const double S = sz[0], Q = sz[C];
-  sz[0] = 0.0; sz[C] = 0.0;
+  // `nslots` copies of the sums ([slot][nb][2][C]): producers with thousands of row tiles spread their atomics over the
+  // copies (same-address fp64 atomics serialise); added here in slot order
+  double S = 0.0, Q = 0.0;
+  for (int sl = 0; sl < nslots; ++sl) {
+    double* sz = sums + ((size_t)sl * nb + q) * 2 * C + ch;
+    S += sz[0]; Q += sz[C];
+    sz[0] = 0.0; sz[C] = 0.0;
+  }
   const double m = S / R;
   double var = Q / R - m * m;
   if (var < 0.0) var = 0.0;
@@ -486,9 +491,10 @@ __global__ __launch_bounds__(256) void bn_sums_finalize_kernel(double* __restric
 
 hipError_t launch_bn_sums_finalize(double* stats, int R, int cout, int nb, const float* gamma, const float* beta,
                                    const float* bias, float* running_mean, float* running_var, float* bn_a, float* bn_c,
-                                   float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st) {
+                                   float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st,
+                                   int nslots) {
   hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3((cout + 255) / 256, nb), dim3(256), 0, st, stats, R, cout, gamma, beta,
-                     bias, running_mean, running_var, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, nbt);
+                     bias, running_mean, running_var, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, nbt, nslots, nb);
   return hipGetLastError();
 }
 
@@ -590,7 +596,7 @@ extern "C" int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R
     e = launch<32, 64, 64, 2, 2, LAY_KQ, LAY_KQ, false, EPI_BNSTATS>(a, nb, st);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3((cout + 255) / 256, nb), dim3(256), 0, st, stats, R, cout, gamma, beta,
-                         bias, running_mean, running_var, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, num_batches_tracked);
+                         bias, running_mean, running_var, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, num_batches_tracked, 1, nb);
       e = hipGetLastError();
     }
   } else {

@@ -117,7 +117,7 @@ struct X6Args {
   int M, N, K;
   int NP, KC;                                           // plane geometry (padded n, k/8 chunks)
   int mtiles, ntiles;
-  double* sums;                                         // EPI_BNSTATS: [nb][2][N] fp64, accumulated with atomics
+  double* sums;  int nslots, nbatch;                    // EPI_BNSTATS: [nslots][nb][2][N] fp64, accumulated with atomics
 };
 
 enum { X6_STORE = 0, X6_BNSTATS = 1 };
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
       const int c = max(0, min(32, M - (m0 + rg * 32)));
       x6_chan_merge(n, mean, m2, (double)c, (double)red[(rg * BN + tid) * 2], (double)red[(rg * BN + tid) * 2 + 1]);
     }
-    double* sz = g.sums + (size_t)z * 2 * N + n0 + tid;
+    double* sz = g.sums + ((size_t)(tm % g.nslots) * g.nbatch + z) * 2 * N + n0 + tid;
     __hip_atomic_fetch_add(sz, n * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(sz + N, m2 + n * mean * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -397,6 +397,161 @@ static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
   }
   if (ni == 1) return x6_launch_ni<1, EPI>(a, nb, st);
   return x6_launch_ni<2, EPI>(a, nb, st);
+}
+
+// ---- weight gradient ----------------------------------------------------------------------------------------------------
+// dW[m][n] = sum_k dY[k][m] X[k][n]: the contraction runs over the token axis, so BOTH operands are activations (split in
+// registers) and both are "k-strided" for the matrix core, whose operand lane (r, h) wants 8 consecutive k of ONE column.
+// Here that is 8 dword loads of 8 consecutive rows at a fixed column — lanes r = consecutive columns, so every load
+// instruction is two fully used 128-B row segments — straight from global/L2 into registers: no LDS, no barriers, each
+// wave streams its own K range.  A workgroup = one 64 x 64 tile of dW x one slab of rows; its 4 waves take a quarter of
+// the slab each (2 x 2 blocks of 32 x 32 per wave: 24 MFMAs per 16 rows), add their tiles through LDS and issue ONE set of
+// fp32 atomics into the pre-zeroed dW (summation order over slabs is run-dependent, like the vendor library's split-K).
+// Loads run three 16-row steps ahead in a 3-deep register ring; the 176-instruction split of the next step's four
+// fragments sits in the MFMA gaps (7-8 per gap: this kernel is VALU-bound at ~1.6x the matrix time — for the long-K,
+// small-output shapes it exists for it is the HBM stream that sets the time).
+struct X6WgradArgs {
+  const float* A;  size_t a_bstride;  int lda;       // dY (nb, K, M)
+  const float* B;  size_t b_bstride;  int ldb;       // X  (nb, K, N)
+  float* C;  size_t c_bstride;  int ldc;             // dW (nb, M, N), zero on entry
+  int M, N, K;
+  int mtiles, ntiles, splits, rows_per_split;        // rows_per_split % 128 == 0
+};
+
+typedef unsigned x6_u32x4 __attribute__((ext_vector_type(4)));
+typedef x6_u32x4 X6WFrag[4][3];               // [A0, A1, B0, B1][hi, mid, lo]: 4 packed bf16 pairs = one MFMA operand each
+
+__device__ __forceinline__ x6_bf16x8 x6w_operand(const x6_u32x4& f) { return __builtin_bit_cast(x6_bf16x8, f); }
+// step I (0..175) of the split of four raw fragments into `fn`: block I / 44, and within a block the four pairs
+// interleaved (4 independent chains).  Single-instruction asm volatile: fixed order, not sunk, not SLP-packed.
+template <int I>
+__device__ __forceinline__ void x6w_op(float (&raw)[4][8], X6WFrag& fn, unsigned (&t0)[4], unsigned (&t1)[4]) {
+  constexpr int blk = I / 44, u = I % 44, p = u & 3, o = u >> 2;
+  float& x0 = raw[blk][2 * p]; float& x1 = raw[blk][2 * p + 1];
+  unsigned w;
+  if constexpr (o == 0) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][0][p] = w; }
+  if constexpr (o == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0[p]) : "v"(fn[blk][0][p]));
+  if constexpr (o == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1[p]) : "v"(fn[blk][0][p]));
+  if constexpr (o == 3) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(t0[p]));
+  if constexpr (o == 4) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x1) : "v"(t1[p]));
+  if constexpr (o == 5) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][1][p] = w; }
+  if constexpr (o == 6) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0[p]) : "v"(fn[blk][1][p]));
+  if constexpr (o == 7) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1[p]) : "v"(fn[blk][1][p]));
+  if constexpr (o == 8) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(t0[p]));
+  if constexpr (o == 9) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x1) : "v"(t1[p]));
+  if constexpr (o == 10) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][2][p] = w; }
+}
+template <int I, int END>
+__device__ __forceinline__ void x6w_ops(float (&raw)[4][8], X6WFrag& fn, unsigned (&t0)[4], unsigned (&t1)[4]) {
+  if constexpr (I < END && I < 176) { x6w_op<I>(raw, fn, t0, t1); x6w_ops<I + 1, END>(raw, fn, t0, t1); }
+}
+// MFMA slot SI (0..23) of a 16-row step: block (i, j) = SI / 6, product t = SI % 6; then 8 split steps in its shadow
+template <int SI, bool SPLIT>
+__device__ __forceinline__ void x6w_slots(const X6WFrag& fc, X6WFrag& fn, x6_f32x16 (&acc)[2][2], x6_f32x16 (&accs)[2][2],
+                                          float (&raw)[4][8], unsigned (&t0)[4], unsigned (&t1)[4]) {
+  if constexpr (SI < 24) {
+    constexpr int i = SI / 12, j = (SI / 6) & 1, t = SI % 6;
+    constexpr int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;         // small terms first, hi*hi last into its own accumulator
+    constexpr int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+    if constexpr (t < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x6w_operand(fc[i][pa]), x6w_operand(fc[2 + j][pb]), accs[i][j], 0, 0, 0);
+    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x6w_operand(fc[i][0]), x6w_operand(fc[2 + j][0]), acc[i][j], 0, 0, 0);
+    if constexpr (SPLIT) x6w_ops<SI * 8, SI * 8 + 8>(raw, fn, t0, t1);
+    __builtin_amdgcn_sched_barrier(0);
+    x6w_slots<SI + 1, SPLIT>(fc, fn, acc, accs, raw, t0, t1);
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_x6_kernel(X6WgradArgs g) {
+  __shared__ float red[4 * 64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.y;
+  // XCD-aware: the tiles of one row slab run on one XCD (its rows are fetched into that L2 once)
+  const int ntile = g.mtiles * g.ntiles;
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+  if (split >= g.splits) return;
+  const int m0 = (tile / g.ntiles) * 64, n0 = (tile % g.ntiles) * 64;
+  const int r = lane & 31, h = lane >> 5;
+  const int rows_per_wave = g.rows_per_split >> 2;
+  const long long k_begin = (long long)split * g.rows_per_split + (long long)w * rows_per_wave;
+  const int T = rows_per_wave >> 4;                                  // 16-row steps of this wave (even)
+  const char* Az = (const char*)(g.A + (size_t)z * g.a_bstride);
+  const char* Bz = (const char*)(g.B + (size_t)z * g.b_bstride);
+  const long long abytes = (long long)g.K * g.lda * 4, bbytes = (long long)g.K * g.ldb * 4;
+
+  // per-lane byte offset of each fragment's first row (8 h) at its column; the 8 rows j of a fragment come from 8
+  // descriptors whose base is advanced by j rows (so the hardware range check stays exact at the end of the tensor);
+  // columns outside the matrix get an offset no range check passes
+  unsigned off[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = m0 + 32 * i + r, cb = n0 + 32 * i + r;
+    off[i] = ca < g.M ? (unsigned)((8 * h * g.lda + ca) * 4) : 0xfffffff0u;
+    off[2 + i] = cb < g.N ? (unsigned)((8 * h * g.ldb + cb) * 4) : 0xfffffff0u;
+  }
+  auto load = [&](float (&raw)[4][8], int s) __attribute__((always_inline)) {
+    const long long row0 = k_begin + 16ll * s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long ao = (row0 + j) * g.lda * 4, bo = (row0 + j) * g.ldb * 4;
+      const long long ra_ = abytes - ao, rb_ = bbytes - bo;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Az + (ra_ > 0 ? ao : 0)), 0,
+                                                                          (int)(ra_ > 0 ? (ra_ > 0x7fffffffll ? 0x7fffffffll : ra_) : 0), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Bz + (rb_ > 0 ? bo : 0)), 0,
+                                                                          (int)(rb_ > 0 ? (rb_ > 0x7fffffffll ? 0x7fffffffll : rb_) : 0), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        raw[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off[i], 0, 0));
+        raw[2 + i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, off[2 + i], 0, 0));
+      }
+    }
+  };
+  float raw0[4][8], raw1[4][8];                 // raw fragments two 16-row steps deep
+  X6WFrag fr0, fr1;
+  unsigned t0[4], t1[4];
+  x6_f32x16 acc[2][2], accs[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[i][j][q] = 0.f; accs[i][j][q] = 0.f; }
+
+  // one 16-row step s: MFMAs on `fc`; the gaps split `rs` (step s + 1) into `fn`; then `rs` is reloaded for step s + 3.
+  // The last step (no split) is peeled out of the loop: two variants of the MFMA chain inside it would put the
+  // accumulators behind phi nodes (the register allocator then copies whole tiles per MFMA).
+  load(raw0, 0);
+  if (T > 1) load(raw1, 1);
+  x6w_ops<0, 176>(raw0, fr0, t0, t1);
+  if (T > 2) load(raw0, 2);
+  for (int s = 0; s + 2 < T; s += 2) {          // buffer roles alternate: 2 steps per trip (T is even)
+    x6w_slots<0, true>(fr0, fr1, acc, accs, raw1, t0, t1);       // step s: splits step s+1 (raw1) ...
+    if (s + 3 < T) load(raw1, s + 3);                             // ... then raw1 <- step s+3
+    x6w_slots<0, true>(fr1, fr0, acc, accs, raw0, t0, t1);       // step s+1: splits step s+2 (raw0)
+    if (s + 4 < T) load(raw0, s + 4);
+  }
+  x6w_slots<0, true>(fr0, fr1, acc, accs, raw1, t0, t1);         // step T-2
+  x6w_slots<0, false>(fr1, fr0, acc, accs, raw0, t0, t1);        // step T-1
+
+  // ---- the four waves' tiles -> LDS -> one atomic add per element
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h, col = 32 * j + r;
+        red[w * 4096 + row * 64 + col] = acc[i][j][q] + accs[i][j][q];
+      }
+  __syncthreads();
+  float* C = g.C + (size_t)z * g.c_bstride;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+    const float v = (red[e] + red[4096 + e]) + (red[8192 + e] + red[12288 + e]);
+    if (m0 + row < g.M && n0 + col < g.N)
+      __hip_atomic_fetch_add(C + (size_t)(m0 + row) * g.ldc + n0 + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
@@ -466,11 +621,15 @@ extern "C" int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, c
       if (!gamma || !beta || !bn_a || !bn_c || !bn_mean || !bn_invstd) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: training needs gamma, beta and the four outputs");
       if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: running stats come in pairs");
     }
-    a.sums = stats;
+    a.sums = stats; a.nbatch = nb;
+    // copies of the sums to spread the row tiles' atomics over (train == 2 leaves the sums for a consumer that knows one copy)
+    const int fit = gkg_linear_stats_doubles() / (nb * 2 * cout), want = (R + 127) / 128 / 64;
+    a.nslots = train == 2 ? 1 : (want < 1 ? 1 : (want > 16 ? 16 : want));
+    if (a.nslots > fit) a.nslots = fit;
     e = x6_launch<X6_BNSTATS>(a, nb, st);
     if (e == hipSuccess && train != 2) {
       e = launch_bn_sums_finalize(stats, R, cout, nb, gamma, beta, bias, running_mean, running_var, bn_a, bn_c, bn_mean,
-                                  bn_invstd, momentum, eps, num_batches_tracked, st);
+                                  bn_invstd, momentum, eps, num_batches_tracked, st, a.nslots);
     }
   } else {
     e = x6_launch<X6_STORE>(a, nb, st);
@@ -494,4 +653,30 @@ extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.M = R; a.N = cin; a.K = cout;
   hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad)");
+}
+
+// dw (nb, cout, cin) += dy^T x over the R rows; dw must be ZERO on entry (the slabs of rows are added with fp32 atomics).
+// dy (nb, R, cout) row pitch ldg / batch stride g_bstride, x (nb, R, cin) row pitch ldx / batch stride x_bstride (floats).
+extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride,
+                                   float* dw, int R, int cin, int cout, int nb, void* stream) {
+  if (!dy || !x || !dw) return gkg_fail(GKG_ERR_NULL, "gkg_linear_wgrad_x6: null pointer");
+  if (R <= 0 || cin <= 0 || cout <= 0 || nb <= 0 || nb > 64 || ldg < cout || ldx < cin)
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6: need R, cin, cout > 0, 1 <= nb <= 64, pitches >= widths");
+  if ((size_t)ldg * 4 * 16 > 0x7fffffffull || (size_t)ldx * 4 * 16 > 0x7fffffffull) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_wgrad_x6: row pitch too large");
+  X6WgradArgs a{};
+  a.A = dy; a.a_bstride = g_bstride; a.lda = ldg;
+  a.B = x; a.b_bstride = x_bstride; a.ldb = ldx;
+  a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
+  a.M = cout; a.N = cin; a.K = R;
+  a.mtiles = (cout + 63) / 64; a.ntiles = (cin + 63) / 64;
+  // about one workgroup per CU: slabs of whole 128-row units (4 waves x 2 steps x 16 rows)
+  const int tiles = a.mtiles * a.ntiles * nb, units = (R + 127) / 128;
+  int splits = (240 + tiles / 2) / tiles;
+  splits = splits < 1 ? 1 : (splits > units ? units : splits);
+  a.rows_per_split = (units + splits - 1) / splits * 128;
+  a.splits = (R + a.rows_per_split - 1) / a.rows_per_split;
+  const int groups = (a.splits + 7) / 8;
+  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(groups * 8 * a.mtiles * a.ntiles, nb), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "wgrad_x6_kernel");
 }

@@ -179,6 +179,17 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
+def _x6_wgrad_ok(dY, x) -> bool:
+    """The streaming x6 weight-gradient kernel (gkg_linear_wgrad_x6: both operands split in registers, fragments loaded
+    straight from global memory, no operand sharing between workgroups).  Measured on MI355X it is NOT a win and is
+    only selected by GKG_GEMM_MATH=x6all (tests): against the vendor library's default kernels it is 1.3-1.6x faster on
+    GKGNet-576's stage-1/2 shapes (R = 663 552 / 165 888 rows, 80-160 channels: 313 vs 523 us) but slower than the
+    TunableOp-selected ones inside the train step (cfg4 step 99.8 -> 104.3 ms), and it collapses once the output
+    needs many 64 x 64 tiles (every tile re-streams the rows: 453 vs 210 us at 41 472 x 400 -> 400).  Its dword-per-lane
+    fragment loads cost 16 address cycles per 256 B; the next version stages rows through LDS by DMA."""
+    return GEMM_MATH == "x6all" and OWN_GEMM != "none" and dY.dtype == _F32 and x.dtype == _F32
+
+
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
     """dW (Cout, Cin) = dY^T (Cout x R) @ x (R x Cin).  The output is tiny and the contraction long (R = B*N),
     so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials.
@@ -186,6 +197,15 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
     R = x.shape[0]
     if out is not None and out.dtype != dY.dtype:
         out = None
+    if _x6_wgrad_ok(dY, x) and dY.stride(1) == 1 and x.stride(1) == 1 and dY.stride(0) % 4 == 0 and x.stride(0) % 4 == 0:
+        cout, cin = dY.shape[1], x.shape[1]
+        if out is None:
+            out = torch.zeros((cout, cin), dtype=_F32, device=x.device)
+        else:
+            out.zero_()
+        _lib.check(_lib.load().gkg_linear_wgrad_x6(_ptr(dY), dY.stride(0), 0, _ptr(x), x.stride(0), 0, _ptr(out), R, cin, cout,
+                                                   1, _stream()), "gkg_linear_wgrad_x6")
+        return out
     if R >= 4096:                # short contractions (the label branch): the partial-sum kernel costs more than it saves
         for S in (8, 6, 4, 3, 2):
             if R % S == 0 and R // S >= 1024:

@@ -238,6 +238,7 @@ int gkg_linear_bn_bwd(const float* dz, int ldg, size_t g_bstride, const float* y
  *   gkg_linear_bn_fwd_x6    gkg_linear_bn_fwd with `planes_fwd` instead of w; x has row pitch ldx and batch stride
  *                           x_bstride (floats; a column slice of a wider matrix is allowed); same train modes / outputs
  *   gkg_linear_dgrad_x6     dx (nb, R, cin) = dy (nb, R, cout; pitch ldg, batch stride g_bstride) w
+ *   gkg_linear_wgrad_x6     dw (nb, cout, cin) += dy^T x (see below)
  * Rows must be 16-byte aligned (base pointer % 16 == 0, pitches % 4 == 0); each batch of x / dy below 4 GiB. */
 size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad);
 int gkg_x6_prep_desc_bytes(void);
@@ -250,6 +251,11 @@ int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* 
                          float* bn_mean, float* bn_invstd, float momentum, float eps, double* stats, void* stream);
 int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R, int cin,
                         int cout, int nb, void* stream);
+/* dw (nb, cout, cin) += dy^T x over the R rows (both operands split in registers; no LDS staging, each wave streams its own
+ * rows).  dw must be ZERO on entry: slabs of rows are added with fp32 atomics (run-dependent summation order, like a
+ * split-K GEMM).  x (nb, R, cin) with row pitch ldx / batch stride x_bstride (floats).  Any cin, cout >= 1. */
+int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride, float* dw,
+                        int R, int cin, int cout, int nb, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Two-kernel train-mode BN (the form the fused block uses when batch statistics are local to the rank): a producer

@@ -58,6 +58,42 @@ def test_forward_and_dgrad_at_fp32_accuracy(R, cin, cout, nb):
     assert e_y < 2e-7 and e_dx < 2e-7                                                   # 2^-23 .. 2^-22 of sum |a b|
 
 
+WSHAPES = [(10368, 320, 320, 1), (10368, 160, 160, 4), (2560, 1280, 320, 1), (20000, 80, 80, 1), (777, 36, 40, 1),
+           (4100, 400, 100, 1), (129, 64, 8, 2), (19, 16, 8, 1), (3000, 1, 3, 1)]
+
+
+@pytest.mark.parametrize("R,cin,cout,nb", WSHAPES)
+def test_wgrad_at_fp32_accuracy(R, cin, cout, nb):
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(R * 3 + cout)
+    x = torch.randn(nb, R, cin, device="cuda", generator=gen) * 2
+    dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
+    dw = torch.zeros(nb, cout, cin, device="cuda")
+    _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin, cout,
+                                       nb, None), "wgrad")
+    ref = torch.bmm(dy.double().transpose(1, 2), x.double())
+    mag = torch.bmm(dy.double().abs().transpose(1, 2), x.double().abs()) + 1e-30
+    e = _rel(dw, ref, mag)
+    f = _rel(torch.bmm(dy.transpose(1, 2), x), ref, mag)
+    assert e <= max(f, 1.2e-7) and e < 2e-7, (e, f)
+
+
+def test_wgrad_column_slices():
+    """dy / x as column slices of wider token-major matrices (the grouped projection's operands)."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(4)
+    R, cin, cout, nb = 1500, 24, 40, 4
+    xw = torch.randn(R, nb * cin, device="cuda")
+    dyw = torch.randn(R, nb * cout, device="cuda")
+    dw = torch.zeros(nb, cout, cin, device="cuda")
+    _lib.check(lib.gkg_linear_wgrad_x6(dyw.data_ptr(), nb * cout, cout, xw.data_ptr(), nb * cin, cin, dw.data_ptr(), R, cin,
+                                       cout, nb, None), "wgrad")
+    want = torch.einsum("rqn,rqk->qnk", dyw.view(R, nb, cout).double(), xw.view(R, nb, cin).double())
+    assert torch.allclose(dw.double(), want, atol=1e-4, rtol=1e-5)
+
+
 def test_column_slices_and_row_pitch():
     """x as a column slice of a wider token-major matrix (the grouped projection's operand) and dy with a row pitch."""
     from gkgnet_amd import _lib

@@ -11,6 +11,10 @@ lib = _lib.load()
 SHAPES = [(10368, 320, 320, 1), (10368, 160, 160, 4), (10368, 640, 320, 1), (10368, 320, 640, 1), (2560, 320, 320, 1),
           (2560, 160, 160, 4), (2560, 640, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1), (41472, 400, 400, 1),
           (41472, 800, 400, 1)]
+if len(sys.argv) > 1 and sys.argv[1] == "cfg4":        # GKGNet-576 (pvig_s) stage shapes at B = 32
+    SHAPES = [(663552, 80, 80, 1), (663552, 160, 80, 1), (663552, 80, 320, 1), (663552, 320, 80, 1), (165888, 160, 160, 1),
+              (165888, 320, 160, 1), (165888, 160, 640, 1), (165888, 640, 160, 1), (41472, 400, 400, 1), (41472, 800, 400, 1),
+              (41472, 400, 1600, 1), (41472, 1600, 400, 1), (10368, 640, 640, 1), (10368, 1280, 640, 1)]
 flush = torch.empty(128 << 20, dtype=torch.float32, device="cuda")
 
 
@@ -42,8 +46,13 @@ for R, cin, cout, nb in SHAPES:
     y = torch.empty(nb, R, cout, device="cuda"); dx = torch.empty(nb, R, cin, device="cuda")
     pf, pd = planes(w, nb, cout, cin)
     stats = fused._stats_scratch(x.device)
+    dw = torch.zeros(nb, cout, cin, device="cuda")
+    vw = timeit(lambda: fused._wgrad(dy[0], x[0]) if nb == 1 else fused._wgrad_grouped(dy, x))
+    xw = timeit(lambda: (dw.zero_(), lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(),
+                                                              R, cin, cout, nb, None)))
+    print(f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: wgrad vendor (split-K bmm) {vw:6.1f}  x6 (incl. memset) {xw:6.1f}", flush=True)
     line = f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: vendor fwd {timeit(lambda: torch.bmm(x, w.transpose(1, 2), out=y)):6.1f} dgrad {timeit(lambda: torch.bmm(dy, w, out=dx)):6.1f} |"
-    for ni in ("auto", "1", "2"):
+    for ni in (("auto",) if len(sys.argv) > 1 else ("auto", "1", "2")):
         if ni == "auto":
             os.environ.pop("GKG_X6_NI", None)
         else:
