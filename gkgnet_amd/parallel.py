@@ -77,10 +77,23 @@ class GradBucket:
         self._pending = []
         self._hooks = []
         self._ready = {}
+        self._zero = {id(p) for p in self.params}   # slots known to hold zeros (the buffer starts zeroed)
 
     def _view(self, p):
         o = self._offset[p]
         return self.flat[o:o + p.numel()].view_as(p)
+
+    def _fill_slot(self, q):
+        """Slot of a non-resident parameter: copy its gradient in, or clear it (once) when there is none."""
+        v = self._view(q)
+        if q.grad is None:
+            if id(q) not in self._zero:
+                v.zero_()
+                self._zero.add(id(q))
+        else:
+            self._zero.discard(id(q))
+            v.copy_(q.grad.reshape(q.shape))
+        q.grad = v
 
     def _point_grads(self):
         for p in self.params:
@@ -88,6 +101,7 @@ class GradBucket:
 
     def zero(self):
         self.flat.zero_()
+        self._zero = {id(p) for p in self.params}
 
     def release(self):
         """Detach ``p.grad`` from the bucket so the next backward writes fresh gradients (no zero-fill and no
@@ -104,16 +118,25 @@ class GradBucket:
         """Bring every gradient into the flat bucket: gradients the fused kernels already wrote in place are left alone,
         the others are copied with one batched copy; parameters without a gradient get zeros.  Re-points ``p.grad`` at
         the bucket views."""
-        src, dst = [], []
+        src, dst, zero = [], [], []
         for p in self.params:
             if self._resident(p):
+                self._zero.discard(id(p))
                 continue
             v = self._view(p)
             if p.grad is None:
-                v.zero_()
+                # e.g. the conv biases in front of train-mode BN (exactly zero gradient, never materialised): their slots
+                # are cleared ONCE and stay clear — a fill launch per such parameter per step cost 4.5 us each inside
+                # the cfg2 step (8 biases: 37 of 1020 us)
+                if id(p) not in self._zero:
+                    zero.append(v)
+                    self._zero.add(id(p))
             else:
+                self._zero.discard(id(p))
                 src.append(p.grad.reshape(p.shape))
                 dst.append(v)
+        if zero:
+            torch._foreach_zero_(zero)
         if src:
             torch._foreach_copy_(dst, src)
         self._point_grads()
@@ -141,12 +164,9 @@ class GradBucket:
                     self._ready[ci] = 0
                     for q in plist:                                  # gradients not written in place: copy this chunk now
                         if not self._resident(q):
-                            v = self._view(q)
-                            if q.grad is None:
-                                v.zero_()
-                            else:
-                                v.copy_(q.grad.reshape(q.shape))
-                            q.grad = v
+                            self._fill_slot(q)
+                        else:
+                            self._zero.discard(id(q))
                     if world > 1:
                         chunk = self.flat[start:end]
                         chunk.div_(world)
@@ -162,12 +182,9 @@ class GradBucket:
                 self._ready[ci] = 0
                 for q in plist:
                     if not self._resident(q):
-                        v = self._view(q)
-                        if q.grad is None:
-                            v.zero_()
-                        else:
-                            v.copy_(q.grad.reshape(q.shape))
-                        q.grad = v
+                        self._fill_slot(q)
+                    else:
+                        self._zero.discard(id(q))
                 if world > 1:
                     chunk = self.flat[start:end]
                     chunk.div_(world)

@@ -124,3 +124,20 @@ def test_shard_batch_partitions():
     for gb, w in ((256, 8), (10, 4), (3, 8)):
         seen = [i for r in range(w) for i in shard_batch(gb, r, w)]
         assert seen == list(range(gb))
+
+
+def test_bucket_slots_of_missing_gradients_stay_zero():
+    """Parameters that receive no gradient keep a zero slot without a fill per step; a slot that held a gradient is cleared
+    again when the gradient disappears."""
+    import torch
+    from gkgnet_amd.parallel import GradBucket
+    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(5))
+    bucket = GradBucket([a, b])
+    for step, use_b in enumerate([False, True, False, False]):
+        bucket.release()
+        loss = (a * 2).sum() + ((b * 3).sum() if use_b else 0)
+        loss.backward()
+        bucket.pack()
+        assert torch.equal(a.grad, torch.full((3,), 2.0)), step
+        assert torch.equal(b.grad, torch.full((5,), 3.0 if use_b else 0.0)), step
+        assert a.grad.data_ptr() == bucket._view(a).data_ptr() and b.grad.data_ptr() == bucket._view(b).data_ptr()
