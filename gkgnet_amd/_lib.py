@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
 ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
+KNN_BF16_CONTRACT = 2
 LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 MR_DETERMINISTIC = 1
 

@@ -46,7 +46,9 @@ struct PrepStrides { int G; size_t sb, sg, sc, sn; };
 // block always fits: PT * c * 4 B <= 48 KB.
 // One launch prepares the queries AND (bipartite graphs) the keys: workgroups blockIdx.x >= nbx1 take the second
 // tensor — for the short label-branch problems a second dependent launch costs as much as the work itself.
-struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; };
+// tb != null: the normalised copy is written as bf16, TOKEN-major (bg, n, cp16) zero-padded to cp16 channels (the operand
+// layout of the bf16 matrix-core contraction) instead of fp32 channel-major th.
+struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; };
 
 template <typename T, bool NORM, int PT>
 __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
@@ -103,6 +105,24 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   }
   // ---- (3) normalise, store, |th|^2
   float q2 = 0.0f;
+  if (S.tb) {                                       // bf16 token-major copy: 16-byte stores of 8 channels
+    uint4* ob = reinterpret_cast<uint4*>(S.tb + ((size_t)bg * Tn + n) * S.cp16);
+    for (int c0 = 0; c0 < S.cp16; c0 += 8) {
+      uint32_t wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v0 = c0 + 2 * u < c ? cp[(c0 + 2 * u) * PT] : 0.0f;
+        float v1 = c0 + 2 * u + 1 < c ? cp[(c0 + 2 * u + 1) * PT] : 0.0f;
+        if (NORM) { v0 = v0 / den; v1 = v1 / den; }
+        q2 = __builtin_fmaf(v0, v0, q2);
+        q2 = __builtin_fmaf(v1, v1, q2);
+        wv[u] = pack_bf16x2(v0, v1);
+      }
+      ob[c0 >> 3] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    sq[(size_t)bg * Tn + n] = q2;
+    return;
+  }
   float* op = th + (size_t)bg * cpad * Tn + n;
 #pragma unroll 8
   for (int ch = 0; ch < c; ++ch) {
@@ -205,6 +225,9 @@ struct KnnArgs {
   int BG, cpad, N, M, k, dilation, kd;
   int splits, tiles_per_split;
   int nqt;              // query tiles per problem
+  const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies
+  const uint16_t* yb;
+  int cp16;
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
@@ -225,7 +248,12 @@ struct KnnArgs {
 // A stale threshold only admits MORE candidates than necessary; the insert itself re-decides with the full (distance,
 // index) key, so the result is bit-identical to the direct form (ties included: keys arrive in increasing index order
 // within a wave, so a later candidate equal to the KD-th entry never displaces it — the strict '<' is exact).
-template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0>
+// BF — the contraction on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: 16x the fp32 rate, and unlike the fp32 MFMA it
+// overlaps the selection's vector work): normalised tokens rounded to bf16, products exact, fp32 accumulation, the squared
+// norms added in fp32.  For callers under bf16 autocast, where the reference itself runs x.y^T in bf16 AND rounds the
+// product matrix to bf16 (torch_edge.py:35-51 under autocast) — this form keeps more of the fp32 answer than that.  Not
+// covered by the bit-exact index contract (the accumulation order inside the 16-deep dot product is the hardware's).
+template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false>
 __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_tile_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x;
@@ -253,7 +281,16 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   const float* yp = a.yh + (size_t)bg * cpad * M;
   const int t_begin = split * a.tiles_per_split;
   float an[KU];
-  {
+  constexpr int KB = 4;                          // BF: k16-steps per key-operand batch
+  const int cp16 = a.cp16, S16 = cp16 >> 4;
+  const uint16_t* ybp = BF ? a.yb + (size_t)bg * M * cp16 : nullptr;
+  uint4 bn_[KB];
+  if (BF) {
+    const int mk0 = min((t_begin + w) * KT + l31, M - 1);
+    const uint4* y0 = reinterpret_cast<const uint4*>(ybp + (size_t)mk0 * cp16 + 8 * kk);
+#pragma unroll
+    for (int u = 0; u < KB; ++u) bn_[u] = u < S16 ? y0[2 * u] : make_uint4(0, 0, 0, 0);
+  } else {
     const int t0 = t_begin + w;
     const int mk0 = min(t0 * KT + l31, M - 1);
     const float* y0 = yp + (size_t)kk * M + mk0;
@@ -266,14 +303,36 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   // order — and each candidate saves two vector adds and a v_readlane (the vector pipe is the contended one).
   // Used by the deep-batch instantiations (KU == 8: channel counts that are multiples of 16); measured a few per cent
   // slower on the KU == 4 ones (c = 200 at 36x36), which keep the three vector adds.
-  constexpr bool FOLD = KU == 8;
+  constexpr bool FOLD = KU == 8 && !BF;
   const float qtail0 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + l31, N - 1)];
   const float qtail1 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + 32 + l31, N - 1)];
   const float sqx = FOLD ? 0.0f : a.sqx[(size_t)bg * N + nc];
 
   // ---- stage the query tile scaled by -2 (exact): xs[ch][64] = -2 * xh (zero for n >= N).
   //      All loads of a pass are issued before the first LDS store.
-  {
+  // BF: xq[64][cp16 + 8] bf16 rows (-2 x, exact; 16 B of padding per row keeps the fragment reads conflict-free)
+  const int qpitch = (cp16 + 8) * 2;             // bytes
+  if (BF) {
+    const uint16_t* xbp = a.xb + (size_t)bg * N * cp16;
+    const int chunks = cp16 >> 3;                  // 16-byte chunks per query row
+    for (int i = tid; i < QT * chunks; i += 256) {
+      const int q = i / chunks, ck = i - q * chunks;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n0 + q < N) v = *reinterpret_cast<const uint4*>(xbp + (size_t)(n0 + q) * cp16 + 8 * ck);
+      // x -> -2x on packed bf16: exponent + 1 and sign flip, zeros stay zeros (|x| <= 1 after normalisation; raw inputs
+      // near the top of the range would overflow to inf like any -2x)
+      auto m2h = [](unsigned hv) -> unsigned {
+        const unsigned e = hv & 0x7f80u;
+        if (e == 0u) return 0u;                                   // zero / denormal
+        if (e == 0x7f80u) return hv ^ 0x8000u;                     // inf / NaN keep their class
+        if (e == 0x7f00u) return ((hv ^ 0x8000u) & 0x8000u) | 0x7f80u;   // overflow -> inf
+        return (hv + 0x80u) ^ 0x8000u;
+      };
+      auto m2 = [&](unsigned wv) { return m2h(wv & 0xffffu) | (m2h(wv >> 16) << 16); };
+      v.x = m2(v.x); v.y = m2(v.y); v.z = m2(v.z); v.w = m2(v.w);
+      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(smem) + q * qpitch + 16 * ck) = v;
+    }
+  } else {
     const float* xp = a.xh + (size_t)bg * cpad * N;
     if ((N & 3) == 0) {
       const int q4 = (tid & 15) * 4;               // 16 float4 per 64-query row, 16 rows per pass
@@ -364,7 +423,38 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     // ---- contraction: acc0 = keys x (-2 queries[0..31]), acc1 = keys x (-2 queries[32..63]).
     //      Key operand double-buffered in registers (KU k-pairs per batch).
     f32x16 acc0 = {0}, acc1 = {0};
-    {
+    if (BF) {
+      // keys = A operand (lane: key l31, 8 channels 16 s + 8 kk ...), the two query blocks = B operands from LDS
+      typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+      const uint4* ykp = reinterpret_cast<const uint4*>(ybp + (size_t)mk * cp16 + 8 * kk);
+      const uint4* ykn = reinterpret_cast<const uint4*>(ybp + (size_t)mk_next * cp16 + 8 * kk);
+      const char* xq0 = reinterpret_cast<const char*>(smem) + l31 * qpitch + 16 * kk;
+      const char* xq1 = xq0 + 32 * qpitch;
+      for (int s0 = 0; s0 < S16; s0 += KB) {
+        const bool last = s0 + KB >= S16;                         // uniform: prefetch the NEXT tile's first batch
+        uint4 ac[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) ac[u] = bn_[u];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          const int sn = last ? u : s0 + KB + u;
+          bn_[u] = sn < S16 ? (last ? ykn : ykp)[2 * sn] : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (s0 + u < S16) {
+            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, ac[u]);
+            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xq0 + 32 * (s0 + u)));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc0, 0, 0, 0);
+            if (two_blocks) {
+              const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xq1 + 32 * (s0 + u)));
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc1, 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
       const float* ykp = yp + (size_t)kk * M + mk;
       const float* ykn = yp + (size_t)kk * M + mk_next;
       const float* xsp = smem + kk * QT + l31;
@@ -614,17 +704,29 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
 
 constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 bytes each: 32 KB per workgroup)
 
-template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0>
+template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false>
 static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   if (BUF > 0) {
     const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 256 * sizeof(float2);
     if (lds < need) lds = need;
   }
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
+}
+
+// bf16 matrix-core contraction (GKG_KNN_BF16_CONTRACT): direct or buffered selection, guarded insert
+template <int KD>
+static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, bool buffered) {
+  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
+  if (buffered) {
+    if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
+    return launch_tile_v<KD, false, 4, false, KNN_BUF, true>(a, grid, lds, st);
+  }
+  if (a.relpos) return launch_tile_v<KD, true, 4, true, 0, true>(a, grid, lds, st);
+  return launch_tile_v<KD, false, 4, true, 0, true>(a, grid, lds, st);
 }
 
 // Short key streams (< 10 key tiles per wave: the 18x18 stage, label graphs over it): insert without the ballot guard.
@@ -700,8 +802,12 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     else { ps.G = 1; ps.sb = (size_t)c * Tn; ps.sg = 0; ps.sc = Tn; ps.sn = 1; }
     return ps;
   };
-  const PrepSet sx{x, xh, sqx, N, strides(N)};
-  const PrepSet sy{y, yh, sqy, M, strides(M)};
+  // bf16 contraction: the normalised copies are bf16 token-major (they fit the fp32 copies' workspace slots); needs
+  // 16 <= c (below that the fp32 staging area is smaller than the bf16 one) — otherwise the flag is ignored
+  const bool bf = (flags & GKG_KNN_BF16_CONTRACT) != 0 && c >= 16;
+  const int cp16 = (c + 15) & ~15;
+  const PrepSet sx{x, xh, sqx, N, strides(N), bf ? (uint16_t*)xh : nullptr, cp16};
+  const PrepSet sy{y, yh, sqy, M, strides(M), bf ? (uint16_t*)yh : nullptr, cp16};
   if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
@@ -713,6 +819,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.BG = BG; a.cpad = p.cpad; a.N = N; a.M = M; a.k = k; a.dilation = dilation; a.kd = p.kd;
   a.splits = p.S; a.tiles_per_split = p.tps;
   a.nqt = (N + QT - 1) / QT;
+  a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
   size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
   size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
@@ -729,7 +836,20 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 <= 150 * 1024;
   const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
   const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));
-  if (buffered) {
+  if (bf) {
+    switch (p.KD) {
+      case 9: e = launch_tile_bf<9>(a, grid, lds, st, buffered); break;
+      case 12: e = launch_tile_bf<12>(a, grid, lds, st, buffered); break;
+      case 16: e = launch_tile_bf<16>(a, grid, lds, st, buffered); break;
+      case 18: e = launch_tile_bf<18>(a, grid, lds, st, buffered); break;
+      case 24: e = launch_tile_bf<24>(a, grid, lds, st, buffered); break;
+      case 27: e = launch_tile_bf<27>(a, grid, lds, st, buffered); break;
+      case 32: e = launch_tile_bf<32>(a, grid, lds, st, buffered); break;
+      case 36: e = launch_tile_bf<36>(a, grid, lds, st, buffered); break;
+      case 48: e = launch_tile_bf<48>(a, grid, lds, st, buffered); break;
+      default: e = launch_tile_bf<64>(a, grid, lds, st, buffered); break;
+    }
+  } else if (buffered) {
     switch (p.KD) {
       case 9: e = launch_tile_buffered<9>(a, grid, lds, st); break;
       case 12: e = launch_tile_buffered<12>(a, grid, lds, st); break;

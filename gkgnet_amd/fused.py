@@ -55,6 +55,10 @@ DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
 # kernel, 1.3-1.4x faster than the vendor fp32 GEMM at cfg2's shapes) for the forward and input-gradient GEMMs of every
 # fp32 projection; "f32" = the fp32-MFMA kernels of csrc/gkg_gemm.hip under the GKG_OWN_GEMM rule above.
 GEMM_MATH = os.environ.get("GKG_GEMM_MATH", "x6")
+# Under bf16 autocast the k-NN distance contraction runs on the bf16 matrix cores (GKG_KNN_BF16_CONTRACT: normalised
+# tokens rounded to bf16, exact products, fp32 accumulation and norms) — the reference computes this product in bf16 there
+# too, and additionally rounds the product matrix to bf16.  GKG_KNN_BF16=0 keeps the fp32 contraction everywhere.
+KNN_BF16 = os.environ.get("GKG_KNN_BF16", "1") != "0"
 
 
 class _WeightPlanes:
@@ -750,6 +754,8 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
     c = C // G
     M = N if y is None else y.shape[1]
     flags = _lib.KNN_NORMALIZE
+    if KNN_BF16 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        flags |= _lib.KNN_BF16_CONTRACT          # the reference's own x.y^T runs in bf16 here (and rounds the result to bf16)
     rp = None
     if relative_pos is not None:
         rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()

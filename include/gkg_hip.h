@@ -50,6 +50,10 @@ extern "C" {
 
 /* gkg_knn_fwd flags */
 #define GKG_KNN_NORMALIZE 1u /* L2-normalise tokens over the group's channels first (torch_edge.py:167-173) */
+#define GKG_KNN_BF16_CONTRACT 2u /* x.y^T on the bf16 matrix cores: tokens rounded to bf16 after normalisation, exact
+                                  * products, fp32 accumulation and fp32 norms.  For callers under bf16 autocast, where the
+                                  * reference computes this product in bf16 and rounds it to bf16.  Outside the bit-exact
+                                  * index contract; ignored for c < 16. */
 
 /* argument errors */
 #define GKG_ERR_NULL -1        /* required pointer is NULL */
