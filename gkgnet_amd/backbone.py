@@ -145,7 +145,16 @@ class GKGNet(nn.Module):
         x = self.stem(inputs) + self.pos_embed
         stage = 0
         edge_index = None
+        # the fused blocks pass channels-last activations through without transposing (fused.CHANNELS_LAST): convert once
+        # here and after each downsample (a no-op when the convolution already returned channels-last)
+        to_cl = fused.CHANNELS_LAST and fused.ENABLED and x.is_cuda
         for i, block in enumerate(self.backbone):
+            if to_cl and isinstance(block, (Downsample,)):
+                x = block(x)
+                x = x.to(dtype=torch.float32, memory_format=torch.channels_last)
+                continue
+            if to_cl and i == 0:
+                x = x.to(dtype=torch.float32, memory_format=torch.channels_last)
             x = block(x)
             if i in self.layer_index:
                 for gl in self.gcn_label[stage]:

@@ -428,6 +428,51 @@ def _tm_dtype(lowp: bool):
 
 
 # ----------------------------------------------------------------------------------------------- layout
+# A block whose input arrives channels-last — logical (B, C, H, W), memory (B, H, W, C): exactly the token-major matrix
+# the block computes on — takes it as a VIEW and returns a channels-last tensor as well (same shape and values as the
+# reference's output, different strides), so a chain of blocks never transposes: it saves nchw_to_tm + the transposing
+# half of tm_affine_to_nchw per block and direction (12 % of the cfg3 forward, 6 % of the cfg4 step).  NCHW-contiguous
+# inputs keep the NCHW-in / NCHW-out behaviour; the GKGNet backbone converts once after the stem and each downsample.
+CHANNELS_LAST = os.environ.get("GKG_CHANNELS_LAST", "1") != "0"
+
+
+def is_channels_last(x) -> bool:
+    return (CHANNELS_LAST and x.dim() == 4 and x.dtype == _F32 and x.shape[1] > 1 and x.shape[2] * x.shape[3] > 1
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _TokenMajorToCL(torch.autograd.Function):
+    """(B*H*W, C) token-major -> logical (B, C, H, W) in channels-last memory (a view).  The backward accepts either
+    memory format: a channels-last gradient is a view again, an NCHW one goes through the layout kernel."""
+
+    @staticmethod
+    def forward(ctx, t, B, H, W):
+        ctx.dims = (B, H, W)
+        return t.view(B, H, W, t.shape[1]).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W = ctx.dims
+        C = g.shape[1]
+        if g.dtype == _F32 and g.permute(0, 2, 3, 1).is_contiguous():
+            return g.permute(0, 2, 3, 1).reshape(B * H * W, C), None, None, None
+        g = g.float().contiguous()
+        out = torch.empty((B * H * W, C), dtype=_F32, device=g.device)
+        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(g), _ptr(out), B, C, H * W, _lib.F32, None, _stream()), "gkg_nchw_to_tm")
+        return out, None, None, None
+
+
+def _block_entry(x, lp):
+    """-> (GEMM operand (T, C), residual, channels_last?).  Channels-last input: both are views of x (bf16 inference: the
+    operand is a cast copy); NCHW input: the layout kernel (_BlockEntry)."""
+    if is_channels_last(x):
+        B, C, H, W = x.shape
+        xt = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        return (xt.to(torch.bfloat16) if lp else xt), xt, True
+    xt, xr = _BlockEntry.apply(x.float().contiguous(), lp)
+    return xt, xr, False
+
+
 class _ToTokenMajor(torch.autograd.Function):
     """(B, C, *spatial) -> (B*N, C)."""
 
@@ -854,7 +899,7 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     N = H * W
     gc = mod.graph_conv
     lp = lowp_inference()
-    xt, x = _BlockEntry.apply(x.float().contiguous(), lp)          # (T, C) and the residual branch
+    xt, x, cl = _block_entry(x, lp)                                 # (T, C) and the residual branch
     x1 = _lin(xt, mod.fc1)                                          # fc1 + BN
     x1b = x1.view(B, N, C)
     yb = None
@@ -866,7 +911,10 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     nn_ = gc.gconv.nn
     a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
                                    _w16_of(nn_[0]) if lp else None)   # (T, 2C)
-    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W),          # fc2 + BN (+ DropPath) + residual, back to NCHW
+    if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
+        out = _lin(a2, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=N)
+        return _TokenMajorToCL.apply(out, B, H, W), edge
+    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W),          # ... back to NCHW
                scale=_drop_scale(mod.drop_path, B, x.device))
     return out, edge
 
@@ -875,7 +923,10 @@ def grapher_label_forward(mod, e, features, groups: int):
     """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
     B, L, C = e.shape
     gc = mod.graph_conv
-    ft = to_token_major(features.float().contiguous()).view(B, -1, C)       # keys / values (B, HW, C)
+    if is_channels_last(features):                                           # keys / values (B, HW, C): a view
+        ft = features.permute(0, 2, 3, 1).reshape(B, -1, C)
+    else:
+        ft = to_token_major(features.float().contiguous()).view(B, -1, C)
     e2 = e.float().reshape(B * L, C).contiguous()
     x1 = _lin(e2, mod.fc1)
     x1b = x1.view(B, L, C)
@@ -909,6 +960,10 @@ def ffn_supported(mod, x) -> bool:
 def ffn_forward(mod, x):
     """reference gkgnet.py:66-72 on token-major activations: two library GEMMs + the BN/GELU/residual kernels."""
     lp = lowp_inference()
-    xt, x = _BlockEntry.apply(x.float().contiguous(), lp)
+    B, C, H, W = x.shape
+    xt, x, cl = _block_entry(x, lp)
     h = _lin(xt, mod.fc1, act=1, out_lowp=lp)
-    return _lin(h, mod.fc2, residual=x, nchw=tuple(x.shape), scale=_drop_scale(mod.drop_path, x.shape[0], x.device))
+    if cl:
+        out = _lin(h, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=H * W)
+        return _TokenMajorToCL.apply(out, B, H, W)
+    return _lin(h, mod.fc2, residual=x, nchw=(B, C, H, W), scale=_drop_scale(mod.drop_path, B, x.device))
