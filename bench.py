@@ -155,7 +155,11 @@ def main():
         compute()
     torch.cuda.synchronize()
     graph = None
-    if not args.no_graph:
+    # host-synchronising collectives (gloo) inside the step cannot be captured: SyncBN all-reduces its statistics in the step
+    capturable = not (world > 1 and args.sync_bn and torch.distributed.get_backend() != "nccl")
+    if not capturable:
+        print("[bench] SyncBN over a non-RCCL backend: the step is launched eagerly", file=sys.stderr)
+    if not args.no_graph and capturable:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
