@@ -202,3 +202,53 @@ def test_captured_step_resplits_the_weights(monkeypatch):
     y = x.double() @ conv.weight.detach().double().view(cout, cin).t()
     want = (y - y.mean(0)) * (y.var(0, unbiased=False) + bn.eps).rsqrt() * bn.weight.detach().double() + bn.bias.detach().double()
     assert torch.allclose(out.double(), want, atol=1e-4)
+
+
+def test_random_shapes_forward_dgrad_wgrad():
+    """Seeded sweep over ragged shapes (rows / channels not multiples of the tile sizes, K tails, batches)."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(20260)
+    for it in range(40):
+        R = int(rng.choice([1, 7, 31, 128, 129, 500, 1000, 4097]))
+        cin = 4 * int(rng.randint(1, 90))
+        cout = 4 * int(rng.randint(1, 90))
+        nb = int(rng.choice([1, 1, 2, 4]))
+        gen = torch.Generator(device="cuda").manual_seed(it)
+        x = torch.randn(nb, R, cin, device="cuda", generator=gen)
+        w = torch.randn(nb, cout, cin, device="cuda", generator=gen) * 0.2
+        dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
+        pf, pd = _planes(lib, w, nb, cout, cin)
+        y = torch.full((nb, R, cout), float("nan"), device="cuda")
+        dx = torch.full((nb, R, cin), float("nan"), device="cuda")
+        dw = torch.zeros(nb, cout, cin, device="cuda")
+        _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 0,
+                                            *([None] * 10), 0.0, 0.0, None, None), "fwd")
+        _lib.check(lib.gkg_linear_dgrad_x6(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb, None),
+                   "dgrad")
+        _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin,
+                                           cout, nb, None), "wgrad")
+        tag = (it, R, cin, cout, nb)
+        assert torch.allclose(y.double(), torch.bmm(x.double(), w.double().transpose(1, 2)), atol=2e-5, rtol=1e-5), tag
+        assert torch.allclose(dx.double(), torch.bmm(dy.double(), w.double()), atol=2e-5, rtol=1e-5), tag
+        assert torch.allclose(dw.double(), torch.bmm(dy.double().transpose(1, 2), x.double()), atol=2e-4, rtol=1e-5), tag
+
+
+def test_non_finite_inputs_poison_only_their_rows():
+    """A NaN / inf in one activation row reaches that output row only (the split turns inf into NaN: hi = inf, residual
+    inf - inf); the K tail of the row before it and the rows of other tiles stay finite."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(2)
+    R, cin, cout = 300, 36, 40                     # K = 36: the last K-step is a tail
+    x = torch.randn(1, R, cin, device="cuda")
+    x[0, 17, 3] = float("nan")
+    x[0, 200, 35] = float("inf")
+    x[0, 201, 0] = float("nan")                    # the element right after row 200's tail in memory
+    w = torch.randn(1, cout, cin, device="cuda")
+    pf, _ = _planes(lib, w, 1, cout, cin)
+    y = torch.empty(1, R, cout, device="cuda")
+    _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, 1, 0,
+                                        *([None] * 10), 0.0, 0.0, None, None), "fwd")
+    bad = ~torch.isfinite(y[0]).all(dim=1)
+    assert bad.nonzero().flatten().tolist() == [17, 200, 201]
