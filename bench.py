@@ -94,6 +94,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (reference DDP semantics)")
+    ap.add_argument("--layout", default="nchw", choices=["nchw", "channels_last"],
+                    help="memory format of the feature map and its upstream gradient: nchw (default: what the reference's own "
+                         "layers hand to a dropped-in Grapher) or channels_last (what the preceding block of gkgnet_amd's "
+                         "backbone hands over: the blocks then chain without layout kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="keep the GEMM library's default kernel selection")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -131,9 +135,13 @@ def main():
     bucket = parallel.GradBucket(params)
 
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)       # every rank its own shard
-    x = torch.randn(B, C, H, H, generator=gen).to(dev).requires_grad_(True)
+    x = torch.randn(B, C, H, H, generator=gen).to(dev)
     e = torch.randn(B, L, C, generator=gen).to(dev).requires_grad_(True)
     cot_x = torch.randn(B, C, H, H, generator=gen).to(dev)
+    if args.layout == "channels_last":            # same values, (B, H, W, C) memory
+        x = x.contiguous(memory_format=torch.channels_last)
+        cot_x = cot_x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
     cot_e = torch.randn(B, L, C, generator=gen).to(dev)
 
     def compute():                       # forward + backward + gradient packing: everything on this GPU
@@ -298,6 +306,7 @@ def main():
                    config=dict(workload=w["desc"], batch_per_gpu=B, global_batch=B * world, C=C, G=w["G"],
                                HW=f"{H}x{H}", k=w["k"], dilation=w["d"], label_tokens=L, bn="sync" if
                                layers.norm_cfg["type"] == "SyncBN" else "local", parallelism=f"dp{world}",
+                               input_layout=args.layout,
                                launch="hipGraph replay of fwd+bwd+grad-pack" if graph is not None else "eager",
                                gemm=gemm_desc,
                                grad_allreduce="one flat RCCL all-reduce per step" if world > 1 else "none (1 GPU)"),

@@ -352,3 +352,42 @@ def test_fused_path_covers_active_droppath(kind):
     for n in g2:
         if n in g1:
             assert torch.allclose(g1[n], g2[n], atol=5e-3, rtol=5e-3), n
+
+
+@pytest.mark.parametrize("r", [1, 2])
+def test_channels_last_input_gives_the_same_block(r):
+    """Grapher -> GrapherLabel on a channels-last feature map (views in, channels-last out) against the same chain on
+    the NCHW-contiguous tensor: identical graphs, outputs and gradients within rounding; the output of the channels-last
+    run is channels-last."""
+    from gkgnet_amd import fused
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    torch.manual_seed(3)
+    B, C, H, G, L = 3, 64, 12, 2, 10
+    g = Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, r, n=H * H, drop_path=0.0, relative_pos=True,
+                use_multi_group=True, num_group=G).cuda().train()
+    gl = GrapherLabel(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, drop_path=0.0, relative_pos=False,
+                      num_nodes=L, use_multi_group=True, num_group=G).cuda().train()
+    x0 = torch.randn(B, C, H, H, device="cuda")
+    e0 = torch.randn(B, L, C, device="cuda")
+    cx, ce = torch.randn(B, C, H, H, device="cuda"), torch.randn(B, L, C, device="cuda")
+    res = {}
+    for fmt in ("nchw", "cl"):
+        x = (x0.contiguous(memory_format=torch.channels_last) if fmt == "cl" else x0.clone()).requires_grad_(True)
+        e = e0.clone().requires_grad_(True)
+        for p in list(g.parameters()) + list(gl.parameters()):
+            p.grad = None
+        out = g(x)
+        e2, edge = gl(e, out)
+        cot = cx.contiguous(memory_format=torch.channels_last) if fmt == "cl" else cx
+        torch.autograd.backward([out, e2], [cot, ce])
+        res[fmt] = (out.detach(), e2.detach(), edge, x.grad, e.grad, [p.grad.clone() for p in g.parameters() if p.grad is not None])
+        if fmt == "cl":
+            assert fused.is_channels_last(out) and fused.is_channels_last(x.grad)
+        else:
+            assert out.is_contiguous()
+    a, b = res["nchw"], res["cl"]
+    assert torch.equal(a[2], b[2])
+    for u, v in zip(a[:2] + a[3:5], b[:2] + b[3:5]):
+        assert torch.allclose(u, v, atol=2e-5, rtol=1e-5), float((u - v).abs().max())
+    for u, v in zip(a[5], b[5]):
+        assert torch.allclose(u, v, atol=2e-4, rtol=1e-4), float((u - v).abs().max())
