@@ -60,15 +60,91 @@ class EdgeConv2d(nn.Module):
         self.in_channels = in_channels
         self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
 
+    def _hip_plan(self, x):
+        """(conv, bn or None, act code) when the HIP aggregation applies: fp32 CUDA tensors, BasicConv = grouped 1x1 conv
+        [+ BatchNorm with a fixed momentum, statistics local to this process] [+ GELU / ReLU], no dropout."""
+        from . import ops
+        if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()):
+            return None
+        mods = list(self.nn)
+        conv = mods[0]
+        if not isinstance(conv, nn.Conv2d) or conv.groups != 4 or conv.out_channels % 4 or conv.in_channels % 4:
+            return None
+        bn, act = None, ops.ACT_NONE
+        for m in mods[1:]:
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                if m.momentum is None or not m.affine or (m.training and torch.distributed.is_available()
+                                                          and torch.distributed.is_initialized()
+                                                          and torch.distributed.get_world_size() > 1
+                                                          and isinstance(m, nn.SyncBatchNorm)):
+                    return None
+                bn = m
+            elif isinstance(m, nn.GELU) and getattr(m, "approximate", "none") == "none":
+                act = ops.ACT_GELU
+            elif isinstance(m, nn.ReLU):
+                act = ops.ACT_RELU
+            else:
+                return None
+        return conv, bn, act
+
     def forward(self, x, edge_index, y=None):
         bg, c = x.shape[:2]
         xt = x.reshape(bg, c, -1)
         src = xt if y is None else y.reshape(bg, c, -1)
         idx = edge_index[0]
         n, k = idx.shape[1:]
+        plan = self._hip_plan(x)
+        if plan is not None and k <= 255:
+            return self._forward_hip(xt, src, idx, *plan)
         x_j = torch.gather(src, 2, idx.reshape(bg, 1, n * k).expand(bg, c, n * k)).reshape(bg, c, n, k)
         x_i = xt.unsqueeze(-1).expand(-1, -1, -1, k)
         return self.nn(torch.cat([x_i, x_j - x_i], dim=1)).max(dim=-1, keepdim=True).values
+
+    def _forward_hip(self, xt, src, idx, conv, bn, act):
+        """The same function without the (B, 2C, N, k) tensor.  Groups 0/1 of the grouped convolution see only x_i: a per-node
+        projection, constant over k, so the max is the value itself and its BN statistics over (B, N, k) equal those over
+        (B, N).  Groups 2/3 see only x_j - x_i: z = Q[idx] - Qc + bias with Q = W src, Qc = W x — two per-node projections
+        and the gather kernels of csrc/gkg_edge.hip (gkg_edge_*)."""
+        from . import ops
+        B, C, N = xt.shape
+        k = idx.shape[2]
+        O = conv.out_channels
+        Oh, ci = O // 2, conv.in_channels // 4                  # channels of each half; inputs per group (= C / 2)
+        W = conv.weight.view(O, ci)
+        bias = conv.bias
+        # groups 0 and 1: inputs x[:, :C/2] and x[:, C/2:]
+        zA = torch.cat([torch.einsum("oc,bcn->bon", W[:O // 4], xt[:, :ci]),
+                        torch.einsum("oc,bcn->bon", W[O // 4:Oh], xt[:, ci:])], dim=1)
+        if bias is not None:
+            zA = zA + bias[:Oh].view(1, -1, 1)
+        cnt = B * N * k
+        if bn is not None:
+            if bn.training or not bn.track_running_stats:
+                mean = zA.mean(dim=(0, 2))
+                var = zA.var(dim=(0, 2), unbiased=False)
+                if bn.training and bn.track_running_stats:
+                    with torch.no_grad():
+                        bn.running_mean[:Oh].mul_(1 - bn.momentum).add_(bn.momentum * mean)
+                        bn.running_var[:Oh].mul_(1 - bn.momentum).add_(bn.momentum * var * (cnt / max(cnt - 1, 1)))
+                        bn.num_batches_tracked += 1
+            else:
+                mean, var = bn.running_mean[:Oh], bn.running_var[:Oh]
+            zA = (zA - mean.view(1, -1, 1)) * torch.rsqrt(var + bn.eps).view(1, -1, 1) * bn.weight[:Oh].view(1, -1, 1) \
+                + bn.bias[:Oh].view(1, -1, 1)
+        if act == ops.ACT_GELU:
+            zA = torch.nn.functional.gelu(zA)
+        elif act == ops.ACT_RELU:
+            zA = torch.relu(zA)
+        # groups 2 and 3: per-node projections of the source / centre tokens, then the gather kernels
+        def proj(t):
+            return torch.cat([torch.einsum("oc,bcn->bon", W[Oh:Oh + O // 4], t[:, :ci]),
+                              torch.einsum("oc,bcn->bon", W[Oh + O // 4:], t[:, ci:])], dim=1)
+        qs = proj(src)
+        qc = qs if src is xt else proj(xt)
+        sl = slice(Oh, O)
+        zB = ops.edge_aggregate(qs, qc, idx, None if bias is None else bias[sl],
+                                None if bn is None else bn.weight[sl], None if bn is None else bn.bias[sl], bn, sl, act)
+        return torch.cat([zA, zB], dim=1).unsqueeze(-1)
 
 
 class GraphConv2d(nn.Module):

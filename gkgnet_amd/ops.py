@@ -117,3 +117,88 @@ def max_relative(x: torch.Tensor, nn_idx: torch.Tensor, y: Optional[torch.Tensor
     if idx.dtype != torch.int64 or idx.dim() != 3 or tuple(idx.shape[:2]) != (xs.shape[0], xs.shape[2]):
         raise _lib.GkgError(f"nn_idx must be int64 (BG,N,k); got {idx.dtype} {tuple(idx.shape)}")
     return _MaxRelative.apply(xs, ys, idx)
+
+
+# ----------------------------------------------------------------------------------------------- EdgeConv aggregation
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+class _EdgeAggregate(torch.autograd.Function):
+    """out[b,o,n] = max_k act(norm(Q[b,o,idx[b,n,k]] - Qc[b,o,n] + bias[o])) for the neighbour-dependent half of
+    EdgeConv's grouped 1x1 convolution (csrc/gkg_edge.hip; reference torch_vertex.py:82-101 + torch_nn.py:57-69).
+    ``bn``: a BatchNorm module or None; gamma / beta / running statistics are the slices of its tensors that belong to these
+    O channels (``sl``).  Train-mode statistics run over all B*N*k elements, like the reference's BN on the (B,O,N,k) tensor."""
+
+    @staticmethod
+    def forward(ctx, qs, qc, nn_idx, bias, gamma, beta, bn, sl, act):
+        lib = _lib.load()
+        _need_cuda(qs, qc, nn_idx)
+        B, O, M = qs.shape
+        N, k = nn_idx.shape[1:]
+        qs, qc, nn_idx = qs.contiguous(), qc.contiguous(), nn_idx.contiguous()
+        dev = qs.device
+        cnt = B * N * k
+        bias_v = torch.zeros(O, dtype=torch.float32, device=dev) if bias is None else bias.detach().float()
+        mean0 = invstd = None
+        train_stats = bn is not None and (bn.training or not bn.track_running_stats)
+        if train_stats:
+            sums = torch.zeros(2 * O, dtype=torch.float64, device=dev)
+            _lib.check(lib.gkg_edge_stats(_ptr(qs), _ptr(qc), _ptr(nn_idx), _ptr(sums), B, O, N, M, k, _stream()), "gkg_edge_stats")
+            m0 = sums[:O] / cnt
+            var = (sums[O:] / cnt - m0 * m0).clamp_min_(0.0)
+            mean0, invstd = m0.float(), torch.rsqrt(var + bn.eps).float()
+            a = gamma.detach().float() * invstd
+            c = beta.detach().float() - a * mean0                      # the conv bias cancels against the batch mean
+            if bn.training and bn.track_running_stats:
+                mom = bn.momentum
+                with torch.no_grad():
+                    bn.running_mean[sl].mul_(1 - mom).add_(mom * (mean0 + bias_v))
+                    bn.running_var[sl].mul_(1 - mom).add_(mom * (var * (cnt / max(cnt - 1, 1))).float())
+        elif bn is not None:                                          # eval: fixed statistics
+            invstd = torch.rsqrt(bn.running_var[sl].float() + bn.eps)
+            mean0 = bn.running_mean[sl].float() - bias_v
+            a = gamma.detach().float() * invstd
+            c = beta.detach().float() - a * mean0
+        else:
+            a = torch.ones(O, dtype=torch.float32, device=dev)
+            c = bias_v.clone()
+        out = torch.empty((B, O, N), dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad[:6])
+        arg = torch.empty((B, O, N), dtype=torch.uint8, device=dev) if need else None
+        _lib.check(lib.gkg_edge_fwd(_ptr(qs), _ptr(qc), _ptr(nn_idx), _ptr(a), _ptr(c), _ptr(out), _ptr(arg), B, O, N, M, k, act,
+                                    _stream()), "gkg_edge_fwd")
+        ctx.save_for_backward(qs, qc, nn_idx, arg, a, c, mean0, invstd)
+        ctx.meta = (B, O, N, M, k, act, cnt, train_stats, bn is not None, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        qs, qc, nn_idx, arg, a, c, mean0, invstd = ctx.saved_tensors
+        B, O, N, M, k, act, cnt, train_stats, has_bn, has_bias = ctx.meta
+        g = g.contiguous().float()
+        dev = g.device
+        dgamma = dbeta = dbias = None
+        mg = mgz = None
+        if has_bn:
+            sums = torch.zeros(2 * O, dtype=torch.float64, device=dev)
+            _lib.check(lib.gkg_edge_bwd_stats(_ptr(g), _ptr(qs), _ptr(qc), _ptr(nn_idx), _ptr(arg), _ptr(a), _ptr(c), _ptr(mean0),
+                                              _ptr(invstd), _ptr(sums), B, O, N, M, k, act, _stream()), "gkg_edge_bwd_stats")
+            dbeta, dgamma = sums[:O].float(), sums[O:].float()
+            if train_stats:
+                mg, mgz = (sums[:O] / cnt).float(), (sums[O:] / cnt).float()
+            elif has_bias:
+                dbias = a * dbeta                                     # eval: u = a (z + bias - running_mean) + beta
+        dqs = torch.zeros_like(qs)
+        dqc = torch.empty_like(qc)
+        _lib.check(lib.gkg_edge_bwd(_ptr(g), _ptr(qs), _ptr(qc), _ptr(nn_idx), _ptr(arg), _ptr(a), _ptr(c), _ptr(mean0), _ptr(invstd),
+                                    _ptr(mg), _ptr(mgz), _ptr(dqs), _ptr(dqc), B, O, N, M, k, act, _stream()), "gkg_edge_bwd")
+        if not has_bn and has_bias:
+            dbias = -dqc.sum(dim=(0, 2))                              # sum of the winning-edge gradients
+        if has_bn and train_stats and has_bias:
+            dbias = torch.zeros(O, dtype=torch.float32, device=dev)   # exactly zero: BN removes the mean
+        return dqs, dqc, None, dbias, dgamma, dbeta, None, None, None
+
+
+def edge_aggregate(qs, qc, nn_idx, bias, gamma, beta, bn, sl, act):
+    return _EdgeAggregate.apply(qs, qc, nn_idx, bias, gamma, beta, bn, sl, act)

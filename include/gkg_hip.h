@@ -107,6 +107,33 @@ int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* argmax, void
                int BG, int c, int N, int M, int k, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * EdgeConv aggregation (Grapher(conv='edge'); reference torch_vertex.py:82-101 EdgeConv2d.forward + torch_nn.py:57-69
+ * BasicConv).  The reference evaluates  max_k act(norm(Conv2d_1x1,groups=4(cat[x_i, x_j - x_i])))  on a (B, 2C, N, k)
+ * tensor.  With the hard-coded groups = 4 the output channels of groups 2 and 3 depend on (x_j - x_i) only, and the
+ * convolution is linear, so for them z[b][o][n][k] = Q[b][o][nn_idx[b][n][k]] - Qc[b][o][n] + bias[o] with the per-node
+ * projections Q = W src, Qc = W x (ordinary GEMMs in the caller: k times less work, no (B, 2C, N, k) tensor).  These four
+ * entry points are the gather side; channel-major fp32 (B, O, N) / (B, O, M), nn_idx (B, N, k), k <= 255.
+ *   gkg_edge_stats      sums[o] += sum (Q[j] - Qc), sums[O + o] += sum (Q[j] - Qc)^2 over all (b, n, k): the batch statistics
+ *                       of train-mode BN (the bias shifts the mean only).  sums: 2*O doubles, zero on entry.
+ *   gkg_edge_fwd        out = max_k act(a[o] (Q[j] - Qc) + c[o]); argmax (optional) = first maximising k.  The caller folds
+ *                       norm and bias into a, c.  act: 0 none, 1 GELU (erf), 2 ReLU.
+ *   gkg_edge_bwd_stats  sums[o] += sum_n g', sums[O + o] += sum_n g' zhat over the argmax elements, g' = g act'(.), zhat =
+ *                       (z - mean0) invstd: dbeta, dgamma and (divided by B N k) the two means of the BN backward.
+ *   gkg_edge_bwd        dz[n][k] = a (g' [k == argmax] - mg - zhat[n][k] mgz) for every edge; dqs[nn_idx] += dz (atomics; dqs
+ *                       zero on entry), dqc[n] = -sum_k dz.  mg == NULL: statistics are constants, only the winning edge
+ *                       carries gradient. */
+int gkg_edge_stats(const float* qs, const float* qc, const int64_t* nn_idx, double* sums, int B, int O, int N, int M, int k,
+                   void* stream);
+int gkg_edge_fwd(const float* qs, const float* qc, const int64_t* nn_idx, const float* a, const float* c, float* out,
+                 uint8_t* argmax, int B, int O, int N, int M, int k, int act, void* stream);
+int gkg_edge_bwd_stats(const float* g, const float* qs, const float* qc, const int64_t* nn_idx, const uint8_t* argmax,
+                       const float* a, const float* c, const float* mean0, const float* invstd, double* sums, int B, int O,
+                       int N, int M, int k, int act, void* stream);
+int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t* nn_idx, const uint8_t* argmax,
+                 const float* a, const float* c, const float* mean0, const float* invstd, const float* mg, const float* mgz,
+                 float* dqs, float* dqc, int B, int O, int N, int M, int k, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Token-major variants used inside the fused Grapher block (activations (B, N, C), C = G*c, fp32).
  * Same arithmetic contracts as above; only the addressing differs.
  *   gkg_knn_fwd_tm : x (B,N,C), y (B,M,C) or NULL; nn_idx/center (B*G, N, k)
