@@ -96,10 +96,16 @@ __global__ __launch_bounds__(256) void x6_prep_kernel(const X6PrepDesc* __restri
   const int n = v % NP, kc = (v / NP) % KC, z = v / (NP * KC);
   const float* w = g.w + (size_t)z * g.N * g.K;
   float f[8];
+  if (!dgrad && n < Nn && kc * 8 + 8 <= Kk && (g.K & 3) == 0) {          // forward orientation: 8 consecutive floats of row n
+    const float4 v0 = *reinterpret_cast<const float4*>(w + (size_t)n * g.K + kc * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(w + (size_t)n * g.K + kc * 8 + 4);
+    f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+  } else {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = kc * 8 + j;
-    f[j] = (n < Nn && k < Kk) ? (dgrad ? w[(size_t)k * g.K + n] : w[(size_t)n * g.K + k]) : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int k = kc * 8 + j;
+      f[j] = (n < Nn && k < Kk) ? (dgrad ? w[(size_t)k * g.K + n] : w[(size_t)n * g.K + k]) : 0.f;
+    }
   }
   uint4 h, m, l;
   x6_split2(f[0], f[1], h.x, m.x, l.x); x6_split2(f[2], f[3], h.y, m.y, l.y);
