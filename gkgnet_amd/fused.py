@@ -414,6 +414,28 @@ def _w16_of(conv) -> torch.Tensor:
     return ent[2]
 
 
+FOLD_EPILOGUE = os.environ.get("GKG_FOLD_EPILOGUE", "1") != "0"
+
+
+def _folded_of(conv, bn):
+    """Inference (eval-mode BN): the BN scale folded into a bf16 copy of the weight and the shift (conv bias and running
+    mean included) as a bf16 bias — (W' (cout, cin), c' (cout)) — cached on the module and refreshed when any of the six
+    tensors it derives from changes.  With them out = act(x W'^T + c') is ONE library GEMM with a bias(+GELU) epilogue."""
+    srcs = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
+    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps,)
+    ent = getattr(conv, "_gkg_fold", None)
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            a = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.float() - a * bn.running_mean.float()
+            if conv.bias is not None:
+                shift = shift + a * conv.bias.float()
+            wf = (conv.weight.float().view(conv.weight.shape[0], -1) * a.view(-1, 1)).to(torch.bfloat16).contiguous()
+            ent = (key, wf, shift.to(torch.bfloat16).contiguous())
+        conv._gkg_fold = ent
+    return ent[1], ent[2]
+
+
 def _mm_t(x, W, W16=None):
     """x (R, cin) @ W (cout, cin)^T -> fp32 (R, cout).  bf16 ``x``: bf16 operands, fp32 accumulate AND fp32 result."""
     if x.dtype == torch.bfloat16:
@@ -884,6 +906,12 @@ def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, ro
     """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
     output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402)."""
     conv, bn = seq[0], seq[1]
+    if (FOLD_EPILOGUE and out_lowp and x.dtype == torch.bfloat16 and residual is None and nchw is None and scale is None
+            and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and conv.weight.dim() == 4
+            and conv.groups == 1):
+        # bf16 inference, activation only feeds the next GEMM: BN folded into the weights, bias (+ GELU) in the GEMM epilogue
+        wf, cf = _folded_of(conv, bn)
+        return torch._addmm_activation(cf, x, wf.t(), use_gelu=(act == 1))
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
     return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
                               rows_per_scale)
