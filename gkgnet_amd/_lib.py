@@ -22,7 +22,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
            "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
-           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
+           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
            "gkg_bn_apply_train", "gkg_bn_bwd_train")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
@@ -98,6 +98,8 @@ def load():
     lib.gkg_bn_bwd_coef.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V, Z, V]
     lib.gkg_linear_bn_bwd.restype = I
     lib.gkg_linear_bn_bwd.argtypes = [V, I, Z, V, V, V, V, V, V, I, I, I, I, C.c_uint, V, Z, V, V]
+    lib.gkg_affine_act_dual.restype = I
+    lib.gkg_affine_act_dual.argtypes = [V, V, V, V, V, V, I, I, I, V, I, V]
     lib.gkg_edge_stats.restype = I
     lib.gkg_edge_stats.argtypes = [V, V, V, V, I, I, I, I, I, V]
     lib.gkg_edge_fwd.restype = I

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          const float* __restrict__ cs, const float* __restrict__ res,
                                                          OutT* __restrict__ out, size_t total4, int C, int ldo,
                                                          size_t o_bstride, const float* __restrict__ row_scale,
-                                                         int rows_per_scale) {
+                                                         int rows_per_scale, uint16_t* __restrict__ out2 = nullptr) {
   const int C4 = C >> 2;
   const int q = blockIdx.y;
   y += (size_t)q * total4 * 4; a += (size_t)q * C; cs += (size_t)q * C; out += (size_t)q * o_bstride;
@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
     stf4(out + r * (size_t)ldo + 4 * cg, o);
+    if (out2) stf4(out2 + r * (size_t)ldo + 4 * cg, o);       // second, bf16 copy of the same values (gkg_affine_act_dual)
   }
 }
 
@@ -552,15 +553,32 @@ extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, co
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
-    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
+    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
   } else {
     float* o = (float*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
-    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");
+}
+
+// gkg_affine_act (one batch, contiguous rows) writing the result twice: fp32 (the residual stream) and its bf16 rounding
+// (the next projection's GEMM operand under bf16 autocast inference) — saves the stand-alone cast pass between blocks.
+extern "C" int gkg_affine_act_dual(const float* y, const float* a, const float* c, const float* res, float* out_f32,
+                                   void* out_bf16, int R, int C, int act, const float* row_scale, int rows_per_scale,
+                                   void* stream) {
+  if (row_scale && rows_per_scale <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act_dual: rows_per_scale must be positive");
+  if (!y || !a || !c || !out_f32 || !out_bf16) return gkg_fail(GKG_ERR_NULL, "gkg_affine_act_dual: null pointer");
+  if (R <= 0 || bad_c(C) || (act != 0 && act != 1)) return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act_dual: bad sizes");
+  const size_t total4 = (size_t)R * (C >> 2);
+  const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), dim3(blocks, 1), dim3(256), 0, st, y, a, c, res, out_f32, total4, C, C, (size_t)0, row_scale, rows_per_scale, (uint16_t*)out_bf16);
+  else hipLaunchKernelGGL((affine_act_kernel<0, float>), dim3(blocks, 1), dim3(256), 0, st, y, a, c, res, out_f32, total4, C, C, (size_t)0, row_scale, rows_per_scale, (uint16_t*)out_bf16);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel (dual)");
 }
 
 extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,

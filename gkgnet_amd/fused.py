@@ -358,9 +358,7 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False, pla
         return Y, a, c, mean, invstd
     _lib.check(fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 0, None, None, None, None, None, None,
                                      None, None, None, None, 0.0, 0.0, None, _stream()), "gkg_linear_bn_fwd")
-    _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
-                                      _ptr(bn.running_var), _ptr(a), _ptr(c), nb * cout, float(bn.eps), _stream()),
-               "gkg_bn_eval_affine")
+    a, c = _bn_eval_ac(lib, bn, bias, nb * cout)
     return Y, a, c, None, None
 
 
@@ -484,13 +482,28 @@ class _TokenMajorToCL(torch.autograd.Function):
         return out, None, None, None
 
 
+def _cl_out(out_tm, B, H, W):
+    """Token-major block output -> channels-last tensor; a bf16 copy emitted by the last kernel rides along as an attribute
+    (keyed on the tensor's version) for the next block's entry."""
+    res = _TokenMajorToCL.apply(out_tm, B, H, W)
+    o16 = getattr(out_tm, "_gkg_bf16_tm", None)
+    if o16 is not None:
+        res._gkg_bf16 = (res._version, o16)
+    return res
+
+
 def _block_entry(x, lp):
     """-> (GEMM operand (T, C), residual, channels_last?).  Channels-last input: both are views of x (bf16 inference: the
     operand is a cast copy); NCHW input: the layout kernel (_BlockEntry)."""
     if is_channels_last(x):
         B, C, H, W = x.shape
         xt = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
-        return (xt.to(torch.bfloat16) if lp else xt), xt, True
+        if lp:
+            # the producing block may have left the bf16 rounding of this very tensor (see _cl_out): no cast pass
+            ent = getattr(x, "_gkg_bf16", None)
+            x16 = ent[1] if ent is not None and ent[0] == x._version and ent[1].shape == xt.shape else xt.to(torch.bfloat16)
+            return x16, xt, True
+        return xt, xt, True
     xt, xr = _BlockEntry.apply(x.float().contiguous(), lp)
     return xt, xr, False
 
@@ -563,6 +576,25 @@ def _sync_group(bn):
     return group if dist.get_world_size(group) > 1 else None
 
 
+def _bn_eval_ac(lib, bn, bias, n):
+    """(a, c) of an eval-mode BN folded with the conv bias: out = a*Y + c.  Cached on the module and recomputed (one
+    small kernel) only when one of the tensors it derives from changed — an inference forward launched it per layer."""
+    srcs = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([bias] if bias is not None else [])
+    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps, n)
+    ent = getattr(bn, "_gkg_eval_ac", None)
+    if ent is None or ent[0] != key or torch.is_grad_enabled():
+        a = torch.empty(n, dtype=_F32, device=bn.weight.device)
+        c = torch.empty_like(a)
+        _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
+                                          _ptr(bn.running_var), _ptr(a), _ptr(c), n, float(bn.eps), _stream()),
+                   "gkg_bn_eval_affine")
+        if torch.is_grad_enabled():
+            return a, c
+        ent = (key, a, c)
+        bn._gkg_eval_ac = ent
+    return ent[1], ent[2]
+
+
 def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
     """Returns (a, c, mean, invstd, sync) for out = a*Y + c; updates running statistics in train mode.
     ``sync`` is None (local statistics) or (group, count): the statistics were summed over the ranks of ``group``
@@ -596,9 +628,7 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
                                        _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), C, nb, float(bn.momentum),
                                        float(bn.eps), nbt, _stream()), "gkg_bn_finalize")
         return a, c, mean, invstd, (group, count)
-    _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
-                                      _ptr(bn.running_var), _ptr(a), _ptr(c), nb * C, float(bn.eps), _stream()),
-               "gkg_bn_eval_affine")
+    a, c = _bn_eval_ac(lib, bn, bias, nb * C)
     return a, c, None, None, None
 
 
@@ -635,7 +665,7 @@ class _LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None, scale=None,
-                rows_per_scale=0):
+                rows_per_scale=0, want16=False):
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
@@ -673,7 +703,13 @@ class _LinearBNAct(torch.autograd.Function):
                 else:
                     a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
             if own or not two:
-                if nchw is None:
+                if nchw is None and want16 and code == _lib.F32:
+                    # bf16 inference, channels-last chain: also emit the bf16 rounding the next block's first GEMM reads
+                    out16 = torch.empty((R, cout), dtype=torch.bfloat16, device=x.device)
+                    _lib.check(lib.gkg_affine_act_dual(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), _ptr(out16), R, cout, act,
+                                                       _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act_dual")
+                    out._gkg_bf16_tm = out16
+                elif nchw is None:
                     _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
                                                   code, _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act")
                 else:
@@ -713,7 +749,7 @@ class _LinearBNAct(torch.autograd.Function):
             dx, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, R * cout, Y, a, c, mean, invstd, x,
                                                     weight.view(cout, cin), R, cin, cout, 1, act,
                                                     ctx.needs_input_grad[0], ctx.gparams)
-            return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
+            return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (cout, cin), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
@@ -727,7 +763,7 @@ class _LinearBNAct(torch.autograd.Function):
         else:
             dx = torch.mm(dY, W)
         dW = _wgrad(dY, x, dWv).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -902,7 +938,7 @@ def fused_supported(mod, x, groups: int) -> bool:
     return ENABLED
 
 
-def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0):
+def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False):
     """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
     output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402)."""
     conv, bn = seq[0], seq[1]
@@ -914,7 +950,7 @@ def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, ro
         return torch._addmm_activation(cf, x, wf.t(), use_gelu=(act == 1))
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
     return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
-                              rows_per_scale)
+                              rows_per_scale, want16)
 
 
 def _drop_scale(drop_path, batch, device):
@@ -940,8 +976,8 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
                                    _w16_of(nn_[0]) if lp else None)   # (T, 2C)
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
-        out = _lin(a2, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=N)
-        return _TokenMajorToCL.apply(out, B, H, W), edge
+        out = _lin(a2, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=N, want16=lp)
+        return _cl_out(out, B, H, W), edge
     out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W),          # ... back to NCHW
                scale=_drop_scale(mod.drop_path, B, x.device))
     return out, edge
@@ -992,6 +1028,6 @@ def ffn_forward(mod, x):
     xt, x, cl = _block_entry(x, lp)
     h = _lin(xt, mod.fc1, act=1, out_lowp=lp)
     if cl:
-        out = _lin(h, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=H * W)
-        return _TokenMajorToCL.apply(out, B, H, W)
+        out = _lin(h, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=H * W, want16=lp)
+        return _cl_out(out, B, H, W)
     return _lin(h, mod.fc2, residual=x, nchw=(B, C, H, W), scale=_drop_scale(mod.drop_path, B, x.device))

@@ -189,6 +189,10 @@ int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias,
 int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
                    int nb, int ldo, size_t out_bstride, int act, int out_dtype, const float* row_scale, int rows_per_scale,
                    void* stream);
+/* gkg_affine_act for one batch of contiguous rows writing the result twice: fp32 (the residual stream) and its bf16
+ * rounding (the next projection's operand in bf16 inference) — no stand-alone cast pass between blocks. */
+int gkg_affine_act_dual(const float* y, const float* a, const float* c, const float* res, float* out_f32, void* out_bf16,
+                        int R, int C, int act, const float* row_scale, int rows_per_scale, void* stream);
 /* Backward of out = act(BN_train(y)): dy, dgamma, dbeta from dout (row pitch ldg, batch stride dout_bstride). */
 int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,

@@ -250,3 +250,22 @@ def test_deterministic_scatter_is_bit_reproducible_and_correct():
                 assert torch.allclose(s1, t1, atol=1e-4, rtol=1e-4)
     finally:
         fused.DETERMINISTIC = old
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_affine_act_dual_writes_both_copies(act):
+    """gkg_affine_act_dual: the fp32 result equals gkg_affine_act's and the second output is its bf16 rounding."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(act)
+    R, C = 1003, 72
+    Y, res = torch.randn(R, C, device="cuda"), torch.randn(R, C, device="cuda")
+    a, c = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    scale = torch.rand(17, device="cuda")
+    o1 = torch.empty(R, C, device="cuda"); o2 = torch.full((R, C), float("nan"), device="cuda")
+    o16 = torch.full((R, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.gkg_affine_act(Y.data_ptr(), a.data_ptr(), c.data_ptr(), res.data_ptr(), o1.data_ptr(), R, C, 1, C, 0, act,
+                                  _lib.F32, scale.data_ptr(), 59, None), "gkg_affine_act")
+    _lib.check(lib.gkg_affine_act_dual(Y.data_ptr(), a.data_ptr(), c.data_ptr(), res.data_ptr(), o2.data_ptr(), o16.data_ptr(),
+                                       R, C, act, scale.data_ptr(), 59, None), "gkg_affine_act_dual")
+    assert torch.equal(o1, o2) and torch.equal(o16, o1.bfloat16())

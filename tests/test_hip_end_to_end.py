@@ -107,3 +107,48 @@ def test_checkpoint_forward_head_metrics_on_device(tmp_path):
     assert np.isfinite(got).all() and got.shape == want.shape
     assert (np.abs(got - want) < 0.05).mean() >= 0.9
     assert abs(mAP(got, targets) - mAP(want, targets)) < 10.0
+
+
+def test_bf16_inference_shortcuts_keep_the_forward():
+    """bf16 autocast inference of the whole backbone with the round-2 layout / epilogue shortcuts on (channels-last
+    chaining, bf16 copy emitted by a block's last kernel, BN folded into the FFN GEMM's bias + GELU epilogue) against the
+    same forward with them off, on the SAME graphs (the second run replays the first run's neighbour lists: with random
+    weights a near-tie flip would otherwise dominate the comparison): equal within what bf16 rounding allows."""
+    from gkgnet_amd import fused
+    torch.manual_seed(5)
+    net, _ = _build()
+    with torch.no_grad():
+        keyed_fill_(net.state_dict(), seed=41)
+    net = net.cuda()
+    imgs = torch.randn(4, 3, 128, 128, device="cuda")
+    net.train()
+    with torch.no_grad():
+        for _ in range(2):
+            net(imgs)                                     # a well-conditioned eval model: calibrate the running statistics
+    net.eval()
+    outs, graphs = {}, []
+    real = fused.knn_graph_tm
+    saved = (fused.CHANNELS_LAST, fused.FOLD_EPILOGUE)
+    try:
+        for mode in ("off", "on"):
+            fused.CHANNELS_LAST = fused.FOLD_EPILOGUE = (mode == "on")
+            it = iter(graphs)
+
+            def knn(*a, **k):
+                if mode == "off":
+                    e = real(*a, **k)
+                    graphs.append(e)
+                    return e
+                return next(it)
+            fused.knn_graph_tm = knn
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                labels, gap, edge = net(imgs)
+            outs[mode] = (labels.float(), gap.float())
+    finally:
+        fused.knn_graph_tm = real
+        fused.CHANNELS_LAST, fused.FOLD_EPILOGUE = saved
+    assert len(graphs) == 16
+    for a, b in zip(outs["on"], outs["off"]):
+        assert a.shape == b.shape and torch.isfinite(a).all() and torch.isfinite(b).all()
+        scale = b.abs().mean().item()
+        assert (a - b).abs().mean().item() <= 0.02 * scale + 1e-3, ((a - b).abs().mean().item(), scale)
