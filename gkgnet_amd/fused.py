@@ -277,6 +277,7 @@ def _bn2_apply(lib, Y, bn, bias, shifted, res, out, R, C, nb, ldo, obs, act, cod
     a = torch.empty(nb * C, dtype=_F32, device=dev)
     c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
     track = bn.training and bn.track_running_stats
+    _touch_stats(bn, track)
     _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(_stats_scratch(dev)), shifted, _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
                                       _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
                                       _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
@@ -349,6 +350,7 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False, pla
         mean = torch.empty_like(a)
         invstd = torch.empty_like(a)
         track = bn.training and bn.track_running_stats
+        _touch_stats(bn, track)
         _lib.check(fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 1, _ptr(bn.weight), _ptr(bn.bias),
                                          _ptr(bias), _ptr(bn.running_mean) if track else None,
                                          _ptr(bn.running_var) if track else None,
@@ -420,9 +422,12 @@ def _folded_of(conv, bn):
     mean included) as a bf16 bias — (W' (cout, cin), c' (cout)) — cached on the module and refreshed when any of the six
     tensors it derives from changes.  With them out = act(x W'^T + c') is ONE library GEMM with a bias(+GELU) epilogue."""
     srcs = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
-    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps,)
+    # the running statistics can change behind the version counters (layers._StatsEpoch): norm layers without the epoch
+    # counter are never cached
+    epoch = getattr(bn, "_gkg_epoch", None)
+    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps, epoch)
     ent = getattr(conv, "_gkg_fold", None)
-    if ent is None or ent[0] != key:
+    if ent is None or ent[0] != key or epoch is None:
         with torch.no_grad():
             a = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
             shift = bn.bias.float() - a * bn.running_mean.float()
@@ -576,19 +581,26 @@ def _sync_group(bn):
     return group if dist.get_world_size(group) > 1 else None
 
 
+def _touch_stats(bn, track):
+    """The kernels about to run update bn's running statistics through raw pointers: invalidate what was derived from them."""
+    if track and hasattr(bn, "_gkg_epoch"):
+        bn._gkg_epoch += 1
+
+
 def _bn_eval_ac(lib, bn, bias, n):
     """(a, c) of an eval-mode BN folded with the conv bias: out = a*Y + c.  Cached on the module and recomputed (one
     small kernel) only when one of the tensors it derives from changed — an inference forward launched it per layer."""
     srcs = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([bias] if bias is not None else [])
-    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps, n)
+    epoch = getattr(bn, "_gkg_epoch", None)
+    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps, n, epoch)
     ent = getattr(bn, "_gkg_eval_ac", None)
-    if ent is None or ent[0] != key or torch.is_grad_enabled():
+    if ent is None or ent[0] != key or epoch is None or torch.is_grad_enabled():
         a = torch.empty(n, dtype=_F32, device=bn.weight.device)
         c = torch.empty_like(a)
         _lib.check(lib.gkg_bn_eval_affine(_ptr(bn.weight), _ptr(bn.bias), _ptr(bias), _ptr(bn.running_mean),
                                           _ptr(bn.running_var), _ptr(a), _ptr(c), n, float(bn.eps), _stream()),
                    "gkg_bn_eval_affine")
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() or epoch is None:
             return a, c
         ent = (key, a, c)
         bn._gkg_eval_ac = ent
@@ -608,6 +620,7 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
         invstd = torch.empty_like(a)
         ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), dev)
         track = bn.training and bn.track_running_stats
+        _touch_stats(bn, track)
         rm = _ptr(bn.running_mean) if track else None
         rv = _ptr(bn.running_var) if track else None
         nbt = _ptr(bn.num_batches_tracked) if track else None

@@ -42,11 +42,23 @@ def _guard_memory_format(norm_forward):
     return forward
 
 
-class GuardedSyncBatchNorm(nn.SyncBatchNorm):
+class _StatsEpoch:
+    """``_gkg_epoch`` changes whenever the running statistics may have changed behind PyTorch's version counters: the fused
+    path's kernels update them through raw pointers (and a captured training step does so without running any Python), so
+    every train() / eval() switch and every eager train-mode update bumps it.  Inference-time caches derived from the
+    statistics (fused._bn_eval_ac, fused._folded_of) are keyed on it."""
+    _gkg_epoch = 0
+
+    def train(self, mode: bool = True):
+        self._gkg_epoch += 1
+        return super().train(mode)
+
+
+class GuardedSyncBatchNorm(_StatsEpoch, nn.SyncBatchNorm):
     forward = _guard_memory_format(nn.SyncBatchNorm.forward)
 
 
-class GuardedBatchNorm2d(nn.BatchNorm2d):
+class GuardedBatchNorm2d(_StatsEpoch, nn.BatchNorm2d):
     forward = _guard_memory_format(nn.BatchNorm2d.forward)
 
 

@@ -152,3 +152,33 @@ def test_bf16_inference_shortcuts_keep_the_forward():
         assert a.shape == b.shape and torch.isfinite(a).all() and torch.isfinite(b).all()
         scale = b.abs().mean().item()
         assert (a - b).abs().mean().item() <= 0.02 * scale + 1e-3, ((a - b).abs().mean().item(), scale)
+
+
+def test_inference_caches_follow_the_running_statistics():
+    """eval -> train steps (the fused kernels update the running statistics through raw pointers) -> eval: the cached
+    eval-mode BN coefficients and folded weights must be rebuilt."""
+    from gkgnet_amd.backbone import FFN
+    torch.manual_seed(3)
+    ffn = FFN(32, 64, act="gelu").cuda()
+    x = torch.randn(2, 32, 10, 10, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def infer():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return ffn(x).float()
+
+    ffn.eval()
+    y0 = infer()
+    ffn.train()
+    for _ in range(3):
+        ffn(torch.randn(2, 32, 10, 10, device="cuda") * 3 + 1)     # moves running_mean / running_var a lot
+    ffn.eval()
+    y1 = infer()
+    from gkgnet_amd import fused
+    fused.ENABLED = False
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            want = ffn(x).float()
+    finally:
+        fused.ENABLED = True
+    assert (y1 - y0).abs().mean() > 0.05 * y0.abs().mean()       # the statistics did change the function
+    assert (y1 - want).abs().mean() <= 0.02 * want.abs().mean() + 1e-3
