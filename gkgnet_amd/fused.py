@@ -137,7 +137,10 @@ class _WeightPlanes:
             if cap != self.capture_id:
                 self.capture_id = cap
                 self.refresh(lib)
-        elif e["version"] != weight._version:
+        elif self.capture_id or e["version"] != weight._version:
+            # eager call: stale by the version counter — or graphs were captured since the last eager refresh, and their
+            # replays may have updated the weights (a captured optimiser step) without any counter moving
+            self.capture_id = 0
             self.refresh(lib)
         return e["pf"], e["pd"]
 
