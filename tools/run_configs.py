@@ -10,7 +10,13 @@ def main():
     ap.add_argument("cfg", choices=["cfg3", "cfg5"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--no-tune", action="store_true", help="keep the GEMM library's default kernel selection")
     args = ap.parse_args()
+    if not args.no_tune:                 # as in bench.py: let TunableOp pick the library GEMM per shape during the first step
+        import torch.cuda.tunable as tunable
+        tunable.enable(True); tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30); tunable.set_max_tuning_iterations(20)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_{args.cfg}.csv"))
     os.environ.setdefault("GKG_RELPOS_DEVICE", "cuda")
     from gkgnet_amd import _lib, layers
     from gkgnet_amd.backbone import GKGNet
