@@ -41,6 +41,7 @@ ENABLED = True          # set False to force the composable (per-op) path, e.g. 
 # R >= 32768 (stage-3/4 of GKGNet-576: 150 vs 186 + 10 us at 41 472 x 400 x 400); in between (cfg2's 10 368 rows) the
 # vendor kernels' finer macro-tiles win by ~3 us per layer.
 OWN_GEMM = os.environ.get("GKG_OWN_GEMM", "auto")
+LONG_K = int(os.environ.get("GKG_OWN_GEMM_LONG_K", "1024"))
 # Two-kernel train-mode BN (fp64-atomic statistics, coefficients derived inline by the consumer, csrc/gkg_dense.hip) vs
 # the three-kernel form (two-stage ordered sums -> finalize -> apply).  Measured at cfg2: the two-kernel form is SLOWER
 # (1.148 vs 1.021 ms/step): every consumer workgroup then starts with a dependent read of freshly atomically-written
@@ -308,6 +309,8 @@ def _own_gemm(x, weight, bn) -> bool:
         R = x.shape[-2]
         if 4096 < R < 32768:
             return False
+        if R <= 4096 and x.shape[-1] >= LONG_K:      # few rows x long contraction (FFN fc2, 2560 x 1280 -> 320): the vendor
+            return False                             # kernel's split-K wins (21 + 10 us of statistics passes vs 34 + 5)
     elif OWN_GEMM not in ("fwd", "all"):
         return False
     return (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None)
