@@ -560,6 +560,129 @@ __global__ __launch_bounds__(256) void wgrad_x6_kernel(X6WgradArgs g) {
   }
 }
 
+// The same workgroup / wave decomposition with the rows staged through LDS: each wave copies the next 16 rows of its own K
+// range (64 columns of dY, 64 of X: 8 KiB) global -> a private 4-stage LDS ring by LDS-DMA — eight 16-byte-per-lane
+// instructions per step where the register form above needs 32 dword loads (16 address cycles per 256 B each: measured
+// texture-address-bound) — and reads the column fragments back with ds_read_b32.  No barriers: a wave only ever reads what
+// it copied itself.  Requires every row of the launch to be inside the tensor (the host gives the ragged remainder to the
+// register-load kernel) and 16-byte aligned rows; columns past M / N are read from a clamped address and zeroed after the
+// LDS read.  Step s issues the DMA of step s + 4, waits until step s + 2 has landed (counted vmcnt) and reads it.
+__global__ __launch_bounds__(256) void wgrad_x6_dma_kernel(X6WgradArgs g) {
+  extern __shared__ float wlds[];               // [4 waves][4 stages][2 operands][16 rows][64 cols], then reused for the reduce
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.y;
+  const int ntile = g.mtiles * g.ntiles;
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+  if (split >= g.splits) return;
+  const int m0 = (tile / g.ntiles) * 64, n0 = (tile % g.ntiles) * 64;
+  const int r = lane & 31, h = lane >> 5;
+  const int rows_per_wave = g.rows_per_split >> 2;
+  const long long k_begin = (long long)split * g.rows_per_split + (long long)w * rows_per_wave;
+  const int T = rows_per_wave >> 4;
+  const char* Az = (const char*)(g.A + (size_t)z * g.a_bstride);
+  const char* Bz = (const char*)(g.B + (size_t)z * g.b_bstride);
+  const unsigned lds0 = (unsigned)(size_t)wlds + w * (4 * 8192);
+
+  // DMA piece p (4 per operand): rows 4p .. 4p+3; lane -> row 4p + (lane >> 4), 16-byte column chunk lane & 15
+  const int prow = lane >> 4, pch = lane & 15;
+  const int ca = min(m0 + 4 * pch, g.M - 4), cb = min(n0 + 4 * pch, g.N - 4);      // clamped: masked after the LDS read
+  const unsigned dA = (unsigned)(((size_t)prow * g.lda + ca) * 4), dB = (unsigned)(((size_t)prow * g.ldb + cb) * 4);
+  const unsigned strideA = (unsigned)g.lda * 16u, strideB = (unsigned)g.ldb * 16u;            // 4 rows, bytes
+  auto dma = [&](int s) __attribute__((always_inline)) {
+    const long long row0 = k_begin + 16ll * s;
+    const char* ab = Az + row0 * g.lda * 4;
+    const char* bb = Bz + row0 * g.ldb * 4;
+    const unsigned dst = lds0 + (s & 3) * 8192;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      x6_dma16(ab, dA + p * strideA, dst + p * 1024);
+      x6_dma16(bb, dB + p * strideB, dst + 4096 + p * 1024);
+    }
+  };
+  // fragment (block i of operand o) of stage st: lane (r, h) reads rows 8h .. 8h+7 at column 32 i + r
+  const bool va0 = m0 + r < g.M, va1 = m0 + 32 + r < g.M, vb0 = n0 + r < g.N, vb1 = n0 + 32 + r < g.N;
+  const bool tail = m0 + 64 > g.M || n0 + 64 > g.N;                                           // uniform
+  auto readfr = [&](float (&raw)[4][8], int s) __attribute__((always_inline)) {
+    const float* base = wlds + w * (4 * 2048) + (s & 3) * 2048 + (8 * h) * 64 + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      raw[0][j] = base[j * 64];
+      raw[1][j] = base[j * 64 + 32];
+      raw[2][j] = base[1024 + j * 64];
+      raw[3][j] = base[1024 + j * 64 + 32];
+    }
+    if (tail) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        raw[0][j] = va0 ? raw[0][j] : 0.f; raw[1][j] = va1 ? raw[1][j] : 0.f;
+        raw[2][j] = vb0 ? raw[2][j] : 0.f; raw[3][j] = vb1 ? raw[3][j] : 0.f;
+      }
+    }
+  };
+  float raw0[4][8], raw1[4][8];
+  X6WFrag fr0, fr1;
+  unsigned t0[4], t1[4];
+  x6_f32x16 acc[2][2], accs[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[i][j][q] = 0.f; accs[i][j][q] = 0.f; }
+
+  // prologue: DMA steps 0..3; read steps 0 and 1; split step 0
+  dma(0);
+  if (T > 1) dma(1);
+  if (T > 2) dma(2);
+  if (T > 3) dma(3);
+  if (T > 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  readfr(raw0, 0);
+  if (T > 1) readfr(raw1, 1);
+  x6w_ops<0, 176>(raw0, fr0, t0, t1);
+  // step s (fr[s&1]): splits raw[(s+1)&1] (step s+1); then DMA step s+4, wait for step s+2, read it into raw[s&1]
+  auto tailwork = [&](float (&rawn)[4][8], int s) __attribute__((always_inline)) {
+    if (s + 4 < T) dma(s + 4);
+    if (s + 2 < T) {
+      if (s + 4 < T) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // steps s+3, s+4 may stay in flight
+      else if (s + 3 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      readfr(rawn, s + 2);
+    }
+  };
+  for (int s = 0; s + 2 < T; s += 2) {
+    x6w_slots<0, true>(fr0, fr1, acc, accs, raw1, t0, t1);     // step s: splits step s+1 (raw1) into fr1
+    tailwork(raw0, s);                                            // raw0 <- step s+2
+    x6w_slots<0, true>(fr1, fr0, acc, accs, raw0, t0, t1);     // step s+1: splits step s+2 (raw0) into fr0
+    tailwork(raw1, s + 1);                                        // raw1 <- step s+3
+  }
+  x6w_slots<0, true>(fr0, fr1, acc, accs, raw1, t0, t1);
+  x6w_slots<0, false>(fr1, fr0, acc, accs, raw0, t0, t1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  __syncthreads();                              // every wave is done with its ring: reuse the LDS for the reduction
+  float* red = wlds;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h, col = 32 * j + r;
+        red[w * 4096 + row * 64 + col] = acc[i][j][q] + accs[i][j][q];
+      }
+  __syncthreads();
+  float* C = g.C + (size_t)z * g.c_bstride;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+    const float v = (red[e] + red[4096 + e]) + (red[8192 + e] + red[12288 + e]);
+    if (m0 + row < g.M && n0 + col < g.N)
+      __hip_atomic_fetch_add(C + (size_t)(m0 + row) * g.ldc + n0 + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
 inline size_t x6_plane_units(int n, int k, int nb) {       // uint4 units of one orientation: B[n][k]
   return (size_t)nb * 3 * ((k + 31) / 32 * 4) * ((n + X6_NPAD - 1) / X6_NPAD * X6_NPAD);
@@ -680,9 +803,39 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   int splits = (240 + tiles / 2) / tiles;
   splits = splits < 1 ? 1 : (splits > units ? units : splits);
   a.rows_per_split = (units + splits - 1) / splits * 128;
-  a.splits = (R + a.rows_per_split - 1) / a.rows_per_split;
-  const int groups = (a.splits + 7) / 8;
-  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(groups * 8 * a.mtiles * a.ntiles, nb), dim3(256), 0, (hipStream_t)stream, a);
-  hipError_t e = hipGetLastError();
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  // rows covered by whole slabs go through the LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and
+  // everything, when they are not) through the register-load kernel
+  const bool aligned = (cin & 3) == 0 && (cout & 3) == 0 && (ldg & 3) == 0 && (ldx & 3) == 0 && (g_bstride & 3) == 0 &&
+                       (x_bstride & 3) == 0 && ((size_t)dy & 15) == 0 && ((size_t)x & 15) == 0 &&
+                       (size_t)R * ldg * 4 < 0xffffffffull && (size_t)R * ldx * 4 < 0xffffffffull &&
+                       getenv("GKG_X6_WGRAD_NO_DMA") == nullptr;
+  const int main_splits = aligned ? R / a.rows_per_split : 0;
+  if (main_splits > 0) {
+    X6WgradArgs m = a;
+    m.K = main_splits * a.rows_per_split; m.splits = main_splits;
+    const size_t sh = 4 * 4 * 8192;
+    static bool once = false;
+    if (!once) {
+      e = hipFuncSetAttribute((const void*)wgrad_x6_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_dma_kernel (attribute)");
+      once = true;
+    }
+    hipLaunchKernelGGL(wgrad_x6_dma_kernel, dim3((main_splits + 7) / 8 * 8 * a.mtiles * a.ntiles, nb), dim3(256), sh, st, m);
+    e = hipGetLastError();
+    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_dma_kernel");
+  }
+  const int done = main_splits * a.rows_per_split, rest = R - done;
+  if (rest > 0) {
+    X6WgradArgs t = a;
+    t.A = dy + (size_t)done * ldg; t.B = x + (size_t)done * ldx; t.K = rest;
+    const int tunits = (rest + 127) / 128;
+    int ts = splits > tunits ? tunits : splits;
+    t.rows_per_split = (tunits + ts - 1) / ts * 128;
+    t.splits = (rest + t.rows_per_split - 1) / t.rows_per_split;
+    hipLaunchKernelGGL(wgrad_x6_kernel, dim3((t.splits + 7) / 8 * 8 * a.mtiles * a.ntiles, nb), dim3(256), 0, st, t);
+    e = hipGetLastError();
+  }
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "wgrad_x6_kernel");
 }

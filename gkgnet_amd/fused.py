@@ -187,15 +187,24 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
+X6_WGRAD = os.environ.get("GKG_X6_WGRAD", "1") != "0"
+
+
 def _x6_wgrad_ok(dY, x) -> bool:
-    """The streaming x6 weight-gradient kernel (gkg_linear_wgrad_x6: both operands split in registers, fragments loaded
-    straight from global memory, no operand sharing between workgroups).  Measured on MI355X it is NOT a win and is
-    only selected by GKG_GEMM_MATH=x6all (tests): against the vendor library's default kernels it is 1.3-1.6x faster on
-    GKGNet-576's stage-1/2 shapes (R = 663 552 / 165 888 rows, 80-160 channels: 313 vs 523 us) but slower than the
-    TunableOp-selected ones inside the train step (cfg4 step 99.8 -> 104.3 ms), and it collapses once the output
-    needs many 64 x 64 tiles (every tile re-streams the rows: 453 vs 210 us at 41 472 x 400 -> 400).  Its dword-per-lane
-    fragment loads cost 16 address cycles per 256 B; the next version stages rows through LDS by DMA."""
-    return GEMM_MATH == "x6all" and OWN_GEMM != "none" and dY.dtype == _F32 and x.dtype == _F32
+    """The streaming x6 weight-gradient kernel (gkg_linear_wgrad_x6: both operands split in registers, each wave copies its
+    own rows through a private LDS ring by DMA; no operand sharing between workgroups) pays for long token axes under small
+    outputs — GKGNet-576's stage-1/2 projections (R = 663 552 / 165 888 rows, 80-640 channels): 179 vs 527 us at 80 -> 80
+    and 162 vs 472 at 320 -> 160 against the vendor library's default split-K; inside the cfg4 train step, where TunableOp
+    has picked the vendor kernels, it TIES them (16 launches, 4.1 ms; step 102.5 vs 102.7-103.5 ms) — kept on so that these
+    layers do not depend on a tuning pass.  It loses once the output needs many 64 x 64 tiles, each of which re-streams the
+    rows (41 472 x 400 -> 400: 49 tiles).  GKG_GEMM_MATH=x6all: every fp32 shape; GKG_X6_WGRAD=0: never."""
+    if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none" or dY.dtype != _F32 or x.dtype != _F32:
+        return False
+    if GEMM_MATH == "x6all":
+        return True
+    R, cout, cin = x.shape[0], dY.shape[1], x.shape[1]
+    tiles = ((cout + 63) // 64) * ((cin + 63) // 64)
+    return X6_WGRAD and not DETERMINISTIC and R >= 65536 and tiles <= 32       # fp32 atomics: run-dependent summation order
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
