@@ -300,6 +300,15 @@ def main():
             if name in kernels and kernels[name]["us_per_step"] > 0:
                 gbs = nbytes / kernels[name]["us_per_step"] / 1e3
                 kernels[name].update(bound="hbm", achieved_GBps=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBPS, 4))
+        if "gemm_x6" in kernels and kernels["gemm_x6"]["us_per_step"] > 0:
+            # the projection GEMMs that run on the split-bf16 kernels: algorithmic fp32 flop (2 R cin cout, reported by the
+            # library per launch) per second, against the fp32-MFMA peak they replace and against their own bound — six
+            # bf16 MFMAs per fp32 block product at the dense bf16 peak (2.5 PFLOP/s / 6)
+            gf = _lib.prof_work("gemm_x6") / prof_steps
+            tf = gf / kernels["gemm_x6"]["us_per_step"] / 1e6
+            kernels["gemm_x6"].update(bound="mfma", algorithmic_flops_per_step=gf, achieved_TFLOPs=round(tf, 1),
+                                      frac_of_fp32_mfma_peak=round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                      frac_of_split_bf16_bound=round(tf / (2500.0 / 6), 4))
         res = dict(metric="Grapher fwd+bwd images/sec", value=round(value, 1), unit="images/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 4), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",

@@ -18,14 +18,14 @@ LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 MR_DETERMINISTIC = 1
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
-           "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
+           "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_prof_work", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
            "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
            "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
            "gkg_bn_apply_train", "gkg_bn_bwd_train")
-PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd")
+PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
 
@@ -138,6 +138,8 @@ def load():
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None
     lib.gkg_prof_read.restype = C.c_int
+    lib.gkg_prof_work.restype = C.c_double
+    lib.gkg_prof_work.argtypes = [C.c_int]
     lib.gkg_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     v = lib.gkg_version()
     if v != ABI_VERSION:
@@ -158,6 +160,11 @@ def prof_enable(on: bool = True):
 
 def prof_reset():
     load().gkg_prof_reset()
+
+
+def prof_work(name):
+    """Algorithmic flop of the launches counted for ``name`` since the last reset (kernels that report it)."""
+    return load().gkg_prof_work(PROF_KERNELS.index(name))
 
 
 def prof_read():

@@ -41,6 +41,7 @@ std::vector<ProfRec> g_recs;          // recorded, not yet read
 std::vector<hipEvent_t> g_free;       // event pool
 double g_ms[GKG_PROF_NUM] = {0};
 long g_cnt[GKG_PROF_NUM] = {0};
+double g_work[GKG_PROF_NUM] = {0};
 constexpr size_t kMaxPending = 1 << 16;
 
 hipEvent_t get_event() {
@@ -63,10 +64,11 @@ void drain_locked() {
 }
 }  // namespace
 
-GkgProfScope::GkgProfScope(int kernel_id, hipStream_t s) : slot(-1), st(s) {
+GkgProfScope::GkgProfScope(int kernel_id, hipStream_t s, double work) : slot(-1), st(s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_recs.size() >= kMaxPending) return;
+  if (kernel_id >= 0 && kernel_id < GKG_PROF_NUM) g_work[kernel_id] += work;
   ProfRec r{kernel_id, get_event(), get_event()};
   if (!r.a || !r.b) return;
   (void)hipEventRecord(r.a, st);
@@ -85,7 +87,13 @@ extern "C" void gkg_prof_enable(int on) { g_prof_on = on != 0; }
 extern "C" void gkg_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   drain_locked();
-  for (int i = 0; i < GKG_PROF_NUM; ++i) { g_ms[i] = 0; g_cnt[i] = 0; }
+  for (int i = 0; i < GKG_PROF_NUM; ++i) { g_ms[i] = 0; g_cnt[i] = 0; g_work[i] = 0; }
+}
+
+extern "C" double gkg_prof_work(int kernel_id) {
+  if (kernel_id < 0 || kernel_id >= GKG_PROF_NUM) return 0.0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  return g_work[kernel_id];
 }
 
 extern "C" int gkg_prof_read(int kernel_id, double* total_ms, long* launches) {

@@ -44,7 +44,7 @@ int gkg_fail_hip(hipError_t e, const char* where);
 
 // Opt-in launch timing (gkg_prof_*): RAII bracket around one kernel launch on `st`.
 struct GkgProfScope {
-  GkgProfScope(int kernel_id, hipStream_t st);
+  GkgProfScope(int kernel_id, hipStream_t st, double work = 0.0);
   ~GkgProfScope();
   int slot;
   hipStream_t st;

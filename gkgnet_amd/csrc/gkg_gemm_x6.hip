@@ -395,6 +395,7 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
 // workgroup per CU) was tried and is slower everywhere (cfg2 fc1 25.8 vs 22.9 us).  GKG_X6_NI=1|2 (read per call) forces one.
 template <int EPI>
 static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_GEMM_X6, st, 2.0 * a.M * a.N * a.K * nb);
   const int mt = (a.M + 127) / 128;
   int ni = (long long)mt * ((a.N + 63) / 64) * nb < 160 ? 1 : 2;
   if (const char* f = getenv("GKG_X6_NI")) {

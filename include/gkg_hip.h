@@ -329,11 +329,15 @@ int gkg_bn_bwd_train(const float* dout, const float* y, const float* a, const fl
 #define GKG_PROF_KNN_MERGE 2
 #define GKG_PROF_MR_FWD 3
 #define GKG_PROF_MR_BWD 4
-#define GKG_PROF_NUM 5
+#define GKG_PROF_GEMM_X6 5  /* gemm_x6_kernel (forward and dgrad launches) */
+#define GKG_PROF_NUM 6
 void gkg_prof_enable(int on);
 void gkg_prof_reset(void);
 /* total milliseconds and number of launches recorded for `kernel_id` since the last reset; 0 on success. */
 int gkg_prof_read(int kernel_id, double* total_ms, long* launches);
+/* Algorithmic work (flop) of the launches counted by gkg_prof_read since the last reset, for the kernels that report it
+ * (GKG_PROF_GEMM_X6: 2 R cin cout nb per launch); 0 otherwise. */
+double gkg_prof_work(int kernel_id);
 
 #ifdef __cplusplus
 }
