@@ -83,7 +83,48 @@ def cpu_baseline(w, B, grapher, label, x, e, cot_x, cot_e, budget_s=12.0, thread
     torch.set_num_threads(old_threads)
     return dict(value=round(B * n / dt, 2), unit="images/s", cores=used, kind="port",
                 sample=f"{n} fwd+bwd steps of the same workload (B={B}) on the oracle (oracle/torch_ref.py), "
-                       f"{dt:.1f}s, torch CPU fp32, {used} threads, {os.cpu_count()} logical cpus visible")
+                       f"{dt:.1f}s, torch CPU fp32, {used} threads; host: {physical_cores()} physical cores / "
+                       f"{os.cpu_count()} logical cpus")
+
+
+def physical_cores() -> int:
+    """Physical cores of this host (unique (package, core) pairs in /proc/cpuinfo; SMT siblings counted once)."""
+    try:
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks as children (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) BEFORE this process has touched the GPU — it never does: it only relays the children's output
+    (rank 0 prints the JSON line) and their exit code.  Mirrors the reference's tools/dist_train.sh:5-7."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -103,10 +144,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))         # no launcher: be the launcher (this process never touches the GPU)
     from gkgnet_amd import _lib, layers, parallel
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -118,15 +161,6 @@ def main():
     w = WORKLOADS[args.workload]
     B, C, H, L = args.batch, w["C"], w["H"], w["L"]
 
-    if not args.no_tune:
-        # The dense projections are plain library GEMMs; let PyTorch's TunableOp pick the fastest rocBLAS /
-        # hipBLASLt solution per shape during the (untimed) warm-up instead of the default heuristic.
-        import torch.cuda.tunable as tunable
-        tunable.enable(True)
-        tunable.tuning_enable(True)
-        tunable.set_max_tuning_duration(30)
-        tunable.set_max_tuning_iterations(40)
-        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_rank{rank}.csv"))
     torch.manual_seed(0)
     grapher, label = build_modules(w, dev)
     parallel.broadcast_parameters(grapher)
@@ -157,78 +191,102 @@ def main():
         compute()
         bucket.all_reduce()
 
-    # The step is ~130 short kernels: launched eagerly it is bound by host launch overhead, so the inner loop is
+    # The step is ~85 short kernels: launched eagerly it is bound by host launch overhead, so the inner loop is
     # captured ONCE into a hipGraph (inputs, weights and the gradient bucket are static buffers) and replayed.
-    for _ in range(2):                   # eager warm-up (also where TunableOp tunes each GEMM shape once)
-        compute()
-    torch.cuda.synchronize()
-    graph = None
     # host-synchronising collectives (gloo) inside the step cannot be captured: SyncBN all-reduces its statistics in the step
     capturable = not (world > 1 and args.sync_bn and torch.distributed.get_backend() != "nccl")
     if not capturable:
         print("[bench] SyncBN over a non-RCCL backend: the step is launched eagerly", file=sys.stderr)
-    if not args.no_graph and capturable:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
+
+    def measure():
+        """eager warm-up -> capture -> (multi-rank: replay-vs-eager vote) -> W untimed + K timed steps.  Returns
+        (elapsed seconds of the K steps on this rank, captured graph or None)."""
+        for _ in range(2):                   # eager warm-up (also where TunableOp, when on, tunes each GEMM shape once)
+            compute()
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph and capturable:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        compute()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                if world > 1:
+                    torch.distributed.barrier()
+                g = torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread may poll events while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     compute()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            if world > 1:
-                torch.distributed.barrier()
-            g = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread may poll events while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                graph = g
+            except Exception as exc:                       # capture is an optimisation: fall back to eager launches
+                print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
                 compute()
-            graph = g
-        except Exception as exc:                       # capture is an optimisation: fall back to eager launches
-            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-            compute()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
 
-    def step():
-        if graph is None:
-            compute()
-        else:
-            graph.replay()
-        bucket.all_reduce()
+        def step():
+            if graph is None:
+                compute()
+            else:
+                graph.replay()
+            bucket.all_reduce()
 
-    if graph is not None and world > 1:
-        # Multi-rank guard (untimed): replay + collective must actually beat eager launches + collective on this
-        # node's runtime; if it does not (the ranks decide together), fall back to eager launches.
-        def timed(fn, n=4):
-            fn()
-            torch.cuda.synchronize()
-            torch.distributed.barrier()
-            t_ = time.perf_counter()
-            for _ in range(n):
+        if graph is not None and world > 1:
+            # Multi-rank guard (untimed): replay + collective must actually beat eager launches + collective on this
+            # node's runtime; if it does not (the ranks decide together), fall back to eager launches.
+            def timed(fn, n=4):
                 fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t_) / n
-        t_cmp = torch.tensor([timed(step), timed(eager_step)], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t_cmp, op=torch.distributed.ReduceOp.MAX)
-        if t_cmp[0].item() > t_cmp[1].item():
-            print(f"[bench] hipGraph replay slower than eager launches under this process group "
-                  f"({1e3 * t_cmp[0].item():.2f} vs {1e3 * t_cmp[1].item():.2f} ms/step); running eagerly", file=sys.stderr)
-            graph = None
+                torch.cuda.synchronize()
+                torch.distributed.barrier()
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_) / n
+            t_cmp = torch.tensor([timed(step), timed(eager_step)], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t_cmp, op=torch.distributed.ReduceOp.MAX)
+            if t_cmp[0].item() > t_cmp[1].item():
+                print(f"[bench] hipGraph replay slower than eager launches under this process group "
+                      f"({1e3 * t_cmp[0].item():.2f} vs {1e3 * t_cmp[1].item():.2f} ms/step); running eagerly", file=sys.stderr)
+                graph = None
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = t.item()
+        return el, graph
+
+    # Leg 1: the GEMM library's default kernel selection — what a drop-in user gets without a tuning pass.
+    elapsed_no_tune, graph = measure()
+    elapsed = elapsed_no_tune
+    if not args.no_tune:
+        # Leg 2 (the headline unless --no-tune): the projections that are still plain library GEMMs get PyTorch's
+        # TunableOp pick of the fastest rocBLAS / hipBLASLt solution per shape during the (untimed) warm-up.
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30)
+        tunable.set_max_tuning_iterations(40)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_rank{rank}.csv"))
+        graph = None
+        elapsed, graph = measure()
 
     # Per-kernel timing for the roofline: the same step, launched eagerly with the library's HIP-event brackets
     # on the launch stream (events cannot bracket individual nodes of a replayed graph).
@@ -240,10 +298,6 @@ def main():
     torch.cuda.synchronize()
     _lib.prof_enable(False)
     prof = _lib.prof_read()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
 
     from gkgnet_amd import fused
     lib_desc = "vendor-library GEMMs (TunableOp-selected)" if not args.no_tune else "vendor-library GEMMs (default heuristic)"
@@ -309,6 +363,23 @@ def main():
             kernels["gemm_x6"].update(bound="mfma", algorithmic_flops_per_step=gf, achieved_TFLOPs=round(tf, 1),
                                       frac_of_fp32_mfma_peak=round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                                       frac_of_split_bf16_bound=round(tf / (2500.0 / 6), 4))
+        # Step-level roofline: every algorithmic flop of the step (the projections' forward + input-gradient +
+        # weight-gradient GEMMs = 3x their forward, plus the two distance contractions) against the dense fp32 matrix peak,
+        # and the bytes that must cross HBM at least once (inputs, cotangents, input gradients, weights and weight
+        # gradients, relative_pos, the edge lists) against 8 TB/s.  The larger of the two times bounds the step.
+        T, TL = B * N, B * L
+        flops_proj = 3.0 * (8.0 * T * C * C + 24.0 * TL * C * C)
+        flops_step = flops_proj + flops_knn
+        n_par = sum(p.numel() for p in params)
+        bytes_step = 4.0 * (3 * B * C * N + 3 * B * L * C + B * C * N) + 8.0 * n_par + 4.0 * N * M + 8.0 * BG * (N + L) * w["k"]
+        t_flop = flops_step / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        t_byte = bytes_step / (PEAK_HBM_GBPS * 1e9)
+        roof_step = dict(bound="mfma" if t_flop >= t_byte else "hbm", algorithmic_flops=flops_step,
+                         algorithmic_bytes=bytes_step, flop_time_ms_at_fp32_peak=round(1e3 * t_flop, 4),
+                         byte_time_ms_at_8TBps=round(1e3 * t_byte, 4), achieved_TFLOPs=round(flops_step / (ms_step * 1e-3) / 1e12, 2),
+                         peak=PEAK_FP32_MFMA_TFLOPS, frac=round(max(t_flop, t_byte) / (ms_step * 1e-3), 4),
+                         note="projections 3 x (8 T C^2 + 24 T_L C^2) + k-NN 2 B C (N M + L N) flop; fp32 matrix peak "
+                              "(the split-bf16 kernels may exceed it: their own bound is the bf16 peak / 6)")
         res = dict(metric="Grapher fwd+bwd images/sec", value=round(value, 1), unit="images/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 4), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -319,12 +390,20 @@ def main():
                                launch="hipGraph replay of fwd+bwd+grad-pack" if graph is not None else "eager",
                                gemm=gemm_desc,
                                grad_allreduce="one flat RCCL all-reduce per step" if world > 1 else "none (1 GPU)"),
-                   roofline=roof, hip_kernels=kernels)
+                   roofline=roof, roofline_step=roof_step, hip_kernels=kernels,
+                   ms_per_step_no_tune=round(1e3 * elapsed_no_tune / args.steps, 4),
+                   gemm_selection="library default (no tuning pass)" if args.no_tune else
+                   "TunableOp pass in the warm-up for the projections still on vendor GEMMs; ms_per_step_no_tune = the same "
+                   "step with the library's default selection")
         if world == 1 and not args.no_cpu_baseline:
-            # the port scales badly past a few dozen threads (tiny per-op work): sweep, report the fastest leg
+            # the port scales badly past a few dozen threads (tiny per-op work): sweep 8 / 32 / all PHYSICAL cores (BASELINE.md
+            # §3), report the fastest leg; the physical core count of the host is stated either way
+            pc = physical_cores()
             legs = [cpu_baseline(w, B, grapher, label, x, e, cot_x, cot_e, budget_s=8.0, threads=t)
-                    for t in sorted({min(8, os.cpu_count()), min(32, os.cpu_count()), os.cpu_count() // 2 or 1})]
+                    for t in sorted({min(8, pc), min(32, pc), pc})]
             res["cpu_baseline"] = max(legs, key=lambda l: l["value"])
+            res["cpu_baseline"]["host_physical_cores"] = pc
+            res["cpu_baseline"]["host_logical_cpus"] = os.cpu_count()
             res["cpu_baseline_sweep"] = {str(l["cores"]): l["value"] for l in legs}
             res["speedup_vs_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)

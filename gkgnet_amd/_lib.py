@@ -14,6 +14,15 @@ ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 KNN_BF16_CONTRACT = 2
+KNN_SELECT_DIRECT = 4
+KNN_SELECT_BUFFERED = 8
+
+
+def knn_select_flags() -> int:
+    """GKG_KNN_SELECT=direct|buffered (measurement / tests) -> the C API's selection-mode flags; read here, per call, so the
+    library's launch path never calls getenv."""
+    sel = os.environ.get("GKG_KNN_SELECT", "")
+    return KNN_SELECT_BUFFERED if sel[:1] == "b" else (KNN_SELECT_DIRECT if sel[:1] == "d" else 0)
 LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 MR_DETERMINISTIC = 1
 

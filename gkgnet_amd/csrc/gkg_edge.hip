@@ -18,6 +18,10 @@
 
 namespace gkg {
 
+// out-of-range neighbour indices (a caller-supplied edge_index, or a k-NN over non-finite inputs) are clamped into the row,
+// like the max-relative kernels do (gkg_mr.hip clamp_idx): never an out-of-bounds read or atomic
+__device__ __forceinline__ int edge_idx(int64_t v, int M) { return (int)(v < 0 ? 0 : (v >= M ? M - 1 : v)); }
+
 __device__ __forceinline__ float edge_act(float u, int act) {
   if (act == 1) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
   if (act == 2) return u > 0.f ? u : 0.f;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     const float c0 = qc[((size_t)b * O + o) * N + n];
     const int64_t* ip = idx + ((size_t)b * N + n) * k;
     for (int kk = 0; kk < k; ++kk) {
-      const double v = (double)(q[ip[kk]] - c0);
+      const double v = (double)(q[edge_idx(ip[kk], M)] - c0);
       s1 += v; s2 += v * v;
     }
   }
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(const float* __restrict__
   float best = 0.f;
   int bk = 0;
   for (int kk = 0; kk < k; ++kk) {
-    const float v = edge_act(__builtin_fmaf(av, q[ip[kk]] - c0, cv), act);
+    const float v = edge_act(__builtin_fmaf(av, q[edge_idx(ip[kk], M)] - c0, cv), act);
     if (kk == 0 || v > best || (v != v && best == best)) { best = v; bk = kk; }      // first maximum; NaN propagates
   }
   out[at] = best;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __rest
   double t1 = 0.0, t2 = 0.0;
   if (n < N) {
     const size_t at = ((size_t)b * O + o) * N + n;
-    const float z = qs[((size_t)b * O + o) * M + idx[((size_t)b * N + n) * k + argmax[at]]] - qc[at];
+    const float z = qs[((size_t)b * O + o) * M + edge_idx(idx[((size_t)b * N + n) * k + argmax[at]], M)] - qc[at];
     const float gv = g[at] * edge_act_grad(__builtin_fmaf(a[o], z, c[o]), act);
     t1 = gv;
     t2 = (double)gv * (double)((z - mean0[o]) * invstd[o]);
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
   const float c0 = qc[at], av = a[o], cv = c[o];
   const int ka = argmax[at];
   if (!DENSE) {                                   // no batch statistics in the way: only the winning edge carries gradient
-    const int64_t j = ip[ka];
+    const int j = edge_idx(ip[ka], M);
     const float dz = av * g[at] * edge_act_grad(__builtin_fmaf(av, q[j] - c0, cv), act);
     atomicAdd(dq + j, dz);
     dqc[at] = -dz;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
   const float m0 = mean0[o], is = invstd[o], gm = mg[o], gz = mgz[o];
   float acc = 0.f;
   for (int kk = 0; kk < k; ++kk) {
-    const int64_t j = ip[kk];
+    const int j = edge_idx(ip[kk], M);
     const float z = q[j] - c0;
     const float gv = kk == ka ? g[at] * edge_act_grad(__builtin_fmaf(av, z, cv), act) : 0.f;
     const float dz = av * (gv - gm - (z - m0) * is * gz);

@@ -710,9 +710,11 @@ static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStre
     const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 256 * sizeof(float2);
     if (lds < need) lds = need;
   }
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+  }
   hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
@@ -830,9 +832,8 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // stage 1 (c=12, kd=18) 15.97 -> 10.61 ms, stage 2 4.46 -> 3.13 ms, stage 3 (c=48, kd=36) 2.59 -> 1.55 ms; pvig_s@576
   // stage 1 2.52 -> 2.42 ms, stage 2 0.96 -> 0.89 ms, label graph over 20 736 keys 250 -> 214 us; it LOSES with wide groups
   // (c=200: query tile 51 KB + buffer -> one workgroup per CU, 607 -> 876 us) and on short streams with 9-entry lists
-  // (cfg2 label graph 24.6 -> 31.5 us).  GKG_KNN_SELECT=direct|buffered overrides the rule (measurement / tests).
-  const char* sel = getenv("GKG_KNN_SELECT");
-  const int force = !sel ? 0 : (sel[0] == 'b' ? 2 : (sel[0] == 'd' ? 1 : 0));
+  // (cfg2 label graph 24.6 -> 31.5 us).  The GKG_KNN_SELECT_DIRECT / _BUFFERED flags override the rule (measurement / tests).
+  const int force = (flags & GKG_KNN_SELECT_BUFFERED) ? 2 : ((flags & GKG_KNN_SELECT_DIRECT) ? 1 : 0);
   const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 <= 150 * 1024;
   const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
   const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));

@@ -67,14 +67,19 @@ class _WeightPlanes:
     kernels on one device.  The planes are a function of the parameter values only, so they are refreshed when a
     parameter's version counter moves (an optimiser step) — ALL registered weights in ONE launch (gkg_x6_prep_weights).
     Inside a hipGraph capture the host cannot see later in-place updates, so the first projection of each capture emits
-    the refresh unconditionally: a captured training step re-splits the weights once per replay."""
+    the refresh unconditionally: a captured training step re-splits the weights once per replay.  Once ANY capture has
+    gone through this registry the version counters prove nothing on the eager side either — a replay (with an in-graph
+    optimiser step) moves the weights after its own re-split and bumps no counter — so from then on (``captured`` is
+    sticky) every eager projection re-splits ITS OWN weight right before use (a one-descriptor launch)."""
 
     def __init__(self, device):
         self.device = device
         self.entries = {}            # id(weight) -> dict
         self.descs = None            # device copy of the descriptor table
+        self.solo = None             # the same descriptors, each numbered from unit 0 (single-weight launches)
         self.unit_ends = []
         self.capture_id = 0
+        self.captured = False
 
     def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None):
         if torch.cuda.is_current_stream_capturing():
@@ -108,6 +113,20 @@ class _WeightPlanes:
                 raise _lib.GkgError("gkg_x6_prep_desc_fill rejected a weight")
             self.unit_ends.append(units)
         self.descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+        solo = ctypes.create_string_buffer(size * max(1, len(live)))
+        for i, e in enumerate(live.values()):
+            e["slot"] = i
+            e["solo_units"] = lib.gkg_x6_prep_desc_fill(solo, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"],
+                                                        e["nb"], 0)
+        self.solo = torch.frombuffer(bytearray(solo.raw), dtype=torch.uint8).to(self.device)
+
+    def refresh_one(self, lib, e):
+        """Re-split one registered weight (eager use after a capture: see the class docstring)."""
+        if self.descs is None:
+            self._build_descs(lib)
+        size = lib.gkg_x6_prep_desc_bytes()
+        _lib.check(lib.gkg_x6_prep_weights(self.solo.data_ptr() + e["slot"] * size, 1, e["solo_units"], _stream()),
+                   "gkg_x6_prep_weights")
 
     def refresh(self, lib):
         """Re-split every registered weight (one launch)."""
@@ -135,14 +154,16 @@ class _WeightPlanes:
             e = self._register(lib, weight, nb, cout, cin, need_f, need_d, e)
         cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
         if cap:
+            self.captured = True
             if cap != self.capture_id:
                 self.capture_id = cap
                 self.refresh(lib)
-        elif self.capture_id or e["version"] != weight._version:
-            # eager call: stale by the version counter — or graphs were captured since the last eager refresh, and their
-            # replays may have updated the weights (a captured optimiser step) without any counter moving
-            self.capture_id = 0
-            self.refresh(lib)
+        elif e["version"] != weight._version:
+            self.refresh(lib)                    # eager call, stale by the version counter (an eager optimiser step)
+        elif self.captured:
+            # graphs exist: any replay since the last eager call may have moved this weight (a captured optimiser step)
+            # without a counter moving, and it may do so again between any two eager calls
+            self.refresh_one(lib, e)
         return e["pf"], e["pd"]
 
 
@@ -178,10 +199,15 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     if not (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None
             and x.shape[-1] % 4 == 0 and weight.shape[0] % 4 == 0):
         return False
-    if GEMM_MATH == "x6all":
-        return True
     R, cin = x.shape[-2], x.shape[-1]
     cout = weight.shape[0] // nb
+    # the C entry points' own limits (gkg_linear_bn_fwd_x6 / gkg_linear_dgrad_x6 return GKG_ERR_UNSUPPORTED / _SHAPE
+    # beyond them): per-group widths multiples of 4, at most 64 groups, operands below 4 GiB per batch, statistics scratch
+    if (cout % 4 or nb > 64 or R * max(cin, cout) * 4 > 0xffffffff
+            or nb * 2 * cout > _lib.load().gkg_linear_stats_doubles()):
+        return False
+    if GEMM_MATH == "x6all":
+        return True
     if nb != 1:
         return False
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
@@ -200,9 +226,11 @@ def _x6_wgrad_ok(dY, x) -> bool:
     rows (41 472 x 400 -> 400: 49 tiles).  GKG_GEMM_MATH=x6all: every fp32 shape; GKG_X6_WGRAD=0: never."""
     if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none" or dY.dtype != _F32 or x.dtype != _F32:
         return False
+    R, cout, cin = x.shape[0], dY.shape[1], x.shape[1]
+    if max(dY.stride(0), x.stride(0)) * 4 * 16 > 0x7fffffff:          # gkg_linear_wgrad_x6's row-pitch limit
+        return False
     if GEMM_MATH == "x6all":
         return True
-    R, cout, cin = x.shape[0], dY.shape[1], x.shape[1]
     tiles = ((cout + 63) // 64) * ((cin + 63) // 64)
     return X6_WGRAD and not DETERMINISTIC and R >= 65536 and tiles <= 32       # fp32 atomics: run-dependent summation order
 
@@ -884,7 +912,7 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
     B, N, C = x.shape
     c = C // G
     M = N if y is None else y.shape[1]
-    flags = _lib.KNN_NORMALIZE
+    flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags()
     if KNN_BF16 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         flags |= _lib.KNN_BF16_CONTRACT          # the reference's own x.y^T runs in bf16 here (and rounds the result to bf16)
     rp = None

@@ -49,7 +49,13 @@ class GradBucket:
       (mmcls/apis/train.py:117-125) — and :meth:`wait` joins them.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
+                 find_unused_parameters: bool = False):
+        # find_unused_parameters (the reference's DDP flag, apis/train.py:124): a parameter without a gradient on THIS
+        # rank may have one on another rank, so after a multi-rank reduce its slot holds the others' average and must be
+        # cleared again next step.  False (default): a parameter unused here is unused everywhere (GKGNet: the conv biases
+        # in front of train-mode BN), its slot stays zero through the all-reduce and is never re-filled.
+        self.find_unused = bool(find_unused_parameters)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -77,6 +83,8 @@ class GradBucket:
         self._pending = []
         self._hooks = []
         self._ready = {}
+        self._complete = set()                      # chunks whose gradients all exist (this backward)
+        self._issued = 0                            # chunks 0 .. _issued-1 have had their all-reduce started
         self._zero = {id(p) for p in self.params}   # slots known to hold zeros (the buffer starts zeroed)
 
     def _view(self, p):
@@ -98,6 +106,7 @@ class GradBucket:
     def _point_grads(self):
         for p in self.params:
             p.grad = self._view(p)
+            p._gkg_handed = False
 
     def zero(self):
         self.flat.zero_()
@@ -108,6 +117,10 @@ class GradBucket:
         per-parameter accumulate kernels); follow the backward with :meth:`pack`."""
         for p in self.params:
             p.grad = None
+            p._gkg_handed = False
+        self._ready = {}
+        self._complete = set()
+        self._issued = 0
 
     def _resident(self, p) -> bool:
         g = p.grad
@@ -141,11 +154,32 @@ class GradBucket:
             torch._foreach_copy_(dst, src)
         self._point_grads()
 
+    def _issue_in_order(self, world, upto_all=False):
+        """Start the all-reduce of every chunk that may go next: chunks are reduced in FIXED chunk order on every rank
+        (chunk i only after chunks 0..i-1), whatever order the hooks fired in — ranks whose backward completes the
+        chunks in different orders (unused parameters on some ranks) still issue identical collective sequences."""
+        while self._issued < len(self.chunks) and (upto_all or self._issued in self._complete):
+            start, end, plist = self.chunks[self._issued]
+            for q in plist:                                      # gradients not written in place: copy this chunk now
+                if not self._resident(q):
+                    self._fill_slot(q)
+                else:
+                    self._zero.discard(id(q))
+            if world > 1:
+                chunk = self.flat[start:end]
+                chunk.div_(world)
+                self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                if self.find_unused:
+                    self._zero.difference_update(id(q) for q in plist)
+            self._issued += 1
+
     def all_reduce(self, async_op: bool = False):
         """Average over ranks with ONE collective over the whole buffer.  No-op in a single process."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         self.flat.div_(dist.get_world_size())
+        if self.find_unused:
+            self._zero.clear()
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
     # ---- overlapped form (eager training loops)
@@ -157,51 +191,42 @@ class GradBucket:
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         for ci, (start, end, plist) in enumerate(self.chunks):
             for p in plist:
-                def hook(param, ci=ci, start=start, end=end, plist=plist, world=world):
+                def hook(param, ci=ci, n=len(plist), world=world):
                     self._ready[ci] = self._ready.get(ci, 0) + 1
-                    if self._ready[ci] < len(plist):
+                    if self._ready[ci] < n:
                         return
-                    self._ready[ci] = 0
-                    for q in plist:                                  # gradients not written in place: copy this chunk now
-                        if not self._resident(q):
-                            self._fill_slot(q)
-                        else:
-                            self._zero.discard(id(q))
-                    if world > 1:
-                        chunk = self.flat[start:end]
-                        chunk.div_(world)
-                        self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                    self._complete.add(ci)
+                    self._issue_in_order(world)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
 
     def wait(self):
         """Join the chunk all-reduces started during the backward; parameters that received no gradient at all (unused
         this step) are zero-filled and their chunks reduced now, so every rank issues the same collectives."""
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        for ci, (start, end, plist) in enumerate(self.chunks):
-            if self._ready.get(ci, 0) != 0:                           # incomplete chunk: some parameter had no gradient
-                self._ready[ci] = 0
-                for q in plist:
-                    if not self._resident(q):
-                        self._fill_slot(q)
-                    else:
-                        self._zero.discard(id(q))
-                if world > 1:
-                    chunk = self.flat[start:end]
-                    chunk.div_(world)
-                    self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        # every chunk not reduced during the backward — hooks that never fired (all of its parameters unused: nothing is
+        # distinguishable from "done" by the counters alone, hence the explicit _issued cursor) or fired partially — is
+        # filled (gradient copied in, or zeros) and reduced now, in chunk order
+        self._issue_in_order(world, upto_all=True)
         for w in self._pending:
             w.wait()
         self._pending = []
+        self._ready = {}
+        self._complete = set()
         self._point_grads()
 
 
 def grad_view(p: torch.nn.Parameter, shape=None):
     """A fresh view of ``p``'s slot in its gradient bucket (None when ``p`` is not bucketed or its ``.grad`` is currently
     attached, i.e. the step accumulates): backward kernels write the gradient there and return the view, which autograd
-    adopts as ``p.grad`` — no separate gradient tensor, no re-pack."""
+    adopts as ``p.grad`` — no separate gradient tensor, no re-pack.  A slot is handed out ONCE per backward
+    (``GradBucket.release`` re-arms it)."""
     b = getattr(p, "_gkg_bucket", None)
-    if b is None or p.grad is not None:
+    if b is None or p.grad is not None or getattr(p, "_gkg_handed", False):
+        # handed out already in this backward (a block or weight used twice in one graph): the second backward node gets
+        # a fresh tensor and autograd ADDS it to the adopted view — two kernels writing the same slot would keep only
+        # the last contribution
         return None
+    p._gkg_handed = True
     flat, o = b
     v = flat[o:o + p.numel()]
     return v.view(p.shape if shape is None else shape)

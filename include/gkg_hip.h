@@ -54,6 +54,8 @@ extern "C" {
                                   * products, fp32 accumulation and fp32 norms.  For callers under bf16 autocast, where the
                                   * reference computes this product in bf16 and rounds it to bf16.  Outside the bit-exact
                                   * index contract; ignored for c < 16. */
+#define GKG_KNN_SELECT_DIRECT 4u   /* force the direct sorted insert / the buffered selection of the tile kernel instead of */
+#define GKG_KNN_SELECT_BUFFERED 8u /* the library's per-shape rule (measurement, tests): identical results either way */
 
 /* argument errors */
 #define GKG_ERR_NULL -1        /* required pointer is NULL */

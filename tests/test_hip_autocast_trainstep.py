@@ -192,3 +192,94 @@ def test_train_step_free_running():
     agree = [float((r["graphs"][gi] == a[f"graph/{gi:02d}"]).mean()) for gi in range(16)]
     assert agree[0] >= 0.999 and min(agree[:8]) >= 0.99, " ".join(f"{v:.3f}" for v in agree)
     print("graph agreement per layer:", " ".join(f"{v:.3f}" for v in agree))
+
+
+def _amp_modules(meta, a):
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    C, k, d, G, L, n = meta["C"], meta["k"], meta["dilation"], meta["G"], meta["L"], meta["n"]
+    g = Grapher(C, k, d, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=True,
+                use_multi_group=True, num_group=G)
+    gl = GrapherLabel(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=False,
+                      num_nodes=L, use_multi_group=True, num_group=G)
+    g.load_state_dict({k_[len("g/sd/"):]: torch.from_numpy(np.array(v)) for k_, v in a.items() if k_.startswith("g/sd/")})
+    gl.load_state_dict({k_[len("gl/sd/"):]: torch.from_numpy(np.array(v)) for k_, v in a.items() if k_.startswith("gl/sd/")})
+    return g.cuda().train(), gl.cuda().train()
+
+
+def test_amp_fp16_train_step_against_reference_fp16_fixture():
+    """F17 — the recipe the reference actually ships: fp16 AMP (configs/gkgnet/gkgnet_coco_576.py:146,
+    mmcls/core/fp16/hooks.py:13-129).  Grapher -> GrapherLabel, TRAIN mode, forward + backward under
+    torch.autocast(float16) with a scaled loss, on the fused token-major path.  Under fp16 autocast the product keeps the plain
+    mixed path: the projection GEMMs take fp16 operands (library GEMM under autocast, fp32 accumulate), everything between
+    them — BN statistics, activations, the k-NN contraction, the aggregation — stays fp32, the backward GEMMs run in fp32
+    (autocast is off inside autograd's backward); none of the bf16-inference shortcuts apply (fused.lowp_inference is
+    bf16 + no_grad only).  Bar = the F14 rule: every output and gradient at least as close to the reference's fp32 result
+    as the reference's own fp16-autocast run is (which moves its k-NN graph: its distance matmul is fp16)."""
+    from gkgnet_amd import fused
+    meta, a = load_fixture("f17_amp_fp16")
+    assert meta["finite"]
+    g, gl = _amp_modules(meta, a)
+    S = meta["loss_scale"]
+    x = _t(a["x"]).requires_grad_(True)
+    e = _t(a["e"]).requires_grad_(True)
+    calls = [0]
+    real = fused.knn_graph_tm
+
+    def counting(*args, **kw):
+        calls[0] += 1
+        return real(*args, **kw)
+    fused.knn_graph_tm = counting
+    try:
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert not fused.lowp_inference()
+            out = g(x)
+            e2, idx = gl(e, out)
+        loss = ((out.float() * _t(a["cot_x"])).sum() + (e2.float() * _t(a["cot_e"])).sum()) * S
+        loss.backward()
+    finally:
+        fused.knn_graph_tm = real
+    assert calls[0] == 2, "both blocks must take the fused token-major path under fp16 autocast"
+    got = dict(out=out.detach().float(), labels=e2.detach().float(), dx=x.grad / S, de=e.grad / S)
+    pg, pl = dict(g.named_parameters()), dict(gl.named_parameters())
+    for w in meta["watch_g"]:
+        got["g/grad/" + w] = pg[w].grad.float() / S
+    for w in meta["watch_l"]:
+        got["gl/grad/" + w] = pl[w].grad.float() / S
+    for key, v in got.items():
+        v = v.cpu().numpy()
+        ref32, ref16 = a["fp32/" + key], a["amp/" + key]
+        assert np.isfinite(v).all(), key
+        err_ref = np.abs(ref16 - ref32).mean()
+        err = np.abs(v - ref32).mean()
+        assert err <= 1.0 * err_ref + 1e-6, (key, err, err_ref)
+    # the graph: label neighbour sets agree with the fp32 reference at least as well as the reference's own fp16 run
+    ref_lab = _set_agreement(a["amp/idx"], a["fp32/idx"])
+    assert _set_agreement(idx.cpu().numpy(), a["fp32/idx"]) >= ref_lab
+
+
+def test_amp_fp16_overflow_surfaces_as_non_finite_gradients():
+    """Dynamic loss scaling (mmcls/core/fp16/hooks.py: skip the step and halve the scale when any gradient is inf / NaN)
+    relies on overflow SURFACING: an inf in the scaled upstream gradient must reach the parameter gradients as inf / NaN —
+    no kernel on the fused path may clamp or zero it — and torch's GradScaler must see it."""
+    meta, a = load_fixture("f17_amp_fp16")
+    g, gl = _amp_modules(meta, a)
+    x = _t(a["x"]).requires_grad_(True)
+    e = _t(a["e"]).requires_grad_(True)
+    params = [p for p in list(g.parameters()) + list(gl.parameters()) if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.1)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 16)
+    before = [p.detach().clone() for p in params]
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = g(x)
+        e2, _ = gl(e, out)
+    cot = _t(a["cot_x"]).clone()
+    cot[0, 0, 0, 0] = float("inf")                                   # an overflowed element of the scaled loss gradient
+    loss = (out.float() * cot).sum() + (e2.float() * _t(a["cot_e"])).sum()
+    scaler.scale(loss).backward()
+    bad = sum(int(not torch.isfinite(p.grad).all()) for p in params if p.grad is not None)
+    assert bad > 0 and not torch.isfinite(x.grad).all(), "the overflow must be visible in the gradients"
+    scaler.step(opt)                                                 # must skip
+    scaler.update()
+    assert scaler.get_scale() == 2.0 ** 15
+    for p, b in zip(params, before):
+        assert torch.equal(p.detach(), b), "GradScaler must skip the step on overflow"

@@ -204,6 +204,47 @@ def test_captured_step_resplits_the_weights(monkeypatch):
     assert torch.allclose(out.double(), want, atol=1e-4)
 
 
+def test_eager_calls_between_replays_of_a_step_that_updates_the_weights(monkeypatch):
+    """capture (forward + in-graph weight update), replay, eager, replay, eager — every eager call must see the
+    weights as the last replay left them (no version counter moves inside a replay, so the planes cannot be trusted once a
+    capture exists)."""
+    from gkgnet_amd import fused
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    torch.manual_seed(12)
+    R, cin, cout = 384, 32, 48
+    conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+    bn = torch.nn.BatchNorm2d(cout).cuda().train()
+    x = torch.randn(R, cin, device="cuda")
+    delta = torch.randn_like(conv.weight) * 0.25
+
+    def fwd():
+        with torch.no_grad():
+            return fused._LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 0, None)
+
+    def want():
+        y = x.double() @ conv.weight.detach().double().view(cout, cin).t()
+        return (y - y.mean(0)) * (y.var(0, unbiased=False) + bn.eps).rsqrt() * bn.weight.detach().double() + bn.bias.detach().double()
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            fwd()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd()
+        conv.weight.data.add_(delta)                    # the "optimiser step" inside the graph: AFTER the in-graph re-split
+    for it in range(3):
+        w_before = conv.weight.detach().clone()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(conv.weight.detach(), w_before + delta)
+        got = fwd()                                     # eager, on the weights the replay left behind
+        torch.cuda.synchronize()
+        assert torch.allclose(got.double(), want(), atol=1e-4), it
+
+
 def test_random_shapes_forward_dgrad_wgrad():
     """Seeded sweep over ragged shapes (rows / channels not multiples of the tile sizes, K tails, batches)."""
     from gkgnet_amd import _lib

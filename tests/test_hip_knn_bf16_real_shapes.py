@@ -1,0 +1,179 @@
+"""The bf16-contraction k-NN (GKG_KNN_BF16_CONTRACT — the mode BASELINE cfg3 / cfg5 run in: bf16 autocast) QUANTIFIED at the
+real stage shapes of GKGNet-576 (pvig_s, G = 2, k = 9) and pvig_m @ 768 (G = 8, k = 18), reduced batch:
+
+  (a) neighbour-set agreement with the bit-exact fp32 path of the same operator on the same inputs, and how much worse (in
+      exact fp64 distance) the neighbours are that it picks instead;
+  (b) the Grapher block's output under autocast with the bf16 contraction vs the product's own fp32 run (no autocast), next
+      to the same error with the fp32 contraction — the F14 rule ("at least as faithful as ...") with a product-fp32
+      stand-in at full size.
+
+Features are spatially structured (smooth fields + noise) like post-fc1+BN activations of an image: with i.i.d. Gaussian
+tokens all candidates are nearly equidistant and ANY 1e-3 perturbation reshuffles the sets, which says nothing about a model.
+The asserted floors are the measured values with margin.
+"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# name: (C, G, H, r, k, d)   — reference torch_edge.py:35-51 (distance), torch_vertex.py:191-205 (pooled keys)
+STAGES = {
+    "s1": (80, 2, 144, 4, 9, 1), "s2": (160, 2, 72, 2, 9, 1), "s3_d2": (400, 2, 36, 1, 9, 2), "s3_d3": (400, 2, 36, 1, 9, 3),
+    "s4_d3": (640, 2, 18, 1, 9, 3),
+    "m2": (192, 8, 96, 2, 18, 1), "m3_d2": (384, 8, 48, 1, 18, 2), "m4_d2": (768, 8, 24, 1, 18, 2),
+}
+# measured on MI355X (r03): set agreement 0.93-0.99, excess mean distance <= 3e-4; asserted with margin
+MIN_AGREEMENT = 0.88
+MAX_EXCESS_DIST = 1.5e-3
+
+
+def _structured(B, C, H, gen):
+    """(B, C, H, H): a few smooth 2-D cosine modes mixed into the channels + 0.35 noise, unit variance per channel."""
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, H, device="cuda"), torch.linspace(0, 1, H, device="cuda"), indexing="ij")
+    modes = []
+    for fy in range(4):
+        for fx in range(4):
+            if fy + fx:
+                modes.append(torch.cos(math.pi * (fy * ys + fx * xs + 0.37 * fy * fx)))
+    Fm = torch.stack(modes)                                               # (15, H, H)
+    mix = torch.randn(B, C, Fm.shape[0], device="cuda", generator=gen) / Fm.shape[0] ** 0.5
+    x = torch.einsum("bcm,mhw->bchw", mix, Fm) * 2.0 + 0.35 * torch.randn(B, C, H, H, device="cuda", generator=gen)
+    return (x - x.mean((0, 2, 3), keepdim=True)) / x.std((0, 2, 3), keepdim=True)
+
+
+@pytest.mark.parametrize("name", sorted(STAGES))
+def test_bf16_contract_neighbour_sets_vs_bit_exact_fp32(name):
+    from gkgnet_amd import fused
+    from gkgnet_amd.relpos import build_relative_pos
+    C, G, H, r, k, d = STAGES[name]
+    B = 2
+    import zlib
+    gen = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = _structured(B, C, H, gen)
+    N = H * H
+    xt = x.permute(0, 2, 3, 1).reshape(B, N, C).contiguous()
+    yt = None
+    if r > 1:
+        yt = torch.nn.functional.avg_pool2d(x, r, r).permute(0, 2, 3, 1).reshape(B, -1, C).contiguous()
+    os.environ["GKG_RELPOS_DEVICE"] = "cuda"
+    rp = build_relative_pos(C, N, r).cuda()
+    old = fused.KNN_BF16
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fused.KNN_BF16 = True
+            e16 = fused.knn_graph_tm(xt, yt, rp, k, d, G)[0]
+            fused.KNN_BF16 = False
+            e32 = fused.knn_graph_tm(xt, yt, rp, k, d, G)[0]             # bit-exact contract path (tests/test_hip_config_shapes.py)
+    finally:
+        fused.KNN_BF16 = old
+    if C // G < 16:
+        assert torch.equal(e16, e32)                                      # c < 16: the flag is ignored
+        return
+    # (a1) set agreement: |set16 & set32| / k per query
+    hit = (e16.unsqueeze(-1) == e32.unsqueeze(-2)).any(-1).float().mean().item()
+    # (a2) how much farther (exact fp64 distance incl. relative_pos) are bf16's picks on average
+    c = C // G
+    xg = torch.nn.functional.normalize(xt.view(B, N, G, c).permute(0, 2, 1, 3).reshape(B * G, N, c).double(), dim=-1)
+    yg = xg if yt is None else torch.nn.functional.normalize(
+        yt.view(B, -1, G, c).permute(0, 2, 1, 3).reshape(B * G, -1, c).double(), dim=-1)
+    exc = 0.0
+    for bg in range(B * G):                                               # per problem: (N, M) fp64 stays small
+        dist = 2 - 2 * xg[bg] @ yg[bg].t() + rp[0].double()
+        exc += (torch.gather(dist, 1, e16[bg]).mean() - torch.gather(dist, 1, e32[bg]).mean()).item()
+    exc /= B * G
+    print(f"[bf16-contract {name}] C={C} G={G} N={N} M={yg.shape[1]} k*d={k * d}: set agreement {hit:.4f}, "
+          f"mean exact-distance excess {exc:.2e}")
+    assert hit >= MIN_AGREEMENT, (name, hit)
+    assert exc <= MAX_EXCESS_DIST, (name, exc)
+
+
+def _reference_style_autocast_graph(x, y, rp, k, d, G):
+    """What the reference's own k-NN does under bf16 autocast (torch_edge.py:35-51, 89-106 with autocast's op rules):
+    F.normalize and the squared norms in fp32, the inner-product matmul on bf16 operands WITH A bf16 RESULT, the sum and
+    topk in fp32.  Same signature as fused.knn_graph_tm (token-major inputs)."""
+    B, N, C = x.shape
+    c = C // G
+    xg = torch.nn.functional.normalize(x.view(B, N, G, c).permute(0, 2, 1, 3).reshape(B * G, N, c), dim=-1)
+    yg = xg if y is None else torch.nn.functional.normalize(
+        y.view(B, -1, G, c).permute(0, 2, 1, 3).reshape(B * G, -1, c), dim=-1)
+    inner = (xg.bfloat16() @ yg.bfloat16().transpose(1, 2)).float()          # bf16 matmul output, as autocast produces it
+    dist = (xg * xg).sum(-1, keepdim=True) - 2 * inner + (yg * yg).sum(-1).unsqueeze(1)
+    if rp is not None:
+        dist = dist + rp.reshape(1, N, -1)
+    nn_idx = torch.topk(-dist, k * d).indices[:, :, ::d].contiguous()
+    center = torch.arange(N, device=x.device).view(1, N, 1).expand_as(nn_idx)
+    return torch.stack([nn_idx, center])
+
+
+@pytest.mark.parametrize("name", ["s1", "s3_d2", "s4_d3", "m3_d2"])
+def test_bf16_contract_grapher_output_vs_product_fp32(name):
+    """Block level, the F14 rule at full size with a product-fp32 stand-in: eval-mode Grapher under bf16 autocast with (1)
+    the bf16-contraction k-NN, (2) the bit-exact fp32 k-NN, (3) a graph built the way the REFERENCE's autocast builds it
+    (bf16 matmul with a bf16 result) — each against the product's own fp32 run of the block.  The product's mode (1) must be
+    at least as faithful as the reference-style graph (3), and within 2x of what bf16 autocast costs with an exact graph
+    (2)."""
+    from gkgnet_amd import fused, layers
+    from gkgnet_amd.grapher import Grapher
+    from tests.util import keyed_fill_
+    C, G, H, r, k, d = STAGES[name]
+    B = 2
+    os.environ["GKG_RELPOS_DEVICE"] = "cuda"
+    layers.norm_cfg["type"] = "BN"
+    torch.manual_seed(0)
+    mod = Grapher(C, k, d, "mr", "gelu", "batch", True, False, 0.2, r, n=H * H, drop_path=0.0, relative_pos=True,
+                  use_multi_group=True, num_group=G)
+    sd = mod.state_dict()
+    keyed_fill_(sd)
+    mod.load_state_dict(sd)
+    mod = mod.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = _structured(B, C, H, gen)
+    old, real = fused.KNN_BF16, fused.knn_graph_tm
+    try:
+        with torch.no_grad():
+            ref = mod(x)                                                  # product fp32
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                fused.KNN_BF16 = True
+                o16 = mod(x).float()
+                fused.KNN_BF16 = False
+                o32 = mod(x).float()
+                fused.knn_graph_tm = _reference_style_autocast_graph
+                oref = mod(x).float()
+    finally:
+        fused.KNN_BF16, fused.knn_graph_tm = old, real
+    den = (ref - x).norm().item()                                         # the block's own contribution (residual removed)
+    e16 = (o16 - ref).norm().item() / den
+    e32 = (o32 - ref).norm().item() / den
+    eref = (oref - ref).norm().item() / den
+    print(f"[bf16-contract block {name}] rel. error of the graph branch vs product fp32: bf16 contraction {e16:.4f}, "
+          f"fp32 contraction {e32:.4f}, reference-style autocast graph {eref:.4f}")
+    assert e16 <= eref + 2e-3, (name, e16, eref)
+    assert e16 <= 2.0 * e32 + 5e-3, (name, e16, e32)
+    assert e16 <= 0.12, (name, e16)
+
+
+def test_device_built_relative_pos_matches_the_reference_constants():
+    """GKG_RELPOS_DEVICE=cuda (what every cfg3 / cfg5 run and the tests above use to skip the 40 s host build) against the
+    reference-generated constants F9 (pos_embed.py:21-85, torch_vertex.py:309-315): float64 GEMM + bicubic resize on the
+    device differ from the host's only by fp32 rounding of the interpolation — atol 2e-6 on values in [-1, 0]."""
+    from gkgnet_amd import relpos
+    from tests.util import load_fixture
+    meta, a = load_fixture("f9_relpos")
+    old = os.environ.get("GKG_RELPOS_DEVICE")
+    os.environ["GKG_RELPOS_DEVICE"] = "cuda"
+    try:
+        for C, n, r in meta["combos"]:
+            got = relpos.build_relative_pos(C, n, r)
+            want = torch.from_numpy(a[f"rp_{C}_{n}_{r}"])
+            assert got.shape == want.shape and got.dtype == want.dtype
+            err = (got - want).abs().max().item()
+            print(f"[relpos device] C={C} n={n} r={r}: max |device - F9| = {err:.2e}")
+            assert err <= 2e-6, (C, n, r, err)
+    finally:
+        if old is None:
+            os.environ.pop("GKG_RELPOS_DEVICE", None)
+        else:
+            os.environ["GKG_RELPOS_DEVICE"] = old

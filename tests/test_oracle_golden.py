@@ -133,3 +133,22 @@ def test_relative_pos_constants():
     base = R.grapher_relative_pos(32, 64, 2)
     got = R.runtime_relative_pos(base, 64, 2, 10, 10)
     assert torch.allclose(got, _t(a["rp_runtime_32_64_2_to_10x10"]), atol=1e-6)
+
+
+def test_amp_fixture_fp32_leg_matches_the_oracle():
+    """F17's fp32 leg (Grapher -> GrapherLabel, train mode, forward + backward) through the oracle: pins the fixture's wiring
+    (weights, cotangents, the label chain) on the CPU side; the fp16-autocast leg is the GPU test's bar
+    (tests/test_hip_autocast_trainstep.py)."""
+    meta, a = load_fixture("f17_amp_fp16")
+    pg = {k_[len("g/sd/"):]: _t(v) for k_, v in a.items() if k_.startswith("g/sd/")}
+    pl = {k_[len("gl/sd/"):]: _t(v) for k_, v in a.items() if k_.startswith("gl/sd/")}
+    x = _t(a["x"]).requires_grad_(True)
+    e = _t(a["e"]).requires_grad_(True)
+    out = R.grapher_forward(x, pg, k=meta["k"], dilation=meta["dilation"], r=1, groups=meta["G"], training=True)
+    e2, idx = R.grapher_label_forward(e, out, pl, k=meta["k"], groups=meta["G"], training=True)
+    ((out * _t(a["cot_x"])).sum() + (e2 * _t(a["cot_e"])).sum()).backward()
+    assert torch.allclose(out, _t(a["fp32/out"]), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(e2, _t(a["fp32/labels"]), atol=1e-4, rtol=1e-4)
+    assert np.array_equal(idx.numpy(), a["fp32/idx"])
+    assert torch.allclose(x.grad, _t(a["fp32/dx"]), atol=1e-5, rtol=1e-3)
+    assert torch.allclose(e.grad, _t(a["fp32/de"]), atol=1e-5, rtol=1e-3)

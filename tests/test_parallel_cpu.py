@@ -141,3 +141,86 @@ def test_bucket_slots_of_missing_gradients_stay_zero():
         assert torch.equal(a.grad, torch.full((3,), 2.0)), step
         assert torch.equal(b.grad, torch.full((5,), 3.0 if use_b else 0.0)), step
         assert a.grad.data_ptr() == bucket._view(a).data_ptr() and b.grad.data_ptr() == bucket._view(b).data_ptr()
+
+
+def test_wait_after_a_step_without_backward_clears_the_gradients():
+    """a chunk whose hooks never fired must not be mistaken for a finished one — wait() fills it (zeros) instead
+    of re-attaching the previous step's reduced gradients."""
+    from gkgnet_amd.parallel import GradBucket
+    w = torch.nn.Parameter(torch.randn(4, 4))
+    v = torch.nn.Parameter(torch.randn(3))
+    bucket = GradBucket([w, v], bucket_bytes=16)
+    bucket.install_overlap_hooks()
+    bucket.release()
+    ((w * w).sum() + v.sum()).backward()
+    bucket.wait()
+    assert float(w.grad.abs().sum()) > 0
+    bucket.release()                      # a step with no backward at all
+    bucket.wait()
+    assert float(w.grad.abs().sum()) == 0.0 and float(v.grad.abs().sum()) == 0.0
+    bucket.release()                      # only one of the two parameters used
+    v.sum().backward()
+    bucket.wait()
+    assert float(w.grad.abs().sum()) == 0.0 and torch.equal(v.grad, torch.ones(3))
+
+
+def _divergent_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from gkgnet_amd.parallel import GradBucket, init_distributed
+    init_distributed("gloo")
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3, 9)]
+    bucket = GradBucket(ps, bucket_bytes=8, find_unused_parameters=True)     # one chunk per parameter, of different sizes
+    assert len(bucket.chunks) == 4
+    bucket.install_overlap_hooks()
+    for step in range(2):
+        bucket.release()
+        # rank 0 uses parameters 0 and 2, rank 1 uses 1 and 3: the chunks complete in different orders on the two ranks
+        # and each rank finishes half of them only inside wait()
+        use = (0, 2) if rank == 0 else (1, 3)
+        sum((ps[i] * (i + 1)).sum() for i in use).backward()
+        bucket.wait()
+    out[rank] = [p.grad.clone() for p in ps]
+    dist.destroy_process_group()
+
+
+def test_chunks_are_reduced_in_fixed_order_when_ranks_use_different_parameters():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_divergent_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for i, (a, b) in enumerate(zip(out[0], out[1])):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, torch.full_like(a, (i + 1) / 2.0))     # one rank contributed i+1, the other 0
+
+
+def test_grad_view_is_handed_out_once_per_backward():
+    """a weight used twice in one graph — the second backward node must not overwrite the slot the first one
+    wrote; it gets a fresh tensor that autograd adds."""
+    from gkgnet_amd.parallel import GradBucket, grad_view
+
+    class WriteInPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            out = grad_view(w)
+            if out is None:
+                out = torch.empty_like(w)
+            torch.mm(g.t(), x, out=out)
+            return g @ w, out
+    w = torch.nn.Parameter(torch.randn(4, 4))
+    bucket = GradBucket([w])
+    x1, x2 = torch.randn(5, 4), torch.randn(6, 4)
+    for _ in range(2):
+        bucket.release()
+        (WriteInPlace.apply(x1, w).sum() + WriteInPlace.apply(x2, w).sum()).backward()
+        bucket.pack()
+        want = torch.ones(5, 4).t() @ x1 + torch.ones(6, 4).t() @ x2
+        assert torch.allclose(w.grad, want, atol=1e-5)
+        assert bucket._resident(w)

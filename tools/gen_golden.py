@@ -404,6 +404,76 @@ def autocast_case(ref, name, *, C, k, d, hw, G, L, B=2, seed=0):
     save(name, meta, **arrays)
 
 
+def amp_fp16_case(ref, name, *, C, k, d, hw, G, L, B=2, seed=0, loss_scale=128.0):
+    """F17: the reference's own training recipe is fp16 AMP (configs/gkgnet/gkgnet_coco_576.py:146 fp16 = dict(loss_scale=
+    'dynamic'); mmcls/models/classifiers/base.py:80 auto_fp16; mmcls/core/fp16/hooks.py:13-129 — with torch >= 1.6 mmcv
+    runs the forward under torch.cuda.amp.autocast and scales the loss).  The reference's Grapher -> GrapherLabel chain in
+    TRAIN mode, forward + backward, (i) in fp32 and (ii) under torch.autocast('cpu', float16) with the loss multiplied by
+    ``loss_scale`` and the gradients divided by it afterwards (CPU half matmul / conv are usable in this torch build: the
+    autocast definition itself, not an fp16-rounded-inputs stand-in).  The product's fp16-autocast path is held to the F14
+    rule: at least as close to the fp32 reference as the reference's own fp16 run is (outputs, input and parameter
+    gradients)."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    n = hw * hw
+    g = ref.vig.Grapher(C, k, d, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=True,
+                        use_multi_group=True, num_group=G)
+    gl = ref.vig.GrapherLabel(C, k, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0,
+                              relative_pos=False, num_nodes=L, use_multi_group=True, num_group=G)
+    randomize_norm_(g, gen)
+    randomize_norm_(gl, gen)
+    x0 = torch.randn(B, C, hw, hw, generator=gen)
+    e0 = torch.randn(B, L, C, generator=gen)
+    cot_x = torch.randn(B, C, hw, hw, generator=gen) / (C * n) ** 0.5
+    cot_e = torch.randn(B, L, C, generator=gen) / (C * L) ** 0.5
+    sd_g = {k_: v.clone() for k_, v in g.state_dict().items()}
+    sd_l = {k_: v.clone() for k_, v in gl.state_dict().items()}
+    watch_g = ["fc1.0.weight", "graph_conv.gconv.nn.0.weight", "fc2.0.weight", "fc2.1.weight", "fc2.1.bias"]
+    watch_l = ["fc1.0.weight", "graph_conv.gconv.nn.0.weight", "ffn.fc1.0.weight", "ffn.fc2.0.weight", "ffn.fc2.1.weight"]
+
+    def run(amp):
+        g.load_state_dict(sd_g); gl.load_state_dict(sd_l)           # running statistics restart for each leg
+        g.train(); gl.train()
+        g.zero_grad(set_to_none=True); gl.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        e = e0.clone().requires_grad_(True)
+        if amp:
+            with torch.autocast("cpu", dtype=torch.float16):
+                out = g(x)
+                e2, idx = gl(e, out)
+            loss = ((out.float() * cot_x).sum() + (e2.float() * cot_e).sum()) * loss_scale
+        else:
+            out = g(x)
+            e2, idx = gl(e, out)
+            loss = (out * cot_x).sum() + (e2 * cot_e).sum()
+        loss.backward()
+        inv = 1.0 / loss_scale if amp else 1.0
+        res = dict(out=out.detach().float().numpy(), labels=e2.detach().float().numpy(), idx=idx.numpy().astype(np.int32),
+                   dx=(x.grad * inv).numpy(), de=(e.grad * inv).numpy())
+        pg, pl = dict(g.named_parameters()), dict(gl.named_parameters())
+        for w in watch_g:
+            res["g/grad/" + w] = (pg[w].grad.float() * inv).numpy()
+        for w in watch_l:
+            res["gl/grad/" + w] = (pl[w].grad.float() * inv).numpy()
+        return res
+
+    r32 = run(False)
+    r16 = run(True)
+    arrays = dict(x=x0.numpy(), e=e0.numpy(), cot_x=cot_x.numpy(), cot_e=cot_e.numpy())
+    arrays.update({"fp32/" + k_: v for k_, v in r32.items()})
+    arrays.update({"amp/" + k_: v for k_, v in r16.items()})
+    arrays.update({"g/sd/" + k_: v.numpy() for k_, v in sd_g.items()})
+    arrays.update({"gl/sd/" + k_: v.numpy() for k_, v in sd_l.items()})
+    finite = all(np.isfinite(v).all() for k_, v in r16.items() if v.dtype.kind == "f")
+    meta = dict(kind="amp_fp16", C=C, k=k, dilation=d, hw=hw, n=n, G=G, L=L, B=B, loss_scale=loss_scale, finite=bool(finite),
+                watch_g=watch_g, watch_l=watch_l,
+                ref="torch_vertex.py:278-403 train mode fwd+bwd under torch.autocast('cpu', torch.float16), loss x loss_scale; "
+                    "configs/gkgnet/gkgnet_coco_576.py:146; mmcls/core/fp16/hooks.py:13-129")
+    save(name, meta, **arrays)
+    for k_ in ("out", "labels", "dx", "de"):
+        print(f"  F17 {k_}: mean|amp - fp32| = {np.abs(r16[k_] - r32[k_]).mean():.3e}  (scale {np.abs(r32[k_]).mean():.3e})")
+
+
 # ----------------------------------------------------------------------------- train-step case
 def paramwise_groups(modules, weight_decay):
     """The reference's paramwise_cfg (configs/gkgnet/gkgnet_coco_576.py:110-117: norm_decay_mult=0, bias_decay_mult=0)
@@ -490,6 +560,8 @@ def main():
             autocast_case(ref, 'f14_autocast_bf16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=14)
         if 'f15' in only:
             train_step_case(ref, 'f15_train_step')
+        if 'f17' in only:
+            amp_fp16_case(ref, 'f17_amp_fp16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=17)
         return
     grapher_case(ref, "f1_grapher_cfg1", C=64, k=9, d=1, r=1, hw=14, G=1, multi=False)
     grapher_case(ref, "f2_grapher_g4", C=64, k=9, d=1, r=1, hw=8, G=4, multi=True, seed=2)
@@ -511,6 +583,7 @@ def main():
     head_case(ref, "f12_head_loss")
     autocast_case(ref, 'f14_autocast_bf16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=14)
     train_step_case(ref, 'f15_train_step')
+    amp_fp16_case(ref, 'f17_amp_fp16', C=64, k=9, d=2, hw=12, G=2, L=20, seed=17)
     coco_case('f16_coco')
     map_case("f13_map")
 
