@@ -33,7 +33,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
            "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
-           "gkg_bn_apply_train", "gkg_bn_bwd_train")
+           "gkg_bn_apply_train", "gkg_bn_bwd_train", "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -143,6 +143,10 @@ def load():
     lib.gkg_bn_apply_train.argtypes = [V, V, I] + [V] * 12 + [I, I, I, I, Z, I, I, I, F, F, V, V]
     lib.gkg_bn_bwd_train.restype = I
     lib.gkg_bn_bwd_train.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, V, V, Z, V]
+    lib.gkg_mr_linear_planes_bytes.restype = Z
+    lib.gkg_mr_linear_planes_bytes.argtypes = [I]
+    lib.gkg_mr_linear_bf16.restype = I
+    lib.gkg_mr_linear_bf16.argtypes = [V] * 7 + [I] * 8 + [V]
     lib.gkg_prof_enable.restype = None
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None

@@ -960,6 +960,52 @@ class _MaxRelativeTM(torch.autograd.Function):
         return gx, gsrc, None, None, None, None
 
 
+# ----------------------------------------------------------------------------------------------- row g1 (inference)
+# bf16 inference: gather + max-relative + interleave + grouped 1x1 projection + BN(eval) + GELU in ONE launch
+# (csrc/gkg_mrgemm.hip) — the [x, m] operand is produced tile by tile in LDS and never written.  GKG_MR_GEMM=0 restores
+# the three-launch form (gkg_mr_fwd_tm -> batched GEMM -> gkg_affine_act).
+MR_GEMM = os.environ.get("GKG_MR_GEMM", "1") != "0"
+
+
+def _mr_planes_of(conv) -> torch.Tensor:
+    """The grouped projection's weight as the bf16 fragment array gkg_mr_linear_bf16 streams: [4][ci_pad/8][co_pad][8]
+    (include/gkg_hip.h), cached on the module and rebuilt when the parameter changes."""
+    w = conv.weight
+    ent = getattr(conv, "_gkg_mrplanes", None)
+    if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
+        co, ci = w.shape[0] // 4, w.shape[1]
+        ci_pad, co_pad = (ci + 15) // 16 * 16, (co + 31) // 32 * 32
+        W = torch.zeros((4, co_pad, ci_pad), dtype=torch.bfloat16, device=w.device)
+        W[:, :co, :ci] = w.detach().reshape(4, co, ci).to(torch.bfloat16)
+        planes = W.view(4, co_pad, ci_pad // 8, 8).permute(0, 2, 1, 3).contiguous()
+        assert planes.numel() * 2 == _lib.load().gkg_mr_linear_planes_bytes(4 * ci // 2)
+        ent = (w._version, w.data_ptr(), planes)
+        conv._gkg_mrplanes = ent
+    return ent[2]
+
+
+def _mr_gemm_ok(nn_, C, lp) -> bool:
+    conv, bn = nn_[0], nn_[1]
+    return (MR_GEMM and lp and not bn.training and bn.track_running_stats and conv.groups == 4 and C % 16 == 0 and C <= 768
+            and conv.weight.shape[0] == 2 * C and conv.weight.shape[1] == C // 2)
+
+
+@torch.no_grad()
+def mr_grouped_linear_eval(x, src, nn_idx, G, conv, bn, act=1):
+    """x (B, N, C) fp32, src (B, M, C) fp32 | None, nn_idx (B*G, N, k) -> act(BN_eval(BasicConv([x, max_k(src[idx] - x)])))
+    as (B*N, 2C) bf16 (reference torch_vertex.py:47-62 + torch_nn.py:57-69)."""
+    lib = _lib.load()
+    B, N, C = x.shape
+    M = N if src is None else src.shape[1]
+    x = x.contiguous()
+    src = None if src is None else src.contiguous()
+    a, c = _bn_eval_ac(lib, bn, conv.bias, 2 * C)
+    out = torch.empty((B * N, 2 * C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.gkg_mr_linear_bf16(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(_mr_planes_of(conv)), _ptr(a), _ptr(c), _ptr(out),
+                                      2 * C, B, G, C // G, N, M, nn_idx.shape[2], act, _stream()), "gkg_mr_linear_bf16")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- block drivers
 def _bn_ok(bn) -> bool:
     if not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) or not bn.affine or bn.momentum is None:
@@ -1027,10 +1073,13 @@ def grapher_forward(mod, x, relative_pos, groups: int):
         pooled = F.avg_pool2d(x1.view(B, H, W, C).permute(0, 3, 1, 2), gc.r, gc.r)
         yb = pooled.permute(0, 2, 3, 1).reshape(B, -1, C)
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
-    U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1, lp)       # (4, T, C/2) interleaved [x, m]
     nn_ = gc.gconv.nn
-    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
-                                   _w16_of(nn_[0]) if lp else None)   # (T, 2C)
+    if _mr_gemm_ok(nn_, C, lp):                                     # row g1: aggregation = the projection's operand producer
+        a2 = mr_grouped_linear_eval(x1b, yb, edge[0], groups, nn_[0], nn_[1])
+    else:
+        U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1, lp)   # (4, T, C/2) interleaved [x, m]
+        a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
+                                       _w16_of(nn_[0]) if lp else None)   # (T, 2C)
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
         out = _lin(a2, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=N, want16=lp)
         return _cl_out(out, B, H, W), edge
@@ -1052,10 +1101,13 @@ def grapher_label_forward(mod, e, features, groups: int):
     x1b = x1.view(B, L, C)
     edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
     lp = lowp_inference()
-    U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1, lp)
     nn_ = gc.gconv.nn
-    a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
-                                   _w16_of(nn_[0]) if lp else None)
+    if _mr_gemm_ok(nn_, C, lp):
+        a2 = mr_grouped_linear_eval(x1b, ft, edge[0], groups, nn_[0], nn_[1])
+    else:
+        U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1, lp)
+        a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
+                                       _w16_of(nn_[0]) if lp else None)
     h2 = _lin(a2, mod.fc2, residual=e2, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
     f1 = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp)
     out = _lin(f1, mod.ffn.fc2, residual=h2, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)

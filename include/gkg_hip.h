@@ -162,6 +162,23 @@ int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax
                   int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SURVEY §8 row g1, inference: the aggregation as the OPERAND PRODUCER of the grouped 1x1 projection.
+ * One launch replaces MRConv2d.forward's gather -> max(x_j - x_i) -> interleave -> BasicConv (Conv2d(2C, 2C, 1,
+ * groups=4) + BN(eval) + GELU) chain (reference torch_vertex.py:47-62, torch_nn.py:57-69): the [x, m] tensor is built
+ * tile by tile in LDS (bf16, round-to-nearest-even — the operand rounding of the reference's autocast convolution) and
+ * consumed by v_mfma_f32_32x32x16_bf16 in place; it never exists in memory.
+ *   x (B, N, C) fp32 token-major; src (B, M, C) fp32 or NULL (self graph); nn_idx (B*G, N, k) int64; C = G*c, C % 16 == 0
+ *   wplanes: bf16 weight fragments [4][ci_pad/8][co_pad][8], ci = co = C/2, ci_pad = ci rounded up to 16, co_pad = co
+ *            rounded up to 32: fragment (q, f, n) = W[q*co + n][8f .. 8f+7] (zero outside); gkg_mr_linear_planes_bytes(C)
+ *   a, cshift (2C) fp32: out = act(a * conv + cshift) per output channel (eval-mode BN folded with the conv bias)
+ *   out (B*N, ldo) bf16, columns [0, 2C) written (column q*co + n), ldo >= 2C, ldo % 8 == 0; act: 0 none, 1 GELU (erf)
+ * The max-relative arithmetic is gkg_mr_fwd_tm's (bit-identical m before rounding). */
+size_t gkg_mr_linear_planes_bytes(int C);
+int gkg_mr_linear_bf16(const float* x, const float* src, const int64_t* nn_idx, const void* wplanes, const float* a,
+                       const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k, int act,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Bandwidth kernels between the dense 1x1 projections (Conv2d 1x1 + SyncBN [+ GELU], reference
  * torch_vertex.py:290-306,334-360; torch_nn.py:57-69).  The projections themselves are plain GEMMs run by the
  * caller in the vendor library on token-major (rows = tokens) fp32 matrices.  `nb` stacks nb independent
