@@ -16,13 +16,21 @@ KNN_NORMALIZE = 1
 KNN_BF16_CONTRACT = 2
 KNN_SELECT_DIRECT = 4
 KNN_SELECT_BUFFERED = 8
+KNN_NO_PREFILTER = 16
+KNN_FORCE_PREFILTER = 32
 
 
 def knn_select_flags() -> int:
-    """GKG_KNN_SELECT=direct|buffered (measurement / tests) -> the C API's selection-mode flags; read here, per call, so the
-    library's launch path never calls getenv."""
+    """GKG_KNN_SELECT=direct|buffered, GKG_KNN_PREFILTER=0|force (measurement / tests) -> the C API's mode flags; read here,
+    per call, so the library's launch path never calls getenv."""
     sel = os.environ.get("GKG_KNN_SELECT", "")
-    return KNN_SELECT_BUFFERED if sel[:1] == "b" else (KNN_SELECT_DIRECT if sel[:1] == "d" else 0)
+    f = KNN_SELECT_BUFFERED if sel[:1] == "b" else (KNN_SELECT_DIRECT if sel[:1] == "d" else 0)
+    pf = os.environ.get("GKG_KNN_PREFILTER", "")
+    if pf == "0" or f:                                             # a forced selection mode means the fp32 tile kernel
+        f |= KNN_NO_PREFILTER
+    elif pf == "force":
+        f |= KNN_FORCE_PREFILTER
+    return f
 LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 MR_DETERMINISTIC = 1
 

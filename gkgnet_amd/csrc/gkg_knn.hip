@@ -46,9 +46,15 @@ struct PrepStrides { int G; size_t sb, sg, sc, sn; };
 // block always fits: PT * c * 4 B <= 48 KB.
 // One launch prepares the queries AND (bipartite graphs) the keys: workgroups blockIdx.x >= nbx1 take the second
 // tensor — for the short label-branch problems a second dependent launch costs as much as the work itself.
-// tb != null: the normalised copy is written as bf16, TOKEN-major (bg, n, cp16) zero-padded to cp16 channels (the operand
-// layout of the bf16 matrix-core contraction) instead of fp32 channel-major th.
-struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; };
+// tb != null: the normalised copy is written as bf16 in OCTET-major planes (bg, cp16 / 8, n, 8), zero-padded to cp16
+// channels — a matrix-core operand fragment (one token, 8 consecutive channels) is 16 contiguous bytes and the fragments of
+// consecutive tokens are adjacent, so a wave's fragment load / store touches 8 full cache lines instead of 32+ partial ones
+// (measured: the token-major (bg, n, cp16) form left the contraction bound by the texture-address path) — instead of fp32
+// channel-major th.
+// tb_lo != null (prefilter mode, see knn_pf_kernel): besides the fp32 channel-major copy th (the exact re-rank reads it) the
+// two leading bf16 terms of every normalised value, hi = bf16(v) and lo = bf16(v - hi), are written as token-major
+// (bg, n, cp16) planes (tb = hi, tb_lo = lo) for the matrix-core prefilter.
+struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; uint16_t* tb_lo; };
 
 template <typename T, bool NORM, int PT>
 __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
@@ -105,8 +111,28 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   }
   // ---- (3) normalise, store, |th|^2
   float q2 = 0.0f;
+  if (S.tb_lo) {                                    // prefilter mode: bf16 hi / lo planes (token-major) + th / sq below
+    // octet-major planes (bg, cp16 / 8, Tn, 8): consecutive tokens are consecutive 16-byte fragments
+    uint4* ohi = reinterpret_cast<uint4*>(S.tb) + (size_t)bg * (S.cp16 >> 3) * Tn + n;
+    uint4* olo = reinterpret_cast<uint4*>(S.tb_lo) + (size_t)bg * (S.cp16 >> 3) * Tn + n;
+    for (int c0 = 0; c0 < S.cp16; c0 += 8) {
+      uint32_t wh[4], wl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v0 = c0 + 2 * u < c ? cp[(c0 + 2 * u) * PT] : 0.0f;
+        float v1 = c0 + 2 * u + 1 < c ? cp[(c0 + 2 * u + 1) * PT] : 0.0f;
+        if (NORM) { v0 = v0 / den; v1 = v1 / den; }
+        const float h0 = __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v0)) << 16);
+        const float h1 = __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v1)) << 16);
+        wh[u] = pack_bf16x2(v0, v1);
+        wl[u] = pack_bf16x2(v0 - h0, v1 - h1);
+      }
+      ohi[(size_t)(c0 >> 3) * Tn] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+      olo[(size_t)(c0 >> 3) * Tn] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    }
+  } else
   if (S.tb) {                                       // bf16 token-major copy: 16-byte stores of 8 channels
-    uint4* ob = reinterpret_cast<uint4*>(S.tb + ((size_t)bg * Tn + n) * S.cp16);
+    uint4* ob = reinterpret_cast<uint4*>(S.tb) + (size_t)bg * (S.cp16 >> 3) * Tn + n;      // octet-major (bg, cp16/8, Tn, 8)
     for (int c0 = 0; c0 < S.cp16; c0 += 8) {
       uint32_t wv[4];
 #pragma unroll
@@ -118,7 +144,7 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
         q2 = __builtin_fmaf(v1, v1, q2);
         wv[u] = pack_bf16x2(v0, v1);
       }
-      ob[c0 >> 3] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      ob[(size_t)(c0 >> 3) * Tn] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
     }
     sq[(size_t)bg * Tn + n] = q2;
     return;
@@ -225,9 +251,13 @@ struct KnnArgs {
   int BG, cpad, N, M, k, dilation, kd;
   int splits, tiles_per_split;
   int nqt;              // query tiles per problem
-  const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies
+  const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies (prefilter: hi planes)
   const uint16_t* yb;
   int cp16;
+  // prefilter mode (knn_pf_kernel)
+  const uint16_t* xb_lo;  // lo planes
+  const uint16_t* yb_lo;
+  float margin;           // 2 * eps: eps bounds |prefilter distance - contract distance| (see knn_pf_kernel)
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
@@ -283,13 +313,13 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   float an[KU];
   constexpr int KB = 4;                          // BF: k16-steps per key-operand batch
   const int cp16 = a.cp16, S16 = cp16 >> 4;
-  const uint16_t* ybp = BF ? a.yb + (size_t)bg * M * cp16 : nullptr;
+  const uint4* ybp = BF ? reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * M : nullptr;   // [octet][key]
   uint4 bn_[KB];
   if (BF) {
     const int mk0 = min((t_begin + w) * KT + l31, M - 1);
-    const uint4* y0 = reinterpret_cast<const uint4*>(ybp + (size_t)mk0 * cp16 + 8 * kk);
+    const uint4* y0 = ybp + (size_t)kk * M + mk0;
 #pragma unroll
-    for (int u = 0; u < KB; ++u) bn_[u] = u < S16 ? y0[2 * u] : make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < KB; ++u) bn_[u] = u < S16 ? y0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
   } else {
     const int t0 = t_begin + w;
     const int mk0 = min(t0 * KT + l31, M - 1);
@@ -313,12 +343,12 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   // BF: xq[64][cp16 + 8] bf16 rows (-2 x, exact; 16 B of padding per row keeps the fragment reads conflict-free)
   const int qpitch = (cp16 + 8) * 2;             // bytes
   if (BF) {
-    const uint16_t* xbp = a.xb + (size_t)bg * N * cp16;
+    const uint4* xbp = reinterpret_cast<const uint4*>(a.xb) + (size_t)bg * (cp16 >> 3) * N;
     const int chunks = cp16 >> 3;                  // 16-byte chunks per query row
     for (int i = tid; i < QT * chunks; i += 256) {
-      const int q = i / chunks, ck = i - q * chunks;
+      const int ck = i >> 6, q = i & 63;           // consecutive threads: consecutive queries of one octet (coalesced)
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (n0 + q < N) v = *reinterpret_cast<const uint4*>(xbp + (size_t)(n0 + q) * cp16 + 8 * ck);
+      if (n0 + q < N) v = xbp[(size_t)ck * N + n0 + q];
       // x -> -2x on packed bf16: exponent + 1 and sign flip, zeros stay zeros (|x| <= 1 after normalisation; raw inputs
       // near the top of the range would overflow to inf like any -2x)
       auto m2h = [](unsigned hv) -> unsigned {
@@ -426,8 +456,8 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     if (BF) {
       // keys = A operand (lane: key l31, 8 channels 16 s + 8 kk ...), the two query blocks = B operands from LDS
       typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-      const uint4* ykp = reinterpret_cast<const uint4*>(ybp + (size_t)mk * cp16 + 8 * kk);
-      const uint4* ykn = reinterpret_cast<const uint4*>(ybp + (size_t)mk_next * cp16 + 8 * kk);
+      const uint4* ykp = ybp + (size_t)kk * M + mk;
+      const uint4* ykn = ybp + (size_t)kk * M + mk_next;
       const char* xq0 = reinterpret_cast<const char*>(smem) + l31 * qpitch + 16 * kk;
       const char* xq1 = xq0 + 32 * qpitch;
       for (int s0 = 0; s0 < S16; s0 += KB) {
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
           const int sn = last ? u : s0 + KB + u;
-          bn_[u] = sn < S16 ? (last ? ykn : ykp)[2 * sn] : make_uint4(0, 0, 0, 0);
+          bn_[u] = sn < S16 ? (last ? ykn : ykp)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -584,6 +614,343 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   }
 }
 
+// ------------------------------------------------------------------------------------------ prefilter + exact re-rank
+// Same contract, same bits, a third of the matrix time: the (64-query x 32-key) distance tiles are first evaluated
+// APPROXIMATELY on the bf16 matrix cores — every normalised fp32 token split into its two leading bf16 terms (hi, lo),
+// three of the four cross products (hi.hi + hi.lo + lo.hi), fp32 accumulation, relative_pos pre-loaded into the
+// accumulators: 3 x 32 cycles per 32x32x16 block where the fp32 MFMA needs 8 x 64, and unlike the fp32 MFMA it runs
+// BESIDE the selection's vector work instead of on its datapath — and only the few candidates that can be among a query's
+// k*d nearest are then re-evaluated EXACTLY (the contract's ordered fmaf chain, bit for bit) and ranked.
+//
+// Why the result is the contract's: let d_e(m) be the contract distance of key m and d_a(m) the prefilter's, with
+// |d_a - d_e| <= eps for every pair (eps below).  Let tau = the KD-th smallest d_a.  The KD keys with the smallest d_a all
+// have d_e <= tau + eps, so the KD-th smallest d_e is <= tau + eps, so every key of the true top-KD has
+// d_a <= d_e + eps <= tau + 2 eps.  The survivors S = {m : d_a(m) <= tau + 2 eps} therefore contain the true top-KD, and
+// ranking S by the exact (d_e, m) keys gives exactly the contract's list (ties included).
+//   eps: with |x^| = |y^| = 1 (normalised tokens; the kernel is only selected with GKG_KNN_NORMALIZE) sum_ch |2 x^ y^| <= 2.
+//   Dropped terms of the split (lo.lo and the residuals |v - hi - lo| <= 2^-18 |v|): <= 3 * 2^-18 * 2 = 2.3e-5; fp32
+//   accumulation of the 3 c products on the matrix core, any order: <= 3 c u * 2, u = 2^-24; the contract's own chain
+//   against the real value: <= c u * 2; the final adds: a few u.  eps = 3e-5 + 6e-7 * cpad covers the sum with margin.
+// Per-wave lists: the 4 waves of a workgroup stream disjoint key tiles, so a wave may have dropped (beyond its KDW-entry
+// list) a key that belongs to S.  That can only have happened if the wave's own KDW-th entry is <= tau + 2 eps; such a query
+// (and one with more than SMAX survivors) takes the SLOW PATH: its lane re-scans all M keys with the exact chain.  KDW
+// exceeds KD for short lists (9 -> 12, 12 -> 16) so that this needs >= KDW of a query's best keys in ONE wave's quarter of
+// the key tiles: ~4^(1-KDW) per query.
+constexpr int PF_EXTRA = 8;       // survivors beyond KD a query may have before it takes the slow path
+
+// The contract's distance (without relative_pos) of query n and key m from the fp32 channel-major normalised copies: the
+// ordered fmaf chain over the cpad (zero-padded) channels with the query pre-scaled by -2 — what knn_tile_kernel's fp32
+// MFMA contraction computes, bit for bit.
+__device__ __forceinline__ float pf_exact_dist(const float* __restrict__ xc, int N, const float* __restrict__ yc, int M,
+                                               int cpad, float sqx, float sqy) {
+  float acc = 0.0f;
+#pragma unroll 8
+  for (int ch = 0; ch < cpad; ++ch) acc = __builtin_fmaf(yc[(size_t)ch * M], -2.0f * xc[(size_t)ch * N], acc);
+  return (sqx + acc) + sqy;                        // the contract's order; relative_pos is added by the caller
+}
+
+template <int KD, int KDW, bool HAS_RP>
+__global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs a) {
+  extern __shared__ float smem[];
+  typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+  constexpr int SMAX = KD + PF_EXTRA;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqt = a.nqt;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, jj = lin >> 3;
+  const int bg = (jj / nqt) * 8 + xcd;               // XCD-aware map, as knn_tile_kernel
+  if (bg >= a.BG) return;
+  const int n0 = (jj % nqt) * QT;
+  const int N = a.N, M = a.M, cpad = a.cpad, cp16 = a.cp16, S16 = cp16 >> 4;
+  const int lane_n = n0 + lane;
+  const int nc = lane_n < N ? lane_n : N - 1;
+  const int kk = lane >> 5, l31 = lane & 31;
+  constexpr int KB = 4;                              // k16-steps per key-operand batch
+  const uint4* yhp = reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * M;       // octet-major planes
+  const uint4* ylp = reinterpret_cast<const uint4*>(a.yb_lo) + (size_t)bg * (cp16 >> 3) * M;
+  uint4 bh_[KB], bl_[KB];
+  {
+    const int mk0 = min(w * KT + l31, M - 1);
+    const uint4* h0 = yhp + (size_t)kk * M + mk0;
+    const uint4* l0 = ylp + (size_t)kk * M + mk0;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      bh_[u] = u < S16 ? h0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
+      bl_[u] = u < S16 ? l0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
+    }
+  }
+  // ---- stage the query tile: hi and lo planes scaled by -2 (exact), rows of cp16 + 8 bf16
+  const int qpitch = (cp16 + 8) * 2;                 // bytes
+  char* xq_hi = reinterpret_cast<char*>(smem);
+  char* xq_lo = xq_hi + QT * qpitch;
+  {
+    const uint4* xhp = reinterpret_cast<const uint4*>(a.xb) + (size_t)bg * (cp16 >> 3) * N;
+    const uint4* xlp = reinterpret_cast<const uint4*>(a.xb_lo) + (size_t)bg * (cp16 >> 3) * N;
+    const int chunks = cp16 >> 3;
+    auto m2h = [](unsigned hv) -> unsigned {
+      const unsigned e = hv & 0x7f80u;
+      if (e == 0u) return 0u;                                   // zero / denormal
+      if (e == 0x7f80u) return hv ^ 0x8000u;                     // inf / NaN keep their class
+      if (e == 0x7f00u) return ((hv ^ 0x8000u) & 0x8000u) | 0x7f80u;   // overflow -> inf
+      return (hv + 0x80u) ^ 0x8000u;
+    };
+    auto m2 = [&](unsigned wv) { return m2h(wv & 0xffffu) | (m2h(wv >> 16) << 16); };
+    for (int i = tid; i < 2 * QT * chunks; i += 256) {
+      const int pl = i >= QT * chunks;
+      const int r = i - pl * QT * chunks;
+      const int ck = r >> 6, q = r & 63;           // consecutive threads: consecutive queries of one octet (coalesced)
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n0 + q < N) v = (pl ? xlp : xhp)[(size_t)ck * N + n0 + q];
+      v.x = m2(v.x); v.y = m2(v.y); v.z = m2(v.z); v.w = m2(v.w);
+      *reinterpret_cast<uint4*>((pl ? xq_lo : xq_hi) + q * qpitch + 16 * ck) = v;
+    }
+  }
+  __syncthreads();
+
+  const float* sqy = a.sqy + (size_t)bg * M;
+  const bool two_blocks = n0 + 32 < N;               // wave-uniform
+  TopList<KDW> top;
+  top.init();
+  const int ktiles = (M + KT - 1) / KT;
+  // relative_pos rows of the two query blocks this lane's accumulator columns belong to
+  const int nq0 = min(n0 + l31, N - 1), nq1 = min(n0 + 32 + l31, N - 1);
+  for (int t = w; t < ktiles; t += NW) {
+    const int m0 = t * KT;
+    const int mk = min(m0 + l31, M - 1);
+    const int mk_next = min((t + NW < ktiles ? t + NW : t) * KT + l31, M - 1);
+    const float sy32 = (m0 + l31 < M) ? sqy[mk] : MASKED_SQ;
+    // accumulators start from relative_pos: lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
+    f32x16 acc0, acc1;
+    if (HAS_RP) {
+      const float* r0 = a.relpos + (size_t)nq0 * M + m0 + 4 * kk;
+      const float* r1 = a.relpos + (size_t)nq1 * M + m0 + 4 * kk;
+      if (m0 + KT <= M && (M & 3) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v0 = *reinterpret_cast<const float4*>(r0 + 8 * g);
+          const float4 v1 = *reinterpret_cast<const float4*>(r1 + 8 * g);
+          acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
+          acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
+        }
+      } else {
+        const int last = M - 1 - m0 - 4 * kk;          // offsets beyond it are clamped (those keys are masked anyway)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int off = max(min(8 * g + j, last), -(m0 + 4 * kk));
+            acc0[4 * g + j] = r0[off];
+            acc1[4 * g + j] = r1[off];
+          }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    }
+    {
+      const uint4* ykh = yhp + (size_t)kk * M + mk;
+      const uint4* ykl = ylp + (size_t)kk * M + mk;
+      const uint4* ynh = yhp + (size_t)kk * M + mk_next;
+      const uint4* ynl = ylp + (size_t)kk * M + mk_next;
+      const char* xh0 = xq_hi + l31 * qpitch + 16 * kk;
+      const char* xl0 = xq_lo + l31 * qpitch + 16 * kk;
+      const char* xh1 = xh0 + 32 * qpitch;
+      const char* xl1 = xl0 + 32 * qpitch;
+      for (int s0 = 0; s0 < S16; s0 += KB) {
+        const bool last = s0 + KB >= S16;                         // uniform: prefetch the NEXT tile's first batch
+        uint4 ah[KB], al[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) { ah[u] = bh_[u]; al[u] = bl_[u]; }
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          const int sn = last ? u : s0 + KB + u;
+          bh_[u] = sn < S16 ? (last ? ynh : ykh)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
+          bl_[u] = sn < S16 ? (last ? ynl : ykl)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (s0 + u < S16) {
+            const bf16x8_t kh = __builtin_bit_cast(bf16x8_t, ah[u]);
+            const bf16x8_t kl = __builtin_bit_cast(bf16x8_t, al[u]);
+            const bf16x8_t qh0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh0 + 32 * (s0 + u)));
+            const bf16x8_t ql0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl0 + 32 * (s0 + u)));
+            if (two_blocks) {                                      // the two accumulator chains alternate: no MFMA
+              const bf16x8_t qh1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh1 + 32 * (s0 + u)));
+              const bf16x8_t ql1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl1 + 32 * (s0 + u)));
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh0, acc0, 0, 0, 0);     // issues right behind the one it
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh1, acc1, 0, 0, 0);     // depends on (small terms first)
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh1, acc1, 0, 0, 0);
+            } else {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh0, acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---- lane l <- all 32 keys of query n0 + l (permlane swap as in knn_tile_kernel); approximate distance (without the
+    //      query's own |x|^2, a per-query constant) = acc + |y|^2, keys past M masked by MASKED_SQ
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float lo[4], hi[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * g + j]),
+                                                         __float_as_uint(acc1[4 * g + j]), false, false);
+        lo[j] = __uint_as_float(sw[0]);
+        hi[j] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = 8 * g + 4 * hh + j;
+          const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
+          top.template insert<KDW >= 18>((hh ? hi[j] : lo[j]) + sy, m0 + row);
+        }
+      }
+    }
+  }
+
+  // ---- the 4 per-wave lists -> LDS; wave 0 merges them per query and collects the survivors
+  __syncthreads();                       // everyone is done with the staged queries
+  float* lv = smem;                      // [NW][KDW][64]
+  int* li = reinterpret_cast<int*>(smem + NW * KDW * 64);
+  int* sidx = li + NW * KDW * 64;        // [SMAX][64] survivor key indices (ascending prefilter distance)
+  int* scnt = sidx + SMAX * 64;          // [64] survivor count; -1: slow path
+  int* npairs = scnt + 64;               // [1] (+3 pad) number of (query, survivor) pairs that need the exact distance
+  uint16_t* plist = reinterpret_cast<uint16_t*>(npairs + 4);     // [SMAX * 64] those pairs, (s << 6) | q
+  double* keys = reinterpret_cast<double*>(smem);                // [SMAX][64] final sort keys, over the dead list area
+#pragma unroll
+  for (int j = 0; j < KDW; ++j) {
+    lv[(w * KDW + j) * 64 + lane] = key_dist(top.key[j]);
+    li[(w * KDW + j) * 64 + lane] = key_index(top.key[j]);
+  }
+  if (tid == 0) *npairs = 0;
+  __syncthreads();
+  const float margin = a.margin;
+  if (w == 0) {
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    float h0 = lv[(0 * KDW) * 64 + lane], h1 = lv[(1 * KDW) * 64 + lane], h2 = lv[(2 * KDW) * 64 + lane],
+          h3 = lv[(3 * KDW) * 64 + lane];
+    int i0 = li[(0 * KDW) * 64 + lane], i1 = li[(1 * KDW) * 64 + lane], i2 = li[(2 * KDW) * 64 + lane],
+        i3 = li[(3 * KDW) * 64 + lane];
+    float tau = INFINITY;
+    int cnt = 0;
+    bool open = true;                    // still collecting
+    float sv_d[SMAX];                    // prefilter distances of the survivors (registers: the loops are unrolled)
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) {
+      int sel = 0; float bv = h0; int bi = i0;
+      if (h1 < bv || (h1 == bv && i1 < bi)) { sel = 1; bv = h1; bi = i1; }
+      if (h2 < bv || (h2 == bv && i2 < bi)) { sel = 2; bv = h2; bi = i2; }
+      if (h3 < bv || (h3 == bv && i3 < bi)) { sel = 3; bv = h3; bi = i3; }
+      if (sel == 0) { ++p0; h0 = p0 < KDW ? lv[(0 * KDW + p0) * 64 + lane] : INFINITY; i0 = p0 < KDW ? li[(0 * KDW + p0) * 64 + lane] : 0x7fffffff; }
+      else if (sel == 1) { ++p1; h1 = p1 < KDW ? lv[(1 * KDW + p1) * 64 + lane] : INFINITY; i1 = p1 < KDW ? li[(1 * KDW + p1) * 64 + lane] : 0x7fffffff; }
+      else if (sel == 2) { ++p2; h2 = p2 < KDW ? lv[(2 * KDW + p2) * 64 + lane] : INFINITY; i2 = p2 < KDW ? li[(2 * KDW + p2) * 64 + lane] : 0x7fffffff; }
+      else { ++p3; h3 = p3 < KDW ? lv[(3 * KDW + p3) * 64 + lane] : INFINITY; i3 = p3 < KDW ? li[(3 * KDW + p3) * 64 + lane] : 0x7fffffff; }
+      if (j == KD - 1) tau = bv;
+      // merged order is ascending, so the survivors are a PREFIX of it: the first candidate that is not taken — beyond the
+      // margin, or not a real key (exhausted lists, keys masked past M) — ends the collection
+      const bool take = open && (j < KD || bv <= tau + margin) && (unsigned)bi < (unsigned)M;
+      if (!take) open = false;
+      if (take) { sidx[j * 64 + lane] = bi; cnt = j + 1; }
+      sv_d[j] = take ? bv : INFINITY;
+    }
+    // more survivors than SMAX?  (the next head is still inside the margin)
+    const float nh = fminf(fminf(h0, h1), fminf(h2, h3));
+    bool slow = open && nh <= tau + margin;
+    // a wave whose list is full and whose last entry is inside the margin may have dropped a survivor
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const float lastv = lv[(ww * KDW + KDW - 1) * 64 + lane];
+      if (lastv <= tau + margin) slow = true;          // +inf (list not full) and NaN never pass
+    }
+    if (!(tau < INFINITY)) slow = false;               // fewer than KD finite candidates at all: nothing was dropped
+    if (lane_n >= N) { slow = false; cnt = 0; }        // padding lanes of the last query tile
+    scnt[lane] = slow ? -1 : cnt;
+    // Sort keys.  A survivor more than `margin` away from both neighbours in this (sorted) list keeps its prefilter
+    // distance (+ |x|^2, the term the prefilter leaves out): its order against every other survivor is already the
+    // contract's (each distance is within eps of the exact one).  The others — near-ties, and everything around the KD-th
+    // rank by construction — get the exact contract distance from the pair pass below.
+    if (!slow) {
+      const float sqxv = a.sqx[(size_t)bg * N + nc];
+#pragma unroll
+      for (int j = 0; j < SMAX; ++j) {
+        if (j < cnt) {
+          const bool near = (j > 0 && sv_d[j] - sv_d[j - 1] <= margin) || (j + 1 < SMAX && j + 1 < cnt && sv_d[j + 1] - sv_d[j] <= margin);
+          if (near) {
+            const int slot = atomicAdd(npairs, 1);
+            plist[slot] = (uint16_t)((j << 6) | lane);
+          } else {
+            keys[j * 64 + lane] = pack_key(sv_d[j] + sqxv, sidx[j * 64 + lane]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- exact contract distance of the pairs that need it: one thread per pair, dense over the workgroup
+  const float* xcb = a.xh + (size_t)bg * cpad * N;
+  const float* ycb = a.yh + (size_t)bg * cpad * M;
+  {
+    const int np = *npairs;
+    for (int p = tid; p < np; p += 256) {
+      const int e = plist[p];
+      const int q = e & 63, sv = e >> 6;
+      const int m = sidx[sv * 64 + q];
+      const int n = min(n0 + q, N - 1);
+      float d = pf_exact_dist(xcb + n, N, ycb + m, M, cpad, a.sqx[(size_t)bg * N + n], sqy[m]);
+      if (HAS_RP) d = d + a.relpos[(size_t)n * M + m];
+      keys[sv * 64 + q] = d == d && d < INFINITY ? pack_key(d, m) : (double)INFINITY;   // NaN / +inf never enter a list
+    }
+  }
+  __syncthreads();
+  if (w != 0) return;
+
+  // ---- wave 0: rank the survivors by their keys; flagged queries re-scan all keys exactly
+  TopList<KD> fin;
+  fin.init();
+  const int myc = scnt[lane];
+#pragma unroll
+  for (int sv = 0; sv < SMAX; ++sv) {
+    if (__builtin_amdgcn_ballot_w64(sv < myc) == 0ull) break;
+    const double kv = sv < myc ? keys[sv * 64 + lane] : (double)INFINITY;
+    fin.template insert_key<false>(kv);
+  }
+  if (__builtin_amdgcn_ballot_w64(myc < 0) != 0ull) {
+    if (myc < 0) {
+      const float sqxv = a.sqx[(size_t)bg * N + nc];
+      for (int m = 0; m < M; ++m) {
+        float d = pf_exact_dist(xcb + nc, N, ycb + m, M, cpad, sqxv, sqy[m]);
+        if (HAS_RP) d = d + a.relpos[(size_t)nc * M + m];
+        if (d == d && d < INFINITY) fin.template insert_key<false>(pack_key(d, m));
+      }
+    }
+  }
+  if (lane_n < N) {
+    const size_t obase = ((size_t)bg * N + nc) * a.k;
+    int outj = 0;
+#pragma unroll
+    for (int j = 0; j < KD; ++j) {
+      if (j < a.kd && j % a.dilation == 0 && outj < a.k) {
+        const int bi = key_index(fin.key[j]);
+        a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;
+        if (a.center) a.center[obase + outj] = lane_n;
+        ++outj;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ split merge
 // One thread per partial-list ELEMENT: its final rank = its position in its own (sorted) list + the number of
 // lexicographically smaller (dist, idx) pairs in every other split's list (binary search).  Ranks are unique,
@@ -656,7 +1023,7 @@ static int pick_splits(int BG, int N, int M) {
 
 struct KnnPlan {
   int cpad, kd, KD, S, tps;
-  size_t off_xh, off_yh, off_sqx, off_sqy, off_pv, off_pi, total;
+  size_t off_xh, off_yh, off_sqx, off_sqy, off_pv, off_pi, off_xp, off_yp, total;
 };
 
 static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_y, KnnPlan* p) {
@@ -687,8 +1054,14 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   if (p->S > 1) {
     p->off_pv = o; o = al(o + sizeof(float) * (size_t)p->S * BG * N * p->kd);
     p->off_pi = o; o = al(o + sizeof(int) * (size_t)p->S * BG * N * p->kd);
+    p->off_xp = p->off_yp = 0;
   } else {
     p->off_pv = p->off_pi = 0;
+    // prefilter mode (un-split problems): bf16 hi + lo planes (BG, T, cp16) of the queries and keys
+    const size_t cp16 = (size_t)((c + 15) & ~15);
+    p->off_xp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * N * cp16);
+    if (has_y) { p->off_yp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * M * cp16); }
+    else p->off_yp = p->off_xp;
   }
   p->total = o;
   return 0;
@@ -759,6 +1132,31 @@ static hipError_t launch_tile_buffered(const KnnArgs& a, dim3 grid, size_t lds, 
   return deep ? launch_tile_v<KD, false, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, false, 4, false, KNN_BUF>(a, grid, lds, st);
 }
 
+// prefilter + exact re-rank (knn_pf_kernel): un-split, normalised, fp32-contract problems
+template <int KD, int KDW>
+static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
+  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
+  const size_t stage = (size_t)2 * QT * (a.cp16 + 8) * 2;
+  const size_t lists = (size_t)2 * NW * KDW * 64 * 4 + (size_t)(KD + PF_EXTRA) * 64 * (4 + 2) + 64 * 4 + 16;
+  const size_t lds = stage > lists ? stage : lists;
+  if (a.relpos) {
+    if (lds > 64 * 1024) {
+      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ea != hipSuccess) return ea;
+    }
+    hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, true>), grid, dim3(256), lds, st, a);
+  } else {
+    if (lds > 64 * 1024) {
+      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ea != hipSuccess) return ea;
+    }
+    hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, false>), grid, dim3(256), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
 template <typename T, int PT>
 static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
   const int nbx1 = (s1.Tn + PT - 1) / PT;
@@ -808,8 +1206,24 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // 16 <= c (below that the fp32 staging area is smaller than the bf16 one) — otherwise the flag is ignored
   const bool bf = (flags & GKG_KNN_BF16_CONTRACT) != 0 && c >= 16;
   const int cp16 = (c + 15) & ~15;
-  const PrepSet sx{x, xh, sqx, N, strides(N), bf ? (uint16_t*)xh : nullptr, cp16};
-  const PrepSet sy{y, yh, sqy, M, strides(M), bf ? (uint16_t*)yh : nullptr, cp16};
+  // prefilter mode: the bit-exact contract path for normalised, un-split problems with lists up to 36 entries (LDS)
+  const size_t pf_stage = (size_t)2 * QT * (cp16 + 8) * 2;
+  // Where it pays (MI355X, tools/bench_ops.py, prefilter vs fp32 tile kernel, us per launch incl. the extra preparation
+  // work): long key streams, where the contraction dominates — pvig_s@576 stage 3 (c = 200, 1296 x 1296) k*d = 18:
+  // 437 + 92 vs 594 + 57, k*d = 27: 525 + 91 vs 827 + 56; stage 2 (c = 80, 5184 x 1296, k*d = 9): 675 + 82 vs 882 + 58;
+  // stage 1 (c = 40, 20736 x 1296): 2203 + 143 vs 2382 + 97.  It loses on short streams, where its serial tail (merge,
+  // exact pass, final ranking in one wave) is not amortised (cfg2 label graph 34 vs 25, C = 640 / k*d = 27 at 18 x 18: 210
+  // vs 119; the cfg2 Grapher graph is a tie: 51 + 22 vs 54 + 15), and against the BUFFERED selection of narrow groups with
+  // long lists (pvig_m: c = 24 / k*d = 18: 4469 vs 3149).  GKG_KNN_FORCE_PREFILTER overrides the rule (tests).
+  const bool pf_pays = M >= 1024 && (p.KD <= 12 ? p.cpad >= 40 : (p.KD <= 27 && p.cpad >= 128));
+  const bool pf = !bf && norm && p.S == 1 && c >= 16 && p.KD <= 36 && !(flags & GKG_KNN_NO_PREFILTER)
+                  && pf_stage <= 150 * 1024 && (pf_pays || (flags & GKG_KNN_FORCE_PREFILTER));
+  uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
+  uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
+  const PrepSet sx{x, xh, sqx, N, strides(N), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), cp16,
+                   pf ? xpl + (size_t)BG * N * cp16 : nullptr};
+  const PrepSet sy{y, yh, sqy, M, strides(M), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), cp16,
+                   pf ? ypl + (size_t)BG * M * cp16 : nullptr};
   if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
@@ -822,7 +1236,25 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.splits = p.S; a.tiles_per_split = p.tps;
   a.nqt = (N + QT - 1) / QT;
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
+  a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
+  if (pf) {
+    a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
+    a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;
+    a.margin = 2.0f * (3.0e-5f + 6.0e-7f * (float)p.cpad);
+    switch (p.KD) {
+      case 9: e = launch_pf<9, 12>(a, grid, st); break;
+      case 12: e = launch_pf<12, 16>(a, grid, st); break;
+      case 16: e = launch_pf<16, 16>(a, grid, st); break;
+      case 18: e = launch_pf<18, 18>(a, grid, st); break;
+      case 24: e = launch_pf<24, 24>(a, grid, st); break;
+      case 27: e = launch_pf<27, 27>(a, grid, st); break;
+      case 32: e = launch_pf<32, 32>(a, grid, st); break;
+      default: e = launch_pf<36, 36>(a, grid, st); break;
+    }
+    if (e != hipSuccess) return gkg_fail_hip(e, "knn_pf_kernel");
+    return 0;
+  }
   size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
   size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
   size_t lds = lds_q > lds_m ? lds_q : lds_m;

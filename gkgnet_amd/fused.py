@@ -482,6 +482,20 @@ def _folded_of(conv, bn):
     return ent[1], ent[2]
 
 
+def _folded_shift32(conv, bn) -> torch.Tensor:
+    """The fp32 shift that goes with _folded_of's weights (cached beside them)."""
+    ent = conv._gkg_fold
+    if len(ent) < 4:
+        with torch.no_grad():
+            a = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.float() - a * bn.running_mean.float()
+            if conv.bias is not None:
+                shift = shift + a * conv.bias.float()
+        ent = ent + (shift.contiguous(),)
+        conv._gkg_fold = ent
+    return ent[3]
+
+
 def _mm_t(x, W, W16=None):
     """x (R, cin) @ W (cout, cin)^T -> fp32 (R, cout).  bf16 ``x``: bf16 operands, fp32 accumulate AND fp32 result."""
     if x.dtype == torch.bfloat16:
@@ -1050,6 +1064,13 @@ def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, ro
         # bf16 inference, activation only feeds the next GEMM: BN folded into the weights, bias (+ GELU) in the GEMM epilogue
         wf, cf = _folded_of(conv, bn)
         return torch._addmm_activation(cf, x, wf.t(), use_gelu=(act == 1))
+    if (FOLD_EPILOGUE and not out_lowp and act == 0 and x.dtype == torch.bfloat16 and residual is None and nchw is None
+            and scale is None and not want16 and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats
+            and conv.weight.dim() == 4 and conv.groups == 1):
+        # bf16 inference, fp32 result wanted (the Grapher's fc1: the k-NN and the aggregation read it in fp32): BN scale
+        # folded into the bf16 weights, the shift as an fp32 bias in the GEMM epilogue, fp32 accumulate AND fp32 output
+        wf, _ = _folded_of(conv, bn)
+        return torch.addmm(_folded_shift32(conv, bn), x, wf.t(), out_dtype=_F32)
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
     return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
                               rows_per_scale, want16)

@@ -56,6 +56,11 @@ extern "C" {
                                   * index contract; ignored for c < 16. */
 #define GKG_KNN_SELECT_DIRECT 4u   /* force the direct sorted insert / the buffered selection of the tile kernel instead of */
 #define GKG_KNN_SELECT_BUFFERED 8u /* the library's per-shape rule (measurement, tests): identical results either way */
+#define GKG_KNN_NO_PREFILTER 16u   /* evaluate every distance with the contract's fp32 chain (knn_tile_kernel) instead of the
+                                    * bf16 matrix-core prefilter + exact re-rank of the survivors (knn_pf_kernel): identical
+                                    * results either way (measurement, tests) */
+#define GKG_KNN_FORCE_PREFILTER 32u /* take the prefilter kernel wherever it is applicable (normalised tokens, un-split keys,
+                                    * k*dilation <= 36, c >= 16), not only where the library's rule says it pays (tests) */
 
 /* argument errors */
 #define GKG_ERR_NULL -1        /* required pointer is NULL */

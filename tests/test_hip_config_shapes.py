@@ -58,20 +58,24 @@ def _dev(a, dtype=torch.float32):
     return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
-@pytest.fixture(params=["auto", "direct", "buffered"])
+@pytest.fixture(params=["auto", "direct", "buffered", "prefilter"])
 def knn_select(request):
-    """The k-NN kernel's selection mode: the library's own rule, or one mode forced (GKG_KNN_SELECT is read per call)."""
+    """The k-NN kernel's mode: the library's own rule, one selection mode of the fp32 tile kernel forced, or the bf16
+    prefilter + exact re-rank kernel forced wherever it applies (GKG_KNN_SELECT / GKG_KNN_PREFILTER are read per call)."""
     import os
-    old = os.environ.get("GKG_KNN_SELECT")
-    if request.param == "auto":
-        os.environ.pop("GKG_KNN_SELECT", None)
-    else:
+    old = {k: os.environ.get(k) for k in ("GKG_KNN_SELECT", "GKG_KNN_PREFILTER")}
+    os.environ.pop("GKG_KNN_SELECT", None)
+    os.environ.pop("GKG_KNN_PREFILTER", None)
+    if request.param == "prefilter":
+        os.environ["GKG_KNN_PREFILTER"] = "force"
+    elif request.param != "auto":
         os.environ["GKG_KNN_SELECT"] = request.param
     yield request.param
-    if old is None:
-        os.environ.pop("GKG_KNN_SELECT", None)
-    else:
-        os.environ["GKG_KNN_SELECT"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("name", sorted(SHAPES))

@@ -183,9 +183,19 @@ def test_fp16_inputs_match_fp32_math_on_rounded_values():
                 assert np.allclose(yg.grad.float().cpu().numpy(), gs, atol=2e-2, rtol=2e-3)
 
 
-@pytest.mark.parametrize("select", ["direct", "buffered"])
+def _set_mode(monkeypatch, select):
+    """direct / buffered: the fp32 tile kernel with that selection mode; prefilter: the bf16 prefilter + exact re-rank kernel
+    wherever it applies (un-split, normalised problems)."""
+    if select == "prefilter":
+        monkeypatch.delenv("GKG_KNN_SELECT", raising=False)
+        monkeypatch.setenv("GKG_KNN_PREFILTER", "force")
+    else:
+        monkeypatch.setenv("GKG_KNN_SELECT", select)
+
+
+@pytest.mark.parametrize("select", ["direct", "buffered", "prefilter"])
 def test_fuzz_random_shapes_bit_exact(select, monkeypatch):
-    monkeypatch.setenv("GKG_KNN_SELECT", select)
+    _set_mode(monkeypatch, select)
     _fuzz_random_shapes()
 
 
@@ -266,9 +276,9 @@ def test_non_finite_inputs_do_not_crash_or_leave_the_index_range():
     assert torch.isfinite(m).all() and torch.isfinite(x.grad).all()
 
 
-@pytest.mark.parametrize("select", ["direct", "buffered"])
+@pytest.mark.parametrize("select", ["direct", "buffered", "prefilter"])
 def test_exact_ties_decide_membership_and_order(select, monkeypatch):
-    monkeypatch.setenv("GKG_KNN_SELECT", select)
+    _set_mode(monkeypatch, select)
     _exact_ties()
 
 
@@ -302,3 +312,22 @@ def _exact_ties():
         got = ops.knn_graph(_dev(x), _dev(y), None if rp is None else _dev(rp).unsqueeze(0), k, d, normalize).cpu().numpy()
         assert np.array_equal(got[0], want_idx), tag
         assert np.array_equal(got[1], want_center), tag
+
+
+def test_prefilter_slow_path_on_massive_ties(monkeypatch):
+    """The prefilter kernel's slow path (a query with more survivors than it can re-rank, or a wave whose list may have
+    dropped one, re-scans all keys with the exact chain): key sets with far more exact ties than a list holds — every key
+    identical; 40 copies of each of 5 keys — must still come out in the contract's order (smaller key index first), bit
+    for bit like the C oracle."""
+    from gkgnet_amd import ops
+    from oracle import c_oracle as O
+    monkeypatch.delenv("GKG_KNN_SELECT", raising=False)
+    monkeypatch.setenv("GKG_KNN_PREFILTER", "force")
+    rng = np.random.RandomState(5)
+    for c, N, M, k, d, nuniq in ((32, 70, 200, 9, 1, 1), (48, 100, 200, 9, 2, 5), (16, 65, 130, 12, 1, 2), (64, 40, 1300, 9, 3, 4)):
+        base = rng.standard_normal((2, c, nuniq)).astype(np.float32)
+        y = np.ascontiguousarray(base[:, :, rng.randint(0, nuniq, size=M)])
+        x = rng.standard_normal((2, c, N)).astype(np.float32)
+        want_idx, _ = O.knn(x, y, None, k, d)
+        edge = ops.knn_graph(_dev(x), _dev(y), None, k, d)
+        assert np.array_equal(edge[0].cpu().numpy(), want_idx), (c, N, M, k, d, nuniq)
