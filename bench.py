@@ -301,15 +301,15 @@ def main():
 
     from gkgnet_amd import fused
     lib_desc = "vendor-library GEMMs (TunableOp-selected)" if not args.no_tune else "vendor-library GEMMs (default heuristic)"
-    gemm_desc = {"all": "own fp32-MFMA kernels (csrc/gkg_gemm.hip): forward with BN-statistics epilogue, dgrad/wgrad with BN-backward prologue",
-                 "fwd": "forward projections: own fp32-MFMA kernels with BN-statistics epilogue (csrc/gkg_gemm.hip); dgrad/wgrad: " + lib_desc,
-                 "auto": "own fp32-MFMA forward kernels with BN-statistics epilogue (csrc/gkg_gemm.hip) where measured faster (R <= 4096 or R >= 32768: here the label branch); otherwise " + lib_desc,
-                 "none": lib_desc}[fused.OWN_GEMM]
-    if fused.GEMM_MATH in ("x6", "x6all") and fused.OWN_GEMM != "none":
-        gemm_desc = ("fp32 projections; " + ("every" if fused.GEMM_MATH == "x6all" else "the long (R >= 8192) and wide-output")
-                     + " forward / input-gradient GEMMs on the bf16 matrix cores with an exact 3-way operand split, 6 cross "
-                     "products, fp32 accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 below the fp32-MFMA kernel's); the rest: "
-                     + gemm_desc)
+    gemm_desc = {"x6": "fp32 projections; the long (R >= 8192) and wide-output forward / input-gradient GEMMs on the bf16 matrix "
+                       "cores with an exact 3-way operand split, 6 cross products, fp32 accumulation (csrc/gkg_gemm_x6.hip: "
+                       "error vs fp64 below an fp32 fma chain's); own fp32-MFMA forward kernels with BN-statistics epilogue "
+                       "(csrc/gkg_gemm.hip) on the label branch (R <= 4096); the rest (weight gradients, grouped / short "
+                       "input gradients): " + lib_desc,
+                 "x6all": "every fp32 projection GEMM (forward, input and weight gradient) on the split-bf16 kernels "
+                          "(csrc/gkg_gemm_x6.hip)",
+                 "f32": "own fp32-MFMA forward kernels with BN-statistics epilogue where measured faster; otherwise " + lib_desc,
+                 "vendor": lib_desc}[fused.GEMM_MATH]
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed

@@ -31,17 +31,16 @@ def knn_select_flags() -> int:
     elif pf == "force":
         f |= KNN_FORCE_PREFILTER
     return f
-LINEAR_DW_ZEROED, LINEAR_DETERMINISTIC = 1, 2
 MR_DETERMINISTIC = 1
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
            "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_prof_work", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
-           "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_workspace_bytes", "gkg_linear_counters", "gkg_linear_stats_doubles",
-           "gkg_linear_bn_fwd", "gkg_bn_bwd_coef", "gkg_linear_bn_bwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
-           "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6", "gkg_bn_scratch_doubles", "gkg_bn_counters", "gkg_bn_stats_accum",
-           "gkg_bn_apply_train", "gkg_bn_bwd_train", "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16")
+           "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_stats_doubles",
+           "gkg_linear_bn_fwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
+           "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
+           "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -103,18 +102,10 @@ def load():
     lib.gkg_bn_bwd_sums.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_bwd_apply.restype = I
     lib.gkg_bn_bwd_apply.argtypes = [V] * 9 + [I, I, I, I, Z, I, V]
-    lib.gkg_linear_workspace_bytes.restype = Z
-    lib.gkg_linear_workspace_bytes.argtypes = [I, I, I, I]
-    lib.gkg_linear_counters.restype = I
-    lib.gkg_linear_counters.argtypes = []
     lib.gkg_linear_bn_fwd.restype = I
     lib.gkg_linear_stats_doubles.restype = I
     lib.gkg_linear_stats_doubles.argtypes = []
     lib.gkg_linear_bn_fwd.argtypes = [V, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V]
-    lib.gkg_bn_bwd_coef.restype = I
-    lib.gkg_bn_bwd_coef.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V, Z, V]
-    lib.gkg_linear_bn_bwd.restype = I
-    lib.gkg_linear_bn_bwd.argtypes = [V, I, Z, V, V, V, V, V, V, I, I, I, I, C.c_uint, V, Z, V, V]
     lib.gkg_affine_act_dual.restype = I
     lib.gkg_affine_act_dual.argtypes = [V, V, V, V, V, V, I, I, I, V, I, V]
     lib.gkg_edge_stats.restype = I
@@ -141,16 +132,6 @@ def load():
     lib.gkg_linear_dgrad_x6.argtypes = [V, I, Z, V, V, I, I, I, I, V]
     lib.gkg_linear_wgrad_x6.restype = I
     lib.gkg_linear_wgrad_x6.argtypes = [V, I, Z, V, I, Z, V, I, I, I, I, V]
-    lib.gkg_bn_scratch_doubles.restype = I
-    lib.gkg_bn_scratch_doubles.argtypes = []
-    lib.gkg_bn_counters.restype = I
-    lib.gkg_bn_counters.argtypes = []
-    lib.gkg_bn_stats_accum.restype = I
-    lib.gkg_bn_stats_accum.argtypes = [V, I, I, I, V, V]
-    lib.gkg_bn_apply_train.restype = I
-    lib.gkg_bn_apply_train.argtypes = [V, V, I] + [V] * 12 + [I, I, I, I, Z, I, I, I, F, F, V, V]
-    lib.gkg_bn_bwd_train.restype = I
-    lib.gkg_bn_bwd_train.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, V, V, Z, V]
     lib.gkg_mr_linear_planes_bytes.restype = Z
     lib.gkg_mr_linear_planes_bytes.argtypes = [I]
     lib.gkg_mr_linear_bf16.restype = I

@@ -407,55 +407,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
   }
 }
 
-// ------------------------------------------------------------------------------------------ BN backward coefficients
-// From the chunk partials of (sum dz, sum dz*yhat) (bn_bwd_stats_kernel in gkg_dense.hip): dbeta, dgamma and the
-// coefficients of  dy = alpha*dz + beta*y + gamma  with
-//   dy = a*(dz - S1/R - yhat*S2/R),  yhat = (y - mean)*invstd   =>  alpha = a,  beta = -a*invstd*S2/R,
-//   gamma = -a*S1/R + a*invstd*mean*S2/R
-__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ part, int nblk, int C,
-                                                          const float* __restrict__ a, const float* __restrict__ mean,
-                                                          const float* __restrict__ invstd, float invR,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          float* __restrict__ coef, float* __restrict__ zero_buf,
-                                                          size_t zero_floats) {
-  __shared__ double lane_sum[8][32];
-  if (zero_buf) {                                  // side job: clear the caller's accumulator (the following wgrad's dW)
-    const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-    for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_floats; i += nthreads) zero_buf[i] = 0.f;
-  }
-  const int t = threadIdx.x & 31, ln = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + t;
-  const int q = blockIdx.y;
-  const int C2 = 2 * C;
-  double acc = 0.0;                                 // lanes 0-3: sum dz (every 4th partial); lanes 4-7: sum dz*yhat
-  if (ch < C) {
-    const float* p = part + (size_t)q * nblk * C2 + (ln >> 2) * C + ch;
-    int b = ln & 3;
-    for (; b + 28 < nblk; b += 32) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + 4 * u) * C2];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; b < nblk; b += 4) acc += (double)p[(size_t)b * C2];
-  }
-  lane_sum[ln][t] = acc;
-  __syncthreads();
-  if (ln != 0 || ch >= C) return;
-  const double S1 = (lane_sum[0][t] + lane_sum[1][t]) + (lane_sum[2][t] + lane_sum[3][t]);
-  const double S2 = (lane_sum[4][t] + lane_sum[5][t]) + (lane_sum[6][t] + lane_sum[7][t]);
-  const size_t o = (size_t)q * C + ch;
-  dbeta[o] = (float)S1;
-  dgamma[o] = (float)S2;
-  const float av = a[o], is = invstd[o], mu = mean[o];
-  const float s1 = (float)S1 * invR, s2 = (float)S2 * invR;
-  float* cf = coef + (size_t)q * 3 * C;
-  cf[ch] = av;
-  cf[C + ch] = -av * is * s2;
-  cf[2 * C + ch] = av * (is * mu * s2 - s1);
-}
-
 }  // namespace gkg
 
 using namespace gkg;
@@ -676,464 +627,4 @@ extern "C" int gkg_bn_bwd_apply(const float* dout, const float* y, const float* 
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, count);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_apply_kernel");
-}
-
-// ------------------------------------------------------------------------------------------ backward, fused-GEMM form
-// First half of the BN backward for the projection kernels of gkg_gemm.hip: statistics pass (parks dz = dout*act'(z) in
-// `dz` when act == 1) + ONE finalize kernel that writes dbeta, dgamma and the (alpha, beta, gamma) coefficients of
-// dy = alpha*dz + beta*y + gamma.  The apply pass does not exist any more: gkg_linear_bn_bwd applies the coefficients
-// while it stages dz / y tiles for the dgrad and wgrad products.
-extern "C" int gkg_bn_bwd_coef(const float* dout, const float* y, const float* a, const float* c, const float* mean,
-                               const float* invstd, float* dz, float* dgamma, float* dbeta, float* coef, int R, int C,
-                               int nb, int ldg, size_t dout_bstride, int act, float* zero_buf, size_t zero_floats,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-  if (!dout || !y || !a || !c || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace || (act == 1 && !dz))
-    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_coef: null pointer");
-  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
-    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_coef: bad sizes");
-  int rpb;
-  const int nblk = stats_blocks(R, C, nb, &rpb);
-  if (workspace_bytes < (size_t)nb * (nblk + 1) * 2 * C * sizeof(float)) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_bn_bwd_coef: workspace too small (gkg_bn_workspace_bytes)");
-  hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)workspace;
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dz);
-  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32, nb), dim3(256), 0, st, part, nblk, C, a, mean, invstd,
-                     1.0f / (float)R, dgamma, dbeta, coef, zero_buf, zero_floats);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_coef");
-}
-
-// ================================================================================================ two-kernel BN
-// Train-mode BN in TWO kernels per direction instead of three.  Every tiny dependent kernel of the step costs ~4.5 us
-// whatever it computes (a dependent chain of cache-missing loads), so the second-stage reduction kernels
-// (reduce_finalize / reduce_partials: 16 launches, ~75 us of the 1 ms cfg2 step) are removed:
-//   producer  (gkg_bn_stats_accum, gkg_bn_bwd_accum, or the projection kernel's own epilogue) adds its per-workgroup
-//             partial sums into ONE fp64 scratch [nb][2][C] with hardware atomics — no second stage;
-//   consumer  (gkg_bn_apply_train[_nchw], gkg_bn_bwd_apply_train) derives the BN coefficients of ITS columns from the
-//             scratch inline (a few dozen fp64 operations per thread, once), applies them, and — as side jobs — writes
-//             the saved mean / invstd / scale / shift (resp. dgamma / dbeta), updates the running statistics, and the
-//             LAST workgroup to have read the scratch (ticket counter) zeroes it again, so one scratch per device
-//             serves every layer and the pair is safe under hipGraph replay.
-namespace gkg {
-
-struct BnCoef { float a, c, mean, invstd; };
-
-// scale / shift of one channel from the fp64 sums.  `shift`: the sums are of (y - shift) (stand-alone statistics pass) or
-// of y itself (shift = 0: projection-kernel epilogue, whose sums are exact in fp64).
-__device__ __forceinline__ BnCoef bn_coef_from_sums(double S, double Q, double shift, double invR, float gamma, float beta,
-                                                   float eps, double* var_out) {
-  const double ms = S * invR;
-  double var = Q * invR - ms * ms;
-  if (var < 0.0) var = 0.0;
-  const double m = ms + shift;
-  BnCoef k;
-  k.invstd = 1.0f / sqrtf((float)var + eps);
-  k.a = gamma * k.invstd;
-  k.c = (float)((double)beta - (double)k.a * m);
-  k.mean = (float)m;
-  *var_out = var;
-  return k;
-}
-
-// Ticket of the "last reader zeroes the scratch" protocol, in two halves so that nobody waits for it: take it right after
-// this workgroup's reads of the scratch have completed (the returning atomic is only ISSUED here), look at it after the
-// main loop.  Counters are sharded per column tile (a single word would serialise ~88 returning atomics per us, i.e.
-// ~9 us for the 768 workgroups of one launch — measured as a 12 % slower step before the sharding).
-__device__ __forceinline__ unsigned bn_take_ticket(unsigned* counter) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned t = 0u;
-  if (threadIdx.x == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return t;
-}
-// true in every thread of the workgroup that holds the LAST of `total` tickets (every other reader is done by then)
-__device__ __forceinline__ bool bn_ticket_is_last(unsigned ticket, unsigned* counter, unsigned total, unsigned* lds_flag) {
-  if (threadIdx.x == 0) {
-    const unsigned last = (ticket == total - 1u) ? 1u : 0u;
-    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *lds_flag = last;
-  }
-  __syncthreads();
-  return *lds_flag != 0u;
-}
-
-// column sums of (y - y[row 0]) and their squares -> fp64 atomics
-__global__ __launch_bounds__(256) void col_stats_accum_kernel(const float* __restrict__ y, double* __restrict__ sums,
-                                                              int R, int C, int rows_per_block) {
-  __shared__ float red[2][ST_RL][4 * ST_CG];
-  const int tid = threadIdx.x;
-  const int cg = tid & (ST_CG - 1), rl = tid >> 4;
-  const int cgi = blockIdx.y * ST_CG + cg;
-  const int q = blockIdx.z;
-  y += (size_t)q * R * C;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(R, r0 + rows_per_block);
-  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
-  if (cgi < (C >> 2)) {
-    const float* p = y + (size_t)4 * cgi;
-    const float4 sh = *reinterpret_cast<const float4*>(p);
-    auto ld = [&](int row) {
-      float4 v = *reinterpret_cast<const float4*>(p + (size_t)row * C);
-      v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
-      return v;
-    };
-    int r = r0 + rl;
-    for (; r + 3 * ST_RL < r1; r += 4 * ST_RL) {
-      const float4 v0 = ld(r), v1 = ld(r + ST_RL), v2 = ld(r + 2 * ST_RL), v3 = ld(r + 3 * ST_RL);
-      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
-      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
-      sq.x += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
-      sq.y += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
-      sq.z += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
-      sq.w += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
-    }
-    for (; r < r1; r += ST_RL) {
-      const float4 v = ld(r);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
-    }
-  }
-  *reinterpret_cast<float4*>(&red[0][rl][4 * cg]) = s;
-  *reinterpret_cast<float4*>(&red[1][rl][4 * cg]) = sq;
-  __syncthreads();
-  if (tid < 8 * ST_CG) {
-    const int which = tid >> 6, col = tid & 63;
-    double acc = 0.0;
-#pragma unroll
-    for (int l = 0; l < ST_RL; ++l) acc += (double)red[which][l][col];
-    const int ch = blockIdx.y * 4 * ST_CG + col;
-    if (ch < C) __hip_atomic_fetch_add(sums + ((size_t)q * 2 + which) * C + ch, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-struct BnTrainArgs {
-  const float* y; const double* sums_ro; double* sums; int shifted;
-  const float* gamma; const float* beta; const float* bias;
-  float* running_mean; float* running_var; long long* nbt;
-  float* a; float* c; float* mean; float* invstd;        // saved for the backward
-  const float* res; void* out;
-  int R, C, nb, ldo; size_t o_bstride;
-  float momentum, eps;
-  unsigned* counter;
-  int rows_per_block;
-};
-
-// saved statistics + running-stat update for one channel (one thread per channel of the workgroups with blockIdx.x == 0)
-__device__ __forceinline__ void bn_side_job(const BnTrainArgs& g, size_t o, const BnCoef& k, double var) {
-  g.a[o] = k.a; g.c[o] = k.c; g.mean[o] = k.mean; g.invstd[o] = k.invstd;
-  if (g.running_mean) {
-    const float bv = g.bias ? g.bias[o] : 0.f;
-    g.running_mean[o] = (1.f - g.momentum) * g.running_mean[o] + g.momentum * (k.mean + bv);
-    const double unb = g.R > 1 ? var * (double)g.R / (double)(g.R - 1) : var;
-    g.running_var[o] = (1.f - g.momentum) * g.running_var[o] + g.momentum * (float)unb;
-  }
-}
-
-// zero columns [c0, c0 + ncols) of both rows of one [2][C] scratch matrix
-__device__ __forceinline__ void bn_zero_scratch(double* sums, int C, int c0, int ncols) {
-  for (int i = threadIdx.x; i < 2 * ncols; i += 256) {
-    const int col = c0 + (i >= ncols ? i - ncols : i);
-    if (col < C) sums[(i >= ncols ? C : 0) + col] = 0.0;
-  }
-}
-
-// out[r][c] = act(a*y + c) (+ res), token-major; a / c derived inline from the scratch
-template <int ACT, typename OutT>
-__global__ __launch_bounds__(256) void bn_apply_train_kernel(BnTrainArgs g) {
-  __shared__ unsigned flag;
-  const int tid = threadIdx.x;
-  const int cg = tid & (ST_CG - 1), rl = tid >> 4;
-  const int cgi = blockIdx.y * ST_CG + cg;
-  const int q = blockIdx.z;
-  const int C = g.C, R = g.R;
-  const float* y = g.y + (size_t)q * R * C;
-  const bool valid = cgi < (C >> 2);
-  BnCoef k[4];
-  double var[4];
-  const double invR = 1.0 / (double)R;
-  if (valid) {
-    const double* S = g.sums_ro + (size_t)q * 2 * C + 4 * cgi;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t o = (size_t)q * C + 4 * cgi + u;
-      const double sh = g.shifted ? (double)y[4 * cgi + u] : 0.0;
-      k[u] = bn_coef_from_sums(S[u], S[C + u], sh, invR, g.gamma[o], g.beta[o], g.eps, &var[u]);
-    }
-  }
-  unsigned* ctr = g.counter + q * gridDim.y + blockIdx.y;           // one ticket counter per (matrix, column tile)
-  const unsigned ticket = bn_take_ticket(ctr);
-  if (blockIdx.x == 0 && rl == 0 && valid) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bn_side_job(g, (size_t)q * C + 4 * cgi + u, k[u], var[u]);
-    if (g.nbt && q == 0 && cgi == 0) *g.nbt += 1;
-  }
-  if (valid) {
-    const int r0 = blockIdx.x * g.rows_per_block;
-    const int r1 = min(R, r0 + g.rows_per_block);
-    OutT* out = static_cast<OutT*>(g.out) + (size_t)q * g.o_bstride;
-    const float* res = g.res ? g.res + (size_t)q * R * C : nullptr;
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += ST_RL) {
-      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
-      float4 o;
-      o.x = __builtin_fmaf(k[0].a, v.x, k[0].c); o.y = __builtin_fmaf(k[1].a, v.y, k[1].c);
-      o.z = __builtin_fmaf(k[2].a, v.z, k[2].c); o.w = __builtin_fmaf(k[3].a, v.w, k[3].c);
-      if (ACT == 1) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
-      if (res) {
-        const float4 rv = *reinterpret_cast<const float4*>(res + (size_t)r * C + 4 * cgi);
-        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-      }
-      stf4(out + (size_t)r * g.ldo + 4 * cgi, o);
-    }
-  }
-  if (bn_ticket_is_last(ticket, ctr, gridDim.x, &flag))
-    bn_zero_scratch(g.sums + (size_t)q * 2 * C, C, blockIdx.y * 4 * ST_CG, 4 * ST_CG);
-}
-
-// out(B,C,N) = a*y_tm + c + res(B,C,N): the block's last layer (BN-apply + residual + layout change), inline coefficients
-__global__ __launch_bounds__(256) void bn_apply_train_nchw_kernel(BnTrainArgs g, int N) {
-  __shared__ float tile[32][33];
-  __shared__ unsigned flag;
-  const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int C = g.C;
-  const int ch = c0 + tx;
-  BnCoef k{0.f, 0.f, 0.f, 0.f};
-  double var = 0.0;
-  if (ch < C) {
-    const double sh = g.shifted ? (double)g.y[ch] : 0.0;
-    k = bn_coef_from_sums(g.sums_ro[ch], g.sums_ro[C + ch], sh, 1.0 / (double)g.R, g.gamma[ch], g.beta[ch], g.eps, &var);
-  }
-  unsigned* ctr = g.counter + blockIdx.y;                           // one ticket counter per 32-channel tile
-  const unsigned ticket = bn_take_ticket(ctr);
-  if (blockIdx.x == 0 && b == 0 && ty == 0 && ch < C) {
-    bn_side_job(g, ch, k, var);
-    if (g.nbt && ch == 0) *g.nbt += 1;
-  }
-  float* out = static_cast<float*>(g.out);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + ty + 8 * i;
-    float v = 0.f;
-    if (ch < C && n < N) v = __builtin_fmaf(k.a, g.y[((size_t)b * N + n) * C + ch], k.c);
-    tile[ty + 8 * i][tx] = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int chh = c0 + ty + 8 * i, n = n0 + tx;
-    if (chh < C && n < N) {
-      const size_t o = ((size_t)b * C + chh) * N + n;
-      float v = tile[tx][ty + 8 * i];
-      if (g.res) v += g.res[o];
-      out[o] = v;
-    }
-  }
-  if (bn_ticket_is_last(ticket, ctr, gridDim.x * gridDim.z, &flag)) bn_zero_scratch(g.sums, C, c0, 32);
-}
-
-// backward statistics -> fp64 atomics (sum dz, sum dz*yhat); parks dz = dout*act'(z) in dz_out when ACT == 1
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_accum_kernel(const float* __restrict__ dout, const float* __restrict__ y,
-                                                           const float* __restrict__ a, const float* __restrict__ cs,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           double* __restrict__ sums, int R, int C, int rows_per_block,
-                                                           int ldg, size_t g_bstride, float* __restrict__ dz_out) {
-  __shared__ float red[2][ST_RL][4 * ST_CG];
-  const int tid = threadIdx.x;
-  const int cg = tid & (ST_CG - 1), rl = tid >> 4;
-  const int cgi = blockIdx.y * ST_CG + cg;
-  const int q = blockIdx.z;
-  y += (size_t)q * R * C; dout += (size_t)q * g_bstride;
-  if (dz_out) dz_out += (size_t)q * R * C;
-  a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(R, r0 + rows_per_block);
-  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
-  if (cgi < (C >> 2)) {
-    const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cgi);
-    const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cgi);
-    const float4 m4 = *reinterpret_cast<const float4*>(mean + 4 * cgi);
-    const float4 i4 = *reinterpret_cast<const float4*>(invstd + 4 * cgi);
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += ST_RL) {
-      const float4 gg = *reinterpret_cast<const float4*>(dout + (size_t)r * ldg + 4 * cgi);
-      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
-      float4 dz = gg;
-      if (ACT == 1) {
-        dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
-        dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
-        *reinterpret_cast<float4*>(dz_out + (size_t)r * C + 4 * cgi) = dz;
-      }
-      s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
-      sq.x += dz.x * ((v.x - m4.x) * i4.x); sq.y += dz.y * ((v.y - m4.y) * i4.y);
-      sq.z += dz.z * ((v.z - m4.z) * i4.z); sq.w += dz.w * ((v.w - m4.w) * i4.w);
-    }
-  }
-  *reinterpret_cast<float4*>(&red[0][rl][4 * cg]) = s;
-  *reinterpret_cast<float4*>(&red[1][rl][4 * cg]) = sq;
-  __syncthreads();
-  if (tid < 8 * ST_CG) {
-    const int which = tid >> 6, col = tid & 63;
-    double acc = 0.0;
-#pragma unroll
-    for (int l = 0; l < ST_RL; ++l) acc += (double)red[which][l][col];
-    const int ch = blockIdx.y * 4 * ST_CG + col;
-    if (ch < C) __hip_atomic_fetch_add(sums + ((size_t)q * 2 + which) * C + ch, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// dy = a*(dz - S1/R - yhat*S2/R) with S1, S2 read inline from the scratch; side jobs: dbeta = S1, dgamma = S2, scratch
-// zeroed by the last reader.  COEF: instead of dy, write the (alpha, beta, gamma) coefficients for the projection kernels'
-// operand prologue (csrc/gkg_gemm.hip) — then only the workgroups with blockIdx.x == 0 exist.
-template <bool COEF>
-__global__ __launch_bounds__(256) void bn_bwd_apply_train_kernel(const float* dz, const float* __restrict__ y,
-                                                                 const float* __restrict__ a, const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, const double* __restrict__ sums_ro,
-                                                                 double* __restrict__ sums, float* dy, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, float* __restrict__ coef, int R, int C,
-                                                                 int nb, int rows_per_block, int ldg, size_t g_bstride,
-                                                                 unsigned* counter, float* __restrict__ zero_buf, size_t zero_floats) {
-  __shared__ unsigned flag;
-  const int tid = threadIdx.x;
-  const int cg = tid & (ST_CG - 1), rl = tid >> 4;
-  const int cgi = blockIdx.y * ST_CG + cg;
-  const int q = blockIdx.z;
-  const bool valid = cgi < (C >> 2);
-  const float invR = 1.0f / (float)R;
-  float al[4], be[4], ga[4];
-  double S1[4], S2[4];
-  if (valid) {
-    const double* S = sums_ro + (size_t)q * 2 * C + 4 * cgi;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t o = (size_t)q * C + 4 * cgi + u;
-      S1[u] = S[u]; S2[u] = S[C + u];
-      const float av = a[o], is = invstd[o], mu = mean[o];
-      const float s1 = (float)S1[u] * invR, s2 = (float)S2[u] * invR;
-      al[u] = av; be[u] = -av * is * s2; ga[u] = av * (is * mu * s2 - s1);
-    }
-  }
-  unsigned* ctr = counter + q * gridDim.y + blockIdx.y;
-  const unsigned ticket = bn_take_ticket(ctr);
-  if (COEF && zero_buf) {
-    const size_t nthreads = (size_t)gridDim.x * gridDim.y * gridDim.z * 256;
-    for (size_t i = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + tid; i < zero_floats; i += nthreads) zero_buf[i] = 0.f;
-  }
-  if (blockIdx.x == 0 && rl == 0 && valid) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t o = (size_t)q * C + 4 * cgi + u;
-      dbeta[o] = (float)S1[u]; dgamma[o] = (float)S2[u];
-      if (COEF) {
-        float* cf = coef + (size_t)q * 3 * C + 4 * cgi + u;
-        cf[0] = al[u]; cf[C] = be[u]; cf[2 * C] = ga[u];
-      }
-    }
-  }
-  if (!COEF && valid) {
-    y += (size_t)q * R * C; dz += (size_t)q * g_bstride; dy += (size_t)q * R * C;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(R, r0 + rows_per_block);
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += ST_RL) {
-      const float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)r * ldg + 4 * cgi);
-      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
-      float4 o;
-      o.x = __builtin_fmaf(al[0], g4.x, __builtin_fmaf(be[0], v.x, ga[0]));
-      o.y = __builtin_fmaf(al[1], g4.y, __builtin_fmaf(be[1], v.y, ga[1]));
-      o.z = __builtin_fmaf(al[2], g4.z, __builtin_fmaf(be[2], v.z, ga[2]));
-      o.w = __builtin_fmaf(al[3], g4.w, __builtin_fmaf(be[3], v.w, ga[3]));
-      *reinterpret_cast<float4*>(dy + (size_t)r * C + 4 * cgi) = o;
-    }
-  }
-  if (bn_ticket_is_last(ticket, ctr, gridDim.x, &flag))
-    bn_zero_scratch(sums + (size_t)q * 2 * C, C, blockIdx.y * 4 * ST_CG, 4 * ST_CG);
-}
-
-}  // namespace gkg
-
-static bool bn2_bad(int R, int C, int nb) {
-  return R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || (size_t)nb * 2 * C > (size_t)gkg_bn_scratch_doubles() ||
-         (size_t)nb * ((C + 31) / 32) > (size_t)gkg_bn_counters();
-}
-
-extern "C" int gkg_bn_scratch_doubles(void) { return 2 * 4096 * 4; }
-extern "C" int gkg_bn_counters(void) { return 1024; }
-
-extern "C" int gkg_bn_stats_accum(const float* y, int R, int C, int nb, double* scratch, void* stream) {
-  if (!y || !scratch) return gkg_fail(GKG_ERR_NULL, "gkg_bn_stats_accum: null pointer");
-  if (bn2_bad(R, C, nb)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_stats_accum: bad sizes");
-  int rpb;
-  const int nblk = stats_blocks(R, C, nb, &rpb);
-  hipLaunchKernelGGL(col_stats_accum_kernel, dim3(nblk, stats_tiles(C), nb), dim3(256), 0, (hipStream_t)stream, y, scratch, R, C, rpb);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : gkg_fail_hip(e, "col_stats_accum_kernel");
-}
-
-extern "C" int gkg_bn_apply_train(const float* y, double* scratch, int shifted, const float* gamma, const float* beta,
-                                  const float* bias, float* running_mean, float* running_var, long long* num_batches_tracked,
-                                  float* a, float* c, float* mean, float* invstd, const float* res, void* out, int R, int C,
-                                  int nb, int ldo, size_t out_bstride, int act, int out_dtype, int nchw_B, float momentum,
-                                  float eps, unsigned* counter, void* stream) {
-  if (!y || !scratch || !gamma || !beta || !a || !c || !mean || !invstd || !out || !counter)
-    return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train: null pointer");
-  if (bn2_bad(R, C, nb) || (act != 0 && act != 1)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: bad sizes");
-  if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train: running stats come in pairs");
-  BnTrainArgs g{};
-  g.y = y; g.sums_ro = scratch; g.sums = scratch; g.shifted = shifted; g.gamma = gamma; g.beta = beta; g.bias = bias;
-  g.running_mean = running_mean; g.running_var = running_var; g.nbt = num_batches_tracked;
-  g.a = a; g.c = c; g.mean = mean; g.invstd = invstd; g.res = res; g.out = out;
-  g.R = R; g.C = C; g.nb = nb; g.ldo = ldo; g.o_bstride = out_bstride; g.momentum = momentum; g.eps = eps; g.counter = counter;
-  hipStream_t st = (hipStream_t)stream;
-  if (nchw_B > 0) {                                 // (B, C, N) output with residual: the block's last layer
-    if (nb != 1 || act != 0 || out_dtype != GKG_F32 || R % nchw_B) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: nchw form needs nb == 1, act == 0, fp32");
-    const int N = R / nchw_B;
-    hipLaunchKernelGGL(bn_apply_train_nchw_kernel, dim3((N + 31) / 32, (C + 31) / 32, nchw_B), dim3(256), 0, st, g, N);
-  } else {
-    if (ldo < C || (ldo & 3) || (out_bstride & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: bad output pitch");
-    if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_bn_apply_train: out_dtype");
-    int rpb;
-    const int nblk = stats_blocks(R, C, nb, &rpb);
-    g.rows_per_block = rpb;
-    const dim3 grid(nblk, stats_tiles(C), nb);
-    if (out_dtype == GKG_BF16) {
-      if (act == 1) hipLaunchKernelGGL((bn_apply_train_kernel<1, uint16_t>), grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL((bn_apply_train_kernel<0, uint16_t>), grid, dim3(256), 0, st, g);
-    } else {
-      if (act == 1) hipLaunchKernelGGL((bn_apply_train_kernel<1, float>), grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL((bn_apply_train_kernel<0, float>), grid, dim3(256), 0, st, g);
-    }
-  }
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_apply_train_kernel");
-}
-
-extern "C" int gkg_bn_bwd_train(const float* dout, const float* y, const float* a, const float* c, const float* mean,
-                                const float* invstd, float* dy, float* dgamma, float* dbeta, float* coef, int R, int C, int nb,
-                                int ldg, size_t dout_bstride, int act, double* scratch, unsigned* counter, float* zero_buf,
-                                size_t zero_floats, void* stream) {
-  if (!dout || !y || !a || !c || !mean || !invstd || !dgamma || !dbeta || !scratch || !counter || (!dy && !coef) || (act == 1 && !dy))
-    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_train: null pointer");
-  if (bn2_bad(R, C, nb) || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1))
-    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_train: bad sizes");
-  int rpb;
-  const int nblk = stats_blocks(R, C, nb, &rpb);
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(nblk, stats_tiles(C), nb);
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_accum_kernel<1>), grid, dim3(256), 0, st, dout, y, a, c, mean, invstd, scratch, R, C, rpb, ldg, dout_bstride, dy);
-  else hipLaunchKernelGGL((bn_bwd_accum_kernel<0>), grid, dim3(256), 0, st, dout, y, a, c, mean, invstd, scratch, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
-  // act == 1: dz is parked in dy (dense) and the apply runs in place on it
-  const float* dzp = act == 1 ? dy : dout;
-  const int ldz = act == 1 ? C : ldg;
-  const size_t zbs = act == 1 ? (size_t)R * C : dout_bstride;
-  if (coef)
-    hipLaunchKernelGGL((bn_bwd_apply_train_kernel<true>), dim3(1, stats_tiles(C), nb), dim3(256), 0, st, dzp, y, a, mean, invstd,
-                       (const double*)scratch, scratch, dy, dgamma, dbeta, coef, R, C, nb, rpb, ldz, zbs, counter, zero_buf, zero_floats);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_train_kernel<false>), grid, dim3(256), 0, st, dzp, y, a, mean, invstd, (const double*)scratch,
-                       scratch, dy, dgamma, dbeta, (float*)nullptr, R, C, nb, rpb, ldz, zbs, counter, (float*)nullptr, (size_t)0);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_train");
 }

@@ -525,44 +525,11 @@ hipError_t launch(const GemmArgs& a, int nbatch, hipStream_t st) {
 
 inline bool bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
 
-// wgrad decomposition: 64x64 output tiles, the R-long contraction split so that all groups together give ~2 workgroups
-// per CU, each split >= 128 rows and a multiple of the LDS stage depth
-struct WgradPlan { int tiles, splits, kper; bool tall; };
-inline WgradPlan wgrad_plan(int R, int cin, int cout, int nb) {
-  WgradPlan p;
-  // many output tiles (fc2, FFN): 128x64 tiles (two accumulator chains per wave, half the operand re-reads) with twice
-  // the splits measured 57 vs 73 us at 320x640; few tiles (fc1, grouped): 64x64
-  p.tall = (long)((cout + 63) / 64) * ((cin + 63) / 64) * nb >= 48 && cout >= 128;
-  p.tiles = ((cout + (p.tall ? 127 : 63)) / (p.tall ? 128 : 64)) * ((cin + 63) / 64);
-  int splits = ((p.tall ? 1024 : 512) + p.tiles * nb - 1) / (p.tiles * nb);
-  const int maxs = (R + 4 * GBK - 1) / (4 * GBK);
-  if (splits > maxs) splits = maxs;
-  if (splits > 64) splits = 64;
-  if (splits < 1) splits = 1;
-  int kper = (R + splits - 1) / splits;
-  kper = (kper + GBK - 1) / GBK * GBK;
-  p.kper = kper;
-  p.splits = (R + kper - 1) / kper;
-  return p;
-}
-
-// Tile choice (measured on MI355X, tools/ubench/gemm_bench.hip): forward and dgrad run fastest on 64x64 workgroup tiles
+// Tile choice (measured on MI355X, tools/ubench/gemm_bench.hip): the forward runs fastest on 64x64 workgroup tiles
 // (one 32x32 MFMA tile per wave) at every shape of this path — 10 368- and 41 472-token stages alike; 128x64 only ties.
 
 }  // namespace
 
-extern "C" size_t gkg_linear_workspace_bytes(int R, int cin, int cout, int nb) {
-  if (R <= 0 || bad_dim(cin) || bad_dim(cout) || nb <= 0) return 0;
-  // backward only: split-K partial tiles of dW (64x64 fp32 each)
-  const WgradPlan wp = wgrad_plan(R, cin, cout, nb);
-  return (size_t)nb * wp.tiles * wp.splits * (wp.tall ? 128 : 64) * 64 * sizeof(float);
-}
-
-extern "C" int gkg_linear_counters() { return 4096; }
-
-// Forward projection + (train) BN statistics.   x (nb, R, cin) row-major, w (nb, cout, cin), y (nb, R, cout).
-// train != 0: writes bn_a / bn_c / bn_mean / bn_invstd [nb][cout] and updates the running statistics (bias folded in);
-// train == 0: plain projection (the caller folds eval-mode BN with gkg_bn_eval_affine).
 extern "C" int gkg_linear_stats_doubles() { return 2 * 4096 * 4; }
 
 // Forward projection + (train) BN statistics.   x (nb, R, cin) row-major, w (nb, cout, cin), y (nb, R, cout).
@@ -582,12 +549,7 @@ extern "C" int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R
   a.M = R; a.N = cout; a.K = cin;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (train == 2) {                                // statistics only: the sums stay in `stats` for gkg_bn_apply_train
-    if (!stats) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd: train == 2 needs the stats scratch");
-    if ((size_t)nb * 2 * cout > (size_t)gkg_linear_stats_doubles()) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_bn_fwd: nb * cout too large for the stats scratch");
-    a.sums = stats;
-    e = launch<32, 64, 64, 2, 2, LAY_KQ, LAY_KQ, false, EPI_BNSTATS>(a, nb, st);
-  } else if (train) {
+  if (train) {
     if (!gamma || !beta || !bn_a || !bn_c || !bn_mean || !bn_invstd || !stats)
       return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd: training needs gamma, beta, the four outputs and the stats scratch");
     if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd: running stats come in pairs");
@@ -603,61 +565,4 @@ extern "C" int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R
     e = launch<32, 64, 64, 2, 2, LAY_KQ, LAY_KQ, false, EPI_STORE>(a, nb, st);
   }
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_f32_kernel (forward)");
-}
-
-// dbeta, dgamma and the (alpha, beta, gamma) coefficients of the BN backward-apply from the statistics partials that
-// gkg_bn_bwd_partials left in `workspace`.
-// Backward of  out = act(BN_train(x W^T)):  dx = dY W,  dW = dY^T x  with dY = BN-backward(dz) applied in the operand
-// prologue (dY is never materialised).  dz (nb, R, cout) row pitch ldg / batch stride g_bstride is the gradient at the
-// BN output (after the activation's derivative); y the saved projection output; coef [nb][3][cout].
-extern "C" int gkg_linear_bn_bwd(const float* dz, int ldg, size_t g_bstride, const float* y, const float* coef,
-                                 const float* x, const float* w, float* dx, float* dw, int R, int cin, int cout, int nb,
-                                 unsigned flags, void* workspace, size_t workspace_bytes, unsigned* counters, void* stream) {
-  const bool ordered = (flags & GKG_LINEAR_DETERMINISTIC) != 0;
-  if (!dz || !y || !coef || !w || (!dx && !dw) || (dw && (!x || (ordered && (!workspace || !counters)))))
-    return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_bwd: null pointer");
-  if (R <= 0 || bad_dim(cin) || bad_dim(cout) || nb <= 0 || nb > 64 || ldg < cout || (ldg & 3) || (g_bstride & 3))
-    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_bn_bwd: bad sizes");
-  if (ldg != cout || g_bstride != (size_t)R * cout) {
-    // the dual prologue reads dz and y with ONE pitch: dz must be dense like y
-    return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_bn_bwd: dz must be dense (ldg == cout)");
-  }
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipSuccess;
-  if (dx) {                                         // dX (R, cin) = dY (R, cout) . W (cout, cin):  A = dY (KQ, dual), B(n=cin, k=cout) = W[k][n] (KM)
-    GemmArgs a{};
-    a.A = dz; a.A2 = y; a.a_bstride = (size_t)R * cout; a.lda = cout;
-    a.B = w; a.b_bstride = (size_t)cout * cin; a.ldb = cin;
-    a.C = dx; a.c_bstride = (size_t)R * cin; a.ldc = cin;
-    a.M = R; a.N = cin; a.K = cout;
-    a.coef = coef; a.coef_stride = cout; a.coef_bstride = (size_t)3 * cout;
-    e = launch<32, 64, 64, 2, 2, LAY_KQ, LAY_KM, true, EPI_STORE>(a, nb, st);
-    if (e != hipSuccess) return gkg_fail_hip(e, "gemm_f32_kernel (dgrad)");
-  }
-  if (dw) {                                         // dW (cout, cin) = dY^T X: contraction over the R tokens, split
-    const WgradPlan wp = wgrad_plan(R, cin, cout, nb);
-    const int tiles = wp.tiles, splits = wp.splits, kper = wp.kper;
-    if (ordered) {
-      if (workspace_bytes < (size_t)nb * tiles * splits * (wp.tall ? 128 : 64) * 64 * sizeof(float))
-        return gkg_fail(GKG_ERR_WORKSPACE, "gkg_linear_bn_bwd: workspace too small (gkg_linear_workspace_bytes)");
-      if (tiles * nb > gkg_linear_counters()) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_bn_bwd: too many output tiles");
-    } else if (!(flags & GKG_LINEAR_DW_ZEROED)) {
-      (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)nb * cout * cin, st);
-    }
-    {                                              // blockIdx.z = group * splits + split
-      GemmArgs a{};
-      a.A = dz; a.A2 = y; a.a_bstride = (size_t)R * cout; a.lda = cout;
-      a.B = x; a.b_bstride = (size_t)R * cin; a.ldb = cin;
-      a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
-      a.M = cout; a.N = cin; a.K = R;
-      a.coef = coef; a.coef_stride = cout; a.coef_bstride = (size_t)3 * cout;
-      a.splits = splits; a.k_per_split = kper; a.kpart = (float*)workspace; a.counters = counters;
-      if (wp.tall) e = ordered ? launch<32, 128, 64, 4, 1, LAY_KM, LAY_KM, true, EPI_SPLITK>(a, nb, st)
-                               : launch<32, 128, 64, 4, 1, LAY_KM, LAY_KM, true, EPI_SPLITK_ATOMIC>(a, nb, st);
-      else e = ordered ? launch<32, 64, 64, 2, 2, LAY_KM, LAY_KM, true, EPI_SPLITK>(a, nb, st)
-                       : launch<32, 64, 64, 2, 2, LAY_KM, LAY_KM, true, EPI_SPLITK_ATOMIC>(a, nb, st);
-      if (e != hipSuccess) return gkg_fail_hip(e, "gemm_f32_kernel (wgrad)");
-    }
-  }
-  return 0;
 }

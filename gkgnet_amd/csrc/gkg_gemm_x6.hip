@@ -392,16 +392,12 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
 // Column-tile width (32 NI).  More columns per wave amortise the 44-instruction A split over more MFMAs (NI = 1 is
 // VALU-bound, NI = 2 about balanced) but leave fewer workgroups: NI = 2, and NI = 1 when that leaves the chip under-filled
 // (few rows: the label branch).  Measured cold-cache per shape with tools/bench_x6.py; NI = 5 (160 columns, one
-// workgroup per CU) was tried and is slower everywhere (cfg2 fc1 25.8 vs 22.9 us).  GKG_X6_NI=1|2 (read per call) forces one.
+// workgroup per CU) was tried and is slower everywhere (cfg2 fc1 25.8 vs 22.9 us).
 template <int EPI>
 static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_GEMM_X6, st, 2.0 * a.M * a.N * a.K * nb);
   const int mt = (a.M + 127) / 128;
   int ni = (long long)mt * ((a.N + 63) / 64) * nb < 160 ? 1 : 2;
-  if (const char* f = getenv("GKG_X6_NI")) {
-    const int v = atoi(f);
-    if (v == 1 || v == 2) ni = v;
-  }
   if (ni == 1) return x6_launch_ni<1, EPI>(a, nb, st);
   return x6_launch_ni<2, EPI>(a, nb, st);
 }
@@ -810,8 +806,7 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   // everything, when they are not) through the register-load kernel
   const bool aligned = (cin & 3) == 0 && (cout & 3) == 0 && (ldg & 3) == 0 && (ldx & 3) == 0 && (g_bstride & 3) == 0 &&
                        (x_bstride & 3) == 0 && ((size_t)dy & 15) == 0 && ((size_t)x & 15) == 0 &&
-                       (size_t)R * ldg * 4 < 0xffffffffull && (size_t)R * ldx * 4 < 0xffffffffull &&
-                       getenv("GKG_X6_WGRAD_NO_DMA") == nullptr;
+                       (size_t)R * ldg * 4 < 0xffffffffull && (size_t)R * ldx * 4 < 0xffffffffull;
   const int main_splits = aligned ? R / a.rows_per_split : 0;
   if (main_splits > 0) {
     X6WgradArgs m = a;

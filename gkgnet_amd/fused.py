@@ -31,35 +31,43 @@ from .parallel import grad_view
 
 _F32 = torch.float32
 ENABLED = True          # set False to force the composable (per-op) path, e.g. in A/B tests
-# Which projections run on the library's own fp32 matrix-core kernels (csrc/gkg_gemm.hip) instead of the vendor GEMM
-# library + separate BN passes: "fwd" (default), "all" (forward, dgrad and wgrad), "none".  Measured at cfg2 on MI355X:
-# the forward kernel with the BN statistics in its epilogue beats vendor GEMM + statistics passes on every layer; the
-# dgrad / wgrad kernels with the BN backward-apply prologue are 20-40 % behind the vendor kernels + apply pass at these
-# shapes (parity at the 41 472-token stages), so the backward keeps the vendor GEMMs unless asked otherwise.
-# "auto" = "fwd" restricted to the row counts where the own forward kernel measured faster than vendor GEMM + statistics
-# passes end to end (tools/bench_gemm.py, MI355X): R <= 4096 (label branch: 11 + 5 vs 10-14 + 9.5 us per layer) and
-# R >= 32768 (stage-3/4 of GKGNet-576: 150 vs 186 + 10 us at 41 472 x 400 x 400); in between (cfg2's 10 368 rows) the
-# vendor kernels' finer macro-tiles win by ~3 us per layer.
-OWN_GEMM = os.environ.get("GKG_OWN_GEMM", "auto")
-LONG_K = int(os.environ.get("GKG_OWN_GEMM_LONG_K", "1024"))
-# Two-kernel train-mode BN (fp64-atomic statistics, coefficients derived inline by the consumer, csrc/gkg_dense.hip) vs
-# the three-kernel form (two-stage ordered sums -> finalize -> apply).  Measured at cfg2: the two-kernel form is SLOWER
-# (1.148 vs 1.021 ms/step): every consumer workgroup then starts with a dependent read of freshly atomically-written
-# sums (served from HBM, not L2) and ends on a ticket round trip, which costs the short workgroups of these kernels more
-# than the removed launch saves (apply 4.4 -> 14 us, backward apply 6.6 -> 13 us).  Kept selectable and tested; off.
-BN_TWO_KERNEL = os.environ.get("GKG_BN_TWO_KERNEL", "0") != "0"
-# True: run-to-run bit-identical backward — ordered reduction of the split weight-gradient products (own-GEMM path) and
-# fixed-order neighbour-gradient scatter (gkg_mr_bwd_tm); the defaults use fp32 atomics.
-DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
-# Arithmetic of the own projection kernels: "x6" (default) = bf16 matrix cores with every fp32 operand split exactly into
-# three bf16 terms, six cross products, fp32 accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 3-4x below the fp32-MFMA
-# kernel, 1.3-1.4x faster than the vendor fp32 GEMM at cfg2's shapes) for the forward and input-gradient GEMMs of every
-# fp32 projection; "f32" = the fp32-MFMA kernels of csrc/gkg_gemm.hip under the GKG_OWN_GEMM rule above.
+
+
+def _env_list(name):
+    return {t.strip() for t in os.environ.get(name, "").split(",") if t.strip()}
+
+
+# ---- run-time switches (all of them; INTEGRATION.md has the table) ---------------------------------------------------
+# GKG_GEMM_MATH — arithmetic of the fp32 projection GEMMs:
+#   "x6" (default)  bf16 matrix cores with every fp32 operand split exactly into three bf16 terms, six cross products, fp32
+#                   accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 3-4x below an fp32 fma chain) for the forward and
+#                   input-gradient GEMMs where it measured faster inside the cfg2 step (rule in _x6), the fp32-MFMA forward
+#                   kernel with BN-statistics epilogue (csrc/gkg_gemm.hip) on the short label-branch matrices, the vendor
+#                   GEMM library for the rest (weight gradients);
+#   "x6all"         every eligible projection on the x6 kernels, weight gradient included;
+#   "f32"           own fp32-MFMA forward kernels under the row-count rule of _own_gemm, vendor GEMMs otherwise;
+#   "vendor"        vendor GEMM library + stand-alone BN passes everywhere.
 GEMM_MATH = os.environ.get("GKG_GEMM_MATH", "x6")
-# Under bf16 autocast the k-NN distance contraction runs on the bf16 matrix cores (GKG_KNN_BF16_CONTRACT: normalised
-# tokens rounded to bf16, exact products, fp32 accumulation and norms) — the reference computes this product in bf16 there
-# too, and additionally rounds the product matrix to bf16.  GKG_KNN_BF16=0 keeps the fp32 contraction everywhere.
-KNN_BF16 = os.environ.get("GKG_KNN_BF16", "1") != "0"
+if GEMM_MATH not in ("x6", "x6all", "f32", "vendor"):
+    raise ValueError(f"GKG_GEMM_MATH={GEMM_MATH!r}: expected x6 | x6all | f32 | vendor")
+# OWN_GEMM: which projections use the own fp32-MFMA FORWARD kernel (statistics in its epilogue): "auto" = the row counts
+# where it measured faster than vendor GEMM + statistics passes end to end (tools/bench_gemm.py, MI355X): R <= 4096 (label
+# branch: 11 + 5 vs 10-14 + 9.5 us per layer) and R >= 32768 (stage 3/4 of GKGNet-576: 150 vs 186 + 10 us at
+# 41 472 x 400 x 400); "fwd" = everywhere (tests); "none" = nowhere.
+OWN_GEMM = "none" if GEMM_MATH == "vendor" else "auto"
+LONG_K = 1024
+# GKG_DETERMINISTIC=1 — run-to-run bit-identical backward: fixed-order neighbour-gradient scatter (gkg_mr_bwd_tm) and no
+# atomically accumulated weight gradients (the streaming x6 wgrad is skipped); the defaults use fp32 atomics.
+DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
+# GKG_DISABLE — comma-separated list of optimisations to switch off (A/B measurements, tests):
+#   knn_bf16       under bf16 autocast the k-NN distance contraction runs on the bf16 matrix cores (GKG_KNN_BF16_CONTRACT:
+#                  the reference computes this product in bf16 there too, and additionally rounds it to bf16)
+#   fold_epilogue  bf16 inference: eval-mode BN folded into the weights, bias (+ GELU) in the library GEMM's epilogue
+#   channels_last  blocks take / return channels-last tensors as views of their token-major matrices
+#   mr_gemm        bf16 inference: aggregation as the operand producer of the grouped projection (one launch, row g1)
+#   x6_wgrad       the streaming x6 weight-gradient kernel on long token axes
+_DISABLED = _env_list("GKG_DISABLE")
+KNN_BF16 = "knn_bf16" not in _DISABLED
 
 
 class _WeightPlanes:
@@ -213,7 +221,7 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
-X6_WGRAD = os.environ.get("GKG_X6_WGRAD", "1") != "0"
+X6_WGRAD = "x6_wgrad" not in _DISABLED
 
 
 def _x6_wgrad_ok(dY, x) -> bool:
@@ -223,16 +231,18 @@ def _x6_wgrad_ok(dY, x) -> bool:
     and 162 vs 472 at 320 -> 160 against the vendor library's default split-K; inside the cfg4 train step, where TunableOp
     has picked the vendor kernels, it TIES them (16 launches, 4.1 ms; step 102.5 vs 102.7-103.5 ms) — kept on so that these
     layers do not depend on a tuning pass.  It loses once the output needs many 64 x 64 tiles, each of which re-streams the
-    rows (41 472 x 400 -> 400: 49 tiles).  GKG_GEMM_MATH=x6all: every fp32 shape; GKG_X6_WGRAD=0: never."""
+    rows (41 472 x 400 -> 400: 49 tiles).  GKG_GEMM_MATH=x6all: every fp32 shape; GKG_DISABLE=x6_wgrad: never."""
     if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none" or dY.dtype != _F32 or x.dtype != _F32:
         return False
     R, cout, cin = x.shape[0], dY.shape[1], x.shape[1]
     if max(dY.stride(0), x.stride(0)) * 4 * 16 > 0x7fffffff:          # gkg_linear_wgrad_x6's row-pitch limit
         return False
+    if DETERMINISTIC:                          # fp32 atomics: run-dependent summation order
+        return False
     if GEMM_MATH == "x6all":
         return True
     tiles = ((cout + 63) // 64) * ((cin + 63) // 64)
-    return X6_WGRAD and not DETERMINISTIC and R >= 65536 and tiles <= 32       # fp32 atomics: run-dependent summation order
+    return X6_WGRAD and R >= 65536 and tiles <= 32
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
@@ -277,21 +287,6 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-_COUNTERS = {}
-
-
-def _counters(device) -> torch.Tensor:
-    """Zero-initialised arrival counters of the projection kernels' last-arriver reductions (every kernel leaves them
-    zero).  One buffer per device, allocated on first use — outside any hipGraph capture, because the warm-up steps
-    that precede a capture run eagerly."""
-    key = (device.type, device.index)
-    t = _COUNTERS.get(key)
-    if t is None:
-        t = torch.zeros(_lib.load().gkg_linear_counters(), dtype=torch.int32, device=device)
-        _COUNTERS[key] = t
-    return t
-
-
 _STATS = {}
 
 
@@ -306,49 +301,17 @@ def _stats_scratch(device) -> torch.Tensor:
     return t
 
 
-def _bn2(bn, Y) -> bool:
-    """Two-kernel train-mode BN (fp64-atomic statistics + inline finalize): batch statistics local to this rank."""
-    return (BN_TWO_KERNEL and Y.dtype == _F32 and (bn.training or not bn.track_running_stats)
-            and _sync_group(bn) is None)
-
-
-def _bn2_apply(lib, Y, bn, bias, shifted, res, out, R, C, nb, ldo, obs, act, code, nchw_B):
-    """Consumer half: out = act(BN(Y)) (+ res); returns the saved (a, c, mean, invstd)."""
-    dev = Y.device
-    a = torch.empty(nb * C, dtype=_F32, device=dev)
-    c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
-    track = bn.training and bn.track_running_stats
-    _touch_stats(bn, track)
-    _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(_stats_scratch(dev)), shifted, _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
-                                      _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
-                                      _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
-                                      _ptr(invstd), _ptr(res), _ptr(out), R, C, nb, ldo, obs, act, code, nchw_B,
-                                      float(bn.momentum), float(bn.eps), _bn_counters(dev).data_ptr(), _stream()),
-               "gkg_bn_apply_train")
-    return a, c, mean, invstd
-
-
-def _bn_counters(device) -> torch.Tensor:
-    """Ticket counters of the two-kernel BN consumers (zero between launches), one buffer per device."""
-    key = ("bn", device.type, device.index)
-    t = _COUNTERS.get(key)
-    if t is None:
-        t = torch.zeros(_lib.load().gkg_bn_counters(), dtype=torch.int32, device=device)
-        _COUNTERS[key] = t
-    return t
-
-
 def _own_gemm(x, weight, bn) -> bool:
-    """fp32 operands outside autocast and batch statistics local to this rank: the projection runs on the library's own
-    fp32 matrix-core kernels with the BN passes fused in (csrc/gkg_gemm.hip).  bf16 autocast and cross-rank SyncBN keep
-    the vendor-GEMM + separate-pass form."""
+    """fp32 operands outside autocast and batch statistics local to this rank: the projection's FORWARD runs on the library's
+    own fp32 matrix-core kernel with the BN statistics in its epilogue (csrc/gkg_gemm.hip).  bf16 autocast and cross-rank
+    SyncBN keep the vendor-GEMM + separate-pass form."""
     if OWN_GEMM == "auto":
         R = x.shape[-2]
         if 4096 < R < 32768:
             return False
         if R <= 4096 and x.shape[-1] >= LONG_K:      # few rows x long contraction (FFN fc2, 2560 x 1280 -> 320): the vendor
             return False                             # kernel's split-K wins (21 + 10 us of statistics passes vs 34 + 5)
-    elif OWN_GEMM not in ("fwd", "all"):
+    elif OWN_GEMM != "fwd":
         return False
     return (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None)
 
@@ -371,7 +334,7 @@ def _grad_outs(gparams, wshape, nch, dev):
     return w, g, b
 
 
-def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False, planes=None):
+def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, planes=None):
     """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue); ``planes``: the
     weight's forward bf16 planes -> gkg_linear_bn_fwd_x6."""
     dev = x.device
@@ -384,11 +347,6 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False, pla
     a = torch.empty(nb * cout, dtype=_F32, device=dev)
     c = torch.empty_like(a)
     train = bn.training or not bn.track_running_stats
-    if train and stats_only:
-        _lib.check(fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, None, None, None, None, None, None,
-                                         None, None, None, None, 0.0, 0.0, _ptr(_stats_scratch(dev)), _stream()),
-                   "gkg_linear_bn_fwd")
-        return Y, None, None, None, None
     if train:
         mean = torch.empty_like(a)
         invstd = torch.empty_like(a)
@@ -405,37 +363,6 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, stats_only=False, pla
                                      None, None, None, None, 0.0, 0.0, None, _stream()), "gkg_linear_bn_fwd")
     a, c = _bn_eval_ac(lib, bn, bias, nb * cout)
     return Y, a, c, None, None
-
-
-def _linear_bwd_own(lib, g, ldg, g_bstride, Y, a, c, mean, invstd, x, W, R, cin, cout, nb, act, need_dx, gparams=None):
-    """dx, dW, dgamma, dbeta of out = act(BN_train(x W^T)): statistics pass (+ dz parked for GELU) -> coefficients ->
-    dgrad / wgrad kernels that apply the BN backward while staging their operand tiles."""
-    dev = Y.device
-    dW, dgamma, dbeta = _grad_outs(gparams, (nb * cout, cin), nb * cout, dev)
-    coef = torch.empty(nb * 3 * cout, dtype=_F32, device=dev)
-    dz = torch.empty_like(Y) if act == 1 else None
-    # the coefficient kernel also clears dW, the accumulator of the split weight-gradient product that follows
-    if BN_TWO_KERNEL:
-        _lib.check(lib.gkg_bn_bwd_train(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
-                                        _ptr(dbeta), _ptr(coef), R, cout, nb, ldg, g_bstride, act, _ptr(_stats_scratch(dev)),
-                                        _bn_counters(dev).data_ptr(), None if DETERMINISTIC else _ptr(dW), dW.numel(),
-                                        _stream()), "gkg_bn_bwd_train")
-    else:
-      ws = _ws(lib.gkg_bn_workspace_bytes(R, cout, nb), dev)
-      _lib.check(lib.gkg_bn_bwd_coef(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma),
-                                   _ptr(dbeta), _ptr(coef), R, cout, nb, ldg, g_bstride, act,
-                                   None if DETERMINISTIC else _ptr(dW), dW.numel(), _ptr(ws), ws.numel(), _stream()),
-                 "gkg_bn_bwd_coef")
-    dzp = dz if act == 1 else g
-    dx = torch.empty((nb, R, cin) if nb > 1 else (R, cin), dtype=_F32, device=dev) if need_dx else None
-    if DETERMINISTIC:
-        flags, ws2, ctr = _lib.LINEAR_DETERMINISTIC, _ws(lib.gkg_linear_workspace_bytes(R, cin, cout, nb), dev), _counters(dev)
-    else:
-        flags, ws2, ctr = _lib.LINEAR_DW_ZEROED, None, None
-    _lib.check(lib.gkg_linear_bn_bwd(_ptr(dzp), cout, R * cout, _ptr(Y), _ptr(coef), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW),
-                                     R, cin, cout, nb, flags, _ptr(ws2), 0 if ws2 is None else ws2.numel(), _ptr(ctr),
-                                     _stream()), "gkg_linear_bn_bwd")
-    return dx, dW, dgamma, dbeta
 
 
 def lowp_inference() -> bool:
@@ -457,7 +384,7 @@ def _w16_of(conv) -> torch.Tensor:
     return ent[2]
 
 
-FOLD_EPILOGUE = os.environ.get("GKG_FOLD_EPILOGUE", "1") != "0"
+FOLD_EPILOGUE = "fold_epilogue" not in _DISABLED
 
 
 def _folded_of(conv, bn):
@@ -515,7 +442,7 @@ def _tm_dtype(lowp: bool):
 # reference's output, different strides), so a chain of blocks never transposes: it saves nchw_to_tm + the transposing
 # half of tm_affine_to_nchw per block and direction (12 % of the cfg3 forward, 6 % of the cfg4 step).  NCHW-contiguous
 # inputs keep the NCHW-in / NCHW-out behaviour; the GKGNet backbone converts once after the stem and each downsample.
-CHANNELS_LAST = os.environ.get("GKG_CHANNELS_LAST", "1") != "0"
+CHANNELS_LAST = "channels_last" not in _DISABLED
 
 
 def is_channels_last(x) -> bool:
@@ -706,12 +633,6 @@ def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg
     """dY, dgamma, dbeta of out = act(BN_train(Y)) from the upstream gradient g; with ``sync`` the two column sums the
     input gradient needs are all-reduced over the ranks (dgamma/dbeta stay local, like torch's SyncBatchNorm: the
     data-parallel gradient exchange averages them)."""
-    if sync is None and BN_TWO_KERNEL:
-        dev = Y.device
-        _lib.check(lib.gkg_bn_bwd_train(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
-                                        _ptr(dbeta), None, R, C, nb, ldg, g_bstride, act, _ptr(_stats_scratch(dev)),
-                                        _bn_counters(dev).data_ptr(), None, 0, _stream()), "gkg_bn_bwd_train")
-        return
     ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), Y.device)
     if sync is None:
         _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
@@ -754,43 +675,29 @@ class _LinearBNAct(torch.autograd.Function):
             out = torch.empty(nchw, dtype=_F32, device=x.device)
         if own:
             x = x.contiguous()
-        two = scale is None and _bn2(bn, x if own else torch.empty(0, dtype=_F32))
         sync = None
-        if own and two:                               # projection kernel (statistics in its epilogue) -> apply: 2 kernels
-            Y = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, stats_only=True, planes=pf)[0]
-            a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 0, res, out, R, cout, 1, cout, 0, act, code,
-                                            0 if nchw is None else nchw[0])
+        if own:                                       # projection kernel with the BN statistics in its epilogue
+            Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
         else:
-            if own:
-                Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
-            else:
-                Y = _mm_t(x, W, w16)
-                if two:                               # vendor GEMM -> statistics (atomics) -> apply (inline finalize)
-                    _lib.check(lib.gkg_bn_stats_accum(_ptr(Y), R, cout, 1, _ptr(_stats_scratch(Y.device)), _stream()),
-                               "gkg_bn_stats_accum")
-                    a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 1, res, out, R, cout, 1, cout, 0, act, code,
-                                                    0 if nchw is None else nchw[0])
-                else:
-                    a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
-            if own or not two:
-                if nchw is None and want16 and code == _lib.F32:
-                    # bf16 inference, channels-last chain: also emit the bf16 rounding the next block's first GEMM reads
-                    out16 = torch.empty((R, cout), dtype=torch.bfloat16, device=x.device)
-                    _lib.check(lib.gkg_affine_act_dual(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), _ptr(out16), R, cout, act,
-                                                       _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act_dual")
-                    out._gkg_bf16_tm = out16
-                elif nchw is None:
-                    _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
-                                                  code, _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act")
-                else:
-                    _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), nchw[0], cout,
-                                                         R // nchw[0], _ptr(scale), _stream()), "gkg_tm_affine_to_nchw")
+            Y = _mm_t(x, W, w16)
+            a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
+        if nchw is None and want16 and code == _lib.F32:
+            # bf16 inference, channels-last chain: also emit the bf16 rounding the next block's first GEMM reads
+            out16 = torch.empty((R, cout), dtype=torch.bfloat16, device=x.device)
+            _lib.check(lib.gkg_affine_act_dual(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), _ptr(out16), R, cout, act,
+                                               _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act_dual")
+            out._gkg_bf16_tm = out16
+        elif nchw is None:
+            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
+                                          code, _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act")
+        else:
+            _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), nchw[0], cout,
+                                                 R // nchw[0], _ptr(scale), _stream()), "gkg_tm_affine_to_nchw")
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, nchw, residual is not None, bias is not None)
         ctx.scale = (scale, rows_per_scale)
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
-        ctx.own = own and OWN_GEMM == "all"
         ctx.pd = pd
         return out
 
@@ -815,11 +722,6 @@ class _LinearBNAct(torch.autograd.Function):
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
         # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean): not materialised
         dbias = None
-        if ctx.own:
-            dx, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, R * cout, Y, a, c, mean, invstd, x,
-                                                    weight.view(cout, cin), R, cin, cout, 1, act,
-                                                    ctx.needs_input_grad[0], ctx.gparams)
-            return dx, dW.view_as(weight), dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (cout, cin), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
@@ -854,14 +756,9 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((R, cout), dtype=dt, device=U.device)
         sync = None
-        two = _bn2(bn, U if own else torch.empty(0, dtype=_F32))
         if own:
             U = U.contiguous()
-            if two:
-                Y = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, stats_only=True, planes=pf)[0]
-                a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 0, None, out, R, co, nb, cout, co, act, code, 0)
-            else:
-                Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, planes=pf)
+            Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, planes=pf)
         else:
             if U.dtype == torch.bfloat16:
                 Wb = weight.to(torch.bfloat16) if w16 is None else w16
@@ -870,20 +767,13 @@ class _GroupedLinearBNAct(torch.autograd.Function):
                 Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
                 if Y.dtype != _F32:
                     Y = Y.float()
-            if two:
-                _lib.check(lib.gkg_bn_stats_accum(_ptr(Y), R, co, nb, _ptr(_stats_scratch(Y.device)), _stream()),
-                           "gkg_bn_stats_accum")
-                a, c, mean, invstd = _bn2_apply(lib, Y, bn, bias, 1, None, out, R, co, nb, cout, co, act, code, 0)
-            else:
-                a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
-        if not two:
-            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
-                                          code, None, 0, _stream()), "gkg_affine_act")
+            a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
+        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
+                                      code, None, 0, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
-        ctx.own = own and OWN_GEMM == "all"
         ctx.pd = pd
         return out
 
@@ -898,10 +788,6 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         g = dout.contiguous()
         if mean is None:
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
-        if ctx.own:
-            dU, dW, dgamma, dbeta = _linear_bwd_own(lib, g, cout, co, Y, a, c, mean, invstd, U, weight.view(nb, co, ci),
-                                                    R, ci, co, nb, act, ctx.needs_input_grad[0], ctx.gparams)
-            return dU, dW.view_as(weight), None, dgamma, dbeta, None, None, None, None
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (nb, co, ci), cout, Y.device)
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync)
@@ -976,9 +862,9 @@ class _MaxRelativeTM(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------------------- row g1 (inference)
 # bf16 inference: gather + max-relative + interleave + grouped 1x1 projection + BN(eval) + GELU in ONE launch
-# (csrc/gkg_mrgemm.hip) — the [x, m] operand is produced tile by tile in LDS and never written.  GKG_MR_GEMM=0 restores
+# (csrc/gkg_mrgemm.hip) — the [x, m] operand is produced tile by tile in LDS and never written.  GKG_DISABLE=mr_gemm restores
 # the three-launch form (gkg_mr_fwd_tm -> batched GEMM -> gkg_affine_act).
-MR_GEMM = os.environ.get("GKG_MR_GEMM", "1") != "0"
+MR_GEMM = "mr_gemm" not in _DISABLED
 
 
 def _mr_planes_of(conv) -> torch.Tensor:

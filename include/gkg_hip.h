@@ -252,41 +252,23 @@ int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const fl
  *                      folded: it cancels in the output and is added to running_mean), saved mean / invstd and updates the
  *                      running statistics.  `stats`: gkg_linear_stats_doubles() doubles, zero on entry, zeroed again
  *                      before the call's work completes (one buffer can serve every layer on a stream).
- *                      train == 2: statistics only — the exact fp64 sums stay in `stats` for gkg_bn_apply_train (shifted = 0).
- *                      `counters` (backward): gkg_linear_counters() zero-initialised unsigned ints, left zero by every call.
- *   gkg_bn_bwd_coef    first half of the BN backward: dz = dout*act'(a*y+c) (stored to `dz` when act == 1, else dz is
- *                      dout itself), dbeta = sum dz, dgamma = sum dz*yhat, and coef [nb][3][C] = (alpha, beta, gamma) with
- *                      dy = alpha*dz + beta*y + gamma  (== a*(dz - mean(dz) - yhat*mean(dz*yhat))).
- *   gkg_linear_bn_bwd  dx = dy w and dw = dy^T x with dy formed from (dz, y, coef) while the operand tiles are staged —
- *                      dy is never written.  dw's token contraction is split over workgroups which add their partial tiles
- *                      into dw with fp32 hardware atomics (dw is cleared first unless GKG_LINEAR_DW_ZEROED says the caller
- *                      did); with GKG_LINEAR_DETERMINISTIC the partial tiles go to `workspace` instead and the
- *                      last-arriving split of an output tile adds them in split order.  dx or dw may be NULL.
+ * The backward of these layers (BN backward passes above, input and weight gradients) runs on the x6 kernels below and the
+ * vendor GEMM library: fp32-MFMA dgrad / wgrad kernels with the BN backward-apply as operand prologue were built in round 2,
+ * measured 20-40 % behind at this path's shapes and removed in round 3.
  */
-#define GKG_LINEAR_DW_ZEROED 1u     /* dw is already zero (e.g. cleared by gkg_bn_bwd_coef's zero_buf) */
-#define GKG_LINEAR_DETERMINISTIC 2u /* ordered split reduction through `workspace` + `counters` */
-size_t gkg_linear_workspace_bytes(int R, int cin, int cout, int nb);
-int gkg_linear_counters(void);
 int gkg_linear_stats_doubles(void);
 int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R, int cin, int cout, int nb, int train,
                       const float* gamma, const float* beta, const float* bias, float* running_mean, float* running_var,
                       long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean, float* bn_invstd,
                       float momentum, float eps, double* stats, void* stream);
-int gkg_bn_bwd_coef(const float* dout, const float* y, const float* a, const float* c, const float* mean,
-                    const float* invstd, float* dz, float* dgamma, float* dbeta, float* coef, int R, int C, int nb,
-                    int ldg, size_t dout_bstride, int act, float* zero_buf /* optional: cleared by the same launches */,
-                    size_t zero_floats, void* workspace, size_t workspace_bytes, void* stream);
-int gkg_linear_bn_bwd(const float* dz, int ldg, size_t g_bstride, const float* y, const float* coef, const float* x,
-                      const float* w, float* dx, float* dw, int R, int cin, int cout, int nb, unsigned flags,
-                      void* workspace, size_t workspace_bytes, unsigned* counters, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The same projections on the bf16 matrix cores at fp32 accuracy (csrc/gkg_gemm_x6.hip): every fp32 operand is split
  * exactly into three bf16 terms and six of the nine cross products are accumulated in fp32 (error vs fp64 measured 3-4x
  * BELOW the fp32-MFMA kernels above).  The WEIGHTS are split ahead of time into bf16 "planes", once per optimiser step and
  * for all layers in one launch; the activations are split inside the GEMM.  Replaces the same reference lines as
- * gkg_linear_bn_fwd (torch_vertex.py:290-306, torch_nn.py:57-69, torch_vertex.py:334-360) and the input-gradient half of
- * gkg_linear_bn_bwd; the weight gradient stays with gkg_linear_bn_bwd / the vendor GEMM.
+ * gkg_linear_bn_fwd (torch_vertex.py:290-306, torch_nn.py:57-69, torch_vertex.py:334-360) plus their input gradient; the
+ * weight gradient runs here for long token axes under small outputs and in the vendor GEMM library otherwise.
  *   gkg_x6_planes_bytes     bytes of one orientation's planes of a weight w (nb, cout, cin): dgrad = 0 forward, 1 dgrad
  *   gkg_x6_prep_desc_bytes  size of one descriptor of the batched split
  *   gkg_x6_prep_desc_fill   writes descriptor `index` into a HOST array (device pointers inside; one of the two plane
@@ -315,32 +297,6 @@ int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* 
  * split-K GEMM).  x (nb, R, cin) with row pitch ldx / batch stride x_bstride (floats).  Any cin, cout >= 1. */
 int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride, float* dw,
                         int R, int cin, int cout, int nb, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * Two-kernel train-mode BN (the form the fused block uses when batch statistics are local to the rank): a producer
- * accumulates column sums into ONE fp64 scratch [nb][2][C] with atomics, the consumer derives the coefficients inline.
- * `scratch`: gkg_bn_scratch_doubles() doubles, zero on entry of the producer, zeroed again by the consumer (its last
- * workgroup); `counter`: gkg_bn_counters() zero-initialised unsigneds the consumer leaves zero.  One scratch / counter per device
- * serves every layer on a stream and survives hipGraph replay.
- *   gkg_bn_stats_accum   producer: sums of (y - y[row 0]) and squares  (shifted = 1 for the consumer).  The projection
- *                        kernel gkg_linear_bn_fwd(train = 2) is the other producer (exact fp64 sums, shifted = 0).
- *   gkg_bn_apply_train   consumer: out = act(BN(y)) (+ res), writes a / c / mean / invstd for the backward and updates
- *                        the running statistics (conv bias folded).  nchw_B > 0: out and res are (B, C, R/B) channel-major.
- *   gkg_bn_bwd_train     both halves of the backward: statistics of dz = dout*act'(z) -> dy (act == 1: in place on the
- *                        parked dz), dgamma, dbeta; with `coef` != NULL the (alpha, beta, gamma) coefficients for
- *                        gkg_linear_bn_bwd are written instead of dy (act == 1 still parks dz in dy) and `zero_buf` is cleared.
- */
-int gkg_bn_scratch_doubles(void);
-int gkg_bn_counters(void);   /* `counter` arguments below: this many zero-initialised unsigned ints */
-int gkg_bn_stats_accum(const float* y, int R, int C, int nb, double* scratch, void* stream);
-int gkg_bn_apply_train(const float* y, double* scratch, int shifted, const float* gamma, const float* beta, const float* bias,
-                       float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
-                       float* mean, float* invstd, const float* res, void* out, int R, int C, int nb, int ldo,
-                       size_t out_bstride, int act, int out_dtype, int nchw_B, float momentum, float eps, unsigned* counter,
-                       void* stream);
-int gkg_bn_bwd_train(const float* dout, const float* y, const float* a, const float* c, const float* mean, const float* invstd,
-                     float* dy, float* dgamma, float* dbeta, float* coef, int R, int C, int nb, int ldg, size_t dout_bstride,
-                     int act, double* scratch, unsigned* counter, float* zero_buf, size_t zero_floats, void* stream);
 
 /*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).

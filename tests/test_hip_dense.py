@@ -7,21 +7,20 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["none", "none-bn3", "fwd", "fwd-bn3", "all", "all-deterministic", "x6", "x6-bn3", "x6all"])
+@pytest.fixture(params=["vendor", "fwd", "x6", "x6all", "x6all-deterministic"])
 def gemm_mode(request):
-    """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("none"), with the
-    own fp32-MFMA forward kernel (BN statistics in the epilogue), with own fp32-MFMA forward + dgrad + wgrad kernels (BN
-    backward-apply as operand prologue; atomic or ordered split reduction), and with the split-bf16 ("x6", the default)
-    forward + dgrad kernels — alone and ("x6all") combined with the fp32-MFMA wgrad / dgrad kernels."""
+    """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("vendor"), with the
+    own fp32-MFMA forward kernel (BN statistics in the epilogue) everywhere ("fwd"), with the default rule ("x6": split-bf16
+    forward + dgrad kernels where they pay) and with every eligible projection — weight gradient included — on the split-bf16
+    kernels ("x6all"; "-deterministic": the atomically accumulated x6 weight gradient is skipped)."""
     from gkgnet_amd import fused
-    old = (fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL, fused.GEMM_MATH)
+    old = (fused.OWN_GEMM, fused.DETERMINISTIC, fused.GEMM_MATH)
     mode = request.param.split("-")[0]
-    fused.GEMM_MATH = "x6all" if mode.startswith("x6") else "f32"
-    fused.OWN_GEMM = {"x6": "auto", "x6all": "all"}.get(mode, mode)
+    fused.GEMM_MATH = {"vendor": "vendor", "fwd": "f32"}.get(mode, mode)
+    fused.OWN_GEMM = {"vendor": "none", "fwd": "fwd"}.get(mode, "auto")
     fused.DETERMINISTIC = request.param.endswith("deterministic")
-    fused.BN_TWO_KERNEL = not request.param.endswith("bn3")      # "-bn3": three-kernel BN (two-stage ordered sums)
     yield request.param
-    fused.OWN_GEMM, fused.DETERMINISTIC, fused.BN_TWO_KERNEL, fused.GEMM_MATH = old
+    fused.OWN_GEMM, fused.DETERMINISTIC, fused.GEMM_MATH = old
 
 
 def _bn(C):
@@ -168,11 +167,11 @@ def test_bf16_outputs_are_the_rounded_fp32_outputs():
 
 
 def test_deterministic_weight_gradient_is_bit_reproducible():
-    """fused.DETERMINISTIC: the split weight-gradient product adds its partial tiles in split order -> two runs agree bit
-    for bit (the default atomic accumulation only agrees to rounding)."""
+    """fused.DETERMINISTIC: no atomically accumulated weight gradient (the split-K products are reduced by a library sum in
+    a fixed order) -> two runs agree bit for bit, also with every projection forced onto the x6 kernels."""
     from gkgnet_amd import fused
-    old = (fused.OWN_GEMM, fused.DETERMINISTIC)
-    fused.OWN_GEMM, fused.DETERMINISTIC = "all", True
+    old = (fused.GEMM_MATH, fused.DETERMINISTIC)
+    fused.GEMM_MATH, fused.DETERMINISTIC = "x6all", True
     try:
         torch.manual_seed(4)
         x = torch.randn(5000, 96, device="cuda")
@@ -187,7 +186,7 @@ def test_deterministic_weight_gradient_is_bit_reproducible():
             grads.append(conv.weight.grad.clone())
         assert torch.equal(grads[0], grads[1])
     finally:
-        fused.OWN_GEMM, fused.DETERMINISTIC = old
+        fused.GEMM_MATH, fused.DETERMINISTIC = old
 
 
 @pytest.mark.parametrize("mode", ["none", "fwd"])

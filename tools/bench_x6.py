@@ -52,11 +52,7 @@ for R, cin, cout, nb in SHAPES:
                                                               R, cin, cout, nb, None)))
     print(f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: wgrad vendor (split-K bmm) {vw:6.1f}  x6 (incl. memset) {xw:6.1f}", flush=True)
     line = f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: vendor fwd {timeit(lambda: torch.bmm(x, w.transpose(1, 2), out=y)):6.1f} dgrad {timeit(lambda: torch.bmm(dy, w, out=dx)):6.1f} |"
-    for ni in (("auto",) if len(sys.argv) > 1 else ("auto", "1", "2")):
-        if ni == "auto":
-            os.environ.pop("GKG_X6_NI", None)
-        else:
-            os.environ["GKG_X6_NI"] = ni
+    for ni in ("auto",):
         f = timeit(lambda: lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 0,
                                                     *([None] * 10), 0.0, 0.0, None, None))
         fs = timeit(lambda: lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
