@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libgkg_hip.so")
-SOURCES = ["gkg_api.hip", "gkg_knn.hip", "gkg_mr.hip", "gkg_dense.hip", "gkg_gemm.hip", "gkg_gemm_x6.hip", "gkg_edge.hip", "gkg_mrgemm.hip"]
+SOURCES = ["gkg_api.hip", "gkg_knn.hip", "gkg_knn_pf.hip", "gkg_mr.hip", "gkg_dense.hip", "gkg_gemm.hip", "gkg_gemm_x6.hip", "gkg_edge.hip", "gkg_mrgemm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-I" + INCLUDE, "-I" + CSRC]
 
@@ -30,7 +30,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    headers = [os.path.join(CSRC, "gkg_common.h"), os.path.join(INCLUDE, "gkg_hip.h")]
+    headers = [os.path.join(CSRC, "gkg_common.h"), os.path.join(CSRC, "gkg_knn_common.h"), os.path.join(INCLUDE, "gkg_hip.h")]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

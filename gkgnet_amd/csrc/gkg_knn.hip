@@ -25,15 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "gkg_common.h"
+#include "gkg_knn_common.h"
 
 namespace gkg {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int QT = 64;   // queries per workgroup (one per lane)
-constexpr int KT = 32;   // keys per MFMA tile
-constexpr int NW = 4;    // waves per workgroup
 
 // ------------------------------------------------------------------------------------------ prep
 struct PrepStrides { int G; size_t sb, sg, sc, sn; };
@@ -160,105 +154,6 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   for (int chp = c; chp < cpad; ++chp) op[(size_t)chp * Tn] = 0.0f;
   sq[(size_t)bg * Tn + n] = q2;
 }
-
-// ------------------------------------------------------------------------------------------ top-KD list
-// Sorted ascending.  A list entry is ONE fp64 key that orders exactly like the pair (distance, key index): the fp32
-// distance converted to fp64 (exact; leaves the low 29 mantissa bits zero) with the index stored in those bits —
-// complemented for negative distances, where a larger mantissa means a smaller value — so "equal distance -> smaller
-// index first" is the plain fp64 '<'.  The sorted insert is then a v_min_f64 + v_max_f64 per slot (fp64 vector ops
-// issue at the fp32 rate on CDNA3/4) instead of compare + v_med3 + two selects per slot: 2 instead of 4 vector
-// instructions per slot, and the index never has to be moved separately.
-//   An fp64 infinity or NaN cannot carry index bits (inf | bits is a NaN), and does not need to: v_min_f64 /
-// v_max_f64 return the non-NaN operand, so a candidate whose distance is +inf or NaN (non-finite inputs only) leaves
-// the list untouched, exactly like the strict '<' of a scalar insert.  Keys past M are masked with a large FINITE
-// |y|^2 (MASKED_SQ) instead of +inf; they can only surface when fewer than k*d real candidates exist at all, and the
-// output stage keeps indices in range for that case.  (A distance is never -0.0: |x|^2 >= +0 heads the sum.)
-constexpr uint32_t IDX_BITS = 0x1fffffffu;          // 29 bits: key index < 2^29
-constexpr float MASKED_SQ = 3.0e38f;
-
-__device__ __forceinline__ double pack_key(float d, int m) {
-  // low 29 bits: m for d >= 0, IDX_BITS - m (== IDX_BITS ^ m) for d < 0
-  const uint32_t flip = (uint32_t)(__float_as_int(d) >> 31) & IDX_BITS;
-  return __longlong_as_double(__double_as_longlong((double)d) + (long long)(flip ^ (uint32_t)m));
-}
-__device__ __forceinline__ float key_dist(double k) {
-  return (float)__longlong_as_double(__double_as_longlong(k) & ~(long long)IDX_BITS);
-}
-__device__ __forceinline__ int key_index(double k) {
-  const long long b = __double_as_longlong(k);
-  if ((b & 0x7fffffffffffffffLL) == 0x7ff0000000000000LL) return 0x7fffffff;      // empty slot (+inf)
-  const uint32_t lo = (uint32_t)b & IDX_BITS;
-  return (int)(b < 0 ? IDX_BITS - lo : lo);
-}
-
-// Raw v_min_f64 / v_max_f64: the builtin forms are preceded by a canonicalising v_max_f64 x,x per operand (sNaN
-// quieting under IEEE mode) — a third of the insert for nothing, the keys are never NaN.
-__device__ __forceinline__ double min_f64(double a, double b) {
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ double max_f64(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-template <int KD>
-struct TopList {
-  double key[KD];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int j = 0; j < KD; ++j) key[j] = (double)INFINITY;
-  }
-  // Sorted insert; a no-op for lanes whose candidate does not beat their KD-th entry, skipped when no lane of the
-  // wave improves.
-  template <bool GUARD>
-  __device__ __forceinline__ void insert(float d, int m) { insert_key<GUARD>(pack_key(d, m)); }
-  template <bool GUARD>
-  __device__ __forceinline__ void insert_key(const double k) {
-    // GUARD: skip the insert when no lane of the wave improves.  Pays once a wave has streamed a few hundred keys per
-    // query (late candidates rarely enter a list); before that it is a compare + branch per candidate for nothing.
-    if (GUARD && __builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
-    // new key[j] = max(old key[j-1], min(old key[j], k)), from the top slot down.  Four slots at a time, the mins
-    // first and then the maxes, so that no v_max_f64 issues right behind the v_min_f64 it depends on.
-    constexpr int U = 4;
-#pragma unroll
-    for (int j0 = KD - 1; j0 >= 1; j0 -= U) {
-      double t[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (j0 - u >= 1) t[u] = min_f64(key[j0 - u], k);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (j0 - u >= 1) key[j0 - u] = max_f64(key[j0 - u - 1], t[u]);
-    }
-    key[0] = min_f64(key[0], k);
-  }
-};
-
-// ------------------------------------------------------------------------------------------ main kernel
-struct KnnArgs {
-  const float* xh;      // (BG, cpad, N) normalised queries
-  const float* yh;      // (BG, cpad, M) normalised keys (== xh for the self graph)
-  const float* sqx;     // (BG, N)
-  const float* sqy;     // (BG, M) (+ >= 32 floats of readable slack)
-  const float* relpos;  // (N, M) or null
-  int64_t* nn_idx;      // (BG, N, k)
-  int64_t* center;      // (BG, N, k) or null
-  float* part_v;        // (S, BG, N, KD) partial lists when S > 1
-  int* part_i;
-  int BG, cpad, N, M, k, dilation, kd;
-  int splits, tiles_per_split;
-  int nqt;              // query tiles per problem
-  const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies (prefilter: hi planes)
-  const uint16_t* yb;
-  int cp16;
-  // prefilter mode (knn_pf_kernel)
-  const uint16_t* xb_lo;  // lo planes
-  const uint16_t* yb_lo;
-  float margin;           // 2 * eps: eps bounds |prefilter distance - contract distance| (see knn_pf_kernel)
-};
 
 // Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
 // waves of one SIMD do NOT overlap (they share the fp32 datapath) — every vector instruction spent on the
@@ -614,343 +509,6 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   }
 }
 
-// ------------------------------------------------------------------------------------------ prefilter + exact re-rank
-// Same contract, same bits, a third of the matrix time: the (64-query x 32-key) distance tiles are first evaluated
-// APPROXIMATELY on the bf16 matrix cores — every normalised fp32 token split into its two leading bf16 terms (hi, lo),
-// three of the four cross products (hi.hi + hi.lo + lo.hi), fp32 accumulation, relative_pos pre-loaded into the
-// accumulators: 3 x 32 cycles per 32x32x16 block where the fp32 MFMA needs 8 x 64, and unlike the fp32 MFMA it runs
-// BESIDE the selection's vector work instead of on its datapath — and only the few candidates that can be among a query's
-// k*d nearest are then re-evaluated EXACTLY (the contract's ordered fmaf chain, bit for bit) and ranked.
-//
-// Why the result is the contract's: let d_e(m) be the contract distance of key m and d_a(m) the prefilter's, with
-// |d_a - d_e| <= eps for every pair (eps below).  Let tau = the KD-th smallest d_a.  The KD keys with the smallest d_a all
-// have d_e <= tau + eps, so the KD-th smallest d_e is <= tau + eps, so every key of the true top-KD has
-// d_a <= d_e + eps <= tau + 2 eps.  The survivors S = {m : d_a(m) <= tau + 2 eps} therefore contain the true top-KD, and
-// ranking S by the exact (d_e, m) keys gives exactly the contract's list (ties included).
-//   eps: with |x^| = |y^| = 1 (normalised tokens; the kernel is only selected with GKG_KNN_NORMALIZE) sum_ch |2 x^ y^| <= 2.
-//   Dropped terms of the split (lo.lo and the residuals |v - hi - lo| <= 2^-18 |v|): <= 3 * 2^-18 * 2 = 2.3e-5; fp32
-//   accumulation of the 3 c products on the matrix core, any order: <= 3 c u * 2, u = 2^-24; the contract's own chain
-//   against the real value: <= c u * 2; the final adds: a few u.  eps = 3e-5 + 6e-7 * cpad covers the sum with margin.
-// Per-wave lists: the 4 waves of a workgroup stream disjoint key tiles, so a wave may have dropped (beyond its KDW-entry
-// list) a key that belongs to S.  That can only have happened if the wave's own KDW-th entry is <= tau + 2 eps; such a query
-// (and one with more than SMAX survivors) takes the SLOW PATH: its lane re-scans all M keys with the exact chain.  KDW
-// exceeds KD for short lists (9 -> 12, 12 -> 16) so that this needs >= KDW of a query's best keys in ONE wave's quarter of
-// the key tiles: ~4^(1-KDW) per query.
-constexpr int PF_EXTRA = 8;       // survivors beyond KD a query may have before it takes the slow path
-
-// The contract's distance (without relative_pos) of query n and key m from the fp32 channel-major normalised copies: the
-// ordered fmaf chain over the cpad (zero-padded) channels with the query pre-scaled by -2 — what knn_tile_kernel's fp32
-// MFMA contraction computes, bit for bit.
-__device__ __forceinline__ float pf_exact_dist(const float* __restrict__ xc, int N, const float* __restrict__ yc, int M,
-                                               int cpad, float sqx, float sqy) {
-  float acc = 0.0f;
-#pragma unroll 8
-  for (int ch = 0; ch < cpad; ++ch) acc = __builtin_fmaf(yc[(size_t)ch * M], -2.0f * xc[(size_t)ch * N], acc);
-  return (sqx + acc) + sqy;                        // the contract's order; relative_pos is added by the caller
-}
-
-template <int KD, int KDW, bool HAS_RP>
-__global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs a) {
-  extern __shared__ float smem[];
-  typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-  constexpr int SMAX = KD + PF_EXTRA;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqt = a.nqt;
-  const int lin = blockIdx.x;
-  const int xcd = lin & 7, jj = lin >> 3;
-  const int bg = (jj / nqt) * 8 + xcd;               // XCD-aware map, as knn_tile_kernel
-  if (bg >= a.BG) return;
-  const int n0 = (jj % nqt) * QT;
-  const int N = a.N, M = a.M, cpad = a.cpad, cp16 = a.cp16, S16 = cp16 >> 4;
-  const int lane_n = n0 + lane;
-  const int nc = lane_n < N ? lane_n : N - 1;
-  const int kk = lane >> 5, l31 = lane & 31;
-  constexpr int KB = 4;                              // k16-steps per key-operand batch
-  const uint4* yhp = reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * M;       // octet-major planes
-  const uint4* ylp = reinterpret_cast<const uint4*>(a.yb_lo) + (size_t)bg * (cp16 >> 3) * M;
-  uint4 bh_[KB], bl_[KB];
-  {
-    const int mk0 = min(w * KT + l31, M - 1);
-    const uint4* h0 = yhp + (size_t)kk * M + mk0;
-    const uint4* l0 = ylp + (size_t)kk * M + mk0;
-#pragma unroll
-    for (int u = 0; u < KB; ++u) {
-      bh_[u] = u < S16 ? h0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
-      bl_[u] = u < S16 ? l0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
-    }
-  }
-  // ---- stage the query tile: hi and lo planes scaled by -2 (exact), rows of cp16 + 8 bf16
-  const int qpitch = (cp16 + 8) * 2;                 // bytes
-  char* xq_hi = reinterpret_cast<char*>(smem);
-  char* xq_lo = xq_hi + QT * qpitch;
-  {
-    const uint4* xhp = reinterpret_cast<const uint4*>(a.xb) + (size_t)bg * (cp16 >> 3) * N;
-    const uint4* xlp = reinterpret_cast<const uint4*>(a.xb_lo) + (size_t)bg * (cp16 >> 3) * N;
-    const int chunks = cp16 >> 3;
-    auto m2h = [](unsigned hv) -> unsigned {
-      const unsigned e = hv & 0x7f80u;
-      if (e == 0u) return 0u;                                   // zero / denormal
-      if (e == 0x7f80u) return hv ^ 0x8000u;                     // inf / NaN keep their class
-      if (e == 0x7f00u) return ((hv ^ 0x8000u) & 0x8000u) | 0x7f80u;   // overflow -> inf
-      return (hv + 0x80u) ^ 0x8000u;
-    };
-    auto m2 = [&](unsigned wv) { return m2h(wv & 0xffffu) | (m2h(wv >> 16) << 16); };
-    for (int i = tid; i < 2 * QT * chunks; i += 256) {
-      const int pl = i >= QT * chunks;
-      const int r = i - pl * QT * chunks;
-      const int ck = r >> 6, q = r & 63;           // consecutive threads: consecutive queries of one octet (coalesced)
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n0 + q < N) v = (pl ? xlp : xhp)[(size_t)ck * N + n0 + q];
-      v.x = m2(v.x); v.y = m2(v.y); v.z = m2(v.z); v.w = m2(v.w);
-      *reinterpret_cast<uint4*>((pl ? xq_lo : xq_hi) + q * qpitch + 16 * ck) = v;
-    }
-  }
-  __syncthreads();
-
-  const float* sqy = a.sqy + (size_t)bg * M;
-  const bool two_blocks = n0 + 32 < N;               // wave-uniform
-  TopList<KDW> top;
-  top.init();
-  const int ktiles = (M + KT - 1) / KT;
-  // relative_pos rows of the two query blocks this lane's accumulator columns belong to
-  const int nq0 = min(n0 + l31, N - 1), nq1 = min(n0 + 32 + l31, N - 1);
-  for (int t = w; t < ktiles; t += NW) {
-    const int m0 = t * KT;
-    const int mk = min(m0 + l31, M - 1);
-    const int mk_next = min((t + NW < ktiles ? t + NW : t) * KT + l31, M - 1);
-    const float sy32 = (m0 + l31 < M) ? sqy[mk] : MASKED_SQ;
-    // accumulators start from relative_pos: lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
-    f32x16 acc0, acc1;
-    if (HAS_RP) {
-      const float* r0 = a.relpos + (size_t)nq0 * M + m0 + 4 * kk;
-      const float* r1 = a.relpos + (size_t)nq1 * M + m0 + 4 * kk;
-      if (m0 + KT <= M && (M & 3) == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 v0 = *reinterpret_cast<const float4*>(r0 + 8 * g);
-          const float4 v1 = *reinterpret_cast<const float4*>(r1 + 8 * g);
-          acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
-          acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
-        }
-      } else {
-        const int last = M - 1 - m0 - 4 * kk;          // offsets beyond it are clamped (those keys are masked anyway)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int off = max(min(8 * g + j, last), -(m0 + 4 * kk));
-            acc0[4 * g + j] = r0[off];
-            acc1[4 * g + j] = r1[off];
-          }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    }
-    {
-      const uint4* ykh = yhp + (size_t)kk * M + mk;
-      const uint4* ykl = ylp + (size_t)kk * M + mk;
-      const uint4* ynh = yhp + (size_t)kk * M + mk_next;
-      const uint4* ynl = ylp + (size_t)kk * M + mk_next;
-      const char* xh0 = xq_hi + l31 * qpitch + 16 * kk;
-      const char* xl0 = xq_lo + l31 * qpitch + 16 * kk;
-      const char* xh1 = xh0 + 32 * qpitch;
-      const char* xl1 = xl0 + 32 * qpitch;
-      for (int s0 = 0; s0 < S16; s0 += KB) {
-        const bool last = s0 + KB >= S16;                         // uniform: prefetch the NEXT tile's first batch
-        uint4 ah[KB], al[KB];
-#pragma unroll
-        for (int u = 0; u < KB; ++u) { ah[u] = bh_[u]; al[u] = bl_[u]; }
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-          const int sn = last ? u : s0 + KB + u;
-          bh_[u] = sn < S16 ? (last ? ynh : ykh)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
-          bl_[u] = sn < S16 ? (last ? ynl : ykl)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-          if (s0 + u < S16) {
-            const bf16x8_t kh = __builtin_bit_cast(bf16x8_t, ah[u]);
-            const bf16x8_t kl = __builtin_bit_cast(bf16x8_t, al[u]);
-            const bf16x8_t qh0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh0 + 32 * (s0 + u)));
-            const bf16x8_t ql0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl0 + 32 * (s0 + u)));
-            if (two_blocks) {                                      // the two accumulator chains alternate: no MFMA
-              const bf16x8_t qh1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh1 + 32 * (s0 + u)));
-              const bf16x8_t ql1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl1 + 32 * (s0 + u)));
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh0, acc0, 0, 0, 0);     // issues right behind the one it
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh1, acc1, 0, 0, 0);     // depends on (small terms first)
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql1, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh1, acc1, 0, 0, 0);
-            } else {
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh0, acc0, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    // ---- lane l <- all 32 keys of query n0 + l (permlane swap as in knn_tile_kernel); approximate distance (without the
-    //      query's own |x|^2, a per-query constant) = acc + |y|^2, keys past M masked by MASKED_SQ
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float lo[4], hi[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * g + j]),
-                                                         __float_as_uint(acc1[4 * g + j]), false, false);
-        lo[j] = __uint_as_float(sw[0]);
-        hi[j] = __uint_as_float(sw[1]);
-      }
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = 8 * g + 4 * hh + j;
-          const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-          top.template insert<KDW >= 18>((hh ? hi[j] : lo[j]) + sy, m0 + row);
-        }
-      }
-    }
-  }
-
-  // ---- the 4 per-wave lists -> LDS; wave 0 merges them per query and collects the survivors
-  __syncthreads();                       // everyone is done with the staged queries
-  float* lv = smem;                      // [NW][KDW][64]
-  int* li = reinterpret_cast<int*>(smem + NW * KDW * 64);
-  int* sidx = li + NW * KDW * 64;        // [SMAX][64] survivor key indices (ascending prefilter distance)
-  int* scnt = sidx + SMAX * 64;          // [64] survivor count; -1: slow path
-  int* npairs = scnt + 64;               // [1] (+3 pad) number of (query, survivor) pairs that need the exact distance
-  uint16_t* plist = reinterpret_cast<uint16_t*>(npairs + 4);     // [SMAX * 64] those pairs, (s << 6) | q
-  double* keys = reinterpret_cast<double*>(smem);                // [SMAX][64] final sort keys, over the dead list area
-#pragma unroll
-  for (int j = 0; j < KDW; ++j) {
-    lv[(w * KDW + j) * 64 + lane] = key_dist(top.key[j]);
-    li[(w * KDW + j) * 64 + lane] = key_index(top.key[j]);
-  }
-  if (tid == 0) *npairs = 0;
-  __syncthreads();
-  const float margin = a.margin;
-  if (w == 0) {
-    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    float h0 = lv[(0 * KDW) * 64 + lane], h1 = lv[(1 * KDW) * 64 + lane], h2 = lv[(2 * KDW) * 64 + lane],
-          h3 = lv[(3 * KDW) * 64 + lane];
-    int i0 = li[(0 * KDW) * 64 + lane], i1 = li[(1 * KDW) * 64 + lane], i2 = li[(2 * KDW) * 64 + lane],
-        i3 = li[(3 * KDW) * 64 + lane];
-    float tau = INFINITY;
-    int cnt = 0;
-    bool open = true;                    // still collecting
-    float sv_d[SMAX];                    // prefilter distances of the survivors (registers: the loops are unrolled)
-#pragma unroll
-    for (int j = 0; j < SMAX; ++j) {
-      int sel = 0; float bv = h0; int bi = i0;
-      if (h1 < bv || (h1 == bv && i1 < bi)) { sel = 1; bv = h1; bi = i1; }
-      if (h2 < bv || (h2 == bv && i2 < bi)) { sel = 2; bv = h2; bi = i2; }
-      if (h3 < bv || (h3 == bv && i3 < bi)) { sel = 3; bv = h3; bi = i3; }
-      if (sel == 0) { ++p0; h0 = p0 < KDW ? lv[(0 * KDW + p0) * 64 + lane] : INFINITY; i0 = p0 < KDW ? li[(0 * KDW + p0) * 64 + lane] : 0x7fffffff; }
-      else if (sel == 1) { ++p1; h1 = p1 < KDW ? lv[(1 * KDW + p1) * 64 + lane] : INFINITY; i1 = p1 < KDW ? li[(1 * KDW + p1) * 64 + lane] : 0x7fffffff; }
-      else if (sel == 2) { ++p2; h2 = p2 < KDW ? lv[(2 * KDW + p2) * 64 + lane] : INFINITY; i2 = p2 < KDW ? li[(2 * KDW + p2) * 64 + lane] : 0x7fffffff; }
-      else { ++p3; h3 = p3 < KDW ? lv[(3 * KDW + p3) * 64 + lane] : INFINITY; i3 = p3 < KDW ? li[(3 * KDW + p3) * 64 + lane] : 0x7fffffff; }
-      if (j == KD - 1) tau = bv;
-      // merged order is ascending, so the survivors are a PREFIX of it: the first candidate that is not taken — beyond the
-      // margin, or not a real key (exhausted lists, keys masked past M) — ends the collection
-      const bool take = open && (j < KD || bv <= tau + margin) && (unsigned)bi < (unsigned)M;
-      if (!take) open = false;
-      if (take) { sidx[j * 64 + lane] = bi; cnt = j + 1; }
-      sv_d[j] = take ? bv : INFINITY;
-    }
-    // more survivors than SMAX?  (the next head is still inside the margin)
-    const float nh = fminf(fminf(h0, h1), fminf(h2, h3));
-    bool slow = open && nh <= tau + margin;
-    // a wave whose list is full and whose last entry is inside the margin may have dropped a survivor
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
-      const float lastv = lv[(ww * KDW + KDW - 1) * 64 + lane];
-      if (lastv <= tau + margin) slow = true;          // +inf (list not full) and NaN never pass
-    }
-    if (!(tau < INFINITY)) slow = false;               // fewer than KD finite candidates at all: nothing was dropped
-    if (lane_n >= N) { slow = false; cnt = 0; }        // padding lanes of the last query tile
-    scnt[lane] = slow ? -1 : cnt;
-    // Sort keys.  A survivor more than `margin` away from both neighbours in this (sorted) list keeps its prefilter
-    // distance (+ |x|^2, the term the prefilter leaves out): its order against every other survivor is already the
-    // contract's (each distance is within eps of the exact one).  The others — near-ties, and everything around the KD-th
-    // rank by construction — get the exact contract distance from the pair pass below.
-    if (!slow) {
-      const float sqxv = a.sqx[(size_t)bg * N + nc];
-#pragma unroll
-      for (int j = 0; j < SMAX; ++j) {
-        if (j < cnt) {
-          const bool near = (j > 0 && sv_d[j] - sv_d[j - 1] <= margin) || (j + 1 < SMAX && j + 1 < cnt && sv_d[j + 1] - sv_d[j] <= margin);
-          if (near) {
-            const int slot = atomicAdd(npairs, 1);
-            plist[slot] = (uint16_t)((j << 6) | lane);
-          } else {
-            keys[j * 64 + lane] = pack_key(sv_d[j] + sqxv, sidx[j * 64 + lane]);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- exact contract distance of the pairs that need it: one thread per pair, dense over the workgroup
-  const float* xcb = a.xh + (size_t)bg * cpad * N;
-  const float* ycb = a.yh + (size_t)bg * cpad * M;
-  {
-    const int np = *npairs;
-    for (int p = tid; p < np; p += 256) {
-      const int e = plist[p];
-      const int q = e & 63, sv = e >> 6;
-      const int m = sidx[sv * 64 + q];
-      const int n = min(n0 + q, N - 1);
-      float d = pf_exact_dist(xcb + n, N, ycb + m, M, cpad, a.sqx[(size_t)bg * N + n], sqy[m]);
-      if (HAS_RP) d = d + a.relpos[(size_t)n * M + m];
-      keys[sv * 64 + q] = d == d && d < INFINITY ? pack_key(d, m) : (double)INFINITY;   // NaN / +inf never enter a list
-    }
-  }
-  __syncthreads();
-  if (w != 0) return;
-
-  // ---- wave 0: rank the survivors by their keys; flagged queries re-scan all keys exactly
-  TopList<KD> fin;
-  fin.init();
-  const int myc = scnt[lane];
-#pragma unroll
-  for (int sv = 0; sv < SMAX; ++sv) {
-    if (__builtin_amdgcn_ballot_w64(sv < myc) == 0ull) break;
-    const double kv = sv < myc ? keys[sv * 64 + lane] : (double)INFINITY;
-    fin.template insert_key<false>(kv);
-  }
-  if (__builtin_amdgcn_ballot_w64(myc < 0) != 0ull) {
-    if (myc < 0) {
-      const float sqxv = a.sqx[(size_t)bg * N + nc];
-      for (int m = 0; m < M; ++m) {
-        float d = pf_exact_dist(xcb + nc, N, ycb + m, M, cpad, sqxv, sqy[m]);
-        if (HAS_RP) d = d + a.relpos[(size_t)nc * M + m];
-        if (d == d && d < INFINITY) fin.template insert_key<false>(pack_key(d, m));
-      }
-    }
-  }
-  if (lane_n < N) {
-    const size_t obase = ((size_t)bg * N + nc) * a.k;
-    int outj = 0;
-#pragma unroll
-    for (int j = 0; j < KD; ++j) {
-      if (j < a.kd && j % a.dilation == 0 && outj < a.k) {
-        const int bi = key_index(fin.key[j]);
-        a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;
-        if (a.center) a.center[obase + outj] = lane_n;
-        ++outj;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ split merge
 // One thread per partial-list ELEMENT: its final rank = its position in its own (sorted) list + the number of
 // lexicographically smaller (dist, idx) pairs in every other split's list (binary search).  Ranks are unique,
@@ -999,7 +557,9 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
 // ================================================================================================ host side
 using namespace gkg;
 
-static const int kListSizes[] = {9, 12, 16, 18, 24, 27, 32, 36, 48, 64};
+// list sizes of the tile kernel: the lengths GKGNet's configurations use (k*d = 9, 18, 27; pvig_m k = 18: 18, 36) plus 16
+// and 64 to cover everything else (each instantiation is a kernel of its own: 6 sizes x 2 x 2 x 3 selection forms)
+static const int kListSizes[] = {9, 16, 18, 27, 36, 64};
 
 static int pick_list(int kd) {
   for (int s : kListSizes) if (s >= kd) return s;
@@ -1132,31 +692,6 @@ static hipError_t launch_tile_buffered(const KnnArgs& a, dim3 grid, size_t lds, 
   return deep ? launch_tile_v<KD, false, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, false, 4, false, KNN_BUF>(a, grid, lds, st);
 }
 
-// prefilter + exact re-rank (knn_pf_kernel): un-split, normalised, fp32-contract problems
-template <int KD, int KDW>
-static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
-  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
-  const size_t stage = (size_t)2 * QT * (a.cp16 + 8) * 2;
-  const size_t lists = (size_t)2 * NW * KDW * 64 * 4 + (size_t)(KD + PF_EXTRA) * 64 * (4 + 2) + 64 * 4 + 16;
-  const size_t lds = stage > lists ? stage : lists;
-  if (a.relpos) {
-    if (lds > 64 * 1024) {
-      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (ea != hipSuccess) return ea;
-    }
-    hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, true>), grid, dim3(256), lds, st, a);
-  } else {
-    if (lds > 64 * 1024) {
-      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (ea != hipSuccess) return ea;
-    }
-    hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, false>), grid, dim3(256), lds, st, a);
-  }
-  return hipGetLastError();
-}
-
 template <typename T, int PT>
 static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
   const int nbx1 = (s1.Tn + PT - 1) / PT;
@@ -1242,16 +777,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
     a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;
     a.margin = 2.0f * (3.0e-5f + 6.0e-7f * (float)p.cpad);
-    switch (p.KD) {
-      case 9: e = launch_pf<9, 12>(a, grid, st); break;
-      case 12: e = launch_pf<12, 16>(a, grid, st); break;
-      case 16: e = launch_pf<16, 16>(a, grid, st); break;
-      case 18: e = launch_pf<18, 18>(a, grid, st); break;
-      case 24: e = launch_pf<24, 24>(a, grid, st); break;
-      case 27: e = launch_pf<27, 27>(a, grid, st); break;
-      case 32: e = launch_pf<32, 32>(a, grid, st); break;
-      default: e = launch_pf<36, 36>(a, grid, st); break;
-    }
+    e = launch_knn_prefilter(a, grid, p.KD, st);
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_pf_kernel");
     return 0;
   }
@@ -1272,27 +798,19 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   if (bf) {
     switch (p.KD) {
       case 9: e = launch_tile_bf<9>(a, grid, lds, st, buffered); break;
-      case 12: e = launch_tile_bf<12>(a, grid, lds, st, buffered); break;
       case 16: e = launch_tile_bf<16>(a, grid, lds, st, buffered); break;
       case 18: e = launch_tile_bf<18>(a, grid, lds, st, buffered); break;
-      case 24: e = launch_tile_bf<24>(a, grid, lds, st, buffered); break;
       case 27: e = launch_tile_bf<27>(a, grid, lds, st, buffered); break;
-      case 32: e = launch_tile_bf<32>(a, grid, lds, st, buffered); break;
       case 36: e = launch_tile_bf<36>(a, grid, lds, st, buffered); break;
-      case 48: e = launch_tile_bf<48>(a, grid, lds, st, buffered); break;
       default: e = launch_tile_bf<64>(a, grid, lds, st, buffered); break;
     }
   } else if (buffered) {
     switch (p.KD) {
       case 9: e = launch_tile_buffered<9>(a, grid, lds, st); break;
-      case 12: e = launch_tile_buffered<12>(a, grid, lds, st); break;
       case 16: e = launch_tile_buffered<16>(a, grid, lds, st); break;
       case 18: e = launch_tile_buffered<18>(a, grid, lds, st); break;
-      case 24: e = launch_tile_buffered<24>(a, grid, lds, st); break;
       case 27: e = launch_tile_buffered<27>(a, grid, lds, st); break;
-      case 32: e = launch_tile_buffered<32>(a, grid, lds, st); break;
       case 36: e = launch_tile_buffered<36>(a, grid, lds, st); break;
-      case 48: e = launch_tile_buffered<48>(a, grid, lds, st); break;
       default: e = launch_tile_buffered<64>(a, grid, lds, st); break;
     }
   } else if (short_stream && p.KD == 9) {
@@ -1300,14 +818,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   } else
   switch (p.KD) {
     case 9: e = launch_tile<9>(a, grid, lds, st); break;
-    case 12: e = launch_tile<12>(a, grid, lds, st); break;
     case 16: e = launch_tile<16>(a, grid, lds, st); break;
     case 18: e = launch_tile<18>(a, grid, lds, st); break;
-    case 24: e = launch_tile<24>(a, grid, lds, st); break;
     case 27: e = launch_tile<27>(a, grid, lds, st); break;
-    case 32: e = launch_tile<32>(a, grid, lds, st); break;
     case 36: e = launch_tile<36>(a, grid, lds, st); break;
-    case 48: e = launch_tile<48>(a, grid, lds, st); break;
     default: e = launch_tile<64>(a, grid, lds, st); break;
   }
   if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");

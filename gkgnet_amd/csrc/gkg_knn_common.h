@@ -1,0 +1,120 @@
+// gkg_knn_common.h — declarations shared by the k-NN kernels (gkg_knn.hip: preparation, fp32 / bf16 tile kernel, split
+// merge, host side; gkg_knn_pf.hip: bf16 prefilter + exact re-rank kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gkg_common.h"
+
+namespace gkg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int QT = 64;   // queries per workgroup (one per lane)
+constexpr int KT = 32;   // keys per MFMA tile
+constexpr int NW = 4;    // waves per workgroup
+
+// ------------------------------------------------------------------------------------------ top-KD list
+// Sorted ascending.  A list entry is ONE fp64 key that orders exactly like the pair (distance, key index): the fp32
+// distance converted to fp64 (exact; leaves the low 29 mantissa bits zero) with the index stored in those bits —
+// complemented for negative distances, where a larger mantissa means a smaller value — so "equal distance -> smaller
+// index first" is the plain fp64 '<'.  The sorted insert is then a v_min_f64 + v_max_f64 per slot (fp64 vector ops
+// issue at the fp32 rate on CDNA3/4) instead of compare + v_med3 + two selects per slot: 2 instead of 4 vector
+// instructions per slot, and the index never has to be moved separately.
+//   An fp64 infinity or NaN cannot carry index bits (inf | bits is a NaN), and does not need to: v_min_f64 /
+// v_max_f64 return the non-NaN operand, so a candidate whose distance is +inf or NaN (non-finite inputs only) leaves
+// the list untouched, exactly like the strict '<' of a scalar insert.  Keys past M are masked with a large FINITE
+// |y|^2 (MASKED_SQ) instead of +inf; they can only surface when fewer than k*d real candidates exist at all, and the
+// output stage keeps indices in range for that case.  (A distance is never -0.0: |x|^2 >= +0 heads the sum.)
+constexpr uint32_t IDX_BITS = 0x1fffffffu;          // 29 bits: key index < 2^29
+constexpr float MASKED_SQ = 3.0e38f;
+
+__device__ __forceinline__ double pack_key(float d, int m) {
+  // low 29 bits: m for d >= 0, IDX_BITS - m (== IDX_BITS ^ m) for d < 0
+  const uint32_t flip = (uint32_t)(__float_as_int(d) >> 31) & IDX_BITS;
+  return __longlong_as_double(__double_as_longlong((double)d) + (long long)(flip ^ (uint32_t)m));
+}
+__device__ __forceinline__ float key_dist(double k) {
+  return (float)__longlong_as_double(__double_as_longlong(k) & ~(long long)IDX_BITS);
+}
+__device__ __forceinline__ int key_index(double k) {
+  const long long b = __double_as_longlong(k);
+  if ((b & 0x7fffffffffffffffLL) == 0x7ff0000000000000LL) return 0x7fffffff;      // empty slot (+inf)
+  const uint32_t lo = (uint32_t)b & IDX_BITS;
+  return (int)(b < 0 ? IDX_BITS - lo : lo);
+}
+
+// Raw v_min_f64 / v_max_f64: the builtin forms are preceded by a canonicalising v_max_f64 x,x per operand (sNaN
+// quieting under IEEE mode) — a third of the insert for nothing, the keys are never NaN.
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int KD>
+struct TopList {
+  double key[KD];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KD; ++j) key[j] = (double)INFINITY;
+  }
+  // Sorted insert; a no-op for lanes whose candidate does not beat their KD-th entry, skipped when no lane of the
+  // wave improves.
+  template <bool GUARD>
+  __device__ __forceinline__ void insert(float d, int m) { insert_key<GUARD>(pack_key(d, m)); }
+  template <bool GUARD>
+  __device__ __forceinline__ void insert_key(const double k) {
+    // GUARD: skip the insert when no lane of the wave improves.  Pays once a wave has streamed a few hundred keys per
+    // query (late candidates rarely enter a list); before that it is a compare + branch per candidate for nothing.
+    if (GUARD && __builtin_amdgcn_ballot_w64(k < key[KD - 1]) == 0ull) return;
+    // new key[j] = max(old key[j-1], min(old key[j], k)), from the top slot down.  Four slots at a time, the mins
+    // first and then the maxes, so that no v_max_f64 issues right behind the v_min_f64 it depends on.
+    constexpr int U = 4;
+#pragma unroll
+    for (int j0 = KD - 1; j0 >= 1; j0 -= U) {
+      double t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 - u >= 1) t[u] = min_f64(key[j0 - u], k);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 - u >= 1) key[j0 - u] = max_f64(key[j0 - u - 1], t[u]);
+    }
+    key[0] = min_f64(key[0], k);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ main kernel
+struct KnnArgs {
+  const float* xh;      // (BG, cpad, N) normalised queries
+  const float* yh;      // (BG, cpad, M) normalised keys (== xh for the self graph)
+  const float* sqx;     // (BG, N)
+  const float* sqy;     // (BG, M) (+ >= 32 floats of readable slack)
+  const float* relpos;  // (N, M) or null
+  int64_t* nn_idx;      // (BG, N, k)
+  int64_t* center;      // (BG, N, k) or null
+  float* part_v;        // (S, BG, N, KD) partial lists when S > 1
+  int* part_i;
+  int BG, cpad, N, M, k, dilation, kd;
+  int splits, tiles_per_split;
+  int nqt;              // query tiles per problem
+  const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies (prefilter: hi planes)
+  const uint16_t* yb;
+  int cp16;
+  // prefilter mode (knn_pf_kernel)
+  const uint16_t* xb_lo;  // lo planes
+  const uint16_t* yb_lo;
+  float margin;           // 2 * eps: eps bounds |prefilter distance - contract distance| (see knn_pf_kernel)
+};
+
+
+// gkg_knn_pf.hip: launches knn_pf_kernel for list size KD (9, 16, 18, 27 or 36)
+hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t st);
+
+}  // namespace gkg
