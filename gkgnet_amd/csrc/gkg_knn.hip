@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     //      positional bias of this lane's query row
     const float sy32 = (m0 + l31 < M) ? sqy[mk] : MASKED_SQ;
     float rp[KT];
-    if (HAS_RP) {
+    if (HAS_RP && !BF) {
       const float* rpp = a.relpos + (size_t)nc * M + m0;
       if (m0 + KT <= M && (M & 3) == 0) {
 #pragma unroll
@@ -348,6 +348,31 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     // ---- contraction: acc0 = keys x (-2 queries[0..31]), acc1 = keys x (-2 queries[32..63]).
     //      Key operand double-buffered in registers (KU k-pairs per batch).
     f32x16 acc0 = {0}, acc1 = {0};
+    if (BF && HAS_RP) {
+      // bf16 form: the accumulators START from relative_pos (lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
+      // of query block row l31): the bias rides through the contraction instead of costing an add per candidate
+      const float* r0 = a.relpos + (size_t)min(n0 + l31, N - 1) * M + m0 + 4 * kk;
+      const float* r1 = a.relpos + (size_t)min(n0 + 32 + l31, N - 1) * M + m0 + 4 * kk;
+      if (m0 + KT <= M && (M & 3) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v0 = *reinterpret_cast<const float4*>(r0 + 8 * g);
+          const float4 v1 = *reinterpret_cast<const float4*>(r1 + 8 * g);
+          acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
+          acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
+        }
+      } else {
+        const int last = M - 1 - m0 - 4 * kk;          // offsets beyond it are clamped (those keys are masked anyway)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int off = max(min(8 * g + j, last), -(m0 + 4 * kk));
+            acc0[4 * g + j] = r0[off];
+            acc1[4 * g + j] = r1[off];
+          }
+      }
+    }
     if (BF) {
       // keys = A operand (lane: key l31, 8 channels 16 s + 8 kk ...), the two query blocks = B operands from LDS
       typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
@@ -443,11 +468,18 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
         for (int j = 0; j < 4; ++j) {
           const int row = 8 * g + 4 * hh + j;                              // increasing key order (tie rule)
           float dist = hh ? hi[j] : lo[j];
-          if (!FOLD) {                                                   // FOLD: both adds already happened on the matrix pipe
-            const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-            dist = (sqx + dist) + sy;
+          if (BF) {
+            // bf16 form (outside the bit-exact contract): relative_pos is already inside, and the query's own |x|^2 — one
+            // constant for all of its candidates, it cannot change their order — is left out; |y|^2 stays (it also masks
+            // the keys past M and keeps zero-norm keys where they belong)
+            dist = dist + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
+          } else {
+            if (!FOLD) {                                                 // FOLD: both adds already happened on the matrix pipe
+              const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
+              dist = (sqx + dist) + sy;
+            }
+            if (HAS_RP) dist = dist + rp[row];
           }
-          if (HAS_RP) dist = dist + rp[row];
           if (BUF > 0) {
             if (dist < thr) {                       // NaN fails, like the insert's strict '<'
               cbuf[bcnt * 256] = make_float2(dist, __int_as_float(m0 + row));
