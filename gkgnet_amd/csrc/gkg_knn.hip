@@ -769,9 +769,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     else { ps.G = 1; ps.sb = (size_t)c * Tn; ps.sg = 0; ps.sc = Tn; ps.sn = 1; }
     return ps;
   };
-  // bf16 contraction: the normalised copies are bf16 token-major (they fit the fp32 copies' workspace slots); needs
-  // 16 <= c (below that the fp32 staging area is smaller than the bf16 one) — otherwise the flag is ignored
-  const bool bf = (flags & GKG_KNN_BF16_CONTRACT) != 0 && c >= 16;
+  // bf16 contraction: the normalised copies are bf16 octet-major planes (they fit the fp32 copies' workspace slots); needs
+  // c >= 9, i.e. cpad >= 16 (below that the fp32 staging area, which sizes the LDS, is smaller than the bf16 one) —
+  // otherwise the flag is ignored
+  const bool bf = (flags & GKG_KNN_BF16_CONTRACT) != 0 && p.cpad >= 16;
   const int cp16 = (c + 15) & ~15;
   // prefilter mode: the bit-exact contract path for normalised, un-split problems with lists up to 36 entries (LDS)
   const size_t pf_stage = (size_t)2 * QT * (cp16 + 8) * 2;

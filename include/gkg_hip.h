@@ -53,7 +53,7 @@ extern "C" {
 #define GKG_KNN_BF16_CONTRACT 2u /* x.y^T on the bf16 matrix cores: tokens rounded to bf16 after normalisation, exact
                                   * products, fp32 accumulation and fp32 norms.  For callers under bf16 autocast, where the
                                   * reference computes this product in bf16 and rounds it to bf16.  Outside the bit-exact
-                                  * index contract; ignored for c < 16. */
+                                  * index contract; ignored for c < 9. */
 #define GKG_KNN_SELECT_DIRECT 4u   /* force the direct sorted insert / the buffered selection of the tile kernel instead of */
 #define GKG_KNN_SELECT_BUFFERED 8u /* the library's per-shape rule (measurement, tests): identical results either way */
 #define GKG_KNN_NO_PREFILTER 16u   /* evaluate every distance with the contract's fp32 chain (knn_tile_kernel) instead of the

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 STAGES = {
     "s1": (80, 2, 144, 4, 9, 1), "s2": (160, 2, 72, 2, 9, 1), "s3_d2": (400, 2, 36, 1, 9, 2), "s3_d3": (400, 2, 36, 1, 9, 3),
     "s4_d3": (640, 2, 18, 1, 9, 3),
-    "m2": (192, 8, 96, 2, 18, 1), "m3_d2": (384, 8, 48, 1, 18, 2), "m4_d2": (768, 8, 24, 1, 18, 2),
+    "m1": (96, 8, 192, 4, 18, 1), "m2": (192, 8, 96, 2, 18, 1), "m3_d2": (384, 8, 48, 1, 18, 2), "m4_d2": (768, 8, 24, 1, 18, 2),
 }
 # measured on MI355X (r03): set agreement 0.93-0.99, excess mean distance <= 3e-4; asserted with margin
 MIN_AGREEMENT = 0.88
@@ -49,7 +49,7 @@ def test_bf16_contract_neighbour_sets_vs_bit_exact_fp32(name):
     from gkgnet_amd import fused
     from gkgnet_amd.relpos import build_relative_pos
     C, G, H, r, k, d = STAGES[name]
-    B = 2
+    B = 1 if name == "m1" else 2
     import zlib
     gen = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) % 1000)
     x = _structured(B, C, H, gen)
@@ -69,8 +69,8 @@ def test_bf16_contract_neighbour_sets_vs_bit_exact_fp32(name):
             e32 = fused.knn_graph_tm(xt, yt, rp, k, d, G)[0]             # bit-exact contract path (tests/test_hip_config_shapes.py)
     finally:
         fused.KNN_BF16 = old
-    if C // G < 16:
-        assert torch.equal(e16, e32)                                      # c < 16: the flag is ignored
+    if C // G < 9:
+        assert torch.equal(e16, e32)                                      # c < 9: the flag is ignored
         return
     # (a1) set agreement: |set16 & set32| / k per query
     hit = (e16.unsqueeze(-1) == e32.unsqueeze(-2)).any(-1).float().mean().item()
