@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
       }
     }
   }
+  if (BUF > 0) smem[(size_t)cpad * QT + (size_t)BUF * 512 + tid] = INFINITY;   // ths (see below)
   __syncthreads();
 
   const int n = lane_n;
@@ -305,6 +306,32 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   float2* cbuf = reinterpret_cast<float2*>(smem + (size_t)cpad * QT) + tid;
   int bcnt = 0;
   float thr = INFINITY;
+  // Shared admission bound (SHARE: the buffered form; in the guarded direct form the two extra selects per candidate cost
+  // more than the saved inserts — C = 640 / k*d = 27 at 18 x 18: 119 -> 157 us — so it keeps its own bound).  The 4 waves of the workgroup keep separate lists
+  // over disjoint key tiles of the SAME 64 queries.  With Q = ceil(KD / 4): the Q best entries of each wave's list are 4 Q
+  // >= KD distinct candidates, so the query's final KD-th distance is <= sh = max over the waves of their Q-th entry — a
+  // much tighter bound than a wave's own KD-th entry (a wave sees a quarter of the keys; its Q-th entry is about where the
+  // final KD-th will be).  Candidates with dist > sh can never reach the final list and are not inserted (dist == sh may tie
+  // in by index: kept).  Each wave publishes its Q-th distance in LDS and reads the others' without synchronisation: a
+  // stale value is an older, LARGER one, still a valid bound.  Results are bit-identical; the sorted inserts — the dominant
+  // cost of long lists — drop by about half (k*d = 36: 136 -> 73 expected inserts per lane over 576 keys).
+  constexpr bool SHARE = BUF > 0 && KD >= 16;    // 9-entry lists: Q = 3 saves too few inserts to pay for the exchange
+  constexpr int QSH = (KD + NW - 1) / NW;
+  float* ths = smem + (size_t)cpad * QT + (size_t)(BUF > 0 ? BUF : 0) * 512;      // [NW][64], behind the candidate buffer
+  float sh = INFINITY;
+  auto refresh_shared = [&]() {
+    const float mine = key_dist(top.key[QSH - 1]);                // +inf while the list holds fewer than Q entries
+    ths[w * 64 + lane] = mine;
+    float m = mine;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) m = fmaxf(m, ths[ww * 64 + lane]);
+    sh = m;
+  };
+  auto next_up = [](float v) -> float {                            // smallest float > v (v finite), +inf stays +inf
+    if (!(v < INFINITY)) return v;
+    const int b = __float_as_int(v);
+    return __int_as_float(v >= 0.0f ? b + 1 : b - 1);
+  };
   auto flush = [&]() {
 #pragma unroll
     for (int i = 0; i < BUF; ++i) {                 // forward branches only: a back edge makes the allocator duplicate the list
@@ -315,6 +342,10 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
     }
     bcnt = 0;
     thr = key_dist(top.key[KD - 1]);               // +inf while the list is not full
+    if (SHARE) {
+      refresh_shared();
+      thr = fminf(thr, next_up(sh));               // strict '<' against own KD-th entry, '<=' against the shared bound
+    }
   };
 
   const int ktiles = (M + KT - 1) / KT;
@@ -671,8 +702,8 @@ constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 by
 
 template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false>
 static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  if (BUF > 0) {
-    const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 256 * sizeof(float2);
+  if (BUF > 0) {                                // candidate buffer + the 4 x 64 shared admission bounds behind the queries
+    const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 256 * sizeof(float2) + NW * 64 * sizeof(float);
     if (lds < need) lds = need;
   }
   if (lds > 64 * 1024) {
@@ -825,7 +856,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // (c=200: query tile 51 KB + buffer -> one workgroup per CU, 607 -> 876 us) and on short streams with 9-entry lists
   // (cfg2 label graph 24.6 -> 31.5 us).  The GKG_KNN_SELECT_DIRECT / _BUFFERED flags override the rule (measurement / tests).
   const int force = (flags & GKG_KNN_SELECT_BUFFERED) ? 2 : ((flags & GKG_KNN_SELECT_DIRECT) ? 1 : 0);
-  const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 <= 150 * 1024;
+  const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 + NW * 64 * 4 <= 150 * 1024;
   const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
   const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));
   if (bf) {
