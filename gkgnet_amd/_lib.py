@@ -10,7 +10,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 KNN_BF16_CONTRACT = 2

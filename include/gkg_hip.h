@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 5
+#define GKG_ABI_VERSION 6
 
 /* dtype codes */
 #define GKG_F32 0

@@ -11,7 +11,7 @@ python bench.py --workload stage3 --no-cpu-baseline > gpurun_out/${TAG}_final_be
 # 2. rocprofv3 --kernel-trace --stats of the same command + condensed views
 bash tools/prof_run.sh ${TAG}_final --steps 20 --warmup 5 > /dev/null
 cd /tmp && export TMPDIR=/tmp
-python $R/tools/prof_graph_steps.py /tmp/${TAG}_final "knn_tile_kernel<9, true" 1400 seq > $R/gpurun_out/${TAG}_final_bench_cfg2_graph_steps.txt
+python $R/tools/prof_graph_steps.py /tmp/${TAG}_final "knn_tile_kernel<9, true" 1100 seq > $R/gpurun_out/${TAG}_final_bench_cfg2_graph_steps.txt
 # 3. secondary configs, per kernel
 for cfg in cfg3 cfg5; do
   rm -rf /tmp/p_$cfg
