@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_ti
   // of once per query tile (measured: FETCH_SIZE 53 -> see profiles/).  Placement only affects speed.
   const int nqt = a.nqt;
   const int lin = blockIdx.x;
+  if (a.wg_flags && a.wg_flags[lin] == 0) return;   // clean-up pass behind knn_pf_kernel: only the tiles it flagged
   const int xcd = lin & 7, jj = lin >> 3;
   const int bg = (jj / nqt) * 8 + xcd;
   if (bg >= a.BG) return;                       // grid is padded to a multiple of 8 problems (uniform exit)
@@ -646,7 +647,7 @@ static int pick_splits(int BG, int N, int M) {
 
 struct KnnPlan {
   int cpad, kd, KD, S, tps;
-  size_t off_xh, off_yh, off_sqx, off_sqy, off_pv, off_pi, off_xp, off_yp, total;
+  size_t off_xh, off_yh, off_sqx, off_sqy, off_pv, off_pi, off_xp, off_yp, off_flags, total;
 };
 
 static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_y, KnnPlan* p) {
@@ -677,7 +678,7 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   if (p->S > 1) {
     p->off_pv = o; o = al(o + sizeof(float) * (size_t)p->S * BG * N * p->kd);
     p->off_pi = o; o = al(o + sizeof(int) * (size_t)p->S * BG * N * p->kd);
-    p->off_xp = p->off_yp = 0;
+    p->off_xp = p->off_yp = p->off_flags = 0;
   } else {
     p->off_pv = p->off_pi = 0;
     // prefilter mode (un-split problems): bf16 hi + lo planes (BG, T, cp16) of the queries and keys
@@ -685,6 +686,7 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
     p->off_xp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * N * cp16);
     if (has_y) { p->off_yp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * M * cp16); }
     else p->off_yp = p->off_xp;
+    p->off_flags = o; o = al(o + sizeof(int) * (size_t)((N + QT - 1) / QT) * ((BG + 7) / 8) * 8);   // one per workgroup
   }
   p->total = o;
   return 0;
@@ -835,15 +837,19 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.splits = p.S; a.tiles_per_split = p.tps;
   a.nqt = (N + QT - 1) / QT;
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
-  a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f;
+  a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
   if (pf) {
     a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
     a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;
     a.margin = 2.0f * (3.0e-5f + 6.0e-7f * (float)p.cpad);
+    a.wg_flags = (int*)(ws + p.off_flags);
+    e = hipMemsetAsync(a.wg_flags, 0, sizeof(int) * (size_t)grid.x, st);
+    if (e != hipSuccess) return gkg_fail_hip(e, "knn_pf_kernel (flags)");
     e = launch_knn_prefilter(a, grid, p.KD, st);
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_pf_kernel");
-    return 0;
+    // fall through: the fp32 tile kernel below runs as the clean-up pass over the tiles the prefilter flagged
+    // (a.wg_flags != null: every other workgroup exits at once)
   }
   size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
   size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);

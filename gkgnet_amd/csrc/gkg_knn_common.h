@@ -111,6 +111,8 @@ struct KnnArgs {
   const uint16_t* xb_lo;  // lo planes
   const uint16_t* yb_lo;
   float margin;           // 2 * eps: eps bounds |prefilter distance - contract distance| (see knn_pf_kernel)
+  int* wg_flags;          // [gridDim.x] or null.  knn_pf_kernel: sets [blockIdx.x] = 1 (and writes no output) for a query
+                          // tile it cannot settle; knn_tile_kernel: when non-null, only flagged workgroups run (clean-up pass)
 };
 
 

@@ -23,10 +23,15 @@ namespace gkg {
 //   accumulation of the 3 c products on the matrix core, any order: <= 3 c u * 2, u = 2^-24; the contract's own chain
 //   against the real value: <= c u * 2; the final adds: a few u.  eps = 3e-5 + 6e-7 * cpad covers the sum with margin.
 // Per-wave lists: the 4 waves of a workgroup stream disjoint key tiles, so a wave may have dropped (beyond its KDW-entry
-// list) a key that belongs to S.  That can only have happened if the wave's own KDW-th entry is <= tau + 2 eps; such a query
-// (and one with more than SMAX survivors) takes the SLOW PATH: its lane re-scans all M keys with the exact chain.  KDW
-// exceeds KD for short lists (9 -> 12, 16 -> 18) so that this needs >= KDW of a query's best keys in ONE wave's quarter of
-// the key tiles: ~4^(1-KDW) per query.
+// list) a key that belongs to S.  That can only have happened if the wave's own KDW-th entry is <= tau + 2 eps.  A query
+// tile with such a query, or with a query that has more than SMAX survivors (masses of exact or near ties: duplicated
+// tokens, degenerate features), is NOT settled here: the workgroup sets its flag, writes nothing, and the host side's
+// clean-up launch — the fp32 tile kernel restricted to the flagged workgroups — computes the tile the plain way.  On
+// ordinary data no tile is flagged (KDW exceeds KD for short lists, 9 -> 12, 16 -> 18, so that the first condition needs
+// >= KDW of a query's best keys in ONE wave's quarter of the key tiles: ~4^(1-KDW) per query) and the clean-up launch is
+// ~1 300 workgroups that exit on their first instruction; on degenerate data the cost is bounded by prefilter + plain
+// kernel.  (An in-lane exact re-scan of all M keys was the first form of this fallback: one degenerate block of the
+// random-init GKGNet-576 train step took 6.9 ms instead of 0.45.)
 constexpr int PF_EXTRA = 8;       // survivors beyond KD a query may have before it takes the slow path
 
 // The contract's distance (without relative_pos) of query n and key m from the fp32 channel-major normalised copies: the
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   float* lv = smem;                      // [NW][KDW][64]
   int* li = reinterpret_cast<int*>(smem + NW * KDW * 64);
   int* sidx = li + NW * KDW * 64;        // [SMAX][64] survivor key indices (ascending prefilter distance)
-  int* scnt = sidx + SMAX * 64;          // [64] survivor count; -1: slow path
+  int* scnt = sidx + SMAX * 64;          // [64] survivor count; -1: tile flagged for the clean-up launch
   int* npairs = scnt + 64;               // [1] (+3 pad) number of (query, survivor) pairs that need the exact distance
   uint16_t* plist = reinterpret_cast<uint16_t*>(npairs + 4);     // [SMAX * 64] those pairs, (s << 6) | q
   double* keys = reinterpret_cast<double*>(smem);                // [SMAX][64] final sort keys, over the dead list area
@@ -266,7 +271,14 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
     }
     if (!(tau < INFINITY)) slow = false;               // fewer than KD finite candidates at all: nothing was dropped
     if (lane_n >= N) { slow = false; cnt = 0; }        // padding lanes of the last query tile
-    scnt[lane] = slow ? -1 : cnt;
+    // any query of the tile unsettled -> the whole tile goes to the clean-up launch (wave-uniform decision)
+    const bool tile_slow = __builtin_amdgcn_ballot_w64(slow) != 0ull;
+    if (tile_slow) {
+      if (lane == 0) a.wg_flags[blockIdx.x] = 1;
+      cnt = -1;
+    }
+    slow = tile_slow;
+    scnt[lane] = cnt;
     // Sort keys.  A survivor more than `margin` away from both neighbours in this (sorted) list keeps its prefilter
     // distance (+ |x|^2, the term the prefilter leaves out): its order against every other survivor is already the
     // contract's (each distance is within eps of the exact one).  The others — near-ties, and everything around the KD-th
@@ -307,25 +319,16 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   __syncthreads();
   if (w != 0) return;
 
-  // ---- wave 0: rank the survivors by their keys; flagged queries re-scan all keys exactly
+  // ---- wave 0: rank the survivors by their keys (a flagged tile writes nothing: the clean-up launch owns it)
+  const int myc = scnt[lane];
+  if (__builtin_amdgcn_ballot_w64(myc < 0) != 0ull) return;
   TopList<KD> fin;
   fin.init();
-  const int myc = scnt[lane];
 #pragma unroll
   for (int sv = 0; sv < SMAX; ++sv) {
     if (__builtin_amdgcn_ballot_w64(sv < myc) == 0ull) break;
     const double kv = sv < myc ? keys[sv * 64 + lane] : (double)INFINITY;
     fin.template insert_key<false>(kv);
-  }
-  if (__builtin_amdgcn_ballot_w64(myc < 0) != 0ull) {
-    if (myc < 0) {
-      const float sqxv = a.sqx[(size_t)bg * N + nc];
-      for (int m = 0; m < M; ++m) {
-        float d = pf_exact_dist(xcb + nc, N, ycb + m, M, cpad, sqxv, sqy[m]);
-        if (HAS_RP) d = d + a.relpos[(size_t)nc * M + m];
-        if (d == d && d < INFINITY) fin.template insert_key<false>(pack_key(d, m));
-      }
-    }
   }
   if (lane_n < N) {
     const size_t obase = ((size_t)bg * N + nc) * a.k;
