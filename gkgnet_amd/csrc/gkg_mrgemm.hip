@@ -31,6 +31,13 @@ namespace gkg {
 typedef float mg_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 mg_bf16x8;
 
+// Compile-time phase ablation (measurement only, tools/ubench/mrgemm_ablate.py builds private copies with -DMG_ABL=<bits>):
+// 1 no neighbour gathers (the centre row stands in), 2 no MFMA loop, 4 no GELU, 8 no index staging (indices = token itself),
+// 16 no output stores.  Run-time flags for the same purpose pushed the per-item arrays into scratch memory (4x slower).
+#ifndef MG_ABL
+#define MG_ABL 0
+#endif
+
 constexpr int MG_ROWS = 64;       // tokens per workgroup
 constexpr int MG_NW = 8;          // waves per workgroup (512 threads)
 constexpr int MG_MAXB = 3;        // 32 x 32 output blocks per wave (wide layers; narrow ones: 2)
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
       int v = 0;
       if (t < g.T) {
         const int b = (int)(t / N), n = (int)(t - (long long)b * N);
-        v = mg_clamp(g.nn_idx[(((size_t)b * g.G + glo + gi) * N + n) * k + jj], M);
+        v = (MG_ABL & 8) ? min(n, M - 1) : mg_clamp(g.nn_idx[(((size_t)b * g.G + glo + gi) * N + n) * k + jj], M);
       }
       ids[e] = v;
     }
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
     const float* sb = srcb + (size_t)b * M * C + ch;
     if (KS > 0) {
 #pragma unroll
-      for (int u = 0; u < KS; ++u) I.nb[u] = *reinterpret_cast<const float4*>(sb + (size_t)ip[u] * C);
+      for (int u = 0; u < KS; ++u) I.nb[u] = (MG_ABL & 1) ? I.xi : *reinterpret_cast<const float4*>(sb + (size_t)ip[u] * C);
     }
   };
   auto finish = [&](const Item& I, int it) __attribute__((always_inline)) {
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
 #pragma unroll
     for (int u = 0; u < MAXB; ++u)
       bq[d][u] = (has[u] && d < S) ? wptr[u][(size_t)(2 * d) * g.co_pad] : make_uint4(0, 0, 0, 0);
-  for (int s0 = 0; s0 < S; s0 += DEPTH) {
+  for (int s0 = 0; s0 < ((MG_ABL & 2) ? 0 : S); s0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int s = s0 + d;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
         float o = __builtin_fmaf(av, acc[u][r], cv);
-        if (g.act == 1) o = mg_gelu(o);
+        if (g.act == 1 && !(MG_ABL & 4)) o = mg_gelu(o);
         *reinterpret_cast<uint16_t*>(st + row * pitch) = __builtin_bit_cast(uint16_t, (__bf16)o);
       }
     }
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
     const int tok = it / CW, r = it - tok * CW;
     const int qi = r / CH, ck = r - qi * CH;
     const long long t = t0 + tok;
-    if (t < g.T)
+    if (t < g.T && !(MG_ABL & 16))
       *reinterpret_cast<uint4*>(g.out + (size_t)t * g.ldo + (q0 + qi) * g.co + 8 * ck) =
           *reinterpret_cast<const uint4*>(mg_lds + qi * qstride + tok * pitch + 16 * ck);
   }
