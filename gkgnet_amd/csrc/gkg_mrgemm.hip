@@ -60,7 +60,19 @@ struct MrGemmArgs {
 __device__ __forceinline__ int mg_clamp(int64_t v, int M) { return (int)(v < 0 ? 0 : (v >= M ? M - 1 : v)); }
 // torch.max semantics (same as gkg_mr.hip::takes): NaN propagates, first maximum wins
 __device__ __forceinline__ bool mg_takes(float v, float best) { return v > best || (v != v && best == best); }
-__device__ __forceinline__ float mg_gelu(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+// GELU (erf form) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): ~15 vector instructions instead of the
+// ~40 of erff.  The result is rounded to bf16 (2^-9 relative), so against the exact erf it differs only where a rounding
+// boundary falls within 1e-7: the compile-time ablation showed erff as 21-26 % of this kernel at every stage shape.
+__device__ __forceinline__ float mg_gelu(float z) {
+  const float x = fabsf(z) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-x * x);          // erf(|z| / sqrt 2)
+  return 0.5f * z * (1.0f + copysignf(e, z));
+}
 
 // QG: conv groups per workgroup.  4 (narrow layers): one workgroup owns 64 tokens x ALL channels — index rows, token rows
 // and output rows are each touched once and fully coalesced; 1 (wide layers): one workgroup per (64 tokens, conv group),
