@@ -154,7 +154,7 @@ def test_train_step_on_reference_graphs(gemm_math, monkeypatch):
     built (the k-NN operator itself is pinned bit-exactly elsewhere).  With the only discontinuous element fixed,
     everything must follow the reference closely:
       losses of both steps 1e-3 relative; pre-clip gradient norms 5e-3; first-step gradients cosine >= 0.9999;
-      parameter deltas after 2 AdamW steps: >= 99 % of the elements within 0.1 * lr of the reference's delta
+      parameter deltas after 2 AdamW steps: >= 99 % of the elements (at most one of a < 100-element tensor) within 0.1 * lr of the reference's delta
       (AdamW's first steps move every element by ~lr * sign(g); only elements with |g| ~ 0 can differ).
     Run with the default projection dispatch, with every projection on the split-bf16 kernels and with none."""
     from gkgnet_amd import fused
@@ -171,7 +171,9 @@ def test_train_step_on_reference_graphs(gemm_math, monkeypatch):
         cos = float((g_ * r_).sum() / (g_.norm() * r_.norm() + 1e-30))
         assert cos >= 0.9999, (k, cos)
         ok = np.abs(r["delta"][k] - a["delta/" + k]) <= 0.1 * meta["lr"]
-        assert ok.mean() >= 0.99, (k, float(ok.mean()))
+        # >= 99 % of the elements — for the 96-element norm weights that is "at most one": a single |g| ~ 0 element whose
+        # sign AdamW amplifies to a full lr step is 1.04 % of such a tensor
+        assert (~ok).sum() <= max(1, 0.01 * ok.size), (k, float(ok.mean()))
     ok = np.abs(r["head_delta"] - a["head_fc1_delta"]) <= 0.1 * meta["lr"]
     assert ok.mean() >= 0.99
 
