@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
       if (ACT == 1) {
         dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
         dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
-        *reinterpret_cast<float4*>(dz_out + (size_t)r * C + 4 * cgi) = dz;
+        if (dz_out) *reinterpret_cast<float4*>(dz_out + (size_t)r * C + 4 * cgi) = dz;
       }
       s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
       sq.x += dz.x * ((v.x - m4.x) * i4.x); sq.y += dz.y * ((v.y - m4.y) * i4.y);
@@ -564,15 +564,16 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   float* sums = part + (size_t)nb * nblk * 2 * C;
-  // With an activation the statistics pass also stores dz = dout*act'(z) into `dy`; the apply pass then runs in
-  // place on it, so erf/exp are evaluated once per element in the whole backward.
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, dy);
+  // With an activation both passes evaluate dz = dout*act'(z) themselves: since GELU' costs ~20 vector instructions (A&S
+  // erf sharing its exponential with the Gaussian) recomputing it in the memory-bound apply pass is cheaper than parking
+  // dz (a full R x C store in the statistics pass); rounds 1-2 stored it, erff being twice as expensive.
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
   else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, part, R, C, rpb, ldg, dout_bstride, (float*)nullptr);
   // dbeta[q] = sum dz ; dgamma[q] = sum dz*yhat
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 31) / 32, nb), dim3(256), 0, st, part, sums, nblk, 2 * C, dbeta, dgamma);
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dy, y, a, c, mean, invstd, sums, dy, total4, C, R, C, (size_t)R * C, (const float*)nullptr);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, (const float*)nullptr);
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, (const float*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd");
