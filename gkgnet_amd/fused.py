@@ -194,6 +194,15 @@ def refresh_weight_planes(device=None):
             reg.refresh(lib)
 
 
+def _vendor_tuned() -> bool:
+    """The caller has PyTorch's TunableOp on: the vendor GEMMs this layer competes with are per-shape tuned kernels, which
+    moves the break-even points of the dispatch rules (they were fitted inside the step under both conditions)."""
+    try:
+        return bool(torch.cuda.tunable.is_enabled())
+    except Exception:
+        return False
+
+
 def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     """This projection GEMM (kind "fwd": y = x W^T, "dgrad": dx = dy W) runs on the x6 kernels.  Eligible: fp32 operands
     outside autocast, batch statistics local to the rank, 16-byte aligned rows.  GKG_GEMM_MATH=x6 then applies the rule
@@ -217,7 +226,10 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     if GEMM_MATH == "x6all":
         return True
     if nb != 1:
-        return False
+        # grouped K = 160 forward at cfg2: x6 + statistics epilogue 33.5 us against vendor GEMM + statistics passes
+        # 23.7 + 11 us with a TunableOp-selected kernel (tie) but 32.9 + 11 us with the library's default selection:
+        # measured in the step, x6 here costs the tuned leg 12 us and saves the untuned leg 20 us
+        return kind == "fwd" and R >= 8192 and not _vendor_tuned()
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
