@@ -668,7 +668,11 @@ class _LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None, scale=None,
-                rows_per_scale=0, want16=False):
+                rows_per_scale=0, want16=False, alias=False):
+        """``alias``: also return ``x`` itself as a second output (a view).  A caller that uses the layer's input again
+        as the residual of a later layer takes the alias for that: both gradient contributions then arrive at THIS node
+        and the input-gradient GEMM adds the residual one in its epilogue (``addmm``), instead of autograd summing two
+        tensors with a stand-alone add kernel."""
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
@@ -711,13 +715,18 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.pd = pd
+        if alias:
+            ctx.set_materialize_grads(False)
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dalias=None):
         lib = _lib.load()
         x, weight, Y, a, c, mean, invstd = ctx.saved_tensors
         act, nchw, has_res, has_bias = ctx.meta
+        if dout is None:                                   # only the alias was used downstream
+            return (dalias,) + (None,) * 14
         R, cin = x.shape
         cout = weight.shape[0]
         dres = dout if has_res else None
@@ -744,10 +753,17 @@ class _LinearBNAct(torch.autograd.Function):
             dx = torch.empty((R, cin), dtype=_F32, device=dY.device)
             _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), cout, R * cout, _ptr(ctx.pd), _ptr(dx), R, cin, cout, 1, _stream()),
                        "gkg_linear_dgrad_x6")
+        elif dalias is not None and dalias.dtype == dY.dtype:
+            dx = torch.addmm(dalias, dY, W)                # the residual-path gradient rides in the GEMM epilogue
+            dalias = None
         else:
             dx = torch.mm(dY, W)
+        if dalias is not None and dx is not None:
+            dx = dx + dalias
+        elif dalias is not None:
+            dx = dalias
         dW = _wgrad(dY, x, dWv).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -952,9 +968,18 @@ def fused_supported(mod, x, groups: int) -> bool:
     return ENABLED
 
 
-def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False):
+def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False, alias=False):
     """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
-    output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402)."""
+    output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402).
+    ``alias``: returns ``(out, x')`` with ``x'`` the input again, to be used as a later layer's residual (see
+    _LinearBNAct.forward)."""
+    if alias:
+        if not (torch.is_grad_enabled() and x.requires_grad):
+            return _lin(x, seq, act, residual, nchw, out_lowp, scale, rows_per_scale, want16), x
+        conv, bn = seq[0], seq[1]
+        w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
+        return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
+                                  rows_per_scale, want16, True)
     conv, bn = seq[0], seq[1]
     if (FOLD_EPILOGUE and out_lowp and x.dtype == torch.bfloat16 and residual is None and nchw is None and scale is None
             and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and conv.weight.dim() == 4
@@ -1016,7 +1041,7 @@ def grapher_label_forward(mod, e, features, groups: int):
     else:
         ft = to_token_major(features.float().contiguous()).view(B, -1, C)
     e2 = e.float().reshape(B * L, C).contiguous()
-    x1 = _lin(e2, mod.fc1)
+    x1, e2r = _lin(e2, mod.fc1, alias=True)                          # e2r: e2 again, for the residual of fc2 (one gradient node)
     x1b = x1.view(B, L, C)
     edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
     lp = lowp_inference()
@@ -1027,9 +1052,9 @@ def grapher_label_forward(mod, e, features, groups: int):
         U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1, lp)
         a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
                                        _w16_of(nn_[0]) if lp else None)
-    h2 = _lin(a2, mod.fc2, residual=e2, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
-    f1 = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp)
-    out = _lin(f1, mod.ffn.fc2, residual=h2, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)
+    h2 = _lin(a2, mod.fc2, residual=e2r, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
+    f1, h2r = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp, alias=True)
+    out = _lin(f1, mod.ffn.fc2, residual=h2r, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)
     return out.view(B, L, C), edge
 
 
