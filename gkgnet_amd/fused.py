@@ -229,7 +229,8 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
         # grouped K = 160 forward at cfg2: x6 + statistics epilogue 33.5 us against vendor GEMM + statistics passes
         # 23.7 + 11 us with a TunableOp-selected kernel (tie) but 32.9 + 11 us with the library's default selection:
         # measured in the step, x6 here costs the tuned leg 12 us and saves the untuned leg 20 us
-        return kind == "fwd" and R >= 8192 and not _vendor_tuned()
+        # (the grouped input gradient likewise: 28.5 us against 23.8 tuned / 34.2 untuned)
+        return R >= 8192 and not _vendor_tuned()
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
