@@ -107,7 +107,8 @@ constexpr int ST_CG = 16;                           // float4 column groups per 
 constexpr int ST_RL = 16;                           // row lanes
 
 __device__ __forceinline__ void stats_block_reduce(float (*red)[ST_RL][4 * ST_CG], const float4& s, const float4& sq,
-                                                   int cg, int rl, float* __restrict__ part, int C, int tile) {
+                                                   int cg, int rl, float* __restrict__ part, int C, int tile,
+                                                   double* __restrict__ asums = nullptr) {
   *reinterpret_cast<float4*>(&red[0][rl][4 * cg]) = s;
   *reinterpret_cast<float4*>(&red[1][rl][4 * cg]) = sq;
   __syncthreads();
@@ -118,7 +119,10 @@ __device__ __forceinline__ void stats_block_reduce(float (*red)[ST_RL][4 * ST_CG
 #pragma unroll
     for (int l = 0; l < ST_RL; ++l) acc += red[which][l][col];
     const int ch = tile * 4 * ST_CG + col;
-    if (ch < C) part[(size_t)which * C + ch] = acc;
+    if (ch < C) {
+      if (asums) __hip_atomic_fetch_add(asums + (size_t)which * C + ch, (double)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else part[(size_t)which * C + ch] = acc;
+    }
   }
 }
 
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ a, const float* __restrict__ cs,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ part, int R, int C, int rows_per_block,
-                                                           int ldg, size_t g_bstride, float* __restrict__ dz_out) {
+                                                           int ldg, size_t g_bstride, float* __restrict__ dz_out,
+                                                           double* __restrict__ asums = nullptr) {
   __shared__ float red[2][ST_RL][4 * ST_CG];
   const int tid = threadIdx.x;
   const int cg = tid & (ST_CG - 1), rl = tid >> 4;
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
   y += (size_t)q * R * C; dout += (size_t)q * g_bstride;
   if (dz_out) dz_out += (size_t)q * R * C;
   a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C;
-  part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
+  if (asums) asums += (size_t)q * 2 * C;                // fp64 column sums accumulated with atomics (no partials, no second stage)
+  else part += ((size_t)q * gridDim.x + blockIdx.x) * 2 * C;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(R, r0 + rows_per_block);
   float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
       sq.z += dz.z * ((v.z - m4.z) * i4.z); sq.w += dz.w * ((v.w - m4.w) * i4.w);
     }
   }
-  stats_block_reduce(red, s, sq, cg, rl, part, C, blockIdx.y);
+  stats_block_reduce(red, s, sq, cg, rl, part, C, blockIdx.y, asums);
 }
 
 // sums[q][0][c], sums[q][1][c] = fixed-order (deterministic) double-precision reduction of the chunk partials.
@@ -389,6 +395,57 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 }
 
 // dy[r][c] = a[c] * (dz - sdz[c]/R - yhat*sdzy[c]/R), dz = dout*act'(a*y+c).  dout may be strided (ldg).
+// fp64-sums form of the apply pass (gkg_bn_bwd_atomic): reads the column sums the statistics pass accumulated with atomics,
+// its first workgroup of every group also emits dbeta / dgamma and clears `zero_buf` (the OTHER scratch buffer: what the
+// previous call accumulated into — nobody reads it any more; this call's own buffer is cleared by the next call).
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_d_kernel(const float* dout, const float* __restrict__ y,
+                                                             const float* __restrict__ a, const float* __restrict__ cs,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const double* __restrict__ dsums, float* dy,
+                                                             size_t total4, int C, int R, int ldg, size_t g_bstride,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             double* __restrict__ zero_buf, size_t zero_doubles) {
+  const int C4 = C >> 2;
+  const float invR = 1.0f / (float)R;
+  const int q = blockIdx.y;
+  y += (size_t)q * total4 * 4; dy += (size_t)q * total4 * 4; dout += (size_t)q * g_bstride;
+  a += (size_t)q * C; cs += (size_t)q * C; mean += (size_t)q * C; invstd += (size_t)q * C; dsums += (size_t)q * 2 * C;
+  if (blockIdx.x == 0) {
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      dbeta[(size_t)q * C + ch] = (float)dsums[ch];
+      dgamma[(size_t)q * C + ch] = (float)dsums[C + ch];
+    }
+    if (q == 0)
+      for (size_t i = threadIdx.x; i < zero_doubles; i += 256) zero_buf[i] = 0.0;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / C4;
+    const int cg = (int)(i - r * C4);
+    const float4 g = *reinterpret_cast<const float4*>(dout + r * (size_t)ldg + 4 * cg);
+    const float4 v = *reinterpret_cast<const float4*>(y + 4 * i);
+    const float4 a4 = *reinterpret_cast<const float4*>(a + 4 * cg);
+    const float4 c4 = *reinterpret_cast<const float4*>(cs + 4 * cg);
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + 4 * cg);
+    const float4 i4 = *reinterpret_cast<const float4*>(invstd + 4 * cg);
+    const double2 sa = *reinterpret_cast<const double2*>(dsums + 4 * cg), sb = *reinterpret_cast<const double2*>(dsums + 4 * cg + 2);
+    const double2 qa = *reinterpret_cast<const double2*>(dsums + C + 4 * cg), qb = *reinterpret_cast<const double2*>(dsums + C + 4 * cg + 2);
+    const float4 s4 = make_float4((float)sa.x, (float)sa.y, (float)sb.x, (float)sb.y);
+    const float4 q4 = make_float4((float)qa.x, (float)qa.y, (float)qb.x, (float)qb.y);
+    float4 dz = g;
+    if (ACT == 1) {
+      dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
+      dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
+    }
+    float4 o;
+    o.x = a4.x * (dz.x - s4.x * invR - ((v.x - m4.x) * i4.x) * (q4.x * invR));
+    o.y = a4.y * (dz.y - s4.y * invR - ((v.y - m4.y) * i4.y) * (q4.y * invR));
+    o.z = a4.z * (dz.z - s4.z * invR - ((v.z - m4.z) * i4.z) * (q4.z * invR));
+    o.w = a4.w * (dz.w - s4.w * invR - ((v.w - m4.w) * i4.w) * (q4.w * invR));
+    *reinterpret_cast<float4*>(dy + 4 * i) = o;
+  }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ y,
                                                            const float* __restrict__ a, const float* __restrict__ cs,
@@ -577,6 +634,33 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
   else hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, (const float*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd");
+}
+
+// gkg_bn_bwd in TWO launches: the statistics pass adds its per-workgroup column sums to `sums` (fp64, 2 * nb * C doubles,
+// ZERO on entry) with atomics — no partial rows, no second-stage reduction kernel — and the apply pass reads them, emits
+// dgamma / dbeta and clears `zero_buf` (zero_doubles doubles; may be NULL / 0).  The caller alternates between two scratch
+// buffers and hands each call the region the PREVIOUS call used as `zero_buf`: every buffer is clean again before its next
+// use without a memset launch or a last-arriver ticket.  fp64 atomics: the sums are run-dependent in their last fp64 bits
+// (deterministic callers keep gkg_bn_bwd).
+extern "C" int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                                 const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                                 size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !dy || !dgamma || !dbeta || !sums)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_atomic: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1) ||
+      (zero_doubles && !zero_buf))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_atomic: bad sizes");
+  int rpb;
+  const int nblk = stats_blocks(R, C, nb, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
+  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
+  const size_t total4 = (size_t)R * (C >> 2);
+  const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_d_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles);
+  else hipLaunchKernelGGL((bn_bwd_apply_d_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_atomic");
 }
 
 // ------------------------------------------------------------------------------------------ cross-rank (SyncBN) halves

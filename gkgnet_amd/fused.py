@@ -642,10 +642,44 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
     return a, c, None, None, None
 
 
+class _BnBwdScratch:
+    """Two fp64 column-sum buffers per device for gkg_bn_bwd_atomic, used alternately: a call accumulates into the clean one
+    and its apply pass clears what the previous call left in the other (stream-ordered, single stream: like _stats_scratch).
+    ``dirty[i]``: doubles of buffer i that hold sums."""
+    DOUBLES = 2 * 4096 * 4
+    _inst = {}
+
+    def __init__(self, device):
+        self.bufs = [torch.zeros(self.DOUBLES, dtype=torch.float64, device=device) for _ in range(2)]
+        self.cur = 0
+        self.dirty = [0, 0]
+
+    @classmethod
+    def of(cls, device):
+        key = (device.type, device.index)
+        inst = cls._inst.get(key)
+        if inst is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GkgError("BN backward scratch first used inside a hipGraph capture; run one eager warm-up step first")
+            inst = cls._inst[key] = cls(device)
+        return inst
+
+
 def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync):
     """dY, dgamma, dbeta of out = act(BN_train(Y)) from the upstream gradient g; with ``sync`` the two column sums the
     input gradient needs are all-reduced over the ranks (dgamma/dbeta stay local, like torch's SyncBatchNorm: the
     data-parallel gradient exchange averages them)."""
+    if sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES:
+        # two launches: statistics with fp64 atomics into one of two alternating scratch buffers, apply (which also clears
+        # what the previous call left in the other buffer) — no partial rows, no second-stage reduction launch
+        sc = _BnBwdScratch.of(Y.device)
+        cur, other = sc.bufs[sc.cur], sc.bufs[sc.cur ^ 1]
+        _lib.check(lib.gkg_bn_bwd_atomic(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
+                                         _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), sc.dirty[sc.cur ^ 1],
+                                         _stream()), "gkg_bn_bwd_atomic")
+        sc.dirty[sc.cur], sc.dirty[sc.cur ^ 1] = 2 * nb * C, 0
+        sc.cur ^= 1
+        return
     ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), Y.device)
     if sync is None:
         _lib.check(lib.gkg_bn_bwd(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),

@@ -222,6 +222,14 @@ int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                size_t dout_bstride, int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* gkg_bn_bwd in two launches instead of three: the statistics pass accumulates its column sums into `sums` (fp64,
+ * 2 * nb * C doubles, ZERO on entry) with atomics, the apply pass reads them, writes dgamma / dbeta and clears `zero_buf`
+ * (`zero_doubles` doubles; NULL / 0: nothing).  The caller alternates between two scratch buffers and passes the region the
+ * previous call used as `zero_buf`, so every buffer is clean before its next use without a memset launch.  The sums are
+ * run-dependent in their last fp64 bits (atomics); callers that need bit-reproducibility use gkg_bn_bwd. */
+int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                      const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                      size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream);
 /* Cross-rank batch statistics (the reference's SyncBatchNorm under DDP, torch_nn.py:37 / mmcv build_norm_layer):
  * gkg_bn_train_stats and gkg_bn_bwd split where the ranks exchange statistics.  Forward: gkg_bn_stats_sums ->
  * caller all-reduces `sums` [nb][2][C] (column sum, sum of squares) and the row count over the ranks ->
