@@ -42,6 +42,39 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
   return cdf + z * 0.39894228040143267794f * gauss;
 }
 
+// Train-mode BN whose statistics came out of the projection kernel's epilogue as fp64 column sums (gkg_linear_bn_fwd* with
+// train == 2): the CONSUMER of the projection — the BN-apply pass — derives scale / shift itself instead of a one-block
+// finalize launch in between.  Every workgroup computes the coefficients of its channels once (into LDS), the first
+// workgroup of each group also writes what the backward needs (a, c, mean, invstd) and updates the running statistics, and
+// clears `zero_buf`: the OTHER of two alternating scratch buffers, i.e. what the previous projection accumulated into (see
+// gkg_bn_bwd_atomic for the protocol).  Same arithmetic as bn_sums_finalize_kernel.
+struct BnDerive {
+  const double* sums;       // [nb][2][C]; null: the caller passes a / c
+  const float* gamma; const float* beta; const float* bias;
+  float* running_mean; float* running_var; long long* nbt;
+  float* a_out; float* c_out; float* mean_out; float* invstd_out;
+  int R; float momentum, eps;
+  double* zero_buf; size_t zero_doubles;
+};
+
+__device__ __forceinline__ void bn_derive_channel(const BnDerive& d, size_t o, double S, double Q, bool side, float& av, float& cv) {
+  const double m = S / d.R;
+  double var = Q / d.R - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)d.eps));
+  av = d.gamma[o] * is;
+  cv = d.beta[o] - av * (float)m;
+  if (side) {
+    d.a_out[o] = av; d.c_out[o] = cv; d.mean_out[o] = (float)m; d.invstd_out[o] = is;
+    if (d.running_mean) {
+      const float bv = d.bias ? d.bias[o] : 0.f;
+      d.running_mean[o] = (1.f - d.momentum) * d.running_mean[o] + d.momentum * ((float)m + bv);
+      const double unb = d.R > 1 ? var * (double)d.R / (double)(d.R - 1) : var;
+      d.running_var[o] = (1.f - d.momentum) * d.running_var[o] + d.momentum * (float)unb;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ layout
 // (B, C, N) channel-major -> (B*N, C) token-major through a padded 32x32 LDS tile (coalesced both sides).
 template <typename OutT>
@@ -68,17 +101,30 @@ __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ a,
                                                                 const float* __restrict__ cs, const float* __restrict__ res,
                                                                 float* __restrict__ out, int C, int N,
-                                                                const float* __restrict__ img_scale) {
+                                                                const float* __restrict__ img_scale, BnDerive d) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float av = 1.f, cv = 0.f;
+  const bool affine = a != nullptr || d.sums != nullptr;
+  if (c0 + tx < C) {
+    if (d.sums) {                                  // every thread derives the pair of its channel (8 rows share it)
+      const bool side = blockIdx.x == 0 && b == 0 && ty == 0;
+      bn_derive_channel(d, c0 + tx, d.sums[c0 + tx], d.sums[C + c0 + tx], side, av, cv);
+      if (side && c0 + tx == 0 && d.nbt) *d.nbt += 1;
+    } else if (a) {
+      av = a[c0 + tx]; cv = cs[c0 + tx];
+    }
+  }
+  if (d.sums && blockIdx.x == 0 && blockIdx.y == 0 && b == 0)
+    for (size_t i = threadIdx.x; i < d.zero_doubles; i += 256) d.zero_buf[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, ch = c0 + tx;
     float v = 0.f;
     if (ch < C && n < N) {
       v = y[((size_t)b * N + n) * C + ch];
-      if (a) v = __builtin_fmaf(a[ch], v, cs[ch]);
+      if (affine) v = __builtin_fmaf(av, v, cv);
     }
     tile[ty + 8 * i][tx] = v;
   }
@@ -366,11 +412,28 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          const float* __restrict__ cs, const float* __restrict__ res,
                                                          OutT* __restrict__ out, size_t total4, int C, int ldo,
                                                          size_t o_bstride, const float* __restrict__ row_scale,
-                                                         int rows_per_scale, uint16_t* __restrict__ out2 = nullptr) {
+                                                         int rows_per_scale, uint16_t* __restrict__ out2, BnDerive d) {
+  extern __shared__ float ac_tab[];                 // derive mode: [2][C] scale / shift of this group
   const int C4 = C >> 2;
   const int q = blockIdx.y;
-  y += (size_t)q * total4 * 4; a += (size_t)q * C; cs += (size_t)q * C; out += (size_t)q * o_bstride;
+  y += (size_t)q * total4 * 4; out += (size_t)q * o_bstride;
   if (res) res += (size_t)q * total4 * 4;
+  if (d.sums) {
+    const bool side = blockIdx.x == 0;
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      float av, cv;
+      bn_derive_channel(d, (size_t)q * C + ch, d.sums[(size_t)q * 2 * C + ch], d.sums[(size_t)q * 2 * C + C + ch], side, av, cv);
+      ac_tab[ch] = av; ac_tab[C + ch] = cv;
+    }
+    if (side && q == 0) {
+      if (threadIdx.x == 0 && d.nbt) *d.nbt += 1;
+      for (size_t i = threadIdx.x; i < d.zero_doubles; i += 256) d.zero_buf[i] = 0.0;
+    }
+    __syncthreads();
+    a = ac_tab; cs = ac_tab + C;
+  } else {
+    a += (size_t)q * C; cs += (size_t)q * C;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
     const size_t r = i / C4;
     const int cg = (int)(i - r * C4);
@@ -529,7 +592,7 @@ extern "C" int gkg_tm_affine_to_nchw(const float* y, const float* a, const float
   if (!y || !out || ((a == nullptr) != (c == nullptr))) return gkg_fail(GKG_ERR_NULL, "gkg_tm_affine_to_nchw: null pointer");
   if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_tm_affine_to_nchw: bad sizes");
   dim3 grid((N + 31) / 32, (C + 31) / 32, B);
-  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, C, N, img_scale);
+  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, a, c, res, out, C, N, img_scale, BnDerive{});
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "tm_affine_to_nchw_kernel");
 }
@@ -580,12 +643,12 @@ extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, co
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
-    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
+    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
   } else {
     float* o = (float*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
-    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");
@@ -602,8 +665,8 @@ extern "C" int gkg_affine_act_dual(const float* y, const float* a, const float* 
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), dim3(blocks, 1), dim3(256), 0, st, y, a, c, res, out_f32, total4, C, C, (size_t)0, row_scale, rows_per_scale, (uint16_t*)out_bf16);
-  else hipLaunchKernelGGL((affine_act_kernel<0, float>), dim3(blocks, 1), dim3(256), 0, st, y, a, c, res, out_f32, total4, C, C, (size_t)0, row_scale, rows_per_scale, (uint16_t*)out_bf16);
+  if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), dim3(blocks, 1), dim3(256), 0, st, y, a, c, res, out_f32, total4, C, C, (size_t)0, row_scale, rows_per_scale, (uint16_t*)out_bf16, BnDerive{});
+  else hipLaunchKernelGGL((affine_act_kernel<0, float>), dim3(blocks, 1), dim3(256), 0, st, y, a, c, res, out_f32, total4, C, C, (size_t)0, row_scale, rows_per_scale, (uint16_t*)out_bf16, BnDerive{});
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel (dual)");
 }
@@ -661,6 +724,46 @@ extern "C" int gkg_bn_bwd_atomic(const float* dout, const float* y, const float*
   else hipLaunchKernelGGL((bn_bwd_apply_d_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_atomic");
+}
+
+// Train-mode BN-apply straight from the projection's fp64 column sums (gkg_linear_bn_fwd / _x6 with train == 2): replaces
+// the finalize launch + gkg_affine_act / gkg_tm_affine_to_nchw.  `sums` [nb][2][C] (this call's scratch buffer, read only),
+// `zero_buf` / `zero_doubles`: the OTHER scratch buffer's dirty region, cleared here (see gkg_bn_bwd_atomic).  Writes the
+// saved a / c / mean / invstd [nb][C], updates running_mean / running_var (conv `bias` folded in) and num_batches_tracked.
+//   nchw_B == 0: out (nb, R, ...) token-major like gkg_affine_act (fp32 out; act, res, row_scale as there)
+//   nchw_B  > 0: out / res are (nchw_B, C, R / nchw_B) channel-major like gkg_tm_affine_to_nchw (nb == 1, act == 0,
+//                row_scale = one factor per image)
+extern "C" int gkg_bn_apply_train(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
+                                  float* mean, float* invstd, const float* res, float* out, int R, int C, int nb, int ldo,
+                                  size_t out_bstride, int act, int nchw_B, const float* row_scale, int rows_per_scale,
+                                  float momentum, float eps, double* zero_buf, size_t zero_doubles, void* stream) {
+  if (!y || !sums || !gamma || !beta || !a || !c || !mean || !invstd || !out)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train: running stats come in pairs");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || (act != 0 && act != 1) || (zero_doubles && !zero_buf) || nchw_B < 0)
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: bad sizes");
+  BnDerive d{sums, gamma, beta, bias, running_mean, running_var, num_batches_tracked, a, c, mean, invstd, R, momentum, eps,
+             zero_buf, zero_doubles};
+  hipStream_t st = (hipStream_t)stream;
+  if (nchw_B > 0) {
+    if (nb != 1 || act != 0 || R % nchw_B) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: channel-major output needs nb == 1, act == 0, R % B == 0");
+    const int N = R / nchw_B;
+    dim3 grid((N + 31) / 32, (C + 31) / 32, nchw_B);
+    hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, st, y, (const float*)nullptr, (const float*)nullptr, res, out, C, N,
+                       row_scale, d);
+  } else {
+    if (row_scale && rows_per_scale <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: rows_per_scale must be positive");
+    if (ldo < C || (ldo & 3) || (out_bstride & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: bad output pitch");
+    const size_t total4 = (size_t)R * (C >> 2);
+    const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    const dim3 grid(blocks, nb);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), lds, st, y, (const float*)nullptr, (const float*)nullptr, res, out, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, d);
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), lds, st, y, (const float*)nullptr, (const float*)nullptr, res, out, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, d);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_apply_train");
 }
 
 // ------------------------------------------------------------------------------------------ cross-rank (SyncBN) halves

@@ -549,7 +549,12 @@ extern "C" int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R
   a.M = R; a.N = cout; a.K = cin;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (train) {
+  if (train == 2) {                                // statistics only: the sums stay in `stats` for gkg_bn_apply_train
+    if (!stats) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd: train == 2 needs the stats scratch");
+    if ((size_t)nb * 2 * cout > (size_t)gkg_linear_stats_doubles()) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_bn_fwd: nb * cout too large for the stats scratch");
+    a.sums = stats;
+    e = launch<32, 64, 64, 2, 2, LAY_KQ, LAY_KQ, false, EPI_BNSTATS>(a, nb, st);
+  } else if (train) {
     if (!gamma || !beta || !bn_a || !bn_c || !bn_mean || !bn_invstd || !stats)
       return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd: training needs gamma, beta, the four outputs and the stats scratch");
     if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd: running stats come in pairs");

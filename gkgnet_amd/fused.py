@@ -643,16 +643,24 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
 
 
 class _BnBwdScratch:
-    """Two fp64 column-sum buffers per device for gkg_bn_bwd_atomic, used alternately: a call accumulates into the clean one
+    """Two fp64 column-sum buffers per device for gkg_bn_apply_train / gkg_bn_bwd_atomic, used alternately: a call accumulates into the clean one
     and its apply pass clears what the previous call left in the other (stream-ordered, single stream: like _stats_scratch).
-    ``dirty[i]``: doubles of buffer i that hold sums."""
+    ``dirty[i]``: doubles of buffer i that hold sums.
+
+    hipGraph captures make the host-side bookkeeping blind (a replay runs its calls without this object seeing them), so:
+    the FIRST call of every capture clears both buffers inside the capture (one memset pair per replay: the replayed
+    sequence is self-contained), and once any capture exists every EAGER call clears both buffers first (correct after any
+    interleaving of replays and eager calls; only mixed capture / eager use pays for it)."""
     DOUBLES = 2 * 4096 * 4
     _inst = {}
 
     def __init__(self, device):
-        self.bufs = [torch.zeros(self.DOUBLES, dtype=torch.float64, device=device) for _ in range(2)]
+        self.store = torch.zeros((2, self.DOUBLES), dtype=torch.float64, device=device)
+        self.bufs = [self.store[0], self.store[1]]
         self.cur = 0
         self.dirty = [0, 0]
+        self.capture_id = 0
+        self.captured = False
 
     @classmethod
     def of(cls, device):
@@ -660,9 +668,65 @@ class _BnBwdScratch:
         inst = cls._inst.get(key)
         if inst is None:
             if torch.cuda.is_current_stream_capturing():
-                raise _lib.GkgError("BN backward scratch first used inside a hipGraph capture; run one eager warm-up step first")
+                raise _lib.GkgError("BN scratch first used inside a hipGraph capture; run one eager warm-up step first")
             inst = cls._inst[key] = cls(device)
         return inst
+
+    def acquire(self, lib, n):
+        """-> (buffer to accumulate into: clean, buffer to clear, doubles to clear); the caller's kernels do the clearing."""
+        cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
+        if cap:
+            self.captured = True
+            if cap != self.capture_id:
+                self.capture_id = cap
+                self._reset()
+        elif self.captured:
+            self._reset()
+        cur, other = self.bufs[self.cur], self.bufs[self.cur ^ 1]
+        zero = self.dirty[self.cur ^ 1]
+        self.dirty[self.cur], self.dirty[self.cur ^ 1] = n, 0
+        self.cur ^= 1
+        return cur, other, zero
+
+    def _reset(self):
+        self.store.fill_(0.0)            # ONE elementwise launch (a captured memset node measured far slower than a kernel node)
+        self.dirty = [0, 0]
+
+
+_BnFwdScratch = _BnBwdScratch       # forward and backward calls alternate through the SAME pair (one reset per capture)
+
+
+def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale):
+    """Projection (statistics in its epilogue) -> BN-apply straight from the fp64 sums: two launches, no finalize kernel.
+    Returns (Y, a, c, mean, invstd)."""
+    dev = x.device
+    cur, other, zero = _BnFwdScratch.of(dev).acquire(lib, 2 * nb * cout)
+    Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
+    none10 = [None] * 10
+    if planes is not None:
+        rc = lib.gkg_linear_bn_fwd_x6(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
+                                      _ptr(cur), _stream())
+    else:
+        rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
+    _lib.check(rc, "gkg_linear_bn_fwd (statistics only)")
+    a = torch.empty(nb * cout, dtype=_F32, device=dev)
+    c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    track = bn.training and bn.track_running_stats
+    _touch_stats(bn, track)
+    _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                      _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                      _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd),
+                                      _ptr(res), _ptr(out), R, cout, nb, ldo, obs, act, nchw_B, _ptr(scale), rows_per_scale,
+                                      float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
+               "gkg_bn_apply_train")
+    return Y, a, c, mean, invstd
+
+
+def _derive_ok(bn, nb, cout, code, want16) -> bool:
+    """Train-mode statistics local to the rank, fp32 output: the BN-apply pass derives its coefficients from the projection
+    kernel's sums (no finalize launch)."""
+    return ("bn_derive" not in _DISABLED and (bn.training or not bn.track_running_stats) and _sync_group(bn) is None
+            and code == _lib.F32 and not want16 and 2 * nb * cout <= _BnBwdScratch.DOUBLES)
 
 
 def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync):
@@ -672,13 +736,10 @@ def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg
     if sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES:
         # two launches: statistics with fp64 atomics into one of two alternating scratch buffers, apply (which also clears
         # what the previous call left in the other buffer) — no partial rows, no second-stage reduction launch
-        sc = _BnBwdScratch.of(Y.device)
-        cur, other = sc.bufs[sc.cur], sc.bufs[sc.cur ^ 1]
+        cur, other, zero = _BnBwdScratch.of(Y.device).acquire(lib, 2 * nb * C)
         _lib.check(lib.gkg_bn_bwd_atomic(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
-                                         _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), sc.dirty[sc.cur ^ 1],
-                                         _stream()), "gkg_bn_bwd_atomic")
-        sc.dirty[sc.cur], sc.dirty[sc.cur ^ 1] = 2 * nb * C, 0
-        sc.cur ^= 1
+                                         _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), zero, _stream()),
+                   "gkg_bn_bwd_atomic")
         return
     ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), Y.device)
     if sync is None:
@@ -727,12 +788,18 @@ class _LinearBNAct(torch.autograd.Function):
         if own:
             x = x.contiguous()
         sync = None
-        if own:                                       # projection kernel with the BN statistics in its epilogue
+        fused_apply = own and _derive_ok(bn, 1, cout, code, want16)
+        if fused_apply:                               # projection (statistics epilogue) -> apply from the sums: 2 launches
+            Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, pf, res, out,
+                                                           cout, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale)
+        elif own:                                     # projection kernel with the BN statistics in its epilogue
             Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
         else:
             Y = _mm_t(x, W, w16)
             a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, cout, 1)
-        if nchw is None and want16 and code == _lib.F32:
+        if fused_apply:
+            pass
+        elif nchw is None and want16 and code == _lib.F32:
             # bf16 inference, channels-last chain: also emit the bf16 rounding the next block's first GEMM reads
             out16 = torch.empty((R, cout), dtype=torch.bfloat16, device=x.device)
             _lib.check(lib.gkg_affine_act_dual(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), _ptr(out16), R, cout, act,
@@ -819,7 +886,12 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         dt, code = _tm_dtype(out_lowp)
         out = torch.empty((R, cout), dtype=dt, device=U.device)
         sync = None
-        if own:
+        fused_apply = own and _derive_ok(bn, nb, co, code, False)
+        if fused_apply:
+            U = U.contiguous()
+            Y, a, c, mean, invstd = _train_apply_from_sums(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, pf, None, out,
+                                                           cout, co, act, 0, None, 0)
+        elif own:
             U = U.contiguous()
             Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, planes=pf)
         else:
@@ -831,8 +903,9 @@ class _GroupedLinearBNAct(torch.autograd.Function):
                 if Y.dtype != _F32:
                     Y = Y.float()
             a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
-        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
-                                      code, None, 0, _stream()), "gkg_affine_act")
+        if not fused_apply:
+            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
+                                          code, None, 0, _stream()), "gkg_affine_act")
         ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         ctx.gparams = (weight, gamma, beta)

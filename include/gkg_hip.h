@@ -222,6 +222,19 @@ int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                size_t dout_bstride, int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Train-mode BN-apply straight from the projection kernel's fp64 column sums (gkg_linear_bn_fwd / gkg_linear_bn_fwd_x6 with
+ * train == 2: statistics only): the consumer derives scale / shift itself — no finalize launch in between.  Every workgroup
+ * computes its channels' coefficients once, the first one per group also writes the saved a / c / mean / invstd [nb][C],
+ * updates running_mean / running_var (conv `bias` folded) and num_batches_tracked, and clears `zero_buf` (`zero_doubles`
+ * doubles): the OTHER of the caller's two alternating scratch buffers, i.e. what the previous projection accumulated into.
+ * nchw_B == 0: token-major output like gkg_affine_act (fp32); nchw_B > 0: (nchw_B, C, R / nchw_B) channel-major output and
+ * residual like gkg_tm_affine_to_nchw (nb == 1, act == 0, row_scale = one factor per image).  Same arithmetic as the
+ * finalize + apply launches it replaces. */
+int gkg_bn_apply_train(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
+                       float* mean, float* invstd, const float* res, float* out, int R, int C, int nb, int ldo,
+                       size_t out_bstride, int act, int nchw_B, const float* row_scale, int rows_per_scale, float momentum,
+                       float eps, double* zero_buf, size_t zero_doubles, void* stream);
 /* gkg_bn_bwd in two launches instead of three: the statistics pass accumulates its column sums into `sums` (fp64,
  * 2 * nb * C doubles, ZERO on entry) with atomics, the apply pass reads them, writes dgamma / dbeta and clears `zero_buf`
  * (`zero_doubles` doubles; NULL / 0: nothing).  The caller alternates between two scratch buffers and passes the region the
@@ -260,6 +273,7 @@ int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const fl
  *                      folded: it cancels in the output and is added to running_mean), saved mean / invstd and updates the
  *                      running statistics.  `stats`: gkg_linear_stats_doubles() doubles, zero on entry, zeroed again
  *                      before the call's work completes (one buffer can serve every layer on a stream).
+  *                      train == 2: statistics only — the fp64 sums stay in `stats` for gkg_bn_apply_train.
  * The backward of these layers (BN backward passes above, input and weight gradients) runs on the x6 kernels below and the
  * vendor GEMM library: fp32-MFMA dgrad / wgrad kernels with the BN backward-apply as operand prologue were built in round 2,
  * measured 20-40 % behind at this path's shapes and removed in round 3.
