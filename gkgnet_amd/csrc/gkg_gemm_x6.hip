@@ -574,8 +574,11 @@ __global__ __launch_bounds__(256) void wgrad_x6_dma_kernel(X6WgradArgs g) {
   if (split >= g.splits) return;
   const int m0 = (tile / g.ntiles) * 64, n0 = (tile % g.ntiles) * 64;
   const int r = lane & 31, h = lane >> 5;
-  const int rows_per_wave = g.rows_per_split >> 2;
-  const long long k_begin = (long long)split * g.rows_per_split + (long long)w * rows_per_wave;
+  // the last slab may be shorter (whole 128-row units: 4 waves x 2 steps x 16 rows)
+  const long long slab0 = (long long)split * g.rows_per_split;
+  const int rows_here = (int)min((long long)g.rows_per_split, (long long)g.K - slab0);
+  const int rows_per_wave = rows_here >> 2;
+  const long long k_begin = slab0 + (long long)w * rows_per_wave;
   const int T = rows_per_wave >> 4;
   const char* Az = (const char*)(g.A + (size_t)z * g.a_bstride);
   const char* Bz = (const char*)(g.B + (size_t)z * g.b_bstride);
@@ -795,22 +798,31 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
   a.M = cout; a.N = cin; a.K = R;
   a.mtiles = (cout + 63) / 64; a.ntiles = (cin + 63) / 64;
-  // about one workgroup per CU: slabs of whole 128-row units (4 waves x 2 steps x 16 rows)
-  const int tiles = a.mtiles * a.ntiles * nb, units = (R + 127) / 128;
-  int splits = (240 + tiles / 2) / tiles;
-  splits = splits < 1 ? 1 : (splits > units ? units : splits);
-  a.rows_per_split = (units + splits - 1) / splits * 128;
+  // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 KiB of LDS rings), so the
+  // launch runs in rounds of 256 workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost),
+  // the fixed cost (ring fill, LDS reduction, 4096 atomics) being worth about 6 units of streaming.
+  const int tiles = a.mtiles * a.ntiles * nb, units = R / 128;
+  int splits = 1;
+  {
+    long long best = -1;
+    for (int sp = 1; sp <= units && sp <= 4096; ++sp) {
+      const long long rounds = ((long long)tiles * sp + 255) / 256;
+      const long long cost = rounds * ((units + sp - 1) / sp + 6);
+      if (best < 0 || cost < best) { best = cost; splits = sp; }
+    }
+  }
+  a.rows_per_split = units > 0 ? (units + splits - 1) / splits * 128 : 128;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
-  // rows covered by whole slabs go through the LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and
-  // everything, when they are not) through the register-load kernel
+  // whole units go through the LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and everything, when they
+  // are not) through the register-load kernel
   const bool aligned = (cin & 3) == 0 && (cout & 3) == 0 && (ldg & 3) == 0 && (ldx & 3) == 0 && (g_bstride & 3) == 0 &&
                        (x_bstride & 3) == 0 && ((size_t)dy & 15) == 0 && ((size_t)x & 15) == 0 &&
                        (size_t)R * ldg * 4 < 0xffffffffull && (size_t)R * ldx * 4 < 0xffffffffull;
-  const int main_splits = aligned ? R / a.rows_per_split : 0;
-  if (main_splits > 0) {
+  const int main_rows = aligned ? units * 128 : 0;
+  if (main_rows > 0) {
     X6WgradArgs m = a;
-    m.K = main_splits * a.rows_per_split; m.splits = main_splits;
+    m.K = main_rows; m.splits = (main_rows + a.rows_per_split - 1) / a.rows_per_split;
     const size_t sh = 4 * 4 * 8192;
     static bool once = false;
     if (!once) {
@@ -818,11 +830,11 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
       if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_dma_kernel (attribute)");
       once = true;
     }
-    hipLaunchKernelGGL(wgrad_x6_dma_kernel, dim3((main_splits + 7) / 8 * 8 * a.mtiles * a.ntiles, nb), dim3(256), sh, st, m);
+    hipLaunchKernelGGL(wgrad_x6_dma_kernel, dim3((m.splits + 7) / 8 * 8 * a.mtiles * a.ntiles, nb), dim3(256), sh, st, m);
     e = hipGetLastError();
     if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_dma_kernel");
   }
-  const int done = main_splits * a.rows_per_split, rest = R - done;
+  const int done = main_rows, rest = R - done;
   if (rest > 0) {
     X6WgradArgs t = a;
     t.A = dy + (size_t)done * ldg; t.B = x + (size_t)done * ldx; t.K = rest;
