@@ -155,6 +155,75 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   sq[(size_t)bg * Tn + n] = q2;
 }
 
+// Small problems (a few ten thousand token-groups: the 18 x 18 stages, the label graphs): one thread per token-group leaves
+// less than one wave per SIMD, each walking three dependent c-long passes (gather, norm chain, divide + |.|^2 chain) — the
+// launch is pure latency (13-14 us at cfg2).  Cooperative form for fp32 token-major input: a 256-thread workgroup owns TK
+// tokens of one (b, g); all threads gather the tile (16 lanes per token row: 256-byte runs), every wave recomputes the
+// ordered norm chain of its token from LDS (no exchange), the divisions and the channel-major stores are spread over
+// 256 / TK channel lanes per token, and the ordered |th|^2 chain runs on the normalised tile.  Same operations in the same
+// order per value: bit-identical outputs.
+template <bool NORM, int TK>
+__global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
+  extern __shared__ float col[];          // [c][TK + 1]
+  constexpr int LP = TK + 1, CL = 256 / TK;      // channel lanes per token
+  const int tid = threadIdx.x;
+  const bool second = (int)blockIdx.x >= nbx1;
+  const PrepSet& S = second ? s2 : s1;
+  const int Tn = S.Tn;
+  const PrepStrides ps = S.ps;
+  const int n0 = ((int)blockIdx.x - (second ? nbx1 : 0)) * TK;
+  const int bg = blockIdx.y;
+  const int nt = min(TK, Tn - n0);
+  const float* tp = static_cast<const float*>(S.t) + (size_t)(bg / ps.G) * ps.sb + (size_t)(bg % ps.G) * ps.sg + (size_t)n0 * ps.sn;
+  const int c4 = c >> 2;
+  // ---- (1) gather: lane (tid & 15) walks the float4s of the rows tid >> 4, + 16, ...
+  for (int q = tid & 15; q < c4; q += 16) {
+    float4 v[TK / 16];
+#pragma unroll
+    for (int u = 0; u < TK / 16; ++u) {
+      const int tok = (tid >> 4) + 16 * u;
+      v[u] = tok < nt ? *reinterpret_cast<const float4*>(tp + (size_t)tok * ps.sn + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < TK / 16; ++u) {
+      const int tok = (tid >> 4) + 16 * u;
+      col[(4 * q + 0) * LP + tok] = v[u].x; col[(4 * q + 1) * LP + tok] = v[u].y;
+      col[(4 * q + 2) * LP + tok] = v[u].z; col[(4 * q + 3) * LP + tok] = v[u].w;
+    }
+  }
+  __syncthreads();
+  const int tok = tid % TK, cl = tid / TK;
+  const float* cp = col + tok;
+  // ---- (2) the token's ordered norm chain (every channel lane recomputes it: no exchange)
+  float den = 1.0f;
+  if (NORM) {
+    float s = 0.0f;
+#pragma unroll 8
+    for (int ch = 0; ch < c; ++ch) { const float v = cp[ch * LP]; s = __builtin_fmaf(v, v, s); }
+    den = fmaxf(sqrtf(s), 1e-12f);
+  }
+  __syncthreads();                          // everyone has read the raw tile
+  // ---- (3) normalise + store: channel lane cl takes channels cl, cl + CL, ...
+  float* op = S.th + (size_t)bg * cpad * Tn + n0 + tok;
+#pragma unroll 4
+  for (int ch = cl; ch < c; ch += CL) {
+    float v = cp[ch * LP];
+    if (NORM) v = v / den;
+    col[ch * LP + tok] = v;
+    if (tok < nt) op[(size_t)ch * Tn] = v;
+  }
+  if (tok < nt)
+    for (int chp = c + cl; chp < cpad; chp += CL) op[(size_t)chp * Tn] = 0.0f;
+  __syncthreads();
+  // ---- (4) ordered |th|^2 chain
+  if (cl == 0 && tok < nt) {
+    float q2 = 0.0f;
+#pragma unroll 8
+    for (int ch = 0; ch < c; ++ch) { const float v = cp[ch * LP]; q2 = __builtin_fmaf(v, v, q2); }
+    S.sq[(size_t)bg * Tn + n0 + tok] = q2;
+  }
+}
+
 // Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
 // waves of one SIMD do NOT overlap (they share the fp32 datapath) — every vector instruction spent on the
 // selection adds to the matrix time, so the per-candidate work is kept minimal: 3 adds for the distance
@@ -768,9 +837,31 @@ static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, 
   else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
 }
 
+template <int TK>
+static void launch_prep_coop(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
+  const int nbx1 = (s1.Tn + TK - 1) / TK;
+  const int nbx2 = s2 ? (s2->Tn + TK - 1) / TK : 0;
+  dim3 grid(nbx1 + nbx2, BG);
+  const size_t lds = (size_t)c * (TK + 1) * sizeof(float);
+  const PrepSet second = s2 ? *s2 : s1;
+  if (norm) hipLaunchKernelGGL((token_prep_coop_kernel<true, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad);
+  else hipLaunchKernelGGL((token_prep_coop_kernel<false, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad);
+}
+
+static bool prep_coop_ok(const PrepSet& s) {       // fp32 token-major rows of whole float4s, fp32 channel-major output
+  return !s.tb && s.ps.sc == 1 && ((s.ps.sn | s.ps.sg | s.ps.sb) & 3) == 0 && ((size_t)s.t & 15) == 0;
+}
+
 template <typename T>
 static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
+  if (sizeof(T) == 4 && (c & 3) == 0 && prep_coop_ok(s1) && (!s2 || prep_coop_ok(*s2)) &&
+      (size_t)(s1.Tn + (s2 ? s2->Tn : 0)) * BG <= 262144) {                          // latency-bound sizes only
+    if (c <= 192) launch_prep_coop<64>(s1, s2, BG, c, cpad, norm, st);               // <= 49 KB tile
+    else if (c <= 384) launch_prep_coop<32>(s1, s2, BG, c, cpad, norm, st);
+    else launch_prep_coop<16>(s1, s2, BG, c, cpad, norm, st);
+    return hipGetLastError();
+  }
   if (c <= 192) launch_prep_pt<T, 64>(s1, s2, BG, c, cpad, norm, st);          // <= 48 KB column block
   else if (c <= 384) launch_prep_pt<T, 32>(s1, s2, BG, c, cpad, norm, st);
   else launch_prep_pt<T, 16>(s1, s2, BG, c, cpad, norm, st);                    // c <= 600 (plan limit)
