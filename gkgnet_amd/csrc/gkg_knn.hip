@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "gkg_knn_common.h"
+#include "gkg_knn_tile.h"
 
 namespace gkg {
 
@@ -224,424 +225,6 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
   }
 }
 
-// Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
-// waves of one SIMD do NOT overlap (they share the fp32 datapath) — every vector instruction spent on the
-// selection adds to the matrix time, so the per-candidate work is kept minimal: 3 adds for the distance
-// (the -2 is folded into the staged queries, |y|^2 is broadcast with v_readlane and doubles as the
-// out-of-range mask), 4 to pack the (distance, index) key and a 2-instruction-per-slot sorted insert.  A sparse variant (per-lane clz walk over a
-// "beats my k-th best" mask with the distances parked in LDS) was measured 1.5-1.7x SLOWER: per-wave lists
-// see only a quarter of the keys, so some lane of 64 passes for almost every candidate and the divergent
-// loop serialises on LDS latency.
-// BUF > 0 — buffered selection.  The sorted insert costs 2*KD+6 vector instructions per candidate and lane, and on gfx950
-// those are paid in matrix time (fp32 MFMA and fp32 VALU do not overlap).  Once a list has seen a few dozen keys almost
-// every candidate fails against its KD-th entry, but per-lane divergence rules out skipping: some lane of 64 passes for
-// almost every candidate.  So a candidate is only TESTED against the lane's (possibly stale) KD-th distance — one compare —
-// and, when it passes, APPENDED raw (distance, index: 8 bytes) to a per-lane LDS buffer of BUF entries; the sorted inserts
-// run in wave-uniform flushes: when some lane's buffer could overflow within the next 8 candidates (and at the end of the
-// stream) every lane inserts its buffered entries, i.e. max-over-lanes(count) insert steps, and refreshes its threshold.
-// A stale threshold only admits MORE candidates than necessary; the insert itself re-decides with the full (distance,
-// index) key, so the result is bit-identical to the direct form (ties included: keys arrive in increasing index order
-// within a wave, so a later candidate equal to the KD-th entry never displaces it — the strict '<' is exact).
-// BF — the contraction on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: 16x the fp32 rate, and unlike the fp32 MFMA it
-// overlaps the selection's vector work): normalised tokens rounded to bf16, products exact, fp32 accumulation, the squared
-// norms added in fp32.  For callers under bf16 autocast, where the reference itself runs x.y^T in bf16 AND rounds the
-// product matrix to bf16 (torch_edge.py:35-51 under autocast) — this form keeps more of the fp32 answer than that.  Not
-// covered by the bit-exact index contract (the accumulation order inside the 16-deep dot product is the hardware's).
-template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false>
-__global__ __launch_bounds__(256, KD <= 12 ? 4 : (KD <= 27 ? 3 : 2)) void knn_tile_kernel(KnnArgs a) {
-  extern __shared__ float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware workgroup -> (problem, query tile) map.  Workgroups are dealt round-robin over the 8 XCDs, each with
-  // its own L2; all query tiles of one (b,g) problem stream the SAME keys, so they are given linear ids that are
-  // congruent mod 8 (same XCD) and adjacent in dispatch order: the keys are then fetched into one L2 once instead
-  // of once per query tile (measured: FETCH_SIZE 53 -> see profiles/).  Placement only affects speed.
-  const int nqt = a.nqt;
-  const int lin = blockIdx.x;
-  if (a.wg_flags && a.wg_flags[lin] == 0) return;   // clean-up pass behind knn_pf_kernel: only the tiles it flagged
-  const int xcd = lin & 7, jj = lin >> 3;
-  const int bg = (jj / nqt) * 8 + xcd;
-  if (bg >= a.BG) return;                       // grid is padded to a multiple of 8 problems (uniform exit)
-  const int split = blockIdx.z;
-  const int n0 = (jj % nqt) * QT;
-  const int N = a.N, M = a.M, cpad = a.cpad;
-
-  // ---- first key batch of this wave's first tile and the lane's |x|^2: issued before the query staging so their
-  //      L2/HBM round trip overlaps it (every workgroup of the launch runs this prologue at the same time)
-  const int lane_n = n0 + lane;
-  const int nc = lane_n < N ? lane_n : N - 1;
-  const int kk = lane >> 5;       // which k of the k-pair this lane feeds
-  const int l31 = lane & 31;
-  const float* yp = a.yh + (size_t)bg * cpad * M;
-  const int t_begin = split * a.tiles_per_split;
-  float an[KU];
-  constexpr int KB = 4;                          // BF: k16-steps per key-operand batch
-  const int cp16 = a.cp16, S16 = cp16 >> 4;
-  const uint4* ybp = BF ? reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * M : nullptr;   // [octet][key]
-  uint4 bn_[KB];
-  if (BF) {
-    const int mk0 = min((t_begin + w) * KT + l31, M - 1);
-    const uint4* y0 = ybp + (size_t)kk * M + mk0;
-#pragma unroll
-    for (int u = 0; u < KB; ++u) bn_[u] = u < S16 ? y0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
-  } else {
-    const int t0 = t_begin + w;
-    const int mk0 = min(t0 * KT + l31, M - 1);
-    const float* y0 = yp + (size_t)kk * M + mk0;
-#pragma unroll
-    for (int u = 0; u < KU; ++u) an[u] = y0[(size_t)(2 * u) * M];
-  }
-
-  // The last k-pair of every contraction adds |x|^2 and |y|^2 on the matrix pipe: keys feed (1, |y|^2), queries
-  // (|x|^2, 1), so acc = fma(|y|^2, 1, fma(1, |x|^2, acc)) — bit for bit ((|x|^2 + (-2 x.y)) + |y|^2), the contract's
-  // order — and each candidate saves two vector adds and a v_readlane (the vector pipe is the contended one).
-  // Used by the deep-batch instantiations (KU == 8: channel counts that are multiples of 16); measured a few per cent
-  // slower on the KU == 4 ones (c = 200 at 36x36), which keep the three vector adds.
-  constexpr bool FOLD = KU == 8 && !BF;
-  const float qtail0 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + l31, N - 1)];
-  const float qtail1 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + 32 + l31, N - 1)];
-  const float sqx = FOLD ? 0.0f : a.sqx[(size_t)bg * N + nc];
-
-  // ---- stage the query tile scaled by -2 (exact): xs[ch][64] = -2 * xh (zero for n >= N).
-  //      All loads of a pass are issued before the first LDS store.
-  // BF: xq[64][cp16 + 8] bf16 rows (-2 x, exact; 16 B of padding per row keeps the fragment reads conflict-free)
-  const int qpitch = (cp16 + 8) * 2;             // bytes
-  if (BF) {
-    const uint4* xbp = reinterpret_cast<const uint4*>(a.xb) + (size_t)bg * (cp16 >> 3) * N;
-    const int chunks = cp16 >> 3;                  // 16-byte chunks per query row
-    for (int i = tid; i < QT * chunks; i += 256) {
-      const int ck = i >> 6, q = i & 63;           // consecutive threads: consecutive queries of one octet (coalesced)
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n0 + q < N) v = xbp[(size_t)ck * N + n0 + q];
-      // x -> -2x on packed bf16: exponent + 1 and sign flip, zeros stay zeros (|x| <= 1 after normalisation; raw inputs
-      // near the top of the range would overflow to inf like any -2x)
-      auto m2h = [](unsigned hv) -> unsigned {
-        const unsigned e = hv & 0x7f80u;
-        if (e == 0u) return 0u;                                   // zero / denormal
-        if (e == 0x7f80u) return hv ^ 0x8000u;                     // inf / NaN keep their class
-        if (e == 0x7f00u) return ((hv ^ 0x8000u) & 0x8000u) | 0x7f80u;   // overflow -> inf
-        return (hv + 0x80u) ^ 0x8000u;
-      };
-      auto m2 = [&](unsigned wv) { return m2h(wv & 0xffffu) | (m2h(wv >> 16) << 16); };
-      v.x = m2(v.x); v.y = m2(v.y); v.z = m2(v.z); v.w = m2(v.w);
-      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(smem) + q * qpitch + 16 * ck) = v;
-    }
-  } else {
-    const float* xp = a.xh + (size_t)bg * cpad * N;
-    if ((N & 3) == 0) {
-      const int q4 = (tid & 15) * 4;               // 16 float4 per 64-query row, 16 rows per pass
-      const bool inb = n0 + q4 < N;                 // N % 4 == 0: a float4 is entirely in or out
-      const float* src = xp + (size_t)(tid >> 4) * N + n0 + q4;
-      float4* dst = reinterpret_cast<float4*>(smem + (tid >> 4) * QT + q4);
-      for (int ch = 0; ch < cpad; ch += 64) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = ch + 16 * u + (tid >> 4);
-          v[u] = (inb && row < cpad) ? *reinterpret_cast<const float4*>(src + (size_t)(ch + 16 * u) * N)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (ch + 16 * u + (tid >> 4) < cpad)
-            dst[(ch + 16 * u) * (QT / 4)] = make_float4(-2.f * v[u].x, -2.f * v[u].y, -2.f * v[u].z, -2.f * v[u].w);
-      }
-    } else {
-      for (int i = tid; i < cpad * QT; i += 1024) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = i + 256 * u;
-          const int ch = j >> 6, q = j & 63;
-          v[u] = (j < cpad * QT && n0 + q < N) ? xp[(size_t)ch * N + n0 + q] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i + 256 * u < cpad * QT) smem[i + 256 * u] = -2.f * v[u];
-      }
-    }
-  }
-  if (BUF > 0) smem[(size_t)cpad * QT + (size_t)BUF * 512 + tid] = INFINITY;   // ths (see below)
-  __syncthreads();
-
-  const int n = lane_n;
-  const float* sqy = a.sqy + (size_t)bg * M;
-
-  const bool two_blocks = n0 + 32 < N;   // wave-uniform
-
-  TopList<KD> top;
-  top.init();
-  // buffered selection state: the buffer lives behind the staged queries, [BUF][256] x {distance, index}
-  float2* cbuf = reinterpret_cast<float2*>(smem + (size_t)cpad * QT) + tid;
-  int bcnt = 0;
-  float thr = INFINITY;
-  // Shared admission bound (SHARE: the buffered form; in the guarded direct form the two extra selects per candidate cost
-  // more than the saved inserts — C = 640 / k*d = 27 at 18 x 18: 119 -> 157 us — so it keeps its own bound).  The 4 waves of the workgroup keep separate lists
-  // over disjoint key tiles of the SAME 64 queries.  With Q = ceil(KD / 4): the Q best entries of each wave's list are 4 Q
-  // >= KD distinct candidates, so the query's final KD-th distance is <= sh = max over the waves of their Q-th entry — a
-  // much tighter bound than a wave's own KD-th entry (a wave sees a quarter of the keys; its Q-th entry is about where the
-  // final KD-th will be).  Candidates with dist > sh can never reach the final list and are not inserted (dist == sh may tie
-  // in by index: kept).  Each wave publishes its Q-th distance in LDS and reads the others' without synchronisation: a
-  // stale value is an older, LARGER one, still a valid bound.  Results are bit-identical; the sorted inserts — the dominant
-  // cost of long lists — drop by about half (k*d = 36: 136 -> 73 expected inserts per lane over 576 keys).
-  constexpr bool SHARE = BUF > 0 && KD >= 16;    // 9-entry lists: Q = 3 saves too few inserts to pay for the exchange
-  constexpr int QSH = (KD + NW - 1) / NW;
-  float* ths = smem + (size_t)cpad * QT + (size_t)(BUF > 0 ? BUF : 0) * 512;      // [NW][64], behind the candidate buffer
-  float sh = INFINITY;
-  auto refresh_shared = [&]() {
-    const float mine = key_dist(top.key[QSH - 1]);                // +inf while the list holds fewer than Q entries
-    ths[w * 64 + lane] = mine;
-    float m = mine;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) m = fmaxf(m, ths[ww * 64 + lane]);
-    sh = m;
-  };
-  auto next_up = [](float v) -> float {                            // smallest float > v (v finite), +inf stays +inf
-    if (!(v < INFINITY)) return v;
-    const int b = __float_as_int(v);
-    return __int_as_float(v >= 0.0f ? b + 1 : b - 1);
-  };
-  auto flush = [&]() {
-#pragma unroll
-    for (int i = 0; i < BUF; ++i) {                 // forward branches only: a back edge makes the allocator duplicate the list
-      if (__builtin_amdgcn_ballot_w64(i < bcnt) == 0ull) break;
-      const float2 e = cbuf[i * 256];
-      const double k = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
-      top.template insert_key<false>(k);
-    }
-    bcnt = 0;
-    thr = key_dist(top.key[KD - 1]);               // +inf while the list is not full
-    if (SHARE) {
-      refresh_shared();
-      thr = fminf(thr, next_up(sh));               // strict '<' against own KD-th entry, '<=' against the shared bound
-    }
-  };
-
-  const int ktiles = (M + KT - 1) / KT;
-  const int t_end = min(t_begin + a.tiles_per_split, ktiles);
-  const int CP = cpad / 2;          // k-pairs; cpad % 8 == 0 -> CP % 4 == 0
-
-  // The first key batch of every later tile is loaded during the PREVIOUS tile's last MFMA batch (before its selection
-  // phase), so no tile starts with an exposed L2 round trip.
-  for (int t = t_begin + w; t < t_end; t += NW) {
-    const int m0 = t * KT;
-    const int mk = min(m0 + l31, M - 1);
-    const int mk_next = min((t + NW < t_end ? t + NW : t) * KT + l31, M - 1);
-    // ---- side inputs of this tile, issued first so their latency hides under the contraction:
-    //      |y|^2 of key m0+l31 (broadcast per candidate with v_readlane; MASKED_SQ sends keys past M to the end of every list) and the
-    //      positional bias of this lane's query row
-    const float sy32 = (m0 + l31 < M) ? sqy[mk] : MASKED_SQ;
-    float rp[KT];
-    if (HAS_RP && !BF) {
-      const float* rpp = a.relpos + (size_t)nc * M + m0;
-      if (m0 + KT <= M && (M & 3) == 0) {
-#pragma unroll
-        for (int j = 0; j < KT / 4; ++j) {
-          const float4 v4 = *reinterpret_cast<const float4*>(rpp + 4 * j);
-          rp[4 * j + 0] = v4.x; rp[4 * j + 1] = v4.y; rp[4 * j + 2] = v4.z; rp[4 * j + 3] = v4.w;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < KT; ++j) rp[j] = rpp[min(j, M - 1 - m0)];
-      }
-    }
-    // ---- contraction: acc0 = keys x (-2 queries[0..31]), acc1 = keys x (-2 queries[32..63]).
-    //      Key operand double-buffered in registers (KU k-pairs per batch).
-    f32x16 acc0 = {0}, acc1 = {0};
-    if (BF && HAS_RP) {
-      // bf16 form: the accumulators START from relative_pos (lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
-      // of query block row l31): the bias rides through the contraction instead of costing an add per candidate
-      const float* r0 = a.relpos + (size_t)min(n0 + l31, N - 1) * M + m0 + 4 * kk;
-      const float* r1 = a.relpos + (size_t)min(n0 + 32 + l31, N - 1) * M + m0 + 4 * kk;
-      if (m0 + KT <= M && (M & 3) == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 v0 = *reinterpret_cast<const float4*>(r0 + 8 * g);
-          const float4 v1 = *reinterpret_cast<const float4*>(r1 + 8 * g);
-          acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
-          acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
-        }
-      } else {
-        const int last = M - 1 - m0 - 4 * kk;          // offsets beyond it are clamped (those keys are masked anyway)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int off = max(min(8 * g + j, last), -(m0 + 4 * kk));
-            acc0[4 * g + j] = r0[off];
-            acc1[4 * g + j] = r1[off];
-          }
-      }
-    }
-    if (BF) {
-      // keys = A operand (lane: key l31, 8 channels 16 s + 8 kk ...), the two query blocks = B operands from LDS
-      typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-      const uint4* ykp = ybp + (size_t)kk * M + mk;
-      const uint4* ykn = ybp + (size_t)kk * M + mk_next;
-      const char* xq0 = reinterpret_cast<const char*>(smem) + l31 * qpitch + 16 * kk;
-      const char* xq1 = xq0 + 32 * qpitch;
-      for (int s0 = 0; s0 < S16; s0 += KB) {
-        const bool last = s0 + KB >= S16;                         // uniform: prefetch the NEXT tile's first batch
-        uint4 ac[KB];
-#pragma unroll
-        for (int u = 0; u < KB; ++u) ac[u] = bn_[u];
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-          const int sn = last ? u : s0 + KB + u;
-          bn_[u] = sn < S16 ? (last ? ykn : ykp)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-          if (s0 + u < S16) {
-            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, ac[u]);
-            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xq0 + 32 * (s0 + u)));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc0, 0, 0, 0);
-            if (two_blocks) {
-              const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xq1 + 32 * (s0 + u)));
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc1, 0, 0, 0);
-            }
-          }
-        }
-      }
-    } else {
-      const float* ykp = yp + (size_t)kk * M + mk;
-      const float* ykn = yp + (size_t)kk * M + mk_next;
-      const float* xsp = smem + kk * QT + l31;
-      float ac[KU];
-      if (two_blocks) {
-        for (int s = 0; s < CP; s += KU) {
-          const bool last = s + KU >= CP;                       // uniform: prefetch the NEXT tile's first batch
-          const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
-#pragma unroll
-          for (int u = 0; u < KU; ++u) ac[u] = an[u];
-#pragma unroll
-          for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
-          __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
-#pragma unroll
-          for (int u = 0; u < KU; ++u) {
-            const float b0 = xsp[(2 * (s + u)) * QT];
-            const float b1 = xsp[(2 * (s + u)) * QT + 32];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, acc1, 0, 0, 0);
-          }
-        }
-        if (FOLD) {
-          const float atail = kk ? sy32 : 1.0f;                // k-pair (1, |y|^2) x (|x|^2, 1)
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(atail, qtail0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(atail, qtail1, acc1, 0, 0, 0);
-        }
-      } else {                                    // tail query tile with <= 32 queries: one query block only
-        for (int s = 0; s < CP; s += KU) {
-          const bool last = s + KU >= CP;
-          const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
-#pragma unroll
-          for (int u = 0; u < KU; ++u) ac[u] = an[u];
-#pragma unroll
-          for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < KU; ++u)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], xsp[(2 * (s + u)) * QT], acc0, 0, 0, 0);
-        }
-        if (FOLD) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kk ? sy32 : 1.0f, qtail0, acc0, 0, 0, 0);
-      }
-    }
-    // ---- lane l needs all 32 keys of ITS query: v_permlane32_swap exchanges the 32-lane halves of the two
-    //      accumulators (vdst.hi <-> src.lo); afterwards lo = key rows (r&3)+8(r>>2), hi = those + 4.
-    //      dist = ((|x|^2 + (-2 x.y)) + |y|^2) + relpos in the reference's order; with FOLD the first two adds happened
-    //      in the contraction's last k-pair, otherwise |y|^2 is broadcast per candidate with v_readlane; it is
-    //      MASKED_SQ for keys past M, which also masks them.
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float lo[4], hi[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * g + j]),
-                                                         __float_as_uint(acc1[4 * g + j]), false, false);
-        lo[j] = __uint_as_float(sw[0]);
-        hi[j] = __uint_as_float(sw[1]);
-      }
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = 8 * g + 4 * hh + j;                              // increasing key order (tie rule)
-          float dist = hh ? hi[j] : lo[j];
-          if (BF) {
-            // bf16 form (outside the bit-exact contract): relative_pos is already inside, and the query's own |x|^2 — one
-            // constant for all of its candidates, it cannot change their order — is left out; |y|^2 stays (it also masks
-            // the keys past M and keeps zero-norm keys where they belong)
-            dist = dist + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-          } else {
-            if (!FOLD) {                                                 // FOLD: both adds already happened on the matrix pipe
-              const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-              dist = (sqx + dist) + sy;
-            }
-            if (HAS_RP) dist = dist + rp[row];
-          }
-          if (BUF > 0) {
-            if (dist < thr) {                       // NaN fails, like the insert's strict '<'
-              cbuf[bcnt * 256] = make_float2(dist, __int_as_float(m0 + row));
-              ++bcnt;
-            }
-          } else {
-            top.template insert<GUARD>(dist, m0 + row);
-          }
-        }
-      }
-      // room for the next 8 candidates?  (the stream's last group flushes unconditionally)
-      if (BUF > 0 && ((g == 3 && t + NW >= t_end) || __builtin_amdgcn_ballot_w64(bcnt > BUF - 8) != 0ull)) flush();
-    }
-  }
-
-  // ---- merge the 4 per-wave lists of each query through LDS
-  __syncthreads();                       // everyone is done with xs / dmat
-  float* lv = smem;                      // [NW][KD][64]
-  int* li = reinterpret_cast<int*>(smem + NW * KD * 64);
-#pragma unroll
-  for (int j = 0; j < KD; ++j) {
-    lv[(w * KD + j) * 64 + lane] = key_dist(top.key[j]);
-    li[(w * KD + j) * 64 + lane] = key_index(top.key[j]);
-  }
-  __syncthreads();
-  if (w != 0) return;
-
-  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-  float h0 = lv[(0 * KD) * 64 + lane], h1 = lv[(1 * KD) * 64 + lane], h2 = lv[(2 * KD) * 64 + lane],
-        h3 = lv[(3 * KD) * 64 + lane];
-  int i0 = li[(0 * KD) * 64 + lane], i1 = li[(1 * KD) * 64 + lane], i2 = li[(2 * KD) * 64 + lane],
-      i3 = li[(3 * KD) * 64 + lane];
-  const int kd = a.kd;
-  const bool partial = a.splits > 1;
-  const size_t obase = ((size_t)bg * N + nc) * a.k;
-  const size_t pbase = (((size_t)split * a.BG + bg) * N + nc) * (size_t)kd;
-  int next_rank = 0, outj = 0;
-  for (int j = 0; j < kd; ++j) {
-    // lexicographic (dist, idx) minimum of the four heads
-    int sel = 0; float bv = h0; int bi = i0;
-    if (h1 < bv || (h1 == bv && i1 < bi)) { sel = 1; bv = h1; bi = i1; }
-    if (h2 < bv || (h2 == bv && i2 < bi)) { sel = 2; bv = h2; bi = i2; }
-    if (h3 < bv || (h3 == bv && i3 < bi)) { sel = 3; bv = h3; bi = i3; }
-    if (sel == 0) { ++p0; h0 = p0 < KD ? lv[(0 * KD + p0) * 64 + lane] : INFINITY; i0 = p0 < KD ? li[(0 * KD + p0) * 64 + lane] : 0x7fffffff; }
-    else if (sel == 1) { ++p1; h1 = p1 < KD ? lv[(1 * KD + p1) * 64 + lane] : INFINITY; i1 = p1 < KD ? li[(1 * KD + p1) * 64 + lane] : 0x7fffffff; }
-    else if (sel == 2) { ++p2; h2 = p2 < KD ? lv[(2 * KD + p2) * 64 + lane] : INFINITY; i2 = p2 < KD ? li[(2 * KD + p2) * 64 + lane] : 0x7fffffff; }
-    else { ++p3; h3 = p3 < KD ? lv[(3 * KD + p3) * 64 + lane] : INFINITY; i3 = p3 < KD ? li[(3 * KD + p3) * 64 + lane] : 0x7fffffff; }
-    if (n < N) {
-      if (partial) {
-        a.part_v[pbase + j] = bv;
-        a.part_i[pbase + j] = bi;
-      } else if (j == next_rank) {
-        a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;   // non-finite distances only: stay in range
-        if (a.center) a.center[obase + outj] = n;
-        ++outj;
-        next_rank += a.dilation;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ split merge
 // One thread per partial-list ELEMENT: its final rank = its position in its own (sorted) list + the number of
 // lexicographically smaller (dist, idx) pairs in every other split's list (binary search).  Ranks are unique,
@@ -767,35 +350,6 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
   // y presence is unknown here: budget for it (upper bound) unless the shapes make it impossible
   if (make_plan(BG, c, N, M, k, dilation, true, &p) != 0) return 0;
   return p.total;
-}
-
-constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 bytes each: 32 KB per workgroup)
-
-template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false>
-static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  if (BUF > 0) {                                // candidate buffer + the 4 x 64 shared admission bounds behind the queries
-    const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 256 * sizeof(float2) + NW * 64 * sizeof(float);
-    if (lds < need) lds = need;
-  }
-  if (lds > 64 * 1024) {
-    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (ea != hipSuccess) return ea;
-  }
-  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF>), grid, dim3(256), lds, st, a);
-  return hipGetLastError();
-}
-
-// bf16 matrix-core contraction (GKG_KNN_BF16_CONTRACT): direct or buffered selection, guarded insert
-template <int KD>
-static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, bool buffered) {
-  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
-  if (buffered) {
-    if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
-    return launch_tile_v<KD, false, 4, false, KNN_BUF, true>(a, grid, lds, st);
-  }
-  if (a.relpos) return launch_tile_v<KD, true, 4, true, 0, true>(a, grid, lds, st);
-  return launch_tile_v<KD, false, 4, true, 0, true>(a, grid, lds, st);
 }
 
 // Short key streams (< 10 key tiles per wave: the 18x18 stage, label graphs over it): insert without the ballot guard.
@@ -956,15 +510,12 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 + NW * 64 * 4 <= 150 * 1024;
   const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
   const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));
+  // enough query tiles to fill the chip with single-wave workgroups (2+ waves per SIMD) and the keys not split: one list per query
+  // (measured, bf16 form, 4 waves -> 1: pvig_s stage 1 1353 -> 1257 us, pvig_m stages 1-3 6661 -> 6051, 1697 -> 1592,
+  // 801 -> 731; it loses when the per-wave query image costs occupancy: stage 2, c = 80, 458 -> 540)
+  const bool solo = p.S == 1 && (size_t)a.nqt * BG >= 2048 && (size_t)QT * (cp16 + 8) * 2 <= 8 * 1024;
   if (bf) {
-    switch (p.KD) {
-      case 9: e = launch_tile_bf<9>(a, grid, lds, st, buffered); break;
-      case 16: e = launch_tile_bf<16>(a, grid, lds, st, buffered); break;
-      case 18: e = launch_tile_bf<18>(a, grid, lds, st, buffered); break;
-      case 27: e = launch_tile_bf<27>(a, grid, lds, st, buffered); break;
-      case 36: e = launch_tile_bf<36>(a, grid, lds, st, buffered); break;
-      default: e = launch_tile_bf<64>(a, grid, lds, st, buffered); break;
-    }
+    e = launch_knn_tile_bf(a, grid, lds, p.KD, buffered, solo, st);
   } else if (buffered) {
     switch (p.KD) {
       case 9: e = launch_tile_buffered<9>(a, grid, lds, st); break;

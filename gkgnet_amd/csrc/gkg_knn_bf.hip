@@ -1,0 +1,34 @@
+// bf16-contraction instantiations of the k-NN tile kernel (GKG_KNN_BF16_CONTRACT: the bf16-autocast inference form) —
+// their own translation unit so that they compile beside the fp32 forms of gkg_knn.hip.
+#include "gkg_knn_tile.h"
+
+using namespace gkg;
+
+// bf16 matrix-core contraction (GKG_KNN_BF16_CONTRACT): direct or buffered selection, guarded insert
+template <int KD>
+static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, bool buffered, bool solo) {
+  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
+  if (buffered && solo) {                       // one wave per 64-query tile, all keys (see the kernel's NWV)
+    if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true, 1>(a, grid, lds, st);
+    return launch_tile_v<KD, false, 4, false, KNN_BUF, true, 1>(a, grid, lds, st);
+  }
+  if (buffered) {
+    if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
+    return launch_tile_v<KD, false, 4, false, KNN_BUF, true>(a, grid, lds, st);
+  }
+  if (a.relpos) return launch_tile_v<KD, true, 4, true, 0, true>(a, grid, lds, st);
+  return launch_tile_v<KD, false, 4, true, 0, true>(a, grid, lds, st);
+}
+
+namespace gkg {
+hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, bool buffered, bool solo, hipStream_t st) {
+  switch (KD) {
+    case 9: return launch_tile_bf<9>(a, grid, lds, st, buffered, solo);
+    case 16: return launch_tile_bf<16>(a, grid, lds, st, buffered, solo);
+    case 18: return launch_tile_bf<18>(a, grid, lds, st, buffered, solo);
+    case 27: return launch_tile_bf<27>(a, grid, lds, st, buffered, solo);
+    case 36: return launch_tile_bf<36>(a, grid, lds, st, buffered, solo);
+    default: return launch_tile_bf<64>(a, grid, lds, st, buffered, solo);
+  }
+}
+}  // namespace gkg

@@ -245,6 +245,55 @@ def test_eager_calls_between_replays_of_a_step_that_updates_the_weights(monkeypa
         assert torch.allclose(got.double(), want(), atol=1e-4), it
 
 
+def test_bn_scratch_protocol_under_capture_replay_and_eager_interleaving():
+    """The two-launch BN passes accumulate fp64 sums in alternating scratch buffers whose host-side cursor cannot see
+    replays: a captured forward + backward with an ODD number of BN passes (3 layers -> 3 forward + 3 backward... plus one
+    extra forward = 7), replayed, followed by eager steps, replayed again — every result must equal the eager-only one."""
+    from gkgnet_amd import fused
+    torch.manual_seed(13)
+    R, C = 640, 64
+    convs = [torch.nn.Conv2d(C, C, 1).cuda() for _ in range(3)]
+    bns = [torch.nn.BatchNorm2d(C).cuda().train() for _ in range(3)]
+    x = torch.randn(R, C, device="cuda", requires_grad=True)
+    params = [p for m in convs + bns for p in m.parameters()]
+
+    def step():
+        h = x
+        for conv, bn in zip(convs, bns):
+            h = fused._LinearBNAct.apply(h, conv.weight, conv.bias, bn.weight, bn.bias, None, bn, 1, None)
+        with torch.no_grad():                            # a seventh BN pass: odd count per step
+            fused._LinearBNAct.apply(h.detach(), convs[0].weight, convs[0].bias, bns[0].weight, bns[0].bias, None, bns[0], 0, None)
+        grads = torch.autograd.grad(h.square().mean(), [x] + params, allow_unused=True)   # conv biases: folded, no gradient
+        return [h.detach()] + [g for g in grads if g is not None]
+
+    def snapshot(vals):
+        return [v.detach().clone() for v in vals]
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ref = snapshot(step())                       # eager reference (batch statistics: identical every time)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = step()
+
+    def check(vals, what):
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(vals, ref)):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (what, i, float((a - b).abs().max()))
+
+    for it in range(3):
+        g.replay()
+        check(outs, f"replay {it}")
+        g.replay()                                      # two replays back to back
+        check(outs, f"second replay {it}")
+        for j in range(it + 1):                         # 1, 2, 3 eager steps in between: both cursor parities
+            check(step(), f"eager {it}.{j}")
+
+
 def test_random_shapes_forward_dgrad_wgrad():
     """Seeded sweep over ragged shapes (rows / channels not multiples of the tile sizes, K tails, batches)."""
     from gkgnet_amd import _lib
