@@ -112,34 +112,44 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const int ktiles = (M + KT - 1) / KT;
   // relative_pos rows of the two query blocks this lane's accumulator columns belong to
   const int nq0 = min(n0 + l31, N - 1), nq1 = min(n0 + 32 + l31, N - 1);
+  // relative_pos rows (the accumulators' initial value) and |y|^2, as 16-byte buffer loads over the workgroup's 64 rows.
+  // AHEAD: those of the NEXT tile are fetched during this tile's selection phase (see knn_tile_kernel's bf16 form) — only
+  // where the 32 extra live registers are free (lists >= 18: already 2 waves per SIMD; measured 438 -> 416 us at pvig_s
+  // stage 3).  With 12-entry lists they cost the third wave per SIMD and the kernel loses (stage 1 2230 -> 2450 us).
+  constexpr bool AHEAD = KDW > 16;
+  float4 rq0[4], rq1[4];
+  float sy_n = MASKED_SQ;
+  const size_t rp_row0 = (size_t)min(n0, N - 1) * M;
+  const size_t rp_left = ((size_t)N * M - rp_row0) * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(HAS_RP ? a.relpos + rp_row0 : a.sqy), 0, (int)(rp_left > 0x7fffffffull ? 0x7fffffffull : rp_left), 0x00020000);
+  const unsigned rp_o0 = (unsigned)(((size_t)l31 * M + 4 * kk) * sizeof(float));
+  const unsigned rp_o1 = (unsigned)(((size_t)(32 + l31) * M + 4 * kk) * sizeof(float));
+  auto fetch_side = [&](int tt) __attribute__((always_inline)) {
+    const int mm0 = tt * KT;
+    sy_n = (mm0 + l31 < M) ? sqy[min(mm0 + l31, M - 1)] : MASKED_SQ;
+    if (HAS_RP) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        rq0[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp_rsrc, (int)(rp_o0 + 32 * g), mm0 * 4, 0));
+        rq1[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp_rsrc, (int)(rp_o1 + 32 * g), mm0 * 4, 0));
+      }
+    }
+  };
+  if (AHEAD && w < ktiles) fetch_side(w);
   for (int t = w; t < ktiles; t += NW) {
     const int m0 = t * KT;
     const int mk = min(m0 + l31, M - 1);
     const int mk_next = min((t + NW < ktiles ? t + NW : t) * KT + l31, M - 1);
-    const float sy32 = (m0 + l31 < M) ? sqy[mk] : MASKED_SQ;
+    if (!AHEAD) fetch_side(t);
+    const float sy32 = sy_n;
     // accumulators start from relative_pos: lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
     f32x16 acc0, acc1;
     if (HAS_RP) {
-      const float* r0 = a.relpos + (size_t)nq0 * M + m0 + 4 * kk;
-      const float* r1 = a.relpos + (size_t)nq1 * M + m0 + 4 * kk;
-      if (m0 + KT <= M && (M & 3) == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 v0 = *reinterpret_cast<const float4*>(r0 + 8 * g);
-          const float4 v1 = *reinterpret_cast<const float4*>(r1 + 8 * g);
-          acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
-          acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
-        }
-      } else {
-        const int last = M - 1 - m0 - 4 * kk;          // offsets beyond it are clamped (those keys are masked anyway)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int off = max(min(8 * g + j, last), -(m0 + 4 * kk));
-            acc0[4 * g + j] = r0[off];
-            acc1[4 * g + j] = r1[off];
-          }
+      for (int g = 0; g < 4; ++g) {
+        acc0[4 * g] = rq0[g].x; acc0[4 * g + 1] = rq0[g].y; acc0[4 * g + 2] = rq0[g].z; acc0[4 * g + 3] = rq0[g].w;
+        acc1[4 * g] = rq1[g].x; acc1[4 * g + 1] = rq1[g].y; acc1[4 * g + 2] = rq1[g].z; acc1[4 * g + 3] = rq1[g].w;
       }
     } else {
 #pragma unroll
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
         }
       }
     }
+    if (AHEAD && t + NW < ktiles) fetch_side(t + NW);  // in flight during the selection below
     // ---- lane l <- all 32 keys of query n0 + l (permlane swap as in knn_tile_kernel); approximate distance (without the
     //      query's own |x|^2, a per-query constant) = acc + |y|^2, keys past M masked by MASKED_SQ
 #pragma unroll
