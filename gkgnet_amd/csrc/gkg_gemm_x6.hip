@@ -798,15 +798,18 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
   a.M = cout; a.N = cin; a.K = R;
   a.mtiles = (cout + 63) / 64; a.ntiles = (cin + 63) / 64;
-  // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 KiB of LDS rings), so the
-  // launch runs in rounds of 256 workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost),
-  // the fixed cost (ring fill, LDS reduction, 4096 atomics) being worth about 6 units of streaming.
+  // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 KiB of LDS rings) and slab s
+  // runs with all its tiles on XCD s % 8 (its rows are fetched into that L2 once), so an XCD's 32 CUs work in rounds over
+  // tiles x ceil(slabs / 8) workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost), the
+  // fixed cost (ring fill, LDS reduction, 4096 atomics) being worth about 6 units of streaming.  (Counting rounds over the
+  // whole chip instead put 36 workgroups on two XCDs at 6 tiles x 42 slabs: 245 -> 393 us at 663 552 x 160 -> 80.)
   const int tiles = a.mtiles * a.ntiles * nb, units = R / 128;
   int splits = 1;
   {
     long long best = -1;
     for (int sp = 1; sp <= units && sp <= 4096; ++sp) {
-      const long long rounds = ((long long)tiles * sp + 255) / 256;
+      const long long per_xcd = (long long)tiles * ((sp + 7) / 8);
+      const long long rounds = (per_xcd + 31) / 32;
       const long long cost = rounds * ((units + sp - 1) / sp + 6);
       if (best < 0 || cost < best) { best = cost; splits = sp; }
     }

@@ -237,25 +237,32 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
 X6_WGRAD = "x6_wgrad" not in _DISABLED
 
 
-def _x6_wgrad_ok(dY, x) -> bool:
+def _x6_wgrad_ok(dY, x, nb=1) -> bool:
     """The streaming x6 weight-gradient kernel (gkg_linear_wgrad_x6: both operands split in registers, each wave copies its
-    own rows through a private LDS ring by DMA; no operand sharing between workgroups) pays for long token axes under small
-    outputs — GKGNet-576's stage-1/2 projections (R = 663 552 / 165 888 rows, 80-640 channels): 179 vs 527 us at 80 -> 80
-    and 162 vs 472 at 320 -> 160 against the vendor library's default split-K; inside the cfg4 train step, where TunableOp
-    has picked the vendor kernels, it TIES them (16 launches, 4.1 ms; step 102.5 vs 102.7-103.5 ms) — kept on so that these
-    layers do not depend on a tuning pass.  It loses once the output needs many 64 x 64 tiles, each of which re-streams the
-    rows (41 472 x 400 -> 400: 49 tiles).  GKG_GEMM_MATH=x6all: every fp32 shape; GKG_DISABLE=x6_wgrad: never."""
+    own rows through a private LDS ring by DMA; no operand sharing between workgroups; row slabs placed per XCD).  Measured
+    inside the cfg2 step (tools/prof_wgrad.sh, us, x6 vs vendor kernel + its partial-sum launch, library-default /
+    TunableOp-selected): 10 368 x 640 -> 320: 42.6 vs 53.7 / 46.1; 10 368 x 320 -> 320: 22.3 vs 51.2 / 27.8; 2 560 x 320 ->
+    320 (25 tiles): 10.3 vs 17.2 / 16.5; the grouped 10 368 x 4 x (160 -> 160): 44.2 vs 52.0 / 34.5; it loses on short
+    contractions under many output tiles (2 560 x 1280 <-> 320, 100
+    tiles: 37.9 vs 24.6 / 23.0; 2 560 x 640 -> 320, 50 tiles: 19.3 vs 18.7 / 12.7).  Cold (tools/bench_x6.py cfg4) it is
+    ahead of the library's default split-K at every GKGNet-576 shape from 41 472 rows up (158 vs 222 us at 400 -> 400,
+    417 vs 529 at 400 -> 1600, 108 vs 172 at 165 888 x 160 -> 160).  GKG_GEMM_MATH=x6all: every fp32 shape;
+    GKG_DISABLE=x6_wgrad: never; GKG_DETERMINISTIC=1: never (fp32 atomics: run-dependent summation order)."""
     if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none" or dY.dtype != _F32 or x.dtype != _F32:
         return False
-    R, cout, cin = x.shape[0], dY.shape[1], x.shape[1]
-    if max(dY.stride(0), x.stride(0)) * 4 * 16 > 0x7fffffff:          # gkg_linear_wgrad_x6's row-pitch limit
+    R, cout, cin = x.shape[-2], dY.shape[-1], x.shape[-1]
+    if max(dY.stride(-2), x.stride(-2)) * 4 * 16 > 0x7fffffff or nb > 64:   # gkg_linear_wgrad_x6's row-pitch / batch limits
         return False
-    if DETERMINISTIC:                          # fp32 atomics: run-dependent summation order
+    if DETERMINISTIC or not X6_WGRAD:
         return False
     if GEMM_MATH == "x6all":
         return True
-    tiles = ((cout + 63) // 64) * ((cin + 63) // 64)
-    return X6_WGRAD and R >= 65536 and tiles <= 32
+    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
+    if _vendor_tuned():
+        # against TunableOp-selected vendor kernels only the few-tile un-grouped shapes stay ahead once the output's memset is
+        # counted (step 0.968 -> 0.977 ms with the full rule, same box; the grouped product: 44.2 vs 29.1 + 5.4 us)
+        return nb == 1 and tiles <= 32 and R >= 2048
+    return R >= 8192 or (R >= 2048 and tiles <= 32)
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
@@ -288,8 +295,17 @@ def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None) -> torch.Tensor:
     nb, R, co = dY.shape
     ci = U.shape[2]
     S = 4
-    if out is not None and out.dtype != dY.dtype:
+    if out is not None and (out.dtype != dY.dtype or not out.is_contiguous()):
         out = None
+    if (_x6_wgrad_ok(dY, U, nb) and dY.stride(2) == 1 and U.stride(2) == 1
+            and all(t.stride(d) % 4 == 0 for t in (dY, U) for d in (0, 1))):
+        if out is None:
+            out = torch.zeros((nb, co, ci), dtype=_F32, device=U.device)
+        else:
+            out.zero_()
+        _lib.check(_lib.load().gkg_linear_wgrad_x6(_ptr(dY), dY.stride(1), dY.stride(0), _ptr(U), U.stride(1), U.stride(0), _ptr(out),
+                                                   R, ci, co, nb, _stream()), "gkg_linear_wgrad_x6 (grouped)")
+        return out
     if R >= 4096 and R % S == 0:
         part = torch.bmm(dY.reshape(nb * S, R // S, co).transpose(1, 2), U.reshape(nb * S, R // S, ci))
         return part.view(nb, S, co, ci).sum(1) if out is None else torch.sum(part.view(nb, S, co, ci), 1, out=out)

@@ -245,6 +245,31 @@ def test_eager_calls_between_replays_of_a_step_that_updates_the_weights(monkeypa
         assert torch.allclose(got.double(), want(), atol=1e-4), it
 
 
+def test_grouped_weight_gradient_on_the_streaming_kernel(monkeypatch):
+    """fused._wgrad_grouped through gkg_linear_wgrad_x6 with a batch of groups (the grouped 1x1 projection's dW), written
+    into a caller-provided slot, against an fp64 evaluation; and the dispatch rule's two legs."""
+    from gkgnet_amd import fused
+    torch.manual_seed(21)
+    nb, R, co, ci = 4, 2304 + 40, 160, 96                     # whole 128-row units + a ragged rest
+    dY = torch.randn(nb, R, co, device="cuda")
+    U = torch.randn(nb, R, ci, device="cuda")
+    want = torch.bmm(dY.double().transpose(1, 2), U.double())
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    slot = torch.full((nb, co, ci), 7.0, device="cuda")      # stale contents must not leak into the sum
+    got = fused._wgrad_grouped(dY, U, slot)
+    assert got.data_ptr() == slot.data_ptr()
+    scale = (dY.double().abs().transpose(1, 2) @ U.double().abs()).max()
+    assert float((got.double() - want).abs().max() / scale) < 2e-6
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6")
+    monkeypatch.setattr(fused, "_vendor_tuned", lambda: False)
+    assert fused._x6_wgrad_ok(dY, U, nb) is True              # library-default GEMM selection: R >= 2048, 24 tiles
+    monkeypatch.setattr(fused, "_vendor_tuned", lambda: True)
+    assert fused._x6_wgrad_ok(dY, U, nb) is False             # TunableOp-selected vendor kernels win the grouped product
+    assert fused._x6_wgrad_ok(dY[0], U[0]) is True            # ... but not the few-tile un-grouped one
+    monkeypatch.setattr(fused, "DETERMINISTIC", True)
+    assert fused._x6_wgrad_ok(dY[0], U[0]) is False           # fp32 atomics: never under GKG_DETERMINISTIC
+
+
 def test_bn_scratch_protocol_under_capture_replay_and_eager_interleaving():
     """The two-launch BN passes accumulate fp64 sums in alternating scratch buffers whose host-side cursor cannot see
     replays: a captured forward + backward with an ODD number of BN passes (3 layers -> 3 forward + 3 backward... plus one
