@@ -419,6 +419,7 @@ struct X6WgradArgs {
   float* C;  size_t c_bstride;  int ldc;             // dW (nb, M, N), zero on entry
   int M, N, K;
   int mtiles, ntiles, splits, rows_per_split;        // rows_per_split % 128 == 0
+  int swap;                                          // wide kernel: A / B roles exchanged, C written transposed
 };
 
 typedef unsigned x6_u32x4 __attribute__((ext_vector_type(4)));
@@ -683,6 +684,182 @@ __global__ __launch_bounds__(256) void wgrad_x6_dma_kernel(X6WgradArgs g) {
   }
 }
 
+// ---- wide form: 64 x 128 output tile per workgroup --------------------------------------------------------------------
+// Same decomposition (a workgroup = one tile of dW x one slab of rows, its 4 waves a quarter of the slab each, private LDS
+// rings filled by DMA, no barriers in the loop), but a wave owns 2 x 4 blocks of 32 x 32: six fragments per 16-row step feed
+// 48 MFMAs, so the split is 264 / 48 = 5.5 vector instructions per MFMA — inside what a bf16 MFMA's shadow hides
+// (tools/ubench/mfma_bf16_fill) — where the 64 x 64 form needs 176 / 24 = 7.3 and runs at ~2.6x its matrix time.  The
+// products are issued product-major over the eight accumulators (a dependent MFMA is 8 slots away), small terms first, all
+// into ONE accumulator per block: 128 accumulator registers + 2 x 48 raw + 2 x 72 split fragments fit the 512 of a
+// one-wave-per-SIMD kernel.  Ring: 3 stages x (16 x 64 of dY | 16 x 128 of X) x 4 B = 36 KiB per wave, 144 KiB per workgroup;
+// step s issues the DMA of step s + 3 into the stage whose rows were read two steps ago, waits (counted vmcnt) for step
+// s + 2 and reads its fragments, which are split during step s + 1.
+typedef x6_u32x4 X6WFragW[6][3];              // [A0, A1, B0, B1, B2, B3][hi, mid, lo]
+
+template <int I>
+__device__ __forceinline__ void x6ww_op(float (&raw)[6][8], X6WFragW& fn, unsigned (&t0)[4], unsigned (&t1)[4]) {
+  constexpr int blk = I / 44, u = I % 44, p = u & 3, o = u >> 2;
+  float& x0 = raw[blk][2 * p]; float& x1 = raw[blk][2 * p + 1];
+  unsigned w;
+  if constexpr (o == 0) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][0][p] = w; }
+  if constexpr (o == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0[p]) : "v"(fn[blk][0][p]));
+  if constexpr (o == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1[p]) : "v"(fn[blk][0][p]));
+  if constexpr (o == 3) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(t0[p]));
+  if constexpr (o == 4) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x1) : "v"(t1[p]));
+  if constexpr (o == 5) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][1][p] = w; }
+  if constexpr (o == 6) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0[p]) : "v"(fn[blk][1][p]));
+  if constexpr (o == 7) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1[p]) : "v"(fn[blk][1][p]));
+  if constexpr (o == 8) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(t0[p]));
+  if constexpr (o == 9) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x1) : "v"(t1[p]));
+  if constexpr (o == 10) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][2][p] = w; }
+}
+template <int I, int END>
+__device__ __forceinline__ void x6ww_ops(float (&raw)[6][8], X6WFragW& fn, unsigned (&t0)[4], unsigned (&t1)[4]) {
+  if constexpr (I < END && I < 264) { x6ww_op<I>(raw, fn, t0, t1); x6ww_ops<I + 1, END>(raw, fn, t0, t1); }
+}
+// MFMA slot SI (0..47) of a 16-row step: product t = SI / 8 (small terms first, hi x hi last), block (i, j) = SI % 8;
+// then its share (5 or 6) of the next step's 264 split instructions
+template <int SI, bool SPLIT>
+__device__ __forceinline__ void x6ww_slots(const X6WFragW& fc, X6WFragW& fn, x6_f32x16 (&acc)[2][4], float (&raw)[6][8],
+                                           unsigned (&t0)[4], unsigned (&t1)[4]) {
+  if constexpr (SI < 48) {
+    constexpr int t = SI / 8, i = (SI % 8) / 4, j = SI % 4;
+    constexpr int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+    constexpr int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x6w_operand(fc[i][pa]), x6w_operand(fc[2 + j][pb]), acc[i][j], 0, 0, 0);
+    if constexpr (SPLIT) x6ww_ops<(SI * 11) / 2, ((SI + 1) * 11) / 2>(raw, fn, t0, t1);
+    __builtin_amdgcn_sched_barrier(0);
+    x6ww_slots<SI + 1, SPLIT>(fc, fn, acc, raw, t0, t1);
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_x6_wide_kernel(X6WgradArgs g) {
+  extern __shared__ float wlds[];               // [4 waves][3 stages][16 x 64 | 16 x 128], then reused for the reduce
+  constexpr int STAGE_BYTES = 16 * 192 * 4, STAGE_F = 16 * 192;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.y;
+  const int ntile = g.mtiles * g.ntiles;
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+  if (split >= g.splits) return;
+  const int m0 = (tile / g.ntiles) * 64, n0 = (tile % g.ntiles) * 128;
+  const int r = lane & 31, h = lane >> 5;
+  const long long slab0 = (long long)split * g.rows_per_split;
+  const int rows_here = (int)min((long long)g.rows_per_split, (long long)g.K - slab0);
+  const int rows_per_wave = rows_here >> 2;
+  const long long k_begin = slab0 + (long long)w * rows_per_wave;
+  const int T = rows_per_wave >> 4;              // even, >= 2
+  const char* Az = (const char*)(g.A + (size_t)z * g.a_bstride);
+  const char* Bz = (const char*)(g.B + (size_t)z * g.b_bstride);
+  const unsigned lds0 = (unsigned)(size_t)wlds + w * (3 * STAGE_BYTES);
+
+  // DMA pieces of 1 KiB: dY 4 x (4 rows x 256 B), X 8 x (2 rows x 512 B); columns past M / N come from a clamped address
+  // and are zeroed after the LDS read
+  const int ca = min(m0 + 4 * (lane & 15), g.M - 4), cb = min(n0 + 4 * (lane & 31), g.N - 4);
+  const unsigned dA = (unsigned)(((size_t)(lane >> 4) * g.lda + ca) * 4), dB = (unsigned)(((size_t)(lane >> 5) * g.ldb + cb) * 4);
+  const unsigned strideA = (unsigned)g.lda * 16u, strideB = (unsigned)g.ldb * 8u;
+  auto dma = [&](int s) __attribute__((always_inline)) {
+    const long long row0 = k_begin + 16ll * s;
+    const char* ab = Az + row0 * g.lda * 4;
+    const char* bb = Bz + row0 * g.ldb * 4;
+    const unsigned dst = lds0 + (s % 3) * STAGE_BYTES;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) x6_dma16(ab, dA + p * strideA, dst + p * 1024);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) x6_dma16(bb, dB + p * strideB, dst + 4096 + p * 1024);
+  };
+  bool va[2], vb[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) va[i] = m0 + 32 * i + r < g.M;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vb[j] = n0 + 32 * j + r < g.N;
+  const bool tail = m0 + 64 > g.M || n0 + 128 > g.N;                                          // uniform
+  auto readfr = [&](float (&raw)[6][8], int s) __attribute__((always_inline)) {
+    const float* ba = wlds + w * (3 * STAGE_F) + (s % 3) * STAGE_F + (8 * h) * 64 + r;
+    const float* bb = wlds + w * (3 * STAGE_F) + (s % 3) * STAGE_F + 1024 + (8 * h) * 128 + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      raw[0][j] = ba[j * 64];
+      raw[1][j] = ba[j * 64 + 32];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) raw[2 + q][j] = bb[j * 128 + 32 * q];
+    }
+    if (tail) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        raw[0][j] = va[0] ? raw[0][j] : 0.f; raw[1][j] = va[1] ? raw[1][j] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[2 + q][j] = vb[q] ? raw[2 + q][j] : 0.f;
+      }
+    }
+  };
+  float raw0[6][8], raw1[6][8];
+  X6WFragW fr0, fr1;
+  unsigned t0[4], t1[4];
+  x6_f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // prologue: DMA steps 0..2; read steps 0 and 1; split step 0
+  dma(0);
+  dma(1);
+  if (T > 2) dma(2);
+  if (T > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  readfr(raw0, 0);
+  readfr(raw1, 1);
+  x6ww_ops<0, 264>(raw0, fr0, t0, t1);
+  // after step s: DMA step s + 3 (its stage held step s, read two steps ago), wait for step s + 2, read it
+  auto tailwork = [&](float (&rawn)[6][8], int s) __attribute__((always_inline)) {
+    if (s + 3 < T) dma(s + 3);
+    if (s + 2 < T) {
+      if (s + 3 < T) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      readfr(rawn, s + 2);
+    }
+  };
+  for (int s = 0; s + 2 < T; s += 2) {
+    x6ww_slots<0, true>(fr0, fr1, acc, raw1, t0, t1);          // step s: splits step s+1 (raw1) into fr1
+    tailwork(raw0, s);                                            // raw0 <- step s+2
+    x6ww_slots<0, true>(fr1, fr0, acc, raw0, t0, t1);          // step s+1: splits step s+2 (raw0) into fr0
+    tailwork(raw1, s + 1);                                        // raw1 <- step s+3
+  }
+  x6ww_slots<0, true>(fr0, fr1, acc, raw1, t0, t1);
+  x6ww_slots<0, false>(fr1, fr0, acc, raw0, t0, t1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  __syncthreads();                              // every wave is done with its ring: reuse the LDS for the reduction
+  float* red = wlds;                            // [4][64][129]: odd pitch, so that the transposed walk below is conflict-free
+  constexpr int RP = 129, RW = 64 * RP;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h, col = 32 * j + r;
+        red[w * RW + row * RP + col] = acc[i][j][q];
+      }
+  __syncthreads();
+  float* C = g.C + (size_t)z * g.c_bstride;
+#pragma unroll 4
+  for (int u = 0; u < 32; ++u) {
+    // consecutive threads walk the dimension that is contiguous in dW: the tile's columns, or (roles exchanged) its rows
+    const int e = tid + 256 * u;
+    const int row = g.swap ? (e & 63) : (e >> 7), col = g.swap ? (e >> 6) : (e & 127);
+    const int o = row * RP + col;
+    const float v = (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]);
+    if (m0 + row < g.M && n0 + col < g.N) {
+      float* dst = g.swap ? C + (size_t)(n0 + col) * g.ldc + m0 + row : C + (size_t)(m0 + row) * g.ldc + n0 + col;
+      __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
 inline size_t x6_plane_units(int n, int k, int nb) {       // uint4 units of one orientation: B[n][k]
   return (size_t)nb * 3 * ((k + 31) / 32 * 4) * ((n + X6_NPAD - 1) / X6_NPAD * X6_NPAD);
@@ -798,12 +975,28 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
   a.M = cout; a.N = cin; a.K = R;
   a.mtiles = (cout + 63) / 64; a.ntiles = (cin + 63) / 64;
-  // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 KiB of LDS rings) and slab s
-  // runs with all its tiles on XCD s % 8 (its rows are fetched into that L2 once), so an XCD's 32 CUs work in rounds over
-  // tiles x ceil(slabs / 8) workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost), the
-  // fixed cost (ring fill, LDS reduction, 4096 atomics) being worth about 6 units of streaming.  (Counting rounds over the
-  // whole chip instead put 36 workgroups on two XCDs at 6 tiles x 42 slabs: 245 -> 393 us at 663 552 x 160 -> 80.)
-  const int tiles = a.mtiles * a.ntiles * nb, units = R / 128;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  // whole 128-row units go through an LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and everything,
+  // when they are not) through the register-load kernel
+  const bool aligned = (cin & 3) == 0 && (cout & 3) == 0 && (ldg & 3) == 0 && (ldx & 3) == 0 && (g_bstride & 3) == 0 &&
+                       (x_bstride & 3) == 0 && ((size_t)dy & 15) == 0 && ((size_t)x & 15) == 0 &&
+                       (size_t)R * ldg * 4 < 0xffffffffull && (size_t)R * ldx * 4 < 0xffffffffull;
+  // 64 x 128 tiles (wgrad_x6_wide_kernel) when one of the two widths pads to 128 at no more than a tenth of extra work
+  // (measured in the cfg2 step, wide vs 64 x 64: 640 -> 320 42.6 -> 35.6 us, 1280 -> 320 37.9 -> 30.9, but 320 -> 320 at
+  // 20 % padding 22.3 -> 24.3); the 128-wide side is cin, or — roles of the operands exchanged, dW written transposed — cout
+  const long long padn = (long long)((cin + 127) / 128) * 128 * 100 / ((long long)a.ntiles * 64);
+  const long long padm = (long long)((cout + 127) / 128) * 128 * 100 / ((long long)a.mtiles * 64);
+  const bool wide = aligned && (padn <= 110 || padm <= 110);
+  const bool swap = wide && padm < padn;
+  const int main_mtiles = !wide ? a.mtiles : (swap ? a.ntiles : a.mtiles);
+  const int main_ntiles = !wide ? a.ntiles : (swap ? (cout + 127) / 128 : (cin + 127) / 128);
+  // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 / 144 KiB of LDS rings) and
+  // slab s runs with all its tiles on XCD s % 8 (its rows are fetched into that L2 once), so an XCD's 32 CUs work in rounds
+  // over tiles x ceil(slabs / 8) workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost), the
+  // fixed cost (ring fill, LDS reduction, the tile's atomics) being worth about 6 units of streaming.  (Counting rounds over
+  // the whole chip instead put 36 workgroups on two XCDs at 6 tiles x 42 slabs: 245 -> 393 us at 663 552 x 160 -> 80.)
+  const int tiles = main_mtiles * main_ntiles * nb, units = R / 128;
   int splits = 1;
   {
     long long best = -1;
@@ -815,27 +1008,29 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
     }
   }
   a.rows_per_split = units > 0 ? (units + splits - 1) / splits * 128 : 128;
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipSuccess;
-  // whole units go through the LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and everything, when they
-  // are not) through the register-load kernel
-  const bool aligned = (cin & 3) == 0 && (cout & 3) == 0 && (ldg & 3) == 0 && (ldx & 3) == 0 && (g_bstride & 3) == 0 &&
-                       (x_bstride & 3) == 0 && ((size_t)dy & 15) == 0 && ((size_t)x & 15) == 0 &&
-                       (size_t)R * ldg * 4 < 0xffffffffull && (size_t)R * ldx * 4 < 0xffffffffull;
   const int main_rows = aligned ? units * 128 : 0;
   if (main_rows > 0) {
     X6WgradArgs m = a;
-    m.K = main_rows; m.splits = (main_rows + a.rows_per_split - 1) / a.rows_per_split;
-    const size_t sh = 4 * 4 * 8192;
-    static bool once = false;
-    if (!once) {
-      e = hipFuncSetAttribute((const void*)wgrad_x6_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_dma_kernel (attribute)");
-      once = true;
+    m.mtiles = main_mtiles; m.ntiles = main_ntiles;
+    if (swap) {                                    // the kernel's "A" (64-wide side) is x, its "B" (128-wide side) dy
+      m.A = x; m.a_bstride = x_bstride; m.lda = ldx; m.M = cin;
+      m.B = dy; m.b_bstride = g_bstride; m.ldb = ldg; m.N = cout;
+      m.swap = 1;
     }
-    hipLaunchKernelGGL(wgrad_x6_dma_kernel, dim3((m.splits + 7) / 8 * 8 * a.mtiles * a.ntiles, nb), dim3(256), sh, st, m);
+    m.K = main_rows; m.splits = (main_rows + a.rows_per_split - 1) / a.rows_per_split;
+    const size_t sh = wide ? (size_t)4 * 3 * 16 * 192 * 4 : (size_t)4 * 4 * 8192;
+    static bool once[2] = {false, false};
+    const void* fn = wide ? (const void*)wgrad_x6_wide_kernel : (const void*)wgrad_x6_dma_kernel;
+    if (!once[wide]) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel (attribute)");
+      once[wide] = true;
+    }
+    const dim3 grid((m.splits + 7) / 8 * 8 * m.mtiles * m.ntiles, nb);
+    if (wide) hipLaunchKernelGGL(wgrad_x6_wide_kernel, grid, dim3(256), sh, st, m);
+    else hipLaunchKernelGGL(wgrad_x6_dma_kernel, grid, dim3(256), sh, st, m);
     e = hipGetLastError();
-    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_dma_kernel");
+    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel");
   }
   const int done = main_rows, rest = R - done;
   if (rest > 0) {

@@ -261,8 +261,8 @@ def _x6_wgrad_ok(dY, x, nb=1) -> bool:
     if _vendor_tuned():
         # against TunableOp-selected vendor kernels only the few-tile un-grouped shapes stay ahead once the output's memset is
         # counted (step 0.968 -> 0.977 ms with the full rule, same box; the grouped product: 44.2 vs 29.1 + 5.4 us)
-        return nb == 1 and tiles <= 32 and R >= 2048
-    return R >= 8192 or (R >= 2048 and tiles <= 32)
+        return nb == 1 and tiles <= 64 and R >= 2048
+    return R >= 8192 or (R >= 2048 and tiles <= 64)
 
 
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
