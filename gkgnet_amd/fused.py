@@ -230,7 +230,9 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
         # 23.7 + 11 us with a TunableOp-selected kernel (tie) but 32.9 + 11 us with the library's default selection:
         # measured in the step, x6 here costs the tuned leg 12 us and saves the untuned leg 20 us
         # (the grouped input gradient likewise: 28.5 us against 23.8 tuned / 34.2 untuned)
-        return R >= 8192 and not _vendor_tuned()
+        # ... and from 32 768 rows up (GKGNet-576 stages 1-3) x6 is ahead of the tuned kernels too: --workload stage3
+        # 3.39 -> 3.28 ms/step, cfg4 train step 97.9 -> 97.2 ms (same box)
+        return R >= 8192 and (not _vendor_tuned() or R >= 32768)
     return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
 
 
@@ -261,7 +263,7 @@ def _x6_wgrad_ok(dY, x, nb=1) -> bool:
     if _vendor_tuned():
         # against TunableOp-selected vendor kernels only the few-tile un-grouped shapes stay ahead once the output's memset is
         # counted (step 0.968 -> 0.977 ms with the full rule, same box; the grouped product: 44.2 vs 29.1 + 5.4 us)
-        return nb == 1 and tiles <= 64 and R >= 2048
+        return (nb == 1 and tiles <= 64 and R >= 2048) or R >= 32768   # long token axes: ahead of the tuned kernels too (stage 3)
     return R >= 8192 or (R >= 2048 and tiles <= 64)
 
 
