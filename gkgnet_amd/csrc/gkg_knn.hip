@@ -484,6 +484,15 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
   a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
+  a.rp_major = 0;
+  // bf16 form with a positional bias at least twice the size of the keys it meets (64 x 4 B of relative_pos against
+  // 2 x cp16 B of a key per (query tile, key) pair, i.e. c <= 64) and enough query tiles to spread over the XCDs: map the
+  // workgroups relative_pos-major (see the kernel).  Measured (tools/bench_knn_bf.py, us): pvig_m stages 1-2 6031 -> 5101,
+  // 1590 -> 1487; pvig_s stage 1 1259 -> 1187.
+  if (bf && relpos && !pf && a.nqt >= 64 && BG >= 8 && (size_t)QT * 4 >= (size_t)cp16 * 2 * 2) {
+    a.rp_major = 1;
+    grid = dim3((unsigned)(((a.nqt + 7) / 8) * 8 * BG), 1, p.S);
+  }
   if (pf) {
     a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
     a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;

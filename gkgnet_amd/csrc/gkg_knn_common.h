@@ -104,6 +104,7 @@ struct KnnArgs {
   int BG, cpad, N, M, k, dilation, kd;
   int splits, tiles_per_split;
   int nqt;              // query tiles per problem
+  int rp_major;         // workgroup -> (problem, query tile) map: 1 = all problems of one query tile adjacent on one XCD
   const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies (prefilter: hi planes)
   const uint16_t* yb;
   int cp16;
