@@ -9,8 +9,13 @@ template <int KD>
 static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, bool buffered, bool solo) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   if (buffered && solo) {                       // one wave per 64-query tile, all keys (see the kernel's NWV)
-    if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true, 1>(a, grid, lds, st);
-    return launch_tile_v<KD, false, 4, false, KNN_BUF, true, 1>(a, grid, lds, st);
+    // 9-entry lists: 12-entry candidate buffers (flush when a lane holds more than 4) — with one short list per query the
+    // fresher threshold is worth more than fuller flushes (cfg3 forward, k-NN kernels 5.08 -> 4.90 ms); longer lists keep
+    // 16 (cfg5, k*d = 18 / 36: 29.8 -> 33.2 ms with 12).  Measured on the models' own activations: random tokens
+    // (tools/bench_knn_bf.py) rank the two the other way round for k*d = 18.
+    constexpr int SBUF = KD <= 12 ? 12 : KNN_BUF;
+    if (a.relpos) return launch_tile_v<KD, true, 4, false, SBUF, true, 1>(a, grid, lds, st);
+    return launch_tile_v<KD, false, 4, false, SBUF, true, 1>(a, grid, lds, st);
   }
   if (buffered) {
     if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
