@@ -18,8 +18,9 @@ static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStr
     return launch_tile_v<KD, false, 4, false, SBUF, true, 1>(a, grid, lds, st);
   }
   if (buffered) {
-    if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
-    return launch_tile_v<KD, false, 4, false, KNN_BUF, true>(a, grid, lds, st);
+    constexpr int WBUF = KD <= 12 ? 12 : KNN_BUF;
+    if (a.relpos) return launch_tile_v<KD, true, 4, false, WBUF, true>(a, grid, lds, st);
+    return launch_tile_v<KD, false, 4, false, WBUF, true>(a, grid, lds, st);
   }
   if (a.relpos) return launch_tile_v<KD, true, 4, true, 0, true>(a, grid, lds, st);
   return launch_tile_v<KD, false, 4, true, 0, true>(a, grid, lds, st);
