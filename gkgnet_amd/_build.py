@@ -30,7 +30,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    headers = [os.path.join(CSRC, "gkg_common.h"), os.path.join(CSRC, "gkg_knn_common.h"), os.path.join(INCLUDE, "gkg_hip.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "gkg_hip.h")]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "gkg_knn_common.h"
+#include "gkg_topk_merge.h"
 
 namespace gkg {
 
@@ -199,7 +200,24 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
     const int b = __float_as_int(v);
     return __int_as_float(v >= 0.0f ? b + 1 : b - 1);
   };
+  // Lists of 16+ entries with a 16-entry buffer: when some lane holds more than 3 candidates the whole batch goes through a
+  // merge network (sort the 16 batch keys, bitonic-merge them into the list: 63 + 120 compare-exchanges at k*d = 36,
+  // generated by tools/gen_topk_merge.py) instead of max-over-lanes sorted inserts of 2 k*d + 6 instructions each — the
+  // same k*d smallest (distance, index) keys.
+  constexpr bool NET = BUF == 16 && KD >= 16;
   auto flush = [&]() {
+    if constexpr (NET) {
+      if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) {
+        double b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float2 e = cbuf[i * TH];
+          b[i] = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+        }
+        TopMerge16<KD>::run(top.key, b);
+        bcnt = 0;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < BUF; ++i) {                 // forward branches only: a back edge makes the allocator duplicate the list
       if (__builtin_amdgcn_ballot_w64(i < bcnt) == 0ull) break;
