@@ -64,11 +64,23 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const int nc = lane_n < N ? lane_n : N - 1;
   const int kk = lane >> 5, l31 = lane & 31;
   constexpr int KB = 4;                              // k16-steps per key-operand batch
+  // key tiles are visited centre-out from the tile under the query tile's own image position when there is a positional
+  // bias (see knn_tile_kernel): lists fill with near-final entries first; the result does not depend on the order
+  const int ktiles = (M + KT - 1) / KT;
+  int c0 = 0;
+  if (HAS_RP) c0 = min(max((int)(((long long)(n0 + QT / 2) * M / N) / KT), 0), ktiles - 1);
+  const int nleft = c0, nright = ktiles - 1 - c0, nboth = min(nleft, nright);
+  auto tile_at = [&](int i) -> int {                 // i-th visited tile, 0 <= i < ktiles
+    if (!HAS_RP) return i;
+    if (i <= 2 * nboth) return (i & 1) ? c0 + ((i + 1) >> 1) : c0 - (i >> 1);
+    return nleft >= nright ? c0 - (i - nboth) : c0 + (i - nboth);
+  };
+  const int t_first = tile_at(min(w, ktiles - 1));
   const uint4* yhp = reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * M;       // octet-major planes
   const uint4* ylp = reinterpret_cast<const uint4*>(a.yb_lo) + (size_t)bg * (cp16 >> 3) * M;
   uint4 bh_[KB], bl_[KB];
   {
-    const int mk0 = min(w * KT + l31, M - 1);
+    const int mk0 = min(t_first * KT + l31, M - 1);
     const uint4* h0 = yhp + (size_t)kk * M + mk0;
     const uint4* l0 = ylp + (size_t)kk * M + mk0;
 #pragma unroll
@@ -109,7 +121,6 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const bool two_blocks = n0 + 32 < N;               // wave-uniform
   TopList<KDW> top;
   top.init();
-  const int ktiles = (M + KT - 1) / KT;
   // relative_pos rows of the two query blocks this lane's accumulator columns belong to
   const int nq0 = min(n0 + l31, N - 1), nq1 = min(n0 + 32 + l31, N - 1);
   // relative_pos rows (the accumulators' initial value) and |y|^2, as 16-byte buffer loads over the workgroup's 64 rows.
@@ -136,11 +147,13 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       }
     }
   };
-  if (AHEAD && w < ktiles) fetch_side(w);
-  for (int t = w; t < ktiles; t += NW) {
+  if (AHEAD && w < ktiles) fetch_side(t_first);
+  for (int iv = w; iv < ktiles; iv += NW) {
+    const int t = tile_at(iv);
+    const int t_next = iv + NW < ktiles ? tile_at(iv + NW) : t;
     const int m0 = t * KT;
     const int mk = min(m0 + l31, M - 1);
-    const int mk_next = min((t + NW < ktiles ? t + NW : t) * KT + l31, M - 1);
+    const int mk_next = min(t_next * KT + l31, M - 1);
     if (!AHEAD) fetch_side(t);
     const float sy32 = sy_n;
     // accumulators start from relative_pos: lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
         }
       }
     }
-    if (AHEAD && t + NW < ktiles) fetch_side(t + NW);  // in flight during the selection below
+    if (AHEAD && iv + NW < ktiles) fetch_side(t_next); // in flight during the selection below
     // ---- lane l <- all 32 keys of query n0 + l (permlane swap as in knn_tile_kernel); approximate distance (without the
     //      query's own |x|^2, a per-query constant) = acc + |y|^2, keys past M masked by MASKED_SQ
 #pragma unroll
