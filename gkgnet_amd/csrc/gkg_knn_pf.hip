@@ -2,6 +2,7 @@
 // contract distances only for the candidates that can matter.  Same results as knn_tile_kernel (gkg_knn.hip), bit for bit;
 // selected by the host side where it is faster (long key streams).  Reference: torch_edge.py:9-51, 54-106, 139-176.
 #include "gkg_knn_common.h"
+#include "gkg_topk_merge.h"
 
 namespace gkg {
 
@@ -45,7 +46,11 @@ __device__ __forceinline__ float pf_exact_dist(const float* __restrict__ xc, int
   return (sqx + acc) + sqy;                        // the contract's order; relative_pos is added by the caller
 }
 
-template <int KD, int KDW, bool HAS_RP>
+// PBUF — buffered selection as in knn_tile_kernel: a candidate is only tested against the lane's (possibly stale) KDW-th
+// distance and, when it passes, appended to a per-lane LDS buffer of PBUF entries behind the staged queries; the lists are
+// updated in wave-uniform flushes (merge network for lists of 16+ entries, sorted inserts below).  0: every candidate goes
+// through the sorted insert (2 KDW + 6 instructions).
+template <int KD, int KDW, bool HAS_RP, int PBUF = 0>
 __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
@@ -121,6 +126,32 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const bool two_blocks = n0 + 32 < N;               // wave-uniform
   TopList<KDW> top;
   top.init();
+  float2* cbuf = reinterpret_cast<float2*>(xq_lo + QT * qpitch) + tid;      // [PBUF][256] behind the staged queries
+  int bcnt = 0;
+  float thr = INFINITY;
+  auto flush = [&]() {
+    if constexpr (PBUF == 16 && KDW >= 16) {
+      if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) {
+        double b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float2 e = cbuf[i * 256];
+          b[i] = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+        }
+        TopMerge16<KDW>::run(top.key, b);
+        bcnt = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (PBUF > 0 ? PBUF : 1); ++i) {   // forward branches only (see knn_tile_kernel)
+      if (__builtin_amdgcn_ballot_w64(i < bcnt) == 0ull) break;
+      const float2 e = cbuf[i * 256];
+      const double k = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+      top.template insert_key<false>(k);
+    }
+    bcnt = 0;
+    thr = key_dist(top.key[KDW - 1]);
+  };
   // relative_pos rows of the two query blocks this lane's accumulator columns belong to
   const int nq0 = min(n0 + l31, N - 1), nq1 = min(n0 + 32 + l31, N - 1);
   // relative_pos rows (the accumulators' initial value) and |y|^2, as 16-byte buffer loads over the workgroup's 64 rows.
@@ -233,9 +264,18 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
         for (int j = 0; j < 4; ++j) {
           const int row = 8 * g + 4 * hh + j;
           const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-          top.template insert<KDW >= 18>((hh ? hi[j] : lo[j]) + sy, m0 + row);
+          const float d = (hh ? hi[j] : lo[j]) + sy;
+          if constexpr (PBUF > 0) {
+            if (d <= thr) {                       // '<=': the tiles are not visited in index order (NaN fails)
+              cbuf[bcnt * 256] = make_float2(d, __int_as_float(m0 + row));
+              ++bcnt;
+            }
+          } else {
+            top.template insert<KDW >= 18>(d, m0 + row);
+          }
         }
       }
+      if (PBUF > 0 && ((g == 3 && iv + NW >= ktiles) || __builtin_amdgcn_ballot_w64(bcnt > PBUF - 8) != 0ull)) flush();
     }
   }
 
@@ -374,28 +414,28 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
 using namespace gkg;
 
 // prefilter + exact re-rank (knn_pf_kernel): un-split, normalised, fp32-contract problems
+template <int KD, int KDW, bool HAS_RP, int PBUF>
+static hipError_t launch_pf_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, HAS_RP, PBUF>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+  }
+  hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, HAS_RP, PBUF>), grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 template <int KD, int KDW>
 static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   const size_t stage = (size_t)2 * QT * (a.cp16 + 8) * 2;
   const size_t lists = (size_t)2 * NW * KDW * 64 * 4 + (size_t)(KD + PF_EXTRA) * 64 * (4 + 2) + 64 * 4 + 16;
-  const size_t lds = stage > lists ? stage : lists;
-  if (a.relpos) {
-    if (lds > 64 * 1024) {
-      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (ea != hipSuccess) return ea;
-    }
-    hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, true>), grid, dim3(256), lds, st, a);
-  } else {
-    if (lds > 64 * 1024) {
-      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (ea != hipSuccess) return ea;
-    }
-    hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, false>), grid, dim3(256), lds, st, a);
-  }
-  return hipGetLastError();
+  // buffered selection where its 32 KiB candidate buffer does not cost a workgroup per CU (narrow groups)
+  const bool buffered = stage + 16 * 256 * 8 <= 52 * 1024;   // c <= 64 (at c = 80 the third workgroup per CU is worth more: 680 -> 824 us)
+  const size_t need = buffered ? stage + 16 * 256 * 8 : stage;
+  const size_t lds = need > lists ? need : lists;
+  if (a.relpos) return buffered ? launch_pf_v<KD, KDW, true, 16>(a, grid, lds, st) : launch_pf_v<KD, KDW, true, 0>(a, grid, lds, st);
+  return buffered ? launch_pf_v<KD, KDW, false, 16>(a, grid, lds, st) : launch_pf_v<KD, KDW, false, 0>(a, grid, lds, st);
 }
 
 namespace gkg {
