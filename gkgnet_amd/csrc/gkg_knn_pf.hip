@@ -130,13 +130,17 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   int bcnt = 0;
   float thr = INFINITY;
   auto flush = [&]() {
-    if constexpr (PBUF == 16 && KDW >= 16) {
+    if constexpr (PBUF >= 12 && KDW >= 16) {
       if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) {
         double b[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float2 e = cbuf[i * 256];
-          b[i] = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+          if (i < PBUF) {
+            const float2 e = cbuf[i * 256];
+            b[i] = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+          } else {
+            b[i] = (double)INFINITY;
+          }
         }
         TopMerge16<KDW>::run(top.key, b);
         bcnt = 0;
@@ -430,12 +434,20 @@ static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   const size_t stage = (size_t)2 * QT * (a.cp16 + 8) * 2;
   const size_t lists = (size_t)2 * NW * KDW * 64 * 4 + (size_t)(KD + PF_EXTRA) * 64 * (4 + 2) + 64 * 4 + 16;
-  // buffered selection where its 32 KiB candidate buffer does not cost a workgroup per CU (narrow groups)
-  const bool buffered = stage + 16 * 256 * 8 <= 52 * 1024;   // c <= 64 (at c = 80 the third workgroup per CU is worth more: 680 -> 824 us)
-  const size_t need = buffered ? stage + 16 * 256 * 8 : stage;
+  // buffered selection with the largest candidate buffer (16 or 12 entries per lane: 32 / 24 KiB) that keeps the
+  // workgroups per CU the register budget allows (3 for lists <= 16, 2 above)
+  const size_t per_wg = (size_t)160 * 1024 / (KDW <= 16 ? 3 : 2);
+  const int pbuf = stage + 16 * 2048 <= per_wg ? 16 : (stage + 12 * 2048 <= per_wg ? 12 : 0);
+  const size_t need = stage + (size_t)pbuf * 2048;
   const size_t lds = need > lists ? need : lists;
-  if (a.relpos) return buffered ? launch_pf_v<KD, KDW, true, 16>(a, grid, lds, st) : launch_pf_v<KD, KDW, true, 0>(a, grid, lds, st);
-  return buffered ? launch_pf_v<KD, KDW, false, 16>(a, grid, lds, st) : launch_pf_v<KD, KDW, false, 0>(a, grid, lds, st);
+  if (a.relpos) {
+    if (pbuf == 16) return launch_pf_v<KD, KDW, true, 16>(a, grid, lds, st);
+    if (pbuf == 12) return launch_pf_v<KD, KDW, true, 12>(a, grid, lds, st);
+    return launch_pf_v<KD, KDW, true, 0>(a, grid, lds, st);
+  }
+  if (pbuf == 16) return launch_pf_v<KD, KDW, false, 16>(a, grid, lds, st);
+  if (pbuf == 12) return launch_pf_v<KD, KDW, false, 12>(a, grid, lds, st);
+  return launch_pf_v<KD, KDW, false, 0>(a, grid, lds, st);
 }
 
 namespace gkg {
