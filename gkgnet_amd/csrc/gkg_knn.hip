@@ -524,7 +524,16 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // 801 -> 731; it loses when the per-wave query image costs occupancy: stage 2, c = 80, 458 -> 540)
   const bool solo = p.S == 1 && (size_t)a.nqt * BG >= 2048 && (size_t)QT * (cp16 + 8) * 2 <= 8 * 1024;
   if (bf) {
-    e = launch_knn_tile_bf(a, grid, lds, p.KD, buffered, solo, st);
+    // bf16 form: the staged query tile is 64 x (cp16 + 8) bf16 — buffered selection with the largest candidate buffer (16 or
+    // 12 entries per lane) that keeps the workgroups per CU the register budget allows
+    const size_t q_bf = (size_t)QT * (cp16 + 8) * 2;
+    const int wgs = relpos ? (p.KD <= 18 ? 3 : 2) : (p.KD <= 12 ? 4 : (p.KD <= 27 ? 3 : 2));
+    const size_t per_wg = (size_t)160 * 1024 / wgs;
+    int wbuf = q_bf + 16 * 2048 + 1024 <= per_wg ? 16 : (q_bf + 12 * 2048 + 1024 <= per_wg ? 12 : 0);
+    const bool pays_bf = p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
+    if (force == 1 || (force == 0 && !pays_bf)) wbuf = 0;
+    if (force == 2 && wbuf == 0) wbuf = 12;
+    e = launch_knn_tile_bf(a, grid, lds, p.KD, wbuf, solo && wbuf > 0, st);
   } else if (buffered) {
     switch (p.KD) {
       case 9: e = launch_tile_buffered<9>(a, grid, lds, st); break;

@@ -6,7 +6,8 @@ using namespace gkg;
 
 // bf16 matrix-core contraction (GKG_KNN_BF16_CONTRACT): direct or buffered selection, guarded insert
 template <int KD>
-static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, bool buffered, bool solo) {
+static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, int wbuf, bool solo) {
+  const bool buffered = wbuf > 0;
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   if (buffered && solo) {                       // one wave per 64-query tile, all keys (see the kernel's NWV)
     // 9-entry lists: 12-entry candidate buffers (flush when a lane holds more than 4) — with one short list per query the
@@ -18,23 +19,29 @@ static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStr
     return launch_tile_v<KD, false, 4, false, SBUF, true, 1>(a, grid, lds, st);
   }
   if (buffered) {
-    constexpr int WBUF = KD <= 12 ? 12 : KNN_BUF;
-    if (a.relpos) return launch_tile_v<KD, true, 4, false, WBUF, true>(a, grid, lds, st);
-    return launch_tile_v<KD, false, 4, false, WBUF, true>(a, grid, lds, st);
+    // 9-entry lists: 12 entries per lane (fresher thresholds); longer lists: 16, or 12 where 16 would cost a workgroup per CU
+    if (KD <= 12 || wbuf < 16) {
+      if (a.relpos) return launch_tile_v<KD, true, 4, false, 12, true>(a, grid, lds, st);
+      return launch_tile_v<KD, false, 4, false, 12, true>(a, grid, lds, st);
+    }
+    if constexpr (KD > 12) {
+      if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
+      return launch_tile_v<KD, false, 4, false, KNN_BUF, true>(a, grid, lds, st);
+    }
   }
   if (a.relpos) return launch_tile_v<KD, true, 4, true, 0, true>(a, grid, lds, st);
   return launch_tile_v<KD, false, 4, true, 0, true>(a, grid, lds, st);
 }
 
 namespace gkg {
-hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, bool buffered, bool solo, hipStream_t st) {
+hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st) {
   switch (KD) {
-    case 9: return launch_tile_bf<9>(a, grid, lds, st, buffered, solo);
-    case 16: return launch_tile_bf<16>(a, grid, lds, st, buffered, solo);
-    case 18: return launch_tile_bf<18>(a, grid, lds, st, buffered, solo);
-    case 27: return launch_tile_bf<27>(a, grid, lds, st, buffered, solo);
-    case 36: return launch_tile_bf<36>(a, grid, lds, st, buffered, solo);
-    default: return launch_tile_bf<64>(a, grid, lds, st, buffered, solo);
+    case 9: return launch_tile_bf<9>(a, grid, lds, st, wbuf, solo);
+    case 16: return launch_tile_bf<16>(a, grid, lds, st, wbuf, solo);
+    case 18: return launch_tile_bf<18>(a, grid, lds, st, wbuf, solo);
+    case 27: return launch_tile_bf<27>(a, grid, lds, st, wbuf, solo);
+    case 36: return launch_tile_bf<36>(a, grid, lds, st, wbuf, solo);
+    default: return launch_tile_bf<64>(a, grid, lds, st, wbuf, solo);
   }
 }
 }  // namespace gkg

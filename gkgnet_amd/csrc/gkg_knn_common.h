@@ -120,6 +120,6 @@ struct KnnArgs {
 // gkg_knn_pf.hip: launches knn_pf_kernel for list size KD (9, 16, 18, 27 or 36)
 hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t st);
 // gkg_knn_bf.hip: the tile kernel's bf16-contraction forms (direct / buffered selection; solo: one wave per query tile)
-hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, bool buffered, bool solo, hipStream_t st);
+hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st);
 
 }  // namespace gkg

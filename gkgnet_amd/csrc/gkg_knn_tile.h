@@ -180,7 +180,9 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
       }
     }
   }
-  if (BUF > 0) smem[(size_t)cpad * QT + (size_t)BUF * 2 * TH + tid] = INFINITY;   // ths (see below)
+  // floats of the staged query tile (bf16 form: 64 rows of cp16 + 8 bf16), behind which the candidate buffer lives
+  const size_t qfloats = BF ? (size_t)QT * (a.cp16 + 8) / 2 : (size_t)cpad * QT;
+  if (BUF > 0) smem[qfloats + (size_t)BUF * 2 * TH + tid] = INFINITY;   // ths (see below)
   __syncthreads();
 
   const int n = lane_n;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   TopList<KD> top;
   top.init();
   // buffered selection state: the buffer lives behind the staged queries, [BUF][256] x {distance, index}
-  float2* cbuf = reinterpret_cast<float2*>(smem + (size_t)cpad * QT) + tid;
+  float2* cbuf = reinterpret_cast<float2*>(smem + qfloats) + tid;
   int bcnt = 0;
   float thr = INFINITY;
   // Shared admission bound (SHARE: the buffered form; in the guarded direct form the two extra selects per candidate cost
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // cost of long lists — drop by about half (k*d = 36: 136 -> 73 expected inserts per lane over 576 keys).
   constexpr bool SHARE = BUF > 0 && KD >= 16 && NWV > 1;   // 9-entry lists: Q = 3 saves too few inserts to pay for the exchange
   constexpr int QSH = (KD + NWV - 1) / NWV;
-  float* ths = smem + (size_t)cpad * QT + (size_t)(BUF > 0 ? BUF : 0) * 2 * TH;      // [NWV][64], behind the candidate buffer
+  float* ths = smem + qfloats + (size_t)(BUF > 0 ? BUF : 0) * 2 * TH;      // [NWV][64], behind the candidate buffer
   float sh = INFINITY;
   auto refresh_shared = [&]() {
     const float mine = key_dist(top.key[QSH - 1]);                // +inf while the list holds fewer than Q entries
@@ -224,15 +226,19 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // merge network (sort the 16 batch keys, bitonic-merge them into the list: 63 + 120 compare-exchanges at k*d = 36,
   // generated by tools/gen_topk_merge.py) instead of max-over-lanes sorted inserts of 2 k*d + 6 instructions each — the
   // same k*d smallest (distance, index) keys.
-  constexpr bool NET = BUF == 16 && KD >= 16;
+  constexpr bool NET = BUF >= 12 && KD >= 16;
   auto flush = [&]() {
     if constexpr (NET) {
       if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) {
         double b[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float2 e = cbuf[i * TH];
-          b[i] = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+          if (i < BUF) {
+            const float2 e = cbuf[i * TH];
+            b[i] = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
+          } else {
+            b[i] = (double)INFINITY;
+          }
         }
         TopMerge16<KD>::run(top.key, b);
         bcnt = 0;
@@ -520,9 +526,15 @@ constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 by
 
 template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false, int NWV = NW>
 static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  if (NWV == 1) lds = (size_t)a.cpad * QT * sizeof(float);          // no merge area
+  // staged query tile: fp32 [cpad][64], or (bf16 form) 64 rows of cp16 + 8 bf16
+  const size_t qbytes = BF ? (size_t)QT * (a.cp16 + 8) * 2 : (size_t)a.cpad * QT * sizeof(float);
+  if (BF) {                                     // the caller sized `lds` for the fp32 tile: keep only what the merge needs
+    const size_t merge = NWV == 1 ? 0 : (size_t)NWV * KD * 64 * 2 * sizeof(float);
+    lds = qbytes > merge ? qbytes : merge;
+  }
+  if (NWV == 1 && !BF) lds = qbytes;            // no merge area
   if (BUF > 0) {                                // candidate buffer + the per-wave shared admission bounds behind the queries
-    const size_t need = (size_t)a.cpad * QT * sizeof(float) + (size_t)BUF * 64 * NWV * sizeof(float2) + NWV * 64 * sizeof(float);
+    const size_t need = qbytes + (size_t)BUF * 64 * NWV * sizeof(float2) + NWV * 64 * sizeof(float);
     if (lds < need) lds = need;
   }
   if (lds > 64 * 1024) {
