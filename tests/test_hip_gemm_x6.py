@@ -270,6 +270,26 @@ def test_grouped_weight_gradient_on_the_streaming_kernel(monkeypatch):
     assert fused._x6_wgrad_ok(dY[0], U[0]) is False           # fp32 atomics: never under GKG_DETERMINISTIC
 
 
+@pytest.mark.parametrize("R,cin,cout,nb", [(1000, 256, 100, 1),      # 64 x 128 tiles, cin on the wide side, ragged rows
+                                            (1000, 320, 256, 1),      # cout on the wide side: operands exchanged, dW transposed
+                                            (2600, 640, 320, 1), (2600, 320, 1280, 1), (777, 128, 128, 3),
+                                            (1000, 320, 320, 1)])     # 20 % padding: stays on 64 x 64 tiles
+def test_weight_gradient_tile_shapes(R, cin, cout, nb):
+    """gkg_linear_wgrad_x6 over the shapes that select each of its tile forms, against fp64."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(R + cin)
+    dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
+    x = torch.randn(nb, R, cin, device="cuda", generator=gen)
+    dw = torch.zeros(nb, cout, cin, device="cuda")
+    _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin, cout,
+                                       nb, None), "gkg_linear_wgrad_x6")
+    torch.cuda.synchronize()
+    want = torch.bmm(dy.double().transpose(1, 2), x.double())
+    scale = torch.bmm(dy.double().abs().transpose(1, 2), x.double().abs()).max()
+    assert float((dw.double() - want).abs().max() / scale) < 2e-6
+
+
 def test_bn_scratch_protocol_under_capture_replay_and_eager_interleaving():
     """The two-launch BN passes accumulate fp64 sums in alternating scratch buffers whose host-side cursor cannot see
     replays: a captured forward + backward with an ODD number of BN passes (3 layers -> 3 forward + 3 backward... plus one
