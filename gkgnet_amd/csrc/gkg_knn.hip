@@ -275,7 +275,7 @@ using namespace gkg;
 
 // list sizes of the tile kernel: the lengths GKGNet's configurations use (k*d = 9, 18, 27; pvig_m k = 18: 18, 36) plus 16
 // and 64 to cover everything else (each instantiation is a kernel of its own: 6 sizes x 2 x 2 x 3 selection forms)
-static const int kListSizes[] = {9, 16, 18, 27, 36, 64};
+static const int kListSizes[] = {9, 18, 27, 36, 64};   // k*d of GKGNet's layers + one catch-all (10..18 share the 18-entry list)
 
 static int pick_list(int kd) {
   for (int s : kListSizes) if (s >= kd) return s;
@@ -350,34 +350,6 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
   // y presence is unknown here: budget for it (upper bound) unless the shapes make it impossible
   if (make_plan(BG, c, N, M, k, dilation, true, &p) != 0) return 0;
   return p.total;
-}
-
-// Short key streams (< 10 key tiles per wave: the 18x18 stage, label graphs over it): insert without the ballot guard.
-// Only for the 9-entry list: with 18 or 27 entries the insert is expensive enough that skipping it wins again
-// (measured: k*d = 27 at 18x18 is 19 % slower without the guard).
-template <int KD>
-static hipError_t launch_tile_short(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
-  const bool deep = (a.cpad % 16) == 0;
-  if (a.relpos) return deep ? launch_tile_v<KD, true, 8, false>(a, grid, lds, st) : launch_tile_v<KD, true, 4, false>(a, grid, lds, st);
-  return deep ? launch_tile_v<KD, false, 8, false>(a, grid, lds, st) : launch_tile_v<KD, false, 4, false>(a, grid, lds, st);
-}
-
-template <int KD>
-static hipError_t launch_tile(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
-  const bool deep = (a.cpad % 16) == 0;      // 8 k-pairs per register batch when the channel count allows
-  if (a.relpos) return deep ? launch_tile_v<KD, true, 8>(a, grid, lds, st) : launch_tile_v<KD, true, 4>(a, grid, lds, st);
-  return deep ? launch_tile_v<KD, false, 8>(a, grid, lds, st) : launch_tile_v<KD, false, 4>(a, grid, lds, st);
-}
-
-// long key streams per wave and / or long lists: buffered selection (see the kernel's comment)
-template <int KD>
-static hipError_t launch_tile_buffered(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  GkgProfScope prof(GKG_PROF_KNN_TILE, st);
-  const bool deep = (a.cpad % 16) == 0;
-  if (a.relpos) return deep ? launch_tile_v<KD, true, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, true, 4, false, KNN_BUF>(a, grid, lds, st);
-  return deep ? launch_tile_v<KD, false, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, false, 4, false, KNN_BUF>(a, grid, lds, st);
 }
 
 template <typename T, int PT>
@@ -534,25 +506,9 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     if (force == 1 || (force == 0 && !pays_bf)) wbuf = 0;
     if (force == 2 && wbuf == 0) wbuf = 12;
     e = launch_knn_tile_bf(a, grid, lds, p.KD, wbuf, solo && wbuf > 0, st);
-  } else if (buffered) {
-    switch (p.KD) {
-      case 9: e = launch_tile_buffered<9>(a, grid, lds, st); break;
-      case 16: e = launch_tile_buffered<16>(a, grid, lds, st); break;
-      case 18: e = launch_tile_buffered<18>(a, grid, lds, st); break;
-      case 27: e = launch_tile_buffered<27>(a, grid, lds, st); break;
-      case 36: e = launch_tile_buffered<36>(a, grid, lds, st); break;
-      default: e = launch_tile_buffered<64>(a, grid, lds, st); break;
-    }
-  } else if (short_stream && p.KD == 9) {
-    e = launch_tile_short<9>(a, grid, lds, st);
-  } else
-  switch (p.KD) {
-    case 9: e = launch_tile<9>(a, grid, lds, st); break;
-    case 16: e = launch_tile<16>(a, grid, lds, st); break;
-    case 18: e = launch_tile<18>(a, grid, lds, st); break;
-    case 27: e = launch_tile<27>(a, grid, lds, st); break;
-    case 36: e = launch_tile<36>(a, grid, lds, st); break;
-    default: e = launch_tile<64>(a, grid, lds, st); break;
+  } else {
+    // fp32 contract forms: direct (guarded / guard-less for short streams) or buffered selection — gkg_knn_f32.hip
+    e = launch_knn_tile_f32(a, grid, lds, p.KD, buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0), st);
   }
   if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");
   if (p.S > 1) {

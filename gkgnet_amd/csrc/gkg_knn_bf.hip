@@ -5,7 +5,9 @@
 using namespace gkg;
 
 // bf16 matrix-core contraction (GKG_KNN_BF16_CONTRACT): direct or buffered selection, guarded insert
-template <int KD>
+// HAS_RP is a compile-time parameter of the launcher: the relative_pos forms are instantiated in this translation unit, the
+// others in gkg_knn_bf_norp.hip (the same source with GKG_KNN_NORP_PART defined).
+template <int KD, bool HAS_RP>
 static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, int wbuf, bool solo) {
   const bool buffered = wbuf > 0;
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
@@ -15,33 +17,42 @@ static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStr
     // 16 (cfg5, k*d = 18 / 36: 29.8 -> 33.2 ms with 12).  Measured on the models' own activations: random tokens
     // (tools/bench_knn_bf.py) rank the two the other way round for k*d = 18.
     constexpr int SBUF = KD <= 12 ? 12 : KNN_BUF;
-    if (a.relpos) return launch_tile_v<KD, true, 4, false, SBUF, true, 1>(a, grid, lds, st);
-    return launch_tile_v<KD, false, 4, false, SBUF, true, 1>(a, grid, lds, st);
+    return launch_tile_v<KD, HAS_RP, 4, false, SBUF, true, 1>(a, grid, lds, st);
   }
   if (buffered) {
     // 9-entry lists: 12 entries per lane (fresher thresholds); longer lists: 16, or 12 where 16 would cost a workgroup per CU
     if (KD <= 12 || wbuf < 16) {
-      if (a.relpos) return launch_tile_v<KD, true, 4, false, 12, true>(a, grid, lds, st);
-      return launch_tile_v<KD, false, 4, false, 12, true>(a, grid, lds, st);
+      return launch_tile_v<KD, HAS_RP, 4, false, 12, true>(a, grid, lds, st);
     }
     if constexpr (KD > 12) {
-      if (a.relpos) return launch_tile_v<KD, true, 4, false, KNN_BUF, true>(a, grid, lds, st);
-      return launch_tile_v<KD, false, 4, false, KNN_BUF, true>(a, grid, lds, st);
+      return launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF, true>(a, grid, lds, st);
     }
   }
-  if (a.relpos) return launch_tile_v<KD, true, 4, true, 0, true>(a, grid, lds, st);
-  return launch_tile_v<KD, false, 4, true, 0, true>(a, grid, lds, st);
+  return launch_tile_v<KD, HAS_RP, 4, true, 0, true>(a, grid, lds, st);
 }
 
 namespace gkg {
-hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st) {
+#ifdef GKG_KNN_NORP_PART
+hipError_t launch_knn_tile_bf_norp(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st) {
   switch (KD) {
-    case 9: return launch_tile_bf<9>(a, grid, lds, st, wbuf, solo);
-    case 16: return launch_tile_bf<16>(a, grid, lds, st, wbuf, solo);
-    case 18: return launch_tile_bf<18>(a, grid, lds, st, wbuf, solo);
-    case 27: return launch_tile_bf<27>(a, grid, lds, st, wbuf, solo);
-    case 36: return launch_tile_bf<36>(a, grid, lds, st, wbuf, solo);
-    default: return launch_tile_bf<64>(a, grid, lds, st, wbuf, solo);
+    case 9: return launch_tile_bf<9, false>(a, grid, lds, st, wbuf, solo);
+    case 18: return launch_tile_bf<18, false>(a, grid, lds, st, wbuf, solo);
+    case 27: return launch_tile_bf<27, false>(a, grid, lds, st, wbuf, solo);
+    case 36: return launch_tile_bf<36, false>(a, grid, lds, st, wbuf, solo);
+    default: return launch_tile_bf<64, false>(a, grid, lds, st, wbuf, solo);
   }
 }
+#else
+hipError_t launch_knn_tile_bf_norp(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st);
+hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st) {
+  if (!a.relpos) return launch_knn_tile_bf_norp(a, grid, lds, KD, wbuf, solo, st);
+  switch (KD) {
+    case 9: return launch_tile_bf<9, true>(a, grid, lds, st, wbuf, solo);
+    case 18: return launch_tile_bf<18, true>(a, grid, lds, st, wbuf, solo);
+    case 27: return launch_tile_bf<27, true>(a, grid, lds, st, wbuf, solo);
+    case 36: return launch_tile_bf<36, true>(a, grid, lds, st, wbuf, solo);
+    default: return launch_tile_bf<64, true>(a, grid, lds, st, wbuf, solo);
+  }
+}
+#endif
 }  // namespace gkg

@@ -1,0 +1,3 @@
+// The bf16-contraction k-NN tile kernel without a positional bias: the same source as gkg_knn_bf.hip, compiled beside it.
+#define GKG_KNN_NORP_PART 1
+#include "gkg_knn_bf.hip"

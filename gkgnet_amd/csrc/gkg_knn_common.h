@@ -121,5 +121,7 @@ struct KnnArgs {
 hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t st);
 // gkg_knn_bf.hip: the tile kernel's bf16-contraction forms (direct / buffered selection; solo: one wave per query tile)
 hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st);
+// gkg_knn_f32.hip: the tile kernel's fp32-contract forms (mode 0 direct + guard, 1 direct without it, 2 buffered)
+hipError_t launch_knn_tile_f32(const KnnArgs& a, dim3 grid, size_t lds, int KD, int mode, hipStream_t st);
 
 }  // namespace gkg

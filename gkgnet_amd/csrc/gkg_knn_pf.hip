@@ -429,7 +429,9 @@ static hipError_t launch_pf_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream
   return hipGetLastError();
 }
 
-template <int KD, int KDW>
+// HAS_RP is a compile-time parameter of the launcher: the relative_pos forms are instantiated in this translation unit,
+// the others in gkg_knn_pf_norp.hip (the same source with GKG_KNN_NORP_PART defined), so that they compile in parallel.
+template <int KD, int KDW, bool HAS_RP>
 static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   const size_t stage = (size_t)2 * QT * (a.cp16 + 8) * 2;
@@ -440,24 +442,31 @@ static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
   const int pbuf = stage + 16 * 2048 <= per_wg ? 16 : (stage + 12 * 2048 <= per_wg ? 12 : 0);
   const size_t need = stage + (size_t)pbuf * 2048;
   const size_t lds = need > lists ? need : lists;
-  if (a.relpos) {
-    if (pbuf == 16) return launch_pf_v<KD, KDW, true, 16>(a, grid, lds, st);
-    if (pbuf == 12) return launch_pf_v<KD, KDW, true, 12>(a, grid, lds, st);
-    return launch_pf_v<KD, KDW, true, 0>(a, grid, lds, st);
-  }
-  if (pbuf == 16) return launch_pf_v<KD, KDW, false, 16>(a, grid, lds, st);
-  if (pbuf == 12) return launch_pf_v<KD, KDW, false, 12>(a, grid, lds, st);
-  return launch_pf_v<KD, KDW, false, 0>(a, grid, lds, st);
+  if (pbuf == 16) return launch_pf_v<KD, KDW, HAS_RP, 16>(a, grid, lds, st);
+  if (pbuf == 12) return launch_pf_v<KD, KDW, HAS_RP, 12>(a, grid, lds, st);
+  return launch_pf_v<KD, KDW, HAS_RP, 0>(a, grid, lds, st);
 }
 
 namespace gkg {
-hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t st) {
+#ifdef GKG_KNN_NORP_PART
+hipError_t launch_knn_prefilter_norp(const KnnArgs& a, dim3 grid, int KD, hipStream_t st) {
   switch (KD) {
-    case 9: return launch_pf<9, 12>(a, grid, st);
-    case 16: return launch_pf<16, 18>(a, grid, st);
-    case 18: return launch_pf<18, 18>(a, grid, st);
-    case 27: return launch_pf<27, 27>(a, grid, st);
-    default: return launch_pf<36, 36>(a, grid, st);
+    case 9: return launch_pf<9, 12, false>(a, grid, st);
+    case 18: return launch_pf<18, 18, false>(a, grid, st);
+    case 27: return launch_pf<27, 27, false>(a, grid, st);
+    default: return launch_pf<36, 36, false>(a, grid, st);
   }
 }
+#else
+hipError_t launch_knn_prefilter_norp(const KnnArgs& a, dim3 grid, int KD, hipStream_t st);
+hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t st) {
+  if (!a.relpos) return launch_knn_prefilter_norp(a, grid, KD, st);
+  switch (KD) {
+    case 9: return launch_pf<9, 12, true>(a, grid, st);
+    case 18: return launch_pf<18, 18, true>(a, grid, st);
+    case 27: return launch_pf<27, 27, true>(a, grid, st);
+    default: return launch_pf<36, 36, true>(a, grid, st);
+  }
+}
+#endif
 }  // namespace gkg

@@ -33,7 +33,7 @@ def run_network(KD, key, batch):
     return [pos[i] for i in range(KD)]
 
 
-@pytest.mark.parametrize("KD", [16, 18, 27, 36, 64])
+@pytest.mark.parametrize("KD", [18, 27, 36, 64])
 def test_merge_network_equals_sorted_union(KD):
     rng = random.Random(100 + KD)
     for trial in range(1500):
@@ -49,7 +49,7 @@ def test_merge_network_equals_sorted_union(KD):
 def test_sort_network_size_and_committed_header_is_current(tmp_path):
     assert len(gen.oddeven_merge_sort(16)) == 63
     body = []
-    for KD in (16, 18, 27, 36, 64):
+    for KD in (18, 27, 36, 64):
         lines, nce = gen.emit(KD)
         body.append((KD, nce, lines))
     committed = open(os.path.join(ROOT, "gkgnet_amd", "csrc", "gkg_topk_merge.h")).read()
