@@ -18,6 +18,27 @@ KNN_SELECT_DIRECT = 4
 KNN_SELECT_BUFFERED = 8
 KNN_NO_PREFILTER = 16
 KNN_FORCE_PREFILTER = 32
+KNN_RELPOS_UNIT = 64
+
+
+def relpos_flags(rp) -> int:
+    """KNN_RELPOS_UNIT when every |relative_pos| <= 1 (the prefilter kernel's precondition, include/gkg_hip.h).  The check
+    is one reduction + a host read, cached ON the tensor object (keyed on its version counter): a module's frozen
+    ``relative_pos`` parameter pays it once, in the eager warm-up; a tensor first seen inside a hipGraph capture is not
+    vouched for (the call then takes the fp32 tile kernel: same results)."""
+    if rp is None:
+        return 0
+    import torch
+    ent = getattr(rp, "_gkg_unit", None)
+    if ent is None or ent[0] != rp._version:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        ent = (rp._version, bool((rp.detach().abs().max() <= 1.0).item()))
+        try:
+            rp._gkg_unit = ent
+        except AttributeError:
+            pass
+    return KNN_RELPOS_UNIT if ent[1] else 0
 
 
 def knn_select_flags() -> int:

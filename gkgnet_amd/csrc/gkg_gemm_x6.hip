@@ -378,11 +378,14 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
   a.mtiles = (a.M + 127) / 128;
   a.ntiles = (a.N + BN - 1) / BN;
   const size_t sh = 3 * 4 * 4096 + 2 * 12 * BN * 16;
-  static bool once = false;
-  if (!once) {
+  // the attribute is per DEVICE (a per-process guard left a second GPU of the same process without it — ADVICE r3)
+  static bool once[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !once[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_x6_kernel<NI, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return e;
-    once = true;
+    if (dev >= 0 && dev < 64) once[dev] = true;
   }
   const int groups = (a.mtiles + 7) / 8;
   hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
@@ -1019,12 +1022,16 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
     }
     m.K = main_rows; m.splits = (main_rows + a.rows_per_split - 1) / a.rows_per_split;
     const size_t sh = wide ? (size_t)4 * 3 * 16 * 192 * 4 : (size_t)4 * 4 * 8192;
-    static bool once[2] = {false, false};
+    // the attribute is per DEVICE: the guard is indexed by the current device (a per-process guard left a second GPU of the
+    // same process without it — ADVICE r3)
+    static bool once[2][64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     const void* fn = wide ? (const void*)wgrad_x6_wide_kernel : (const void*)wgrad_x6_dma_kernel;
-    if (!once[wide]) {
+    if (dev < 0 || dev >= 64 || !once[wide][dev]) {
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
       if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel (attribute)");
-      once[wide] = true;
+      if (dev >= 0 && dev < 64) once[wide][dev] = true;
     }
     const dim3 grid((m.splits + 7) / 8 * 8 * m.mtiles * m.ntiles, nb);
     if (wide) hipLaunchKernelGGL(wgrad_x6_wide_kernel, grid, dim3(256), sh, st, m);

@@ -434,7 +434,11 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // vs 119; the cfg2 Grapher graph is a tie: 51 + 22 vs 54 + 15), and against the BUFFERED selection of narrow groups with
   // long lists (pvig_m: c = 24 / k*d = 18: 4469 vs 3149).  GKG_KNN_FORCE_PREFILTER overrides the rule (tests).
   const bool pf_pays = M >= 1024 && (p.KD <= 12 ? p.cpad >= 40 : (p.KD <= 27 && p.cpad >= 128));
-  const bool pf = !bf && norm && p.S == 1 && c >= 16 && p.KD <= 36 && !(flags & GKG_KNN_NO_PREFILTER)
+  // The prefilter's error bound (knn_pf_kernel, step 3) is derived for |relative_pos| <= 1: the bias is the initial value of
+  // the accumulators, so the rounding of the accumulation scales with |bias| + 2.  A call with a bias takes the prefilter only
+  // when the caller vouches for that range (GKG_KNN_RELPOS_UNIT; GKGNet's bias -2 PE PE^T / D lies in [-1, 0]) — ADVICE r3.
+  const bool rp_ok = !relpos || (flags & GKG_KNN_RELPOS_UNIT);
+  const bool pf = !bf && norm && p.S == 1 && c >= 16 && p.KD <= 36 && !(flags & GKG_KNN_NO_PREFILTER) && rp_ok
                   && pf_stage <= 150 * 1024 && (pf_pays || (flags & GKG_KNN_FORCE_PREFILTER));
   uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
   uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
@@ -468,7 +472,9 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   if (pf) {
     a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
     a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;
-    a.margin = 2.0f * (3.0e-5f + 6.0e-7f * (float)p.cpad);
+    // eps = split terms dropped (3 * 2^-18 * 2 = 2.3e-5) + fp32 accumulation of the 3c products, the bias and |y|^2 on partial
+    // sums <= |bias| + 2 <= 3 (9c * 2^-24) + the contract's own chain (2c * 2^-24): 11 c u = 6.6e-7 c; margin = 2 eps
+    a.margin = 2.0f * (3.0e-5f + 7.0e-7f * (float)p.cpad);
     a.wg_flags = (int*)(ws + p.off_flags);
     e = hipMemsetAsync(a.wg_flags, 0, sizeof(int) * (size_t)grid.x, st);
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_pf_kernel (flags)");

@@ -9,8 +9,9 @@ using namespace gkg;
 // others in gkg_knn_bf_norp.hip (the same source with GKG_KNN_NORP_PART defined).
 template <int KD, bool HAS_RP>
 static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st, int wbuf, bool solo) {
-  const bool buffered = wbuf > 0;
+  const bool buffered = wbuf > 0 && KD <= 36;   // 64-entry lists: direct insert only (the buffered forms spilled to scratch)
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
+  if constexpr (KD <= 36) {
   if (buffered && solo) {                       // one wave per 64-query tile, all keys (see the kernel's NWV)
     // 9-entry lists: 12-entry candidate buffers (flush when a lane holds more than 4) — with one short list per query the
     // fresher threshold is worth more than fuller flushes (cfg3 forward, k-NN kernels 5.08 -> 4.90 ms); longer lists keep
@@ -28,6 +29,7 @@ static hipError_t launch_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, hipStr
       return launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF, true>(a, grid, lds, st);
     }
   }
+  }   // KD <= 36
   return launch_tile_v<KD, HAS_RP, 4, true, 0, true>(a, grid, lds, st);
 }
 

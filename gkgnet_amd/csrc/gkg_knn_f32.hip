@@ -12,7 +12,11 @@ template <int KD, bool HAS_RP>
 static hipError_t launch_tile_f32(const KnnArgs& a, dim3 grid, size_t lds, int mode, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   const bool deep = (a.cpad % 16) == 0;      // 8 k-pairs per register batch when the channel count allows
-  if (mode == 2) return deep ? launch_tile_v<KD, HAS_RP, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF>(a, grid, lds, st);
+  // the catch-all 64-entry list has no buffered form: its list (128 registers) + the 16-entry batch + the merge network's
+  // temporaries spilled 100-400 VGPRs to scratch in every such instantiation; the guarded direct insert fits
+  if constexpr (KD <= 36) {
+    if (mode == 2) return deep ? launch_tile_v<KD, HAS_RP, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF>(a, grid, lds, st);
+  }
   if constexpr (KD == 9) {
     if (mode == 1) return deep ? launch_tile_v<KD, HAS_RP, 8, false>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false>(a, grid, lds, st);
   }

@@ -288,8 +288,17 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
 }
 
 static size_t mg_lds_bytes(const MrGemmArgs& g, int QG) {
-  const int ch_per_wg = QG * g.Cq;
-  const int NG = QG == 4 ? g.G : (g.c >= g.Cq ? 1 : (ch_per_wg + g.c - 1) / g.c + 1);   // upper bound on k-NN groups touched
+  // k-NN groups touched by one workgroup's channels, exactly as the kernel computes it: the maximum over the conv groups q0
+  // of (last channel) / c - (first channel) / c + 1.  (c >= Cq does NOT imply one group: with G = 3, Cq = C / 4 < c = C / 3
+  // and conv group 1 straddles k-NN groups 0 and 1 — ADVICE r3.)
+  int NG = g.G;
+  if (QG != 4) {
+    NG = 1;
+    for (int q0 = 0; q0 < 4; ++q0) {
+      const int n = ((q0 + 1) * g.Cq - 1) / g.c - (q0 * g.Cq) / g.c + 1;
+      if (n > NG) NG = n;
+    }
+  }
   return (size_t)QG * MG_ROWS * (g.ci_pad + 8) * 2 + (size_t)MG_ROWS * NG * g.k * 4;
 }
 

@@ -668,7 +668,15 @@ class _BnBwdScratch:
     hipGraph captures make the host-side bookkeeping blind (a replay runs its calls without this object seeing them), so:
     the FIRST call of every capture clears both buffers inside the capture (one memset pair per replay: the replayed
     sequence is self-contained), and once any capture exists every EAGER call clears both buffers first (correct after any
-    interleaving of replays and eager calls; only mixed capture / eager use pays for it)."""
+    interleaving of replays and eager calls; only mixed capture / eager use pays for it).
+
+    Streams: the pair is shared by every stream of the device.  Eager calls from a stream other than the previous
+    eager caller's first wait for that stream (``wait_stream``: everything the previous user enqueued, its apply pass
+    included, completes before this call's atomics start), so blocks driven from two streams by ONE host thread — a
+    side-stream evaluation during training — serialise on the pair instead of mixing their sums.  Concurrent host THREADS
+    are not supported (like the rest of the fused path's per-device scratch).  A failed launch between acquire() and the
+    apply pass leaves sums behind that the bookkeeping calls clean: callers report it through ``poison()`` and the next
+    acquire() clears both buffers."""
     DOUBLES = 2 * 4096 * 4
     _inst = {}
 
@@ -679,6 +687,8 @@ class _BnBwdScratch:
         self.dirty = [0, 0]
         self.capture_id = 0
         self.captured = False
+        self.poisoned = False
+        self.last_stream = None
 
     @classmethod
     def of(cls, device):
@@ -698,8 +708,13 @@ class _BnBwdScratch:
             if cap != self.capture_id:
                 self.capture_id = cap
                 self._reset()
-        elif self.captured:
-            self._reset()
+        else:
+            here = torch.cuda.current_stream(self.store.device)
+            if self.last_stream is not None and self.last_stream != here:
+                here.wait_stream(self.last_stream)
+            self.last_stream = here
+            if self.captured or self.poisoned:
+                self._reset()
         cur, other = self.bufs[self.cur], self.bufs[self.cur ^ 1]
         zero = self.dirty[self.cur ^ 1]
         self.dirty[self.cur], self.dirty[self.cur ^ 1] = n, 0
@@ -709,6 +724,11 @@ class _BnBwdScratch:
     def _reset(self):
         self.store.fill_(0.0)            # ONE elementwise launch (a captured memset node measured far slower than a kernel node)
         self.dirty = [0, 0]
+        self.poisoned = False
+
+    def poison(self):
+        """A launch between acquire() and its apply pass failed: the buffers' contents are unknown."""
+        self.poisoned = True
 
 
 _BnFwdScratch = _BnBwdScratch       # forward and backward calls alternate through the SAME pair (one reset per capture)
@@ -718,25 +738,30 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
     """Projection (statistics in its epilogue) -> BN-apply straight from the fp64 sums: two launches, no finalize kernel.
     Returns (Y, a, c, mean, invstd)."""
     dev = x.device
-    cur, other, zero = _BnFwdScratch.of(dev).acquire(lib, 2 * nb * cout)
-    Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
-    none10 = [None] * 10
-    if planes is not None:
-        rc = lib.gkg_linear_bn_fwd_x6(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
-                                      _ptr(cur), _stream())
-    else:
-        rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
-    _lib.check(rc, "gkg_linear_bn_fwd (statistics only)")
-    a = torch.empty(nb * cout, dtype=_F32, device=dev)
-    c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
-    track = bn.training and bn.track_running_stats
-    _touch_stats(bn, track)
-    _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
-                                      _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
-                                      _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd),
-                                      _ptr(res), _ptr(out), R, cout, nb, ldo, obs, act, nchw_B, _ptr(scale), rows_per_scale,
-                                      float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
-               "gkg_bn_apply_train")
+    scratch = _BnFwdScratch.of(dev)
+    cur, other, zero = scratch.acquire(lib, 2 * nb * cout)
+    try:
+        Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
+        none10 = [None] * 10
+        if planes is not None:
+            rc = lib.gkg_linear_bn_fwd_x6(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
+                                          _ptr(cur), _stream())
+        else:
+            rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
+        _lib.check(rc, "gkg_linear_bn_fwd (statistics only)")
+        a = torch.empty(nb * cout, dtype=_F32, device=dev)
+        c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        track = bn.training and bn.track_running_stats
+        _touch_stats(bn, track)
+        _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                          _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                          _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd),
+                                          _ptr(res), _ptr(out), R, cout, nb, ldo, obs, act, nchw_B, _ptr(scale), rows_per_scale,
+                                          float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
+                   "gkg_bn_apply_train")
+    except Exception:
+        scratch.poison()                 # sums may sit in a buffer the bookkeeping calls clean: cleared at the next acquire
+        raise
     return Y, a, c, mean, invstd
 
 
@@ -754,10 +779,15 @@ def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg
     if sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES:
         # two launches: statistics with fp64 atomics into one of two alternating scratch buffers, apply (which also clears
         # what the previous call left in the other buffer) — no partial rows, no second-stage reduction launch
-        cur, other, zero = _BnBwdScratch.of(Y.device).acquire(lib, 2 * nb * C)
-        _lib.check(lib.gkg_bn_bwd_atomic(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
-                                         _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), zero, _stream()),
-                   "gkg_bn_bwd_atomic")
+        scratch = _BnBwdScratch.of(Y.device)
+        cur, other, zero = scratch.acquire(lib, 2 * nb * C)
+        try:
+            _lib.check(lib.gkg_bn_bwd_atomic(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
+                                             _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), zero, _stream()),
+                       "gkg_bn_bwd_atomic")
+        except Exception:
+            scratch.poison()
+            raise
         return
     ws = _ws(lib.gkg_bn_workspace_bytes(R, C, nb), Y.device)
     if sync is None:
@@ -974,6 +1004,7 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
         rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
         if tuple(rp.shape) != (N, M):
             raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+        flags |= _lib.relpos_flags(relative_pos)
     edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device=x.device)
     ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
     rc = lib.gkg_knn_fwd_tm(_ptr(x), _ptr(y), _ptr(rp), edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k,

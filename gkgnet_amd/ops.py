@@ -59,7 +59,7 @@ def knn_graph(x: torch.Tensor, y: Optional[torch.Tensor] = None, relative_pos: O
         rp = relative_pos.detach().to(torch.float32).reshape(-1, relative_pos.shape[-1]).contiguous()
         if tuple(rp.shape) != (N, M):
             raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
-    flags = (_lib.KNN_NORMALIZE if normalize else 0) | _lib.knn_select_flags()
+    flags = (_lib.KNN_NORMALIZE if normalize else 0) | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
     dt = _DT[xq.dtype]
     edge = torch.empty((2 if want_center else 1, BG, N, k), dtype=torch.int64, device=xq.device)
     nbytes = lib.gkg_knn_workspace_bytes(BG, c, N, M, k, dilation, dt, flags)

@@ -212,7 +212,8 @@ class GradBucket:
         self._pending = []
         self._ready = {}
         self._complete = set()
-        self._point_grads()
+        self._issued = 0            # re-arm the cursor: a following backward (zero() + backward, or an accumulating one)
+        self._point_grads()         # without release() must start its chunk all-reduces again
 
 
 def grad_view(p: torch.nn.Parameter, shape=None):

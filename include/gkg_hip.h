@@ -61,6 +61,10 @@ extern "C" {
                                     * results either way (measurement, tests) */
 #define GKG_KNN_FORCE_PREFILTER 32u /* take the prefilter kernel wherever it is applicable (normalised tokens, un-split keys,
                                     * k*dilation <= 36, c >= 16), not only where the library's rule says it pays (tests) */
+#define GKG_KNN_RELPOS_UNIT 64u     /* the caller guarantees |relative_pos| <= 1 everywhere (GKGNet's bias -2 PE PE^T / D lies
+                                    * in [-1, 0], pos_embed.py:21-29): precondition of the prefilter kernel's error bound when a
+                                    * bias is given.  Without it a call with a bias always takes knn_tile_kernel (same results,
+                                    * no range assumption) */
 
 /* argument errors */
 #define GKG_ERR_NULL -1        /* required pointer is NULL */

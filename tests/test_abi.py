@@ -41,3 +41,22 @@ def test_cpu_tensors_are_rejected_not_routed_to_a_fallback():
         ops.knn_graph(torch.zeros(1, 4, 8), None, None, 3, 1)
     with pytest.raises(_lib.GkgError):
         ops.max_relative(torch.zeros(1, 4, 8), torch.zeros(1, 8, 3, dtype=torch.int64))
+
+
+def test_no_kernel_runs_out_of_scratch_memory():
+    """the max-relative kernels (gather / scatter, every form) carry NO scratch memory — run-time
+    `mode` / `arg_kind` branches once sent the float4s of the scatter's inner loop through it — and no kernel of the library
+    spills more than a handful of registers (the 64-entry buffered k-NN forms spilled 100-400 and were removed).  Read from
+    the AMDGPU metadata notes of the gfx950 code objects embedded in the shipped library (tools/kernel_meta.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    from gkgnet_amd import _build
+    ks = kernel_meta.kernels(_build.build())
+    assert len(ks) > 100
+    mr = {n: k for n, k in ks.items() if "mr_" in n and "mr_linear" not in n}
+    assert len(mr) >= 30, sorted(mr)
+    bad = {n: k.get("private_segment_fixed_size") for n, k in mr.items() if k.get("private_segment_fixed_size", 0) != 0}
+    assert not bad, bad
+    heavy = {n: k.get("vgpr_spill_count") for n, k in ks.items() if k.get("vgpr_spill_count", 0) > 8}
+    assert not heavy, heavy

@@ -1,5 +1,6 @@
 """SURVEY §8 row g1 (inference): gather + max(x_j - x_i) + interleave + grouped 1x1 projection + BN(eval) + GELU in one launch
-(csrc/gkg_mrgemm.hip) against (i) a plain torch fp32 statement of the same definition on the same bf16-rounded operands and
+(csrc/gkg_mrgemm.hip) against (i) the C ORACLE's aggregation (oracle/c_oracle.mr_fwd) followed by a dense grouped 1x1 convolution
+(F.conv2d, groups=4) of the oracle's interleaved output on the same bf16-rounded operands and
 (ii) the product's own three-launch form (gkg_mr_fwd_tm -> batched GEMM -> gkg_affine_act), which the reference-generated
 fixtures pin.  Reference: torch_vertex.py:47-62, torch_nn.py:57-69."""
 import numpy as np
@@ -11,28 +12,27 @@ pytestmark = pytest.mark.gpu
 # (B, G, C, N, M (None = self graph), k)
 CASES = [(2, 2, 80, 150, None, 9), (2, 4, 320, 324, None, 9), (3, 2, 160, 100, 25, 9), (1, 2, 400, 1296, None, 9),
          (2, 2, 640, 324, None, 9), (2, 8, 768, 70, None, 18), (2, 8, 192, 333, 90, 18), (2, 1, 48, 65, None, 5),
-         (4, 4, 320, 80, 324, 9), (1, 2, 16, 64, None, 3), (1, 8, 96, 1000, 250, 18)]
+         (4, 4, 320, 80, 324, 9), (1, 2, 16, 64, None, 3), (1, 8, 96, 1000, 250, 18),
+         (2, 3, 288, 100, None, 9)]       # G = 3: a conv group (C/4 channels) straddles two k-NN groups (C/3) — ADVICE r3
 
 
-def _definition(x, src, idx, G, W, a, c):
-    """fp32 torch: m = max_k(src[idx] - x); u = interleave -> bf16; per conv group y = u W^T (fp32); gelu(a y + c) -> bf16"""
+def _definition(x, src, idx, G, conv_weight, a, c):
+    """Expected value from the ORACLE: m = oracle mr_fwd (C, bit-exact contract of max_k(src[idx] - x), torch_vertex.py:49-54);
+    [x, m] interleaved exactly like the reference's cat (torch_vertex.py:61), rounded to bf16 (the kernel's operand type);
+    the reference's BasicConv as a dense F.conv2d(groups=4) with the bf16-rounded weight in fp32 (torch_nn.py:57-69);
+    gelu(a y + c) -> bf16."""
+    from oracle import c_oracle as O
     B, N, C = x.shape
     cg = C // G
-    s = x if src is None else src
-    m = torch.empty_like(x)
-    for g in range(G):
-        sl = slice(g * cg, (g + 1) * cg)
-        ii = idx.view(B, G, N, -1)[:, g]                                    # (B, N, k)
-        nb = torch.gather(s[:, :, sl].unsqueeze(1).expand(B, N, s.shape[1], cg), 2, ii.unsqueeze(-1).expand(B, N, ii.shape[-1], cg))
-        m[:, :, sl] = (nb - x[:, :, sl].unsqueeze(2)).max(2).values
-    Cq = C // 4
-    outs = []
-    for q in range(4):
-        u = torch.stack([x[:, :, q * Cq:(q + 1) * Cq], m[:, :, q * Cq:(q + 1) * Cq]], -1).reshape(B * N, 2 * Cq)
-        y = u.bfloat16().float() @ W[q].bfloat16().float().t()
-        outs.append(y)
-    y = torch.cat(outs, 1)
-    return torch.nn.functional.gelu(a * y + c).bfloat16()
+    xc = x.permute(0, 2, 1).reshape(B, G, cg, N).reshape(B * G, cg, N).cpu().numpy()          # the reference's (B*G, c, N)
+    sc = None if src is None else src.permute(0, 2, 1).reshape(B * G, cg, src.shape[1]).cpu().numpy()
+    m, _ = O.mr_fwd(xc, sc, idx.cpu().numpy())
+    m = torch.from_numpy(m).reshape(B, C, N, 1)
+    xr = x.permute(0, 2, 1).reshape(B, C, N, 1).cpu()
+    u = torch.cat([xr.unsqueeze(2), m.unsqueeze(2)], dim=2).reshape(B, 2 * C, N, 1)               # torch_vertex.py:61
+    y = torch.nn.functional.conv2d(u.bfloat16().float(), conv_weight.cpu().bfloat16().float(), None, groups=4)
+    y = y.reshape(B, 2 * C, N).permute(0, 2, 1).reshape(B * N, 2 * C)
+    return torch.nn.functional.gelu(a.cpu() * y + c.cpu()).bfloat16().cuda()
 
 
 @pytest.mark.parametrize("B,G,C,N,M,k", CASES)
@@ -51,7 +51,7 @@ def test_fused_aggregation_projection_matches_its_definition(B, G, C, N, M, k):
     inv = torch.rsqrt(bn.running_var + bn.eps)
     a = bn.weight * inv
     c = bn.bias + a * (conv.bias - bn.running_mean)
-    want = _definition(x, src, idx, G, conv.weight.detach().view(4, C // 2, C // 2), a.detach(), c.detach()).float()
+    want = _definition(x, src, idx, G, conv.weight.detach(), a.detach(), c.detach()).float()
     assert got.shape == want.shape == (B * N, 2 * C)
     # bf16 outputs of fp32 accumulations that differ in summation order: a rounding boundary may flip -> 1 bf16 ulp
     err = (got - want).abs()

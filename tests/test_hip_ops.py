@@ -331,3 +331,26 @@ def test_prefilter_slow_path_on_massive_ties(monkeypatch):
         want_idx, _ = O.knn(x, y, None, k, d)
         edge = ops.knn_graph(_dev(x), _dev(y), None, k, d)
         assert np.array_equal(edge[0].cpu().numpy(), want_idx), (c, N, M, k, d, nuniq)
+
+
+def test_prefilter_is_not_taken_for_a_bias_outside_its_error_bound(monkeypatch):
+    """the prefilter's error bound assumes |relative_pos| <= 1.  With a bias far outside that range (|rp| up to
+    300, where the matrix-core accumulation error exceeds the margin) the call must still return the contract's graph even
+    with the prefilter forced: the Python layer does not vouch for the range (no GKG_KNN_RELPOS_UNIT) and the library
+    takes the fp32 tile kernel."""
+    from gkgnet_amd import _lib, ops
+    from oracle import c_oracle as O
+    monkeypatch.delenv("GKG_KNN_SELECT", raising=False)
+    monkeypatch.setenv("GKG_KNN_PREFILTER", "force")
+    rng = np.random.RandomState(11)
+    x = rng.standard_normal((2, 64, 150)).astype(np.float32)
+    y = rng.standard_normal((2, 64, 1100)).astype(np.float32)
+    # near-equal large biases: candidates separated by the fp32 rounding of (bias + distance), not by the bias itself
+    rp = (-300.0 + 1e-3 * rng.random_sample((150, 1100))).astype(np.float32)
+    rp_dev = _dev(rp).unsqueeze(0)
+    assert _lib.relpos_flags(rp_dev) == 0
+    small = _dev(-rng.random_sample((150, 1100)).astype(np.float32)).unsqueeze(0)
+    assert _lib.relpos_flags(small) == _lib.KNN_RELPOS_UNIT
+    want_idx, _ = O.knn(x, y, rp, 9, 2)
+    edge = ops.knn_graph(_dev(x), _dev(y), rp_dev, 9, 2)
+    assert np.array_equal(edge[0].cpu().numpy(), want_idx)

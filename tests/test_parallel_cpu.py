@@ -224,3 +224,34 @@ def test_grad_view_is_handed_out_once_per_backward():
         want = torch.ones(5, 4).t() @ x1 + torch.ones(6, 4).t() @ x2
         assert torch.allclose(w.grad, want, atol=1e-5)
         assert bucket._resident(w)
+
+
+def _no_release_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from gkgnet_amd.parallel import GradBucket, init_distributed
+    init_distributed("gloo")
+    ps = [torch.nn.Parameter(torch.ones(n)) for n in (4, 6, 3)]
+    bucket = GradBucket(ps, bucket_bytes=8)
+    bucket.install_overlap_hooks()
+    seen = []
+    for step in range(3):
+        bucket.zero()                                   # gradients stay attached: the backward accumulates into the bucket
+        sum((p * float(rank + 1)).sum() for p in ps).backward()
+        bucket.wait()
+        seen.append([p.grad.clone() for p in ps])
+    out[rank] = seen
+    dist.destroy_process_group()
+
+
+def test_overlap_hooks_reduce_every_step_without_release():
+    """wait() must re-arm the chunk cursor — a zero() + backward + wait() loop that never calls release() has to
+    average the gradients in EVERY step (rank contributions 1 and 2 -> 1.5), not only in the first."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_no_release_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for step in range(3):
+        for a, b in zip(out[0][step], out[1][step]):
+            assert torch.equal(a, b), step
+            assert torch.allclose(a, torch.full_like(a, 1.5)), (step, a)
