@@ -34,7 +34,22 @@ WORKLOADS = {
                     desc="reference stage-4 shape: Grapher(C640,G2,k9,d3,18x18)+GrapherLabel(L80) fwd+bwd"),
     "stage3": dict(C=400, G=2, H=36, k=9, d=2, r=1, L=80,
                    desc="reference stage-3 shape: Grapher(C400,G2,k9,d2,36x36)+GrapherLabel(L80) fwd+bwd"),
+    # GKGNet-576 stage 1: 20 736 image tokens x 1 296 pooled keys per image, T = 663 552 rows at B = 32 — the shape where the
+    # gather / scatter kernels are genuinely HBM-bandwidth-bound (roofline_hbm)
+    "stage1": dict(C=80, G=2, H=144, k=9, d=1, r=4, L=80, cpu_sample=2,
+                   desc="reference stage-1 shape: Grapher(C80,G2,k9,d1,r4,144x144,relpos)+GrapherLabel(L80) fwd+bwd"),
 }
+# whole-backbone workloads (BASELINE.json configs[2..4]): run_backbone()
+BACKBONE_WORKLOADS = {
+    "cfg3": dict(kind="forward", kw=dict(choice="s", k=9, k_label_gcn=9, n_classes=80, size=576), B=32,
+                 desc="BASELINE cfg3: full GKGNet-576 (pvig_s) forward, B=32, bf16 autocast, all 16 graph layers on the HIP kernels"),
+    "cfg5": dict(kind="forward", kw=dict(choice="m", k=18, k_label_gcn=18, n_classes=80, size=768, num_group=8), B=16,
+                 desc="BASELINE cfg5: pvig_m 768x768 forward, k=18 G=8, B=16, bf16 autocast"),
+    "cfg4": dict(kind="train", kw=dict(choice="s", k=9, k_label_gcn=9, n_classes=80, size=576, drop_path=0.1), B=32,
+                 desc="BASELINE cfg4: GKGNet-576 training step (ASL x10 + smoothed BCE, AdamW, clip 5.0), fp32, B=32 per GPU, "
+                      "data-parallel with RCCL gradient all-reduce"),
+}
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak (no sparsity)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 PEAK_HBM_GBPS = 8000.0
 
@@ -51,7 +66,13 @@ def build_modules(w, device):
 
 def cpu_baseline(w, B, grapher, label, x, e, cot_x, cot_e, budget_s=12.0, threads=None):
     """Oracle (torch-CPU restatement of the reference) timed on this box's host cores: the reported baseline.
-    ``threads``: torch intra-op threads for this leg (None: torch's default = all cores it is given)."""
+    ``threads``: torch intra-op threads for this leg (None: torch's default = all cores it is given).  Workloads with a
+    ``cpu_sample`` entry time the oracle on that many images of the batch (the reference materialises the (B G, N, M)
+    distance tensor: 6.9 GB at stage 1 / B = 32)."""
+    sb = min(B, w.get("cpu_sample", B))
+    if sb < B:
+        x, e, cot_x, cot_e = x[:sb], e[:sb], cot_x[:sb], cot_e[:sb]
+        B = sb
     from oracle import torch_ref as R
     old_threads = torch.get_num_threads()
     if threads:
@@ -62,8 +83,8 @@ def cpu_baseline(w, B, grapher, label, x, e, cot_x, cot_e, budget_s=12.0, thread
         for k, v in d.items():
             if v.dtype.is_floating_point and "running" not in k and k != "relative_pos":
                 v.requires_grad_(True)
-    xc, ec = x.detach().cpu(), e.detach().cpu()
-    cx, ce = cot_x.cpu(), cot_e.cpu()
+    xc, ec = x.detach().cpu().contiguous(), e.detach().cpu()
+    cx, ce = cot_x.cpu().contiguous(), cot_e.cpu()
 
     def step():
         xg, eg = xc.clone().requires_grad_(True), ec.clone().requires_grad_(True)
@@ -110,6 +131,16 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def rank_devices(rank, world, local):
+    """["rank r: cuda:i (device name)", ...] for every rank of the job (gathered over the process group)."""
+    mine = f"rank {rank}: cuda:{local} ({torch.cuda.get_device_name(local)})"
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    torch.distributed.all_gather_object(out, mine)
+    return out
+
+
 def spawn_ranks(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher: start N ranks as children (torch.distributed.run, one per GPU,
     rendezvous on 127.0.0.1) BEFORE this process has touched the GPU — it never does: it only relays the children's output
@@ -127,13 +158,232 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def cpu_baseline_backbone(net, head, img, tgt, kind, budget_s=20.0, threads=None):
+    """CPU baseline of the whole-backbone workloads: a CPU copy of the same network with the graph operators routed to
+    the ORACLE (oracle/torch_ref.py's reference-order k-NN / gather / max; the composable modules around them are plain
+    torch — conv2d, batch_norm — exactly what the reference runs: tests/test_backbone.py::
+    test_wiring_reproduces_reference_with_oracle_operators pins this arrangement to the reference bit for bit), fp32,
+    on a BOUNDED sample of the batch.  ``kind``: "forward" (eval, no_grad) or "train" (forward + loss + backward)."""
+    import copy
+    import gkgnet_amd.graph as graph
+    from oracle import torch_ref as R
+    old_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    real = graph.ops
+    graph.ops = type("OracleOps", (), {
+        "knn_graph": staticmethod(lambda x, y, rp, k, d: R.knn_graph(x, y, rp, k, d)),
+        "max_relative": staticmethod(lambda x, idx, y=None: R.max_relative(x, idx, y))})
+    try:
+        cnet = copy.deepcopy(net).float().cpu()
+        chead = None if head is None else copy.deepcopy(head).float().cpu()
+        ci = img.detach().float().cpu()
+        ct = None if tgt is None else tgt.detach().float().cpu()
+
+        def step():
+            if kind == "forward":
+                with torch.no_grad():
+                    cnet(ci)
+            else:
+                cnet.zero_grad(set_to_none=True)
+                losses = chead.forward_train(cnet(ci), ct)
+                (losses["bce_loss"] + losses["asy_loss"]).backward()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s * 0.5 or n >= 10:
+                break
+    finally:
+        graph.ops = real
+        used = torch.get_num_threads()
+        torch.set_num_threads(old_threads)
+    b = ci.shape[0]
+    return dict(value=round(b * n / dt, 3), unit="images/s", cores=used, kind="port",
+                sample=f"{n} {'forward passes' if kind == 'forward' else 'forward + loss + backward passes'} of the same network on "
+                       f"{b} image(s) of the batch, graph operators = oracle/torch_ref.py, fp32, {dt:.1f}s, {used} torch threads; "
+                       f"host: {physical_cores()} physical cores / {os.cpu_count()} logical cpus")
+
+
+def run_backbone(args):
+    """--workload cfg3 | cfg5 (full-backbone forward, bf16 autocast, eval) and cfg4 (training step, fp32): the same JSON
+    schema as the block workloads.  Reference: gkgnet.py:263-284 (forward), label_query_head.py:70-83 + configs/gkgnet/
+    gkgnet_coco_576.py:110-126 (loss / optimiser), apis/train.py:117-125 (DDP)."""
+    spec = BACKBONE_WORKLOADS[args.workload]
+    os.environ.setdefault("GKG_RELPOS_DEVICE", "cuda")
+    from gkgnet_amd import _lib, fused, layers, parallel
+    from gkgnet_amd.backbone import GKGNet
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    devices = rank_devices(rank, world, local)
+    backend = torch.distributed.get_backend() if world > 1 else None
+    kind = spec["kind"]
+    layers.norm_cfg["type"] = "SyncBN" if (args.sync_bn and world > 1 and kind == "train") else "BN"
+    if not args.no_tune:                 # library GEMM selection per shape, tuned during the warm-up passes
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30)
+        tunable.set_max_tuning_iterations(20 if kind == "forward" else 10)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gkg_tunableop_{args.workload}_rank{rank}.csv"))
+    B = args.batch or spec["B"]
+    kw = dict(spec["kw"])
+    size = kw["size"]
+    torch.manual_seed(0)
+    t_build = time.perf_counter()
+    net = GKGNet(**kw).to(dev)
+    build_s = time.perf_counter() - t_build
+    gen = torch.Generator().manual_seed(100 + rank)
+    img = torch.randn(B, 3, size, size, generator=gen).to(dev)
+    steps = args.steps if args.steps != 50 else (10 if kind == "forward" else 6)      # default K sized to finish in minutes
+    warmup = args.warmup if args.warmup != 10 else 3
+    head = tgt = None
+    n_graph = sum(1 for m in net.modules() if type(m).__name__ in ("Grapher", "GrapherLabel"))
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = t.item()
+        return el
+
+    def profile(fn, n=2):
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        prof = _lib.prof_read()
+        work = {k: _lib.prof_work(k) / n for k in ("knn_tile", "mr_fwd", "mr_bwd", "gemm_x6")}
+        return {k: dict(us_per_step=round(1e3 * v[0] / n, 1), launches_per_step=v[1] // n) for k, v in prof.items() if v[1]}, work
+
+    legs = {}
+    if kind == "forward":
+        net.eval()
+
+        def fwd():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return net(img)
+        names = ["exact", "bf16"] if args.knn == "both" else [args.knn]
+        for name in names:
+            fused.KNN_BF16 = name == "bf16"
+            el = timed(fwd)
+            kernels, work = profile(fwd)
+            legs[name] = (el, kernels, work)
+        fused.KNN_BF16 = names[0] == "bf16"
+        headline = names[0]
+        step_desc = "forward (eval, bf16 autocast)"
+        dtype = "bf16"
+        metric = "GKGNet forward images/sec"
+    else:
+        from gkgnet_amd.head import LabelQueryHead, build_optimizer
+        net.train()
+        head = LabelQueryHead(kw["n_classes"], GKGNet.arch_settings[kw["choice"]]["channels"][-1]).to(dev).train()
+        parallel.broadcast_parameters(net)
+        parallel.broadcast_parameters(head)
+        params = [p for p in list(net.parameters()) + list(head.parameters()) if p.requires_grad]
+        bucket = parallel.GradBucket(params)
+        opt = build_optimizer([net, head])
+        tgt = (torch.rand(B, kw["n_classes"], generator=gen) < 0.04).float().to(dev)
+        bucket.install_overlap_hooks()       # chunk all-reduces start during the backward (the reference's DDP reducer)
+
+        def train_step():
+            bucket.release()
+            losses = head.forward_train(net(img), tgt)
+            (losses["bce_loss"] + losses["asy_loss"]).backward()
+            bucket.wait()
+            torch.nn.utils.clip_grad_norm_(params, 5.0)
+            opt.step()
+        el = timed(train_step)
+        kernels, work = profile(train_step, 1)
+        legs["train"] = (el, kernels, work)
+        headline = "train"
+        step_desc = "forward + ASL x10 + smoothed BCE + backward + grad all-reduce + clip 5.0 + AdamW"
+        dtype = "f32"
+        metric = "GKGNet train-step images/sec"
+
+    if rank == 0:
+        el, kernels, work = legs[headline]
+        ms_step = 1e3 * el / steps
+        value = world * B * steps / el
+        roof = None
+        if "knn_tile" in kernels and kernels["knn_tile"]["us_per_step"] > 0:
+            us = kernels["knn_tile"]["us_per_step"]
+            ach = work["knn_tile"] / (us * 1e-6) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS if headline == "bf16" else PEAK_FP32_MFMA_TFLOPS
+            roof = dict(kernel="knn_tile_kernel / knn_pf_kernel (all k-NN launches of the step)", bound="mfma",
+                        achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                        us_per_step=us, launches_per_step=kernels["knn_tile"]["launches_per_step"],
+                        algorithmic_flops_per_step=work["knn_tile"],
+                        note="algorithmic 2 B C N M flop of every graph layer (SURVEY §8d) / summed HIP-event time of the k-NN "
+                             "launches; peak: dense fp32 matrix peak for the index-exact contract (the prefilter kernel does the "
+                             "bulk on the bf16 cores and may exceed it), dense bf16 peak for the opt-in bf16 contraction")
+        roof_hbm = {}
+        for name in ("mr_fwd", "mr_bwd"):
+            if name in kernels and work.get(name, 0) > 0:
+                gbs = work[name] / kernels[name]["us_per_step"] / 1e3
+                roof_hbm[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                                      frac=round(gbs / PEAK_HBM_GBPS, 4), algorithmic_bytes_per_step=work[name],
+                                      us_per_step=kernels[name]["us_per_step"])
+        res = dict(metric=metric, value=round(value, 1), unit="images/s", n_gpus=world, steps=steps, warmup=warmup,
+                   ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype=dtype,
+                   data="synthetic (random-init weights, N(0,1) images" + (", 4 % positive labels)" if kind == "train" else ")"),
+                   config=dict(workload=spec["desc"], step=step_desc, batch_per_gpu=B, global_batch=B * world,
+                               input=f"{size}x{size}", graph_layers_on_hip=n_graph, k=kw["k"], groups=kw.get("num_group", 2),
+                               bn=("sync" if layers.norm_cfg["type"] == "SyncBN" else "local") if kind == "train" else "eval",
+                               parallelism=f"dp{world}", world_size=world, backend=backend or "none (single process)",
+                               devices=devices, launch="eager (host-launched kernels)",
+                               knn=("index-exact contract (library default; same graphs as fp32)" if headline != "bf16" else
+                                    "bf16 contraction (opt-in GKG_KNN_BF16_CONTRACT)"),
+                               gemm_selection="library default" if args.no_tune else "TunableOp pass in the warm-up",
+                               grad_allreduce=("n/a (inference)" if kind == "forward" else
+                                               ("none (1 GPU)" if world == 1 else
+                                                f"chunked {'RCCL' if backend == 'nccl' else backend} all-reduces started from "
+                                                f"post-accumulate hooks during backward"))),
+                   roofline=roof, roofline_hbm=roof_hbm, hip_kernels=kernels,
+                   peak_mem_GiB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), model_build_s=round(build_s, 1))
+        if kind == "forward":
+            for name, (e2, k2, w2) in legs.items():
+                res[f"ms_per_step_knn_{name}"] = round(1e3 * e2 / steps, 3)
+                if "knn_tile" in k2:
+                    res[f"knn_us_per_step_{name}"] = k2["knn_tile"]["us_per_step"]
+        if world == 1 and not args.no_cpu_baseline:
+            sb = 1 if kind == "forward" else 2
+            res["cpu_baseline"] = cpu_baseline_backbone(net, head, img[:sb], None if tgt is None else tgt[:sb], kind)
+            res["cpu_baseline"]["host_physical_cores"] = physical_cores()
+            res["speedup_vs_cpu"] = round(value / max(res["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(BACKBONE_WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 32; cfg5: 16)")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (reference DDP semantics)")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "channels_last"],
                     help="memory format of the feature map and its upstream gradient: nchw (default: what the reference's own "
@@ -142,10 +392,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="keep the GEMM library's default kernel selection")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--knn", default="both", choices=["both", "exact", "bf16"],
+                    help="cfg3 / cfg5 (bf16 autocast): which k-NN legs to time — exact (the bit-exact index contract, same graphs as "
+                         "fp32: the default mode of the library) and / or bf16 (the opt-in GKG_KNN_BF16_CONTRACT contraction)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))         # no launcher: be the launcher (this process never touches the GPU)
+    if args.workload in BACKBONE_WORKLOADS:
+        return run_backbone(args)
+    if args.batch is None:
+        args.batch = 32
     from gkgnet_amd import _lib, layers, parallel
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
@@ -154,6 +411,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    devices = rank_devices(rank, world, local)
     layers.norm_cfg["type"] = "SyncBN" if (args.sync_bn and world > 1) else "BN"
     # --sync-bn: the statistics all-reduces sit inside the step.  Capturing them into the hipGraph is attempted like
     # everything else (RCCL collectives are capturable); if capture fails, or replay loses the untimed vote against eager
@@ -194,9 +452,15 @@ def main():
     # The step is ~85 short kernels: launched eagerly it is bound by host launch overhead, so the inner loop is
     # captured ONCE into a hipGraph (inputs, weights and the gradient bucket are static buffers) and replayed.
     # host-synchronising collectives (gloo) inside the step cannot be captured: SyncBN all-reduces its statistics in the step
-    capturable = not (world > 1 and args.sync_bn and torch.distributed.get_backend() != "nccl")
+    backend = torch.distributed.get_backend() if world > 1 else None
+    capturable = not (world > 1 and args.sync_bn and backend != "nccl")
     if not capturable:
         print("[bench] SyncBN over a non-RCCL backend: the step is launched eagerly", file=sys.stderr)
+    # N > 1 over RCCL: the gradient all-reduce is captured INTO the step's hipGraph (RCCL collectives are capturable: the
+    # collective becomes a node on RCCL's stream, joined back before the end of the graph) — one graph launch per step, no
+    # host-issued collective between replays (reference: the DDP reducer inside backward, mmcls/apis/train.py:117-125).
+    # Host-synchronising backends (gloo: the 1-GPU exercise) keep the collective outside the graph.
+    state = {"reduce_in_graph": False}
 
     def measure():
         """eager warm-up -> capture -> (multi-rank: replay-vs-eager vote) -> W untimed + K timed steps.  Returns
@@ -216,11 +480,26 @@ def main():
                 torch.cuda.synchronize()
                 if world > 1:
                     torch.distributed.barrier()
-                g = torch.cuda.CUDAGraph()
-                # thread_local: RCCL's watchdog thread may poll events while this thread captures
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    compute()
-                graph = g
+                state["reduce_in_graph"] = False
+                if world > 1 and backend == "nccl":
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            compute()
+                            bucket.all_reduce()
+                        graph = g
+                        state["reduce_in_graph"] = True
+                    except Exception as exc:
+                        print(f"[bench] capturing the RCCL all-reduce into the step failed ({type(exc).__name__}: {exc}); "
+                              f"the collective stays outside the graph", file=sys.stderr)
+                        graph = None
+                        torch.cuda.synchronize()
+                if graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: RCCL's watchdog thread may poll events while this thread captures
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        compute()
+                    graph = g
             except Exception as exc:                       # capture is an optimisation: fall back to eager launches
                 print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
                 graph = None
@@ -233,6 +512,8 @@ def main():
                 compute()
             else:
                 graph.replay()
+                if state["reduce_in_graph"]:
+                    return
             bucket.all_reduce()
 
         if graph is not None and world > 1:
@@ -253,6 +534,7 @@ def main():
                 print(f"[bench] hipGraph replay slower than eager launches under this process group "
                       f"({1e3 * t_cmp[0].item():.2f} vs {1e3 * t_cmp[1].item():.2f} ms/step); running eagerly", file=sys.stderr)
                 graph = None
+                state["reduce_in_graph"] = False
 
         for _ in range(args.warmup):
             step()
@@ -344,16 +626,17 @@ def main():
                         algorithmic_flops_per_step=flops_knn)
         kernels = {k: dict(us_per_step=round(1e3 * v[0] / prof_steps, 2), launches_per_step=v[1] // prof_steps)
                    for k, v in prof.items() if v[1]}
-        # HBM-bound companions of the k-NN kernel: algorithmic bytes / measured time, vs 8 TB/s
-        e4, Cq = 4, C
-        by_fwd = e4 * B * Cq * N * 2 + 8 * BG * N * w["k"] + B * Cq * N \
-            + e4 * B * Cq * (L + N) + e4 * B * Cq * L + 8 * BG * L * w["k"] + B * Cq * L
-        by_bwd = e4 * B * Cq * N * 3 + 8 * BG * N * w["k"] + B * Cq * N \
-            + e4 * B * Cq * L * 2 + e4 * B * Cq * N + 8 * BG * L * w["k"] + B * Cq * L
-        for name, nbytes in (("mr_fwd", by_fwd), ("mr_bwd", by_bwd)):
+        # HBM-bound companions of the k-NN kernel (the gather + max-relative forward and its scatter backward): ALGORITHMIC
+        # bytes per SURVEY §8d, reported by the library per launch (gkg_prof_work), / measured time, vs 8 TB/s
+        roof_hbm = {}
+        for name, kern in (("mr_fwd", "mr_fwd_tm_kernel"), ("mr_bwd", "mr_bwd_tm_scatter_kernel")):
             if name in kernels and kernels[name]["us_per_step"] > 0:
+                nbytes = _lib.prof_work(name) / prof_steps
                 gbs = nbytes / kernels[name]["us_per_step"] / 1e3
                 kernels[name].update(bound="hbm", achieved_GBps=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBPS, 4))
+                roof_hbm[name] = dict(kernel=kern, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                                      frac=round(gbs / PEAK_HBM_GBPS, 4), algorithmic_bytes_per_step=nbytes,
+                                      us_per_step=kernels[name]["us_per_step"], launches_per_step=kernels[name]["launches_per_step"])
         if "gemm_x6" in kernels and kernels["gemm_x6"]["us_per_step"] > 0:
             # the projection GEMMs that run on the split-bf16 kernels: algorithmic fp32 flop (2 R cin cout, reported by the
             # library per launch) per second, against the fp32-MFMA peak they replace and against their own bound — six
@@ -388,9 +671,13 @@ def main():
                                layers.norm_cfg["type"] == "SyncBN" else "local", parallelism=f"dp{world}",
                                input_layout=args.layout,
                                launch="hipGraph replay of fwd+bwd+grad-pack" if graph is not None else "eager",
-                               gemm=gemm_desc,
-                               grad_allreduce="one flat RCCL all-reduce per step" if world > 1 else "none (1 GPU)"),
-                   roofline=roof, roofline_step=roof_step, hip_kernels=kernels,
+                               gemm=gemm_desc, world_size=world, backend=backend or "none (single process)",
+                               devices=devices,
+                               grad_allreduce=("none (1 GPU)" if world == 1 else
+                                               f"one flat {'RCCL' if backend == 'nccl' else backend} all-reduce per step, " +
+                                               ("captured inside the step's hipGraph" if state["reduce_in_graph"] else
+                                                "issued by the host after the replay"))),
+                   roofline=roof, roofline_hbm=roof_hbm, roofline_step=roof_step, hip_kernels=kernels,
                    ms_per_step_no_tune=round(1e3 * elapsed_no_tune / args.steps, 4),
                    gemm_selection="library default (no tuning pass)" if args.no_tune else
                    "TunableOp pass in the warm-up for the projections still on vendor GEMMs; ms_per_step_no_tune = the same "

@@ -22,7 +22,7 @@ KNN_RELPOS_UNIT = 64
 
 
 def relpos_flags(rp) -> int:
-    """KNN_RELPOS_UNIT when every |relative_pos| <= 1 (the prefilter kernel's precondition, include/gkg_hip.h).  The check
+    """KNN_RELPOS_UNIT when every |relative_pos| <= 1.125 (the prefilter kernel's precondition, include/gkg_hip.h).  The check
     is one reduction + a host read, cached ON the tensor object (keyed on its version counter): a module's frozen
     ``relative_pos`` parameter pays it once, in the eager warm-up; a tensor first seen inside a hipGraph capture is not
     vouched for (the call then takes the fp32 tile kernel: same results)."""
@@ -33,7 +33,7 @@ def relpos_flags(rp) -> int:
     if ent is None or ent[0] != rp._version:
         if torch.cuda.is_current_stream_capturing():
             return 0
-        ent = (rp._version, bool((rp.detach().abs().max() <= 1.0).item()))
+        ent = (rp._version, bool((rp.detach().abs().max() <= 1.125).item()))
         try:
             rp._gkg_unit = ent
         except AttributeError:

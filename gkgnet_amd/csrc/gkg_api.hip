@@ -76,6 +76,12 @@ GkgProfScope::GkgProfScope(int kernel_id, hipStream_t s, double work) : slot(-1)
   slot = (int)g_recs.size() - 1;
 }
 
+void gkg_prof_add_work(int kernel_id, double work) {
+  if (!g_prof_on || kernel_id < 0 || kernel_id >= GKG_PROF_NUM) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_work[kernel_id] += work;
+}
+
 GkgProfScope::~GkgProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -42,6 +42,10 @@ hipError_t launch_bn_sums_finalize(double* stats, int R, int cout, int nb, const
 int gkg_fail(int code, const char* msg);
 int gkg_fail_hip(hipError_t e, const char* where);
 
+// Adds algorithmic work to a profiled kernel's counter without timing anything (the k-NN entry point reports the
+// contraction's 2 BG c N M flop once per call; the tile / prefilter launch scopes underneath do the timing).
+void gkg_prof_add_work(int kernel_id, double work);
+
 // Opt-in launch timing (gkg_prof_*): RAII bracket around one kernel launch on `st`.
 struct GkgProfScope {
   GkgProfScope(int kernel_id, hipStream_t st, double work = 0.0);

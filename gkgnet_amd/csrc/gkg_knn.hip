@@ -434,7 +434,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // vs 119; the cfg2 Grapher graph is a tie: 51 + 22 vs 54 + 15), and against the BUFFERED selection of narrow groups with
   // long lists (pvig_m: c = 24 / k*d = 18: 4469 vs 3149).  GKG_KNN_FORCE_PREFILTER overrides the rule (tests).
   const bool pf_pays = M >= 1024 && (p.KD <= 12 ? p.cpad >= 40 : (p.KD <= 27 && p.cpad >= 128));
-  // The prefilter's error bound (knn_pf_kernel, step 3) is derived for |relative_pos| <= 1: the bias is the initial value of
+  // The prefilter's error bound (knn_pf_kernel, step 3) is derived for |relative_pos| <= 1.125: the bias is the initial value of
   // the accumulators, so the rounding of the accumulation scales with |bias| + 2.  A call with a bias takes the prefilter only
   // when the caller vouches for that range (GKG_KNN_RELPOS_UNIT; GKGNet's bias -2 PE PE^T / D lies in [-1, 0]) — ADVICE r3.
   const bool rp_ok = !relpos || (flags & GKG_KNN_RELPOS_UNIT);
@@ -450,6 +450,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   if (e != hipSuccess) return gkg_fail_hip(e, "token_prep");
+  gkg_prof_add_work(GKG_PROF_KNN_TILE, 2.0 * BG * (double)c * N * (double)M);    // algorithmic flop of the distance contraction
   KnnArgs a;
   a.xh = xh; a.yh = yh; a.sqx = sqx; a.sqy = sqy; a.relpos = relpos;
   a.nn_idx = nn_idx; a.center = center;
@@ -473,7 +474,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
     a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;
     // eps = split terms dropped (3 * 2^-18 * 2 = 2.3e-5) + fp32 accumulation of the 3c products, the bias and |y|^2 on partial
-    // sums <= |bias| + 2 <= 3 (9c * 2^-24) + the contract's own chain (2c * 2^-24): 11 c u = 6.6e-7 c; margin = 2 eps
+    // sums <= |bias| + 2 <= 3.125 (9.4c * 2^-24) + the contract's own chain (2c * 2^-24): 11.4 c u = 6.8e-7 c; margin = 2 eps
     a.margin = 2.0f * (3.0e-5f + 7.0e-7f * (float)p.cpad);
     a.wg_flags = (int*)(ws + p.off_flags);
     e = hipMemsetAsync(a.wg_flags, 0, sizeof(int) * (size_t)grid.x, st);

@@ -21,10 +21,10 @@ namespace gkg {
 // ranking S by the exact (d_e, m) keys gives exactly the contract's list (ties included).
 //   eps: with |x^| = |y^| = 1 (normalised tokens; the kernel is only selected with GKG_KNN_NORMALIZE) sum_ch |2 x^ y^| <= 2.
 //   Dropped terms of the split (lo.lo and the residuals |v - hi - lo| <= 2^-18 |v|): <= 3 * 2^-18 * 2 = 2.3e-5; fp32
-//   accumulation of the 3 c products on the matrix core, any order, on partial sums <= |bias| + 2 <= 3 (the bias is the
-//   accumulators' initial value: hence the |relative_pos| <= 1 precondition, GKG_KNN_RELPOS_UNIT): <= 3 c u * 3, u = 2^-24;
-//   the contract's own chain against the real value: <= c u * 2; the final adds: a few u.  eps = 3e-5 + 7e-7 * cpad
-//   (11 c u = 6.6e-7 c) covers the sum.
+//   accumulation of the 3 c products on the matrix core, any order, on partial sums <= |bias| + 2 <= 3.125 (the bias is the
+//   accumulators' initial value: hence the |relative_pos| <= 1.125 precondition, GKG_KNN_RELPOS_UNIT): <= 3 c u * 3.125,
+//   u = 2^-24; the contract's own chain against the real value: <= c u * 2; the final adds: a few u.
+//   eps = 3e-5 + 7e-7 * cpad (11.4 c u = 6.8e-7 c) covers the sum.
 // Per-wave lists: the 4 waves of a workgroup stream disjoint key tiles, so a wave may have dropped (beyond its KDW-entry
 // list) a key that belongs to S.  That can only have happened if the wave's own KDW-th entry is <= tau + 2 eps.  A query
 // tile with such a query, or with a query that has more than SMAX survivors (masses of exact or near ties: duplicated

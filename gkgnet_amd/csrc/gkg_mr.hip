@@ -672,8 +672,13 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode is 0 or 1");
   if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode 1 needs C % 16 == 0");
   if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: out_dtype is GKG_F32 or GKG_BF16");
+  const bool has_src = src != nullptr;
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
-  GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream);
+  // algorithmic bytes (SURVEY §8d "MR gather-max fwd"): x + (keys) + int64 indices + m (+ 1 byte of argmax per element)
+  const double e_out = out_dtype == GKG_BF16 ? 2.0 : 4.0;
+  const double work = 4.0 * B * (double)G * c * N + (has_src ? 4.0 * B * (double)G * c * M : 0.0) + 8.0 * B * (double)G * N * k
+                      + e_out * B * (double)G * c * N + (argmax ? 1.0 * B * (double)G * c * N : 0.0);
+  GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream, work);
   // one channel quad per thread: two quads per thread (shared index row) measured 20 % slower at cfg2 — the kernel
   // wants more threads in flight, not fewer index loads
   const long bpi = ((long)N * (G * c / 4) + 255) / 256;
@@ -730,7 +735,10 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode 1 needs C % 16 == 0");
   if (!gsrc && M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: self graph needs M == N");
   hipStream_t st = (hipStream_t)stream;
-  GkgProfScope prof(GKG_PROF_MR_BWD, st);
+  // algorithmic bytes (SURVEY §8d "MR bwd"): g + int64 indices + argmax + gx (+ gsrc)
+  const double work = 4.0 * B * (double)G * c * N + 8.0 * B * (double)G * N * k + 1.0 * B * (double)G * c * N
+                      + 4.0 * B * (double)G * c * N + (gsrc ? 4.0 * B * (double)G * c * M : 0.0);
+  GkgProfScope prof(GKG_PROF_MR_BWD, st, work);
   const int C = G * c;
   const size_t T = (size_t)B * N;
   const size_t total = T * (C / 4);

@@ -61,9 +61,10 @@ extern "C" {
                                     * results either way (measurement, tests) */
 #define GKG_KNN_FORCE_PREFILTER 32u /* take the prefilter kernel wherever it is applicable (normalised tokens, un-split keys,
                                     * k*dilation <= 36, c >= 16), not only where the library's rule says it pays (tests) */
-#define GKG_KNN_RELPOS_UNIT 64u     /* the caller guarantees |relative_pos| <= 1 everywhere (GKGNet's bias -2 PE PE^T / D lies
-                                    * in [-1, 0], pos_embed.py:21-29): precondition of the prefilter kernel's error bound when a
-                                    * bias is given.  Without it a call with a bias always takes knn_tile_kernel (same results,
+#define GKG_KNN_RELPOS_UNIT 64u     /* the caller guarantees |relative_pos| <= 1.125 everywhere (GKGNet's bias -2 PE PE^T / D lies
+                                    * in [-1, 0], pos_embed.py:21-29; its bicubic resize for pooled keys, torch_vertex.py:311-315,
+                                    * can overshoot by a fraction of a percent): precondition of the prefilter kernel's error
+                                    * bound when a bias is given.  Without it a call with a bias always takes knn_tile_kernel (same results,
                                     * no range assumption) */
 
 /* argument errors */
@@ -341,8 +342,11 @@ void gkg_prof_enable(int on);
 void gkg_prof_reset(void);
 /* total milliseconds and number of launches recorded for `kernel_id` since the last reset; 0 on success. */
 int gkg_prof_read(int kernel_id, double* total_ms, long* launches);
-/* Algorithmic work (flop) of the launches counted by gkg_prof_read since the last reset, for the kernels that report it
- * (GKG_PROF_GEMM_X6: 2 R cin cout nb per launch); 0 otherwise. */
+/* Algorithmic work of the launches counted by gkg_prof_read since the last reset, for the kernels that report it:
+ * GKG_PROF_GEMM_X6: flop, 2 R cin cout nb per launch; GKG_PROF_KNN_TILE: flop of the distance contraction, 2 BG c N M per
+ * gkg_knn_fwd[_tm] call (SURVEY §8d flops_knn); GKG_PROF_MR_FWD / _BWD (token-major entry points): BYTES per SURVEY §8d —
+ * fwd: x + keys (bipartite) + int64 indices + m + 1 B/element of argmax when saved; bwd: g + indices + argmax + gx + gsrc;
+ * 0 otherwise. */
 double gkg_prof_work(int kernel_id);
 
 #ifdef __cplusplus

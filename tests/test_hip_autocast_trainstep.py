@@ -20,8 +20,10 @@ def _set_agreement(a, b):
     return float(np.mean([(np.isin(x, y)).mean() for x, y in zip(a, b)]))
 
 
-def test_autocast_bf16_against_reference_autocast_fixture():
-    """F14: Grapher -> GrapherLabel under torch.autocast(bf16), eval, no_grad.
+@pytest.mark.parametrize("knn", ["exact", "bf16"])
+def test_autocast_bf16_against_reference_autocast_fixture(knn, monkeypatch):
+    """F14: Grapher -> GrapherLabel under torch.autocast(bf16), eval, no_grad; ``knn``: the library default (index-exact
+    contract: the same kernels as the fp32 path) and the opt-in bf16 contraction (GKG_ENABLE=knn_bf16).
 
     What "parity" means under bf16: the reference's own autocast run (bf16 convolutions AND a bf16 distance matmul)
     deviates from its fp32 run by  err_ref = mean|ref_autocast - ref_fp32|  and keeps only ~85 % of the fp32
@@ -32,6 +34,7 @@ def test_autocast_bf16_against_reference_autocast_fixture():
         mean|prod - ref_autocast| <= 1.5 * err_ref,   max|prod - ref_autocast| <= 0.35 * scale."""
     from gkgnet_amd import fused
     from gkgnet_amd.grapher import Grapher, GrapherLabel
+    monkeypatch.setattr(fused, "KNN_BF16", knn == "bf16")
     meta, a = load_fixture("f14_autocast_bf16")
     C, k, d, G, L, n = meta["C"], meta["k"], meta["dilation"], meta["G"], meta["L"], meta["n"]
     g = Grapher(C, k, d, "mr", "gelu", "batch", True, False, 0.2, 1, n=n, drop_path=0.0, relative_pos=True,

@@ -43,6 +43,7 @@ def test_bf16_contraction_matches_its_definition(B, G, c, N, M, k, d, relpos, se
     Mk = N if M is None else M
     rp = -torch.rand(1, N, Mk, device="cuda", generator=gen) if relpos else None
     with torch.autocast("cuda", dtype=torch.bfloat16):
+        monkeypatch.setattr(fused, "KNN_BF16", True)                  # opt-in mode (GKG_ENABLE=knn_bf16)
         edge = fused.knn_graph_tm(x, y, rp, k, d, G)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         monkeypatch.setattr(fused, "KNN_BF16", False)

@@ -24,24 +24,37 @@ def test_fused_syncbn_over_rccl():
     T.run_two_ranks(backend="nccl")
 
 
-def test_bench_starts_its_own_ranks_without_a_launcher():
-    """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment: the parent spawns the two ranks itself (it never
-    touches the GPU), relays rank 0's JSON line and exits with the children's code.  On a 1-GPU box the two ranks share the
-    device over gloo (GKG_DIST_BACKEND=gloo; RCCL refuses duplicate devices) — the N > 1 control flow of the driver's
-    scaling run: shard seeds, flat gradient all-reduce, max-over-ranks timing."""
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_bench_starts_its_own_ranks_without_a_launcher(sync_bn):
+    """``python bench.py --gpus 2 [--sync-bn]`` with no WORLD_SIZE in the environment: the parent spawns the two ranks itself
+    (it never touches the GPU), relays rank 0's JSON line and exits with the children's code.  On a 1-GPU box the two ranks
+    share the device over gloo (GKG_DIST_BACKEND=gloo; RCCL refuses duplicate devices) — the N > 1 control flow of the
+    driver's scaling run: shard seeds, flat gradient all-reduce, max-over-ranks timing; with --sync-bn the cross-rank batch
+    statistics of every BN layer inside the fused blocks (the reference's DDP semantics).  The JSON line names the world
+    size, the backend and every rank's device."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    if torch.cuda.device_count() < 2:
+    two = torch.cuda.device_count() >= 2
+    if not two:
         env["GKG_DIST_BACKEND"] = "gloo"
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--no-tune", "--no-cpu-baseline", "--batch", "4"], env=env, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-tune",
+           "--no-cpu-baseline", "--batch", "4"] + (["--sync-bn"] if sync_bn else [])
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["config"]["global_batch"] == 8
-    assert res["value"] > 0 and res["scaling"] == "weak" and res["config"]["parallelism"] == "dp2"
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and cfg["global_batch"] == 8
+    assert res["value"] > 0 and res["scaling"] == "weak" and cfg["parallelism"] == "dp2"
+    assert cfg["world_size"] == 2 and cfg["backend"] == ("nccl" if two else "gloo")
+    assert len(cfg["devices"]) == 2 and cfg["devices"][0].startswith("rank 0: cuda:") and cfg["devices"][1].startswith("rank 1: cuda:")
+    assert cfg["bn"] == ("sync" if sync_bn else "local")
+    if two:
+        assert "captured inside the step's hipGraph" in cfg["grad_allreduce"]
+    else:
+        assert "issued by the host" in cfg["grad_allreduce"]

@@ -92,14 +92,26 @@ def test_real_shape_blocks_fused_vs_composable_and_autocast_forward(cfg):
         # gradient elements to the other neighbour: element-wise for >= 99.9 %, bounded in norm
         okg = ((d1 - d2).abs() <= 2e-3 + 2e-3 * d2.abs()).float().mean().item()
         assert okg >= 0.999 and ((d1 - d2).norm() / d2.norm()).item() < 2e-2, (name, okg)
-    # ---- (2) the config's own mode: eval, bf16 autocast, every graph layer on the fused HIP path
+    # ---- (2) the config's own mode: eval, bf16 autocast, every graph layer on the fused HIP path — and the graphs it builds
+    # there are the CONTRACT's, index for index: the first k-NN call of every distinct (queries, keys, channels, list) shape
+    # is re-evaluated by the C oracle on the very tokens the kernel saw ("bit-exact neighbor indices" in
+    # the run mode of cfg3 / cfg5; the bf16 contraction is opt-in, GKG_ENABLE=knn_bf16)
+    import numpy as np
+    from oracle import c_oracle as O
+    assert fused.KNN_BF16 is False, "the index-exact k-NN must be the default under autocast"
     net.eval()
     calls = {"n": 0}
+    seen = {}
     real = fused.knn_graph_tm
 
-    def counting(*a, **k):
+    def counting(x, y, rp, k, d, G):
         calls["n"] += 1
-        return real(*a, **k)
+        edge = real(x, y, rp, k, d, G)
+        key = (tuple(x.shape), None if y is None else tuple(y.shape), k, d, G, rp is not None)
+        if key not in seen:
+            seen[key] = (x.detach().clone(), None if y is None else y.detach().clone(),
+                         None if rp is None else rp.detach().clone(), k, d, G, edge[0].clone())
+        return edge
     fused.knn_graph_tm = counting
     try:
         img = torch.randn(B, 3, size, size, device="cuda")
@@ -112,3 +124,14 @@ def test_real_shape_blocks_fused_vs_composable_and_autocast_forward(cfg):
     assert torch.isfinite(labels.float()).all() and torch.isfinite(gap.float()).all()
     last_tokens = (size // 32) ** 2
     assert edge.dtype == torch.int64 and int(edge.min()) >= 0 and int(edge.max()) < last_tokens
+    assert len(seen) >= 8, sorted(seen)               # 4 stages x (Grapher, GrapherLabel) at least
+
+    def groups_major(t, G):                           # (B, T, C) token-major -> the reference's (B*G, c, T)
+        Bt, T, C = t.shape
+        return t.float().view(Bt, T, G, C // G).permute(0, 2, 3, 1).reshape(Bt * G, C // G, T).cpu().numpy()
+    for key, (x, y, rp, k, d, G, nn_idx) in seen.items():
+        assert x.dtype == torch.float32, key          # the k-NN reads fp32 tokens under autocast (fc1's fp32 output)
+        want, _ = O.knn(groups_major(x, G), None if y is None else groups_major(y, G),
+                        None if rp is None else rp.float().reshape(-1, rp.shape[-1]).cpu().numpy(), k, d)
+        got = nn_idx.cpu().numpy()
+        assert np.array_equal(got, want), (key, float((got != want).mean()))
