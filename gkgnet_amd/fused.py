@@ -221,8 +221,13 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     if not (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None
             and x.shape[-1] % 4 == 0 and weight.shape[0] % 4 == 0):
         return False
-    R, cin = x.shape[-2], x.shape[-1]
-    cout = weight.shape[0] // nb
+    return _x6_rule(x.shape[-2], x.shape[-1], weight.shape[0] // nb, nb, kind)
+
+
+def _x6_rule(R, cin, cout, nb, kind) -> bool:
+    """The shape part of _x6 (operand dtypes / autocast / SyncBN already checked by the caller)."""
+    if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none":
+        return False
     # the C entry points' own limits (gkg_linear_bn_fwd_x6 / gkg_linear_dgrad_x6 return GKG_ERR_UNSUPPORTED / _SHAPE
     # beyond them): per-group widths multiples of 4, at most 64 groups, operands below 4 GiB per batch, statistics scratch
     if (cout % 4 or nb > 64 or R * max(cin, cout) * 4 > 0xffffffff
@@ -739,16 +744,20 @@ class _BnBwdScratch:
 _BnFwdScratch = _BnBwdScratch       # forward and backward calls alternate through the SAME pair (one reset per capture)
 
 
-def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale):
+def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale,
+                           launch=None):
     """Projection (statistics in its epilogue) -> BN-apply straight from the fp64 sums: two launches, no finalize kernel.
-    Returns (Y, a, c, mean, invstd)."""
+    Returns (Y, a, c, mean, invstd).  ``launch(Y, sums) -> rc``: a caller-supplied producer of Y and its column sums (the
+    fused aggregation + projection kernel) instead of the plain projection of ``x``."""
     dev = x.device
     scratch = _BnFwdScratch.of(dev)
     cur, other, zero = scratch.acquire(lib, 2 * nb * cout)
     try:
         Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
         none10 = [None] * 10
-        if planes is not None:
+        if launch is not None:
+            rc = launch(Y, cur)
+        elif planes is not None:
             rc = lib.gkg_linear_bn_fwd_x6(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
                                           _ptr(cur), _stream())
         else:
@@ -1050,6 +1059,104 @@ class _MaxRelativeTM(torch.autograd.Function):
         return gx, gsrc, None, None, None, None
 
 
+# ----------------------------------------------------------------------------------------------- row g1 (training / fp32)
+# fp32 train step: gather + max-relative + interleave as the A-operand producer of the grouped projection on the split-bf16
+# matrix-core arithmetic (csrc/gkg_mrgemm_x6.hip), BN column sums in its epilogue, BN-apply (+ GELU) derived from the sums:
+# TWO launches for MRConv2d.forward (torch_vertex.py:47-62 + torch_nn.py:57-69) instead of gkg_mr_fwd_tm -> grouped GEMM ->
+# statistics passes -> apply.  GKG_DISABLE=mr_x6 restores the separate launches.
+#   GKG_DISABLE=mr_save_u: the interleaved [x, m] operand is NOT written by the forward; the backward rebuilds it for the
+#   weight gradient from x, src and the saved winning rows (gkg_mr_regather_tm: one dword gather per channel).  Default: the
+#   forward stores it as a by-product (26.5 MB at cfg2 — measured cheaper than the extra backward launch; at GKGNet-576's
+#   stage 1 it is 425 MB per block that the re-gather form does not hold between forward and backward).
+MR_X6 = "mr_x6" not in _DISABLED
+MR_SAVE_U = "mr_save_u" not in _DISABLED
+
+
+def _mr_x6_ok(x, src, nn_, C, G) -> bool:
+    conv, bn = nn_[0], nn_[1]
+    M = x.shape[1] if src is None else src.shape[1]
+    return (MR_X6 and GEMM_MATH in ("x6", "x6all") and OWN_GEMM != "none" and x.dtype == _F32 and conv.weight.dtype == _F32
+            and not torch.is_autocast_enabled() and torch.is_grad_enabled() and _sync_group(bn) is None
+            and conv.groups == 4 and C % 16 == 0 and (C // G) % 4 == 0 and M <= 65536
+            and conv.weight.shape[0] == 2 * C and conv.weight.shape[1] == C // 2
+            and C <= _lib.load().gkg_mr_linear_x6_max_channels()
+            and _derive_ok(bn, 4, C // 2, _lib.F32, False) and 4 * 2 * (C // 2) <= _lib.load().gkg_linear_stats_doubles())
+
+
+class _MRGroupedLinearBNAct(torch.autograd.Function):
+    """out (T, 2C) = act(BN_train(BasicConv([x, max_k(src[idx] - x)]))) — _MaxRelativeTM + _GroupedLinearBNAct as one autograd
+    node around the fused kernel.  x (B, N, C), src (B, M, C) | None, nn_idx (B*G, N, k)."""
+
+    @staticmethod
+    def forward(ctx, x, src, nn_idx, G, weight, bias, gamma, beta, bn, act):
+        lib = _lib.load()
+        B, N, C = x.shape
+        M = N if src is None else src.shape[1]
+        T, ci, co = B * N, C // 2, C // 2
+        x = x.contiguous()
+        src = None if src is None else src.contiguous()
+        x6d = _x6_rule(T, ci, co, 4, "dgrad")
+        pf, pd = _planes(lib, weight, 4, co, ci, True, x6d)
+        arg = torch.empty((B, N, C), dtype=torch.int16, device=x.device)
+        U = torch.empty((4, T, ci), dtype=_F32, device=x.device) if MR_SAVE_U else None
+        out = torch.empty((T, 2 * C), dtype=_F32, device=x.device)
+        k = nn_idx.shape[2]
+
+        def launch(Y, sums):
+            return lib.gkg_mr_linear_x6(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(pf), _ptr(Y), _ptr(arg), _ptr(U), _ptr(sums),
+                                        B, G, C // G, N, M, k, _stream())
+        Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, None, bias, bn, T, ci, co, 4, None, None, out, 2 * C, co, act, 0,
+                                                       None, 0, launch=launch)
+        ctx.save_for_backward(x, src, nn_idx, arg, U, weight, Y, a, c, mean, invstd)
+        ctx.meta = (B, G, C, N, M, k, act)
+        ctx.gparams = (weight, gamma, beta)
+        ctx.pd = pd if x6d else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, src, nn_idx, arg, U, weight, Y, a, c, mean, invstd = ctx.saved_tensors
+        B, G, C, N, M, k, act = ctx.meta
+        T, ci, co = B * N, C // 2, C // 2
+        g = dout.contiguous()
+        dY = torch.empty_like(Y)
+        dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (4, co, ci), 2 * C, Y.device)
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, T, co, 4, 2 * C, co, act, None)
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gx = gsrc = None
+        if need_in:
+            if ctx.pd is not None:
+                dU = torch.empty((4, T, ci), dtype=_F32, device=dY.device)
+                _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), co, T * co, _ptr(ctx.pd), _ptr(dU), T, ci, co, 4, _stream()),
+                           "gkg_linear_dgrad_x6")
+            else:
+                dU = torch.bmm(dY, weight.view(4, co, ci))
+        if U is None:                                   # the weight gradient's operand, rebuilt from the saved winning rows
+            U = torch.empty((4, T, ci), dtype=_F32, device=dY.device)
+            _lib.check(lib.gkg_mr_regather_tm(_ptr(x), _ptr(src), _ptr(arg), _ptr(U), B, N, M, C, _stream()), "gkg_mr_regather_tm")
+        dW = _wgrad_grouped(dY, U, dWv).view_as(weight)
+        if need_in:
+            gx = torch.empty((B, N, C), dtype=_F32, device=dY.device)
+            gsrc = torch.empty((B, M, C), dtype=_F32, device=dY.device) if src is not None else None
+            _lib.check(lib.gkg_mr_bwd_tm(_ptr(dU), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 1, 1,
+                                         _lib.MR_DETERMINISTIC if DETERMINISTIC else 0, _stream()), "gkg_mr_bwd_tm")
+        return gx, gsrc, None, None, dW, None, dgamma, dbeta, None, None      # dbias == 0 exactly (see _LinearBNAct)
+
+
+def _aggregate_project(x1b, yb, nn_idx, groups, nn_, C, lp):
+    """MRConv2d.forward on token-major tensors -> (T, 2C): the fused launches where they apply, else aggregation kernel +
+    grouped projection."""
+    if _mr_gemm_ok(nn_, C, lp):                                     # row g1, bf16 inference: one launch
+        return mr_grouped_linear_eval(x1b, yb, nn_idx, groups, nn_[0], nn_[1])
+    if _mr_x6_ok(x1b, yb, nn_, C, groups):                          # row g1, fp32 training: fused kernel + BN-apply from its sums
+        return _MRGroupedLinearBNAct.apply(x1b, yb, nn_idx, groups, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias,
+                                           nn_[1], 1)
+    U = _MaxRelativeTM.apply(x1b, yb, nn_idx, groups, 1, lp)        # (4, T, C/2) interleaved [x, m]
+    return _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
+                                     _w16_of(nn_[0]) if lp else None)   # (T, 2C)
+
+
 # ----------------------------------------------------------------------------------------------- row g1 (inference)
 # bf16 inference: gather + max-relative + interleave + grouped 1x1 projection + BN(eval) + GELU in ONE launch
 # (csrc/gkg_mrgemm.hip) — the [x, m] operand is produced tile by tile in LDS and never written.  GKG_DISABLE=mr_gemm restores
@@ -1179,13 +1286,7 @@ def grapher_forward(mod, x, relative_pos, groups: int):
         pooled = F.avg_pool2d(x1.view(B, H, W, C).permute(0, 3, 1, 2), gc.r, gc.r)
         yb = pooled.permute(0, 2, 3, 1).reshape(B, -1, C)
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
-    nn_ = gc.gconv.nn
-    if _mr_gemm_ok(nn_, C, lp):                                     # row g1: aggregation = the projection's operand producer
-        a2 = mr_grouped_linear_eval(x1b, yb, edge[0], groups, nn_[0], nn_[1])
-    else:
-        U = _MaxRelativeTM.apply(x1b, yb, edge[0], groups, 1, lp)   # (4, T, C/2) interleaved [x, m]
-        a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
-                                       _w16_of(nn_[0]) if lp else None)   # (T, 2C)
+    a2 = _aggregate_project(x1b, yb, edge[0], groups, gc.gconv.nn, C, lp)   # row g1: aggregation = the projection's operand producer
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
         out = _lin(a2, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=N, want16=lp)
         return _cl_out(out, B, H, W), edge
@@ -1207,13 +1308,7 @@ def grapher_label_forward(mod, e, features, groups: int):
     x1b = x1.view(B, L, C)
     edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
     lp = lowp_inference()
-    nn_ = gc.gconv.nn
-    if _mr_gemm_ok(nn_, C, lp):
-        a2 = mr_grouped_linear_eval(x1b, ft, edge[0], groups, nn_[0], nn_[1])
-    else:
-        U = _MaxRelativeTM.apply(x1b, ft, edge[0], groups, 1, lp)
-        a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
-                                       _w16_of(nn_[0]) if lp else None)
+    a2 = _aggregate_project(x1b, ft, edge[0], groups, gc.gconv.nn, C, lp)
     h2 = _lin(a2, mod.fc2, residual=e2r, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
     f1, h2r = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp, alias=True)
     out = _lin(f1, mod.ffn.fc2, residual=h2r, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)

@@ -326,6 +326,26 @@ int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float*
                         int R, int cin, int cout, int nb, void* stream);
 
 /*
+ * SURVEY §8 row g1, training / fp32 form (csrc/gkg_mrgemm_x6.hip): MRConv2d.forward's gather + max-relative + interleave
+ * (torch_vertex.py:47-62) as the A-operand producer of BasicConv's grouped 1x1 convolution (torch_nn.py:57-61, bias folded
+ * into the BN behind it) at the accuracy of gkg_linear_bn_fwd_x6, with the train-mode BN column sums in the epilogue: ONE
+ * launch instead of gkg_mr_fwd_tm -> grouped GEMM -> statistics passes.
+ *   y (4, T, C/2) fp32, T = B N: conv group q's pre-BN output (column j = output channel q C/2 + j);
+ *   x (B, N, C) fp32 token-major, src (B, M, C) or NULL (self graph, M == N), nn_idx (B*G, N, k) int64, C = G c,
+ *   C % 16 == 0, c % 4 == 0, C <= gkg_mr_linear_x6_max_channels();
+ *   planes_fwd: FORWARD x6 planes of the weight as (nb = 4, cout = C/2, cin = C/2) (gkg_x6_planes_bytes(C/2, C/2, 4, 0));
+ *   arg (T, C) u16 or NULL: winning neighbour ROW per channel (gkg_mr_bwd_tm's arg_kind 1; M <= 65536);
+ *   u (4, T, C/2) fp32 or NULL: the interleaved [x, m] operand (the weight gradient's input) — NULL: never written, rebuilt in
+ *   the backward by gkg_mr_regather_tm from x, src and arg (bit-identical);
+ *   stats [4][2][C/2] fp64 or NULL: sum y and sum y^2 per output channel are ADDED with atomics (gkg_bn_apply_train's input).
+ * m and arg are bit-identical to gkg_mr_fwd_tm (first maximum wins, NaN propagates).
+ */
+int gkg_mr_linear_x6_max_channels(void);
+int gkg_mr_linear_x6(const float* x, const float* src, const int64_t* nn_idx, const void* planes_fwd, float* y, void* arg,
+                     float* u, double* stats, int B, int G, int c, int N, int M, int k, void* stream);
+int gkg_mr_regather_tm(const float* x, const float* src, const void* arg, float* u, int B, int N, int M, int C, void* stream);
+
+/*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).
  * When enabled, every kernel launch made by this library is bracketed by hipEventRecord on the SAME
  * stream it is launched on.  gkg_prof_read synchronises on the recorded events (so call it outside any
