@@ -62,7 +62,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_linear_bn_fwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
-           "gkg_mr_linear_x6", "gkg_mr_linear_x6_max_channels", "gkg_mr_regather_tm")
+           "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -162,8 +162,8 @@ def load():
     lib.gkg_mr_linear_planes_bytes.argtypes = [I]
     lib.gkg_mr_linear_bf16.restype = I
     lib.gkg_mr_linear_bf16.argtypes = [V] * 7 + [I] * 8 + [V]
-    lib.gkg_mr_linear_x6_max_channels.restype = I
-    lib.gkg_mr_linear_x6_max_channels.argtypes = []
+    lib.gkg_mr_linear_x6_supported.restype = I
+    lib.gkg_mr_linear_x6_supported.argtypes = [I, I, I]
     lib.gkg_mr_linear_x6.restype = I
     lib.gkg_mr_linear_x6.argtypes = [V] * 8 + [I] * 6 + [V]
     lib.gkg_mr_regather_tm.restype = I

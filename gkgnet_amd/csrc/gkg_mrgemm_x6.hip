@@ -37,6 +37,13 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 mx_bf16x8;
 typedef __bf16 mx_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float mx_f32x2 __attribute__((ext_vector_type(2)));
 
+// Compile-time phase ablation (measurement only: tools/ubench/mrgemm_x6_ablate.py builds private copies with -DMX_ABL=<bits>):
+// 1 no neighbour gathers (the centre row stands in), 2 no MFMA loop, 4 no weight loads (fragments stay zero), 8 no index
+// staging, 16 no y / u / arg stores, 32 no statistics, 64 no operand split (hi plane only, mid = lo = 0).
+#ifndef MX_ABL
+#define MX_ABL 0
+#endif
+
 constexpr int MX_ROWS = 64;       // tokens per workgroup
 constexpr int MX_NW = 8;          // waves per workgroup
 constexpr int MX_NPAD = 128;      // the x6 planes pad their n axis to this (gkg_gemm_x6.hip: X6_NPAD)
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
       int v = 0;
       if (t < g.T) {
         const int b = (int)(t / N), n = (int)(t - (long long)b * N);
-        v = mx_clamp(g.nn_idx[(((size_t)b * g.G + glo + gi) * N + n) * k + jj], M);
+        v = (MX_ABL & 8) ? min(n, M - 1) : mx_clamp(g.nn_idx[(((size_t)b * g.G + glo + gi) * N + n) * k + jj], M);
       }
       ids[e] = v;
     }
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
     const float* sb = srcb + (size_t)b * M * C + ch;
     if (KS > 0) {
 #pragma unroll
-      for (int u = 0; u < KS; ++u) I.nb[u] = *reinterpret_cast<const float4*>(sb + (size_t)ip[u] * C);
+      for (int u = 0; u < KS; ++u) I.nb[u] = (MX_ABL & 1) ? I.xi : *reinterpret_cast<const float4*>(sb + (size_t)ip[u] * C);
     }
   };
   auto finish = [&](const Item& I, int it) __attribute__((always_inline)) {
@@ -184,18 +191,22 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
           if (mx_takes(d3, best.w)) { best.w = d3; a3 = row; }
         }
       }
-      if (g.arg)
+      if (g.arg && !(MX_ABL & 16))
         *reinterpret_cast<uint2*>(g.arg + (size_t)t * C + ch) =
             make_uint2((uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16));
-      if (g.u) {
+      if (g.u && !(MX_ABL & 16)) {
         float* up = g.u + ((size_t)(q0 + qi) * g.T + t) * (size_t)g.ci + 8 * quad;
         *reinterpret_cast<float4*>(up) = make_float4(xi.x, best.x, xi.y, best.y);
         *reinterpret_cast<float4*>(up + 4) = make_float4(xi.z, best.z, xi.w, best.w);
       }
-      mx_split2(xi.x, best.x, vh.x, vm.x, vl.x);
-      mx_split2(xi.y, best.y, vh.y, vm.y, vl.y);
-      mx_split2(xi.z, best.z, vh.z, vm.z, vl.z);
-      mx_split2(xi.w, best.w, vh.w, vm.w, vl.w);
+      if (MX_ABL & 64) {
+        vh = make_uint4(mx_cvt2(xi.x, best.x), mx_cvt2(xi.y, best.y), mx_cvt2(xi.z, best.z), mx_cvt2(xi.w, best.w));
+      } else {
+        mx_split2(xi.x, best.x, vh.x, vm.x, vl.x);
+        mx_split2(xi.y, best.y, vh.y, vm.y, vl.y);
+        mx_split2(xi.z, best.z, vh.z, vm.z, vl.z);
+        mx_split2(xi.w, best.w, vh.w, vm.w, vl.w);
+      }
     }
     unsigned char* dst = mx_lds + qi * qstride + I.tok * pitch + 16 * quad;
     *reinterpret_cast<uint4*>(dst) = vh;
@@ -250,8 +261,8 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bq[d][pl] = d < S ? wp[pl * wplane + (size_t)(2 * d) * g.NP] : make_uint4(0, 0, 0, 0);
-    for (int s0 = 0; s0 < S; s0 += DEPTH) {
+      for (int pl = 0; pl < 3; ++pl) bq[d][pl] = (d < S && !(MX_ABL & 4)) ? wp[pl * wplane + (size_t)(2 * d) * g.NP] : make_uint4(0, 0, 0, 0);
+    for (int s0 = 0; s0 < ((MX_ABL & 2) ? 0 : S); s0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
         const int s = s0 + d;
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
           const mx_bf16x8 bh = __builtin_bit_cast(mx_bf16x8, bq[d][0]);
           const mx_bf16x8 bm = __builtin_bit_cast(mx_bf16x8, bq[d][1]);
           const mx_bf16x8 bl = __builtin_bit_cast(mx_bf16x8, bq[d][2]);
-          if (s + DEPTH < S) {
+          if (s + DEPTH < S && !(MX_ABL & 4)) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bq[d][pl] = wp[pl * wplane + (size_t)(2 * (s + DEPTH)) * g.NP];
           }
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += accs[r];
     const int col = 32 * cb + l31;
-    if (col < g.co) {
+    if (col < g.co && !(MX_ABL & 16)) {
       float* yp = g.y + ((size_t)(q0 + qi) * g.T + rbase) * (size_t)g.co + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
         if (row < cnt) yp[(size_t)row * g.co] = acc[r];
       }
     }
-    if (g.sums) {
+    if (g.sums && !(MX_ABL & 32)) {
       float sm = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sm += (r & 3) + 8 * (r >> 2) + 4 * kg < cnt ? acc[r] : 0.f;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(64 * MX_NW, WPE) void mr_linear_x6_kernel(MrX6Args 
       if (kg == 0) { float* o = red + ((size_t)(rb * QG + qi) * g.co_pad + col) * 2; o[0] = mean; o[1] = m2; }
     }
   }
-  if (!g.sums) return;
+  if (!g.sums || (MX_ABL & 32)) return;
   // the tile's two row blocks Chan-merged in fp64, ONE fp64 atomic pair per column and tile: S += n mean, Q += M2 + n mean^2
   __syncthreads();
   for (int e = tid; e < QG * g.co_pad; e += NT) {
@@ -380,17 +391,35 @@ static hipError_t mx_launch(const MrX6Args& g, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifndef MX_DEPTH
+#define MX_DEPTH 2
+#endif
 template <int QG>
 static hipError_t mx_launch_k(const MrX6Args& g, hipStream_t st) {
-  if (g.k == 9) return mx_launch<9, QG, 4, 2>(g, st);
-  return mx_launch<0, QG, 4, 2>(g, st);
+  if (g.k == 9) return mx_launch<9, QG, 4, MX_DEPTH>(g, st);
+  return mx_launch<0, QG, 4, MX_DEPTH>(g, st);
 }
 
 }  // namespace gkg
 using namespace gkg;
 
-// Largest C this build's tile shape covers (LDS: three bf16 planes of 64 x (C/2 + 8) per conv group within 160 KB).
-extern "C" int gkg_mr_linear_x6_max_channels(void) { return 768; }
+static void mx_geometry(MrX6Args& g, int G, int c, int k) {
+  const int C = G * c;
+  g.G = G; g.c = c; g.k = k; g.C = C; g.Cq = C / 4; g.ci = C / 2; g.co = C / 2;
+  g.ci_pad = (g.ci + 15) & ~15; g.co_pad = (g.co + 31) & ~31;
+  g.NP = (g.co + MX_NPAD - 1) / MX_NPAD * MX_NPAD; g.KC = (g.ci + 31) / 32 * 4;       // x6_prep_kernel's plane geometry
+}
+
+// 1 when gkg_mr_linear_x6 covers (G groups of c channels, k neighbours): C = G c a multiple of 16, c of 4, and the tile —
+// three bf16 planes of 64 x (C/2 + 8) per conv group + the index rows + the reduction area — within the CU's 160 KB of LDS.
+extern "C" int gkg_mr_linear_x6_supported(int G, int c, int k) {
+  if (G <= 0 || c <= 0 || k <= 0 || k > 64) return 0;
+  const long long C = (long long)G * c;
+  if ((C & 15) || (c & 3) || C > 4096) return 0;
+  MrX6Args g{};
+  mx_geometry(g, G, c, k);
+  return mx_lds_bytes(g, 1) <= 160 * 1024 ? 1 : 0;
+}
 
 // y (4, T, co) fp32 = Conv1x1_{groups=4}([x, max_k(src[idx] - x)] interleaved) WITHOUT bias, T = B N, co = ci = C / 2, at the
 // accuracy of gkg_linear_bn_fwd_x6 (split-bf16, six products, fp32 accumulation), token-major inputs:
@@ -407,16 +436,15 @@ extern "C" int gkg_mr_linear_x6(const float* x, const float* src, const int64_t*
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 64)
     return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_linear_x6: bad sizes (need > 0, k <= 64)");
   const long long C = (long long)G * c;
-  if ((C & 15) || (c & 3) || C > gkg_mr_linear_x6_max_channels())
-    return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_linear_x6: need C % 16 == 0, c % 4 == 0, C <= 768");
+  if (!gkg_mr_linear_x6_supported(G, c, k))
+    return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_linear_x6: need C % 16 == 0, c % 4 == 0 and a tile within 160 KB of LDS (gkg_mr_linear_x6_supported)");
   if (!src && M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_linear_x6: self graph needs M == N");
   if (arg && M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_linear_x6: the u16 row index needs M <= 65536");
   MrX6Args g;
   g.x = x; g.src = src; g.nn_idx = nn_idx; g.planes = (const uint4*)planes_fwd; g.y = y; g.arg = (uint16_t*)arg; g.u = u;
   g.sums = stats;
-  g.B = B; g.G = G; g.c = c; g.N = N; g.M = M; g.k = k; g.C = (int)C; g.Cq = (int)C / 4; g.ci = (int)C / 2; g.co = (int)C / 2;
-  g.ci_pad = (g.ci + 15) & ~15; g.co_pad = (g.co + 31) & ~31;
-  g.NP = (g.co + MX_NPAD - 1) / MX_NPAD * MX_NPAD; g.KC = (g.ci + 31) / 32 * 4;       // x6_prep_kernel's plane geometry
+  g.B = B; g.N = N; g.M = M;
+  mx_geometry(g, G, c, k);
   g.T = (long long)B * N;
   const long long tiles = (g.T + MX_ROWS - 1) / MX_ROWS;
   if (tiles * 4 > 0x7fffffffLL / 2) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_linear_x6: too many tokens");
@@ -429,7 +457,6 @@ extern "C" int gkg_mr_linear_x6(const float* x, const float* src, const int64_t*
   GkgProfScope prof(GKG_PROF_MR_FWD, st, work);
   // narrow layers: one workgroup per token tile with all 4 conv groups while its LDS image stays below 64 KB
   const bool all_groups = mx_lds_bytes(g, 4) <= 64 * 1024;
-  if (mx_lds_bytes(g, 1) > 160 * 1024) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_linear_x6: C too large for the LDS tile");
   const hipError_t e = all_groups ? mx_launch_k<4>(g, st) : mx_launch_k<1>(g, st);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_linear_x6_kernel");
 }

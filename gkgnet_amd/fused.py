@@ -1072,14 +1072,14 @@ MR_X6 = "mr_x6" not in _DISABLED
 MR_SAVE_U = "mr_save_u" not in _DISABLED
 
 
-def _mr_x6_ok(x, src, nn_, C, G) -> bool:
+def _mr_x6_ok(x, src, nn_, C, G, k) -> bool:
     conv, bn = nn_[0], nn_[1]
     M = x.shape[1] if src is None else src.shape[1]
     return (MR_X6 and GEMM_MATH in ("x6", "x6all") and OWN_GEMM != "none" and x.dtype == _F32 and conv.weight.dtype == _F32
             and not torch.is_autocast_enabled() and torch.is_grad_enabled() and _sync_group(bn) is None
             and conv.groups == 4 and C % 16 == 0 and (C // G) % 4 == 0 and M <= 65536
             and conv.weight.shape[0] == 2 * C and conv.weight.shape[1] == C // 2
-            and C <= _lib.load().gkg_mr_linear_x6_max_channels()
+            and _lib.load().gkg_mr_linear_x6_supported(G, C // G, k)
             and _derive_ok(bn, 4, C // 2, _lib.F32, False) and 4 * 2 * (C // 2) <= _lib.load().gkg_linear_stats_doubles())
 
 
@@ -1149,7 +1149,7 @@ def _aggregate_project(x1b, yb, nn_idx, groups, nn_, C, lp):
     grouped projection."""
     if _mr_gemm_ok(nn_, C, lp):                                     # row g1, bf16 inference: one launch
         return mr_grouped_linear_eval(x1b, yb, nn_idx, groups, nn_[0], nn_[1])
-    if _mr_x6_ok(x1b, yb, nn_, C, groups):                          # row g1, fp32 training: fused kernel + BN-apply from its sums
+    if _mr_x6_ok(x1b, yb, nn_, C, groups, nn_idx.shape[2]):                          # row g1, fp32 training: fused kernel + BN-apply from its sums
         return _MRGroupedLinearBNAct.apply(x1b, yb, nn_idx, groups, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias,
                                            nn_[1], 1)
     U = _MaxRelativeTM.apply(x1b, yb, nn_idx, groups, 1, lp)        # (4, T, C/2) interleaved [x, m]

@@ -332,7 +332,7 @@ int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float*
  * launch instead of gkg_mr_fwd_tm -> grouped GEMM -> statistics passes.
  *   y (4, T, C/2) fp32, T = B N: conv group q's pre-BN output (column j = output channel q C/2 + j);
  *   x (B, N, C) fp32 token-major, src (B, M, C) or NULL (self graph, M == N), nn_idx (B*G, N, k) int64, C = G c,
- *   C % 16 == 0, c % 4 == 0, C <= gkg_mr_linear_x6_max_channels();
+ *   C % 16 == 0, c % 4 == 0 and gkg_mr_linear_x6_supported(G, c, k) (the 64-token tile must fit the CU's LDS: C <= 640 .. 768);
  *   planes_fwd: FORWARD x6 planes of the weight as (nb = 4, cout = C/2, cin = C/2) (gkg_x6_planes_bytes(C/2, C/2, 4, 0));
  *   arg (T, C) u16 or NULL: winning neighbour ROW per channel (gkg_mr_bwd_tm's arg_kind 1; M <= 65536);
  *   u (4, T, C/2) fp32 or NULL: the interleaved [x, m] operand (the weight gradient's input) — NULL: never written, rebuilt in
@@ -340,7 +340,7 @@ int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float*
  *   stats [4][2][C/2] fp64 or NULL: sum y and sum y^2 per output channel are ADDED with atomics (gkg_bn_apply_train's input).
  * m and arg are bit-identical to gkg_mr_fwd_tm (first maximum wins, NaN propagates).
  */
-int gkg_mr_linear_x6_max_channels(void);
+int gkg_mr_linear_x6_supported(int G, int c, int k);
 int gkg_mr_linear_x6(const float* x, const float* src, const int64_t* nn_idx, const void* planes_fwd, float* y, void* arg,
                      float* u, double* stats, int B, int G, int c, int N, int M, int k, void* stream);
 int gkg_mr_regather_tm(const float* x, const float* src, const void* arg, float* u, int B, int N, int M, int C, void* stream);
