@@ -455,7 +455,10 @@ extern "C" int gkg_mr_linear_x6(const float* x, const float* src, const int64_t*
   const double work = 4.0 * g.T * (double)C + (src ? 4.0 * B * (double)M * C : 0.0) + 8.0 * B * (double)G * N * k
                       + 4.0 * g.T * (double)C + (arg ? 1.0 * g.T * (double)C : 0.0);
   GkgProfScope prof(GKG_PROF_MR_FWD, st, work);
-  // narrow layers: one workgroup per token tile with all 4 conv groups while its LDS image stays below 64 KB
+  // narrow layers: one workgroup per token tile with all 4 conv groups while its LDS image stays below 64 KB.
+  // (A persistent producer / consumer form — one workgroup per CU, double-buffered A planes, 4 gather waves feeding 4 MFMA
+  // waves — was built and measured slower at every stage shape: 49-56 vs 46 us at cfg2, profiles/
+  // r04_ubench_mrgemm_x6_persistent_form_experiment.txt; EXPERIMENTS.md has the phase timings.)
   const bool all_groups = mx_lds_bytes(g, 4) <= 64 * 1024;
   const hipError_t e = all_groups ? mx_launch_k<4>(g, st) : mx_launch_k<1>(g, st);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_linear_x6_kernel");
