@@ -308,7 +308,7 @@ def run_backbone(args):
         bucket.install_overlap_hooks()       # chunk all-reduces start during the backward (the reference's DDP reducer)
 
         def train_step():
-            bucket.release()
+            bucket.release(prezero=True)
             losses = head.forward_train(net(img), tgt)
             (losses["bce_loss"] + losses["asy_loss"]).backward()
             bucket.wait()
@@ -437,7 +437,7 @@ def main():
     cot_e = torch.randn(B, L, C, generator=gen).to(dev)
 
     def compute():                       # forward + backward + gradient packing: everything on this GPU
-        bucket.release()
+        bucket.release(prezero=True)     # ONE fill of the flat gradient buffer instead of a zero-fill per atomically accumulated dW
         x.grad = None
         e.grad = None
         out = grapher(x)

@@ -288,7 +288,7 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
         cout, cin = dY.shape[1], x.shape[1]
         if out is None:
             out = torch.zeros((cout, cin), dtype=_F32, device=x.device)
-        else:
+        elif not getattr(out, "_gkg_zero", False):          # a bucket slot cleared by GradBucket.release(prezero=True) is clean
             out.zero_()
         _lib.check(_lib.load().gkg_linear_wgrad_x6(_ptr(dY), dY.stride(0), 0, _ptr(x), x.stride(0), 0, _ptr(out), R, cin, cout,
                                                    1, _stream()), "gkg_linear_wgrad_x6")
@@ -313,7 +313,7 @@ def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None) -> torch.Tensor:
             and all(t.stride(d) % 4 == 0 for t in (dY, U) for d in (0, 1))):
         if out is None:
             out = torch.zeros((nb, co, ci), dtype=_F32, device=U.device)
-        else:
+        elif not getattr(out, "_gkg_zero", False):
             out.zero_()
         _lib.check(_lib.load().gkg_linear_wgrad_x6(_ptr(dY), dY.stride(1), dY.stride(0), _ptr(U), U.stride(1), U.stride(0), _ptr(out),
                                                    R, ci, co, nb, _stream()), "gkg_linear_wgrad_x6 (grouped)")
@@ -1063,12 +1063,17 @@ class _MaxRelativeTM(torch.autograd.Function):
 # fp32 train step: gather + max-relative + interleave as the A-operand producer of the grouped projection on the split-bf16
 # matrix-core arithmetic (csrc/gkg_mrgemm_x6.hip), BN column sums in its epilogue, BN-apply (+ GELU) derived from the sums:
 # TWO launches for MRConv2d.forward (torch_vertex.py:47-62 + torch_nn.py:57-69) instead of gkg_mr_fwd_tm -> grouped GEMM ->
-# statistics passes -> apply.  GKG_DISABLE=mr_x6 restores the separate launches.
-#   GKG_DISABLE=mr_save_u: the interleaved [x, m] operand is NOT written by the forward; the backward rebuilds it for the
-#   weight gradient from x, src and the saved winning rows (gkg_mr_regather_tm: one dword gather per channel).  Default: the
-#   forward stores it as a by-product (26.5 MB at cfg2 — measured cheaper than the extra backward launch; at GKGNet-576's
-#   stage 1 it is 425 MB per block that the re-gather form does not hold between forward and backward).
-MR_X6 = "mr_x6" not in _DISABLED
+# statistics passes -> apply.  Built, bit-checked against the oracle (tests/test_hip_mrgemm_x6.py) and MEASURED in round 4:
+# inside the step it is 1-4 % SLOWER than the separate launches at every shape tried (ms/step fused vs separate, TunableOp
+# leg / library-default leg: cfg2 0.942 / 0.981 vs 0.931 / 0.971, cfg2ref 2.225 / 2.331 vs 2.181 / 2.262, stage3 3.215 vs
+# 3.114, stage1 8.00 vs 7.70) — its matrix phase runs at 128 registers per wave with the weight fragments two steps ahead
+# (18 of its 46 us at cfg2) where gemm_x6_kernel streams both operands through LDS-DMA rings, and that costs more than the
+# 26.5 MB [x, m] round trip it removes (EXPERIMENTS.md has the phase ablation and the persistent producer / consumer variant
+# that was tried on top).  So it is OPT-IN: GKG_ENABLE=mr_x6.
+#   GKG_DISABLE=mr_save_u (with mr_x6): the interleaved [x, m] operand is NOT written by the forward; the backward rebuilds it
+#   for the weight gradient from x, src and the saved winning rows (gkg_mr_regather_tm: one dword gather per channel) — 425 MB
+#   per block less held between forward and backward at GKGNet-576's stage 1, one more launch in the backward.
+MR_X6 = "mr_x6" in _ENABLED
 MR_SAVE_U = "mr_save_u" not in _DISABLED
 
 

@@ -130,10 +130,11 @@ def test_autograd_node_matches_the_separate_launches(label, save_u, monkeypatch)
         assert float((a[key] - ref).abs().max()) <= tol, (key, float((a[key] - ref).abs().max()), tol)
 
 
-def test_blocks_take_the_fused_launch_in_an_fp32_train_step():
-    """Grapher + GrapherLabel, fp32, train mode: MRConv2d.forward runs as the fused launch (no stand-alone gkg_mr_fwd_tm), and
-    the step matches the torch-CPU oracle within the 1e-3 contract (forward and input gradients)."""
+def test_blocks_take_the_fused_launch_in_an_fp32_train_step(monkeypatch):
+    """Grapher + GrapherLabel, fp32, train mode, GKG_ENABLE=mr_x6: MRConv2d.forward runs as the fused launch (no stand-alone
+    gkg_mr_fwd_tm), and the step matches the torch-CPU oracle within the 1e-3 contract (forward and input gradients)."""
     from gkgnet_amd import _lib, fused, layers
+    monkeypatch.setattr(fused, "MR_X6", True)
     from gkgnet_amd.grapher import Grapher, GrapherLabel
     from oracle import torch_ref as R
     layers.norm_cfg["type"] = "BN"

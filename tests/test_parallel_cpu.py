@@ -255,3 +255,27 @@ def test_overlap_hooks_reduce_every_step_without_release():
         for a, b in zip(out[0][step], out[1][step]):
             assert torch.equal(a, b), step
             assert torch.allclose(a, torch.full_like(a, 1.5)), (step, a)
+
+
+def test_release_prezero_marks_slots_clean_once():
+    """release(prezero=True): ONE fill of the flat buffer; every slot handed out by grad_view() in the following backward
+    carries the "holds zeros" mark exactly once (atomically accumulating kernels skip their own zero-fill), slots of
+    parameters without a gradient already hold what pack() would write, and a plain release() hands out unmarked views."""
+    from gkgnet_amd.parallel import GradBucket, grad_view
+    w, v, unused = (torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2)))
+    bucket = GradBucket([w, v, unused])
+    bucket.flat.fill_(7.0)                              # stale contents
+    bucket.release(prezero=True)
+    assert float(bucket.flat.abs().sum()) == 0.0
+    a = grad_view(w)
+    assert getattr(a, "_gkg_zero", False) and float(a.abs().sum()) == 0.0
+    assert grad_view(w) is None                         # handed out once per backward
+    a.add_(1.0)                                         # an "atomic accumulation" into the clean slot
+    w.grad = a
+    v.grad = torch.full((5,), 2.0)
+    bucket.pack()
+    assert torch.equal(w.grad, torch.ones(3, 4)) and torch.equal(v.grad, torch.full((5,), 2.0))
+    assert float(unused.grad.abs().sum()) == 0.0
+    bucket.release()                                    # no pre-zero: the view is not marked (its contents are stale)
+    b = grad_view(w)
+    assert b is not None and not getattr(b, "_gkg_zero", False)

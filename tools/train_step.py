@@ -49,7 +49,7 @@ def main():
     bucket.install_overlap_hooks()       # chunk all-reduces start during the backward (the reference's DDP reducer)
 
     def step():
-        bucket.release()
+        bucket.release(prezero=True)
         feats = net(img)
         losses = head.forward_train(feats, tgt)
         loss = losses["bce_loss"] + losses["asy_loss"]
