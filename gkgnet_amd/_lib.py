@@ -53,6 +53,7 @@ def knn_select_flags() -> int:
         f |= KNN_FORCE_PREFILTER
     return f
 MR_DETERMINISTIC = 1
+MR_FP32_ATOMICS = 2
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
            "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_prof_work", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",

@@ -436,6 +436,164 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
   }
 }
 
+// ---- exact integer accumulation (round 4; the default LDS-image form) -------------------------------------------------------
+// Hardware fact (tools/ubench/lds_atomic_rate.hip, profiles/r04_ubench_lds_atomic_rate.txt, SQ counters in
+// profiles/r04_pmc_mr_stage1.txt): on gfx950 `ds_add_f32` retires at ~170 cycles per wave instruction (2.7 cycles per LANE,
+// whatever the addresses), `ds_add_u64` at 30-66, `ds_add_u32` at 16-31.  The fp32 scatter above spends two thirds of its
+// time in the LDS atomic unit.  This form accumulates in 64-bit FIXED POINT instead:
+//   sweep 1  over the workgroup's (image, channel chunk): gx = direct - gm (bipartite graphs) and the largest |gm| bit
+//            pattern (ds_max_u32) -> e_max, the scale of this workgroup;
+//   sweep 2  every gm becomes  sign * (24-bit mantissa << sh),  sh = e - e_max + SHMAX  with SHMAX = 38 - bits(N): the
+//            largest value keeps 24 + SHMAX bits, the sum of up to N of them fits 62 bits, values down to 2^-SHMAX of the
+//            largest keep their FULL mantissa (29 binary orders at N = 324, 23 at N = 20 736; below that the low bits are
+//            truncated — against a total that is then >= 2^24 times larger); one ds_add_u64 per value;
+//   store    acc * 2^(e_max - 150 - SHMAX) rounded ONCE to fp32 (+ the token's own "direct - gm" seed for self graphs).
+// Integer addition is associative: the result does not depend on the order the lanes arrive in — bit-identical from run
+// to run (this form also serves GKG_MR_DETERMINISTIC) — and every sum is correctly rounded from an exact total where an
+// fp32 atomic chain rounds after every addend.  Non-finite gradients (the GradScaler overflow protocol needs inf / NaN
+// to reach the parameters) show up as e_max = 255: the workgroup then re-runs the fp32-atomic form on the same LDS.
+__device__ __forceinline__ long long mr_to_fixed(float v, int emax, int shmax) {
+  const unsigned bits = __float_as_uint(v);
+  const int e = (int)((bits >> 23) & 0xff);
+  const unsigned long long mant = (unsigned long long)((bits & 0x7fffffu) | (e ? 0x800000u : 0u));
+  const int sh = (e ? e : 1) - emax + shmax;
+  const unsigned long long mag = sh >= 0 ? (mant << sh) : (mant >> min(-sh, 63));
+  return (bits >> 31) ? -(long long)mag : (long long)mag;
+}
+__device__ __forceinline__ float mr_from_fixed(long long a, int emax, int shmax) {
+  return (float)__builtin_ldexp((double)a, emax - 150 - shmax);
+}
+
+template <bool SELF, int MODE, int AK>
+__device__ __forceinline__ void mr_scatter_f32_body(float* acc, const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                    const uint8_t* __restrict__ argmax, float* __restrict__ gx,
+                                                    float* __restrict__ gsrc, int b, int G, int c, int N, int M, int k, int CW,
+                                                    int ch0, size_t T, bool write_gx) {
+  const int C = G * c;
+  const int cw4 = CW >> 2;
+  const int tid = threadIdx.x;
+  const int qd = tid % cw4, tl = tid / cw4, TL = 256 / cw4;
+  const int ch = ch0 + 4 * qd;
+  if (tl < TL) {
+    for (int m = tl; m < M; m += TL) {
+      float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SELF) {
+        float4 direct, gm;
+        load_grad<MODE>(gin, T, (size_t)b * N + m, C, ch, MODE, direct, gm);
+        seed = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+      }
+      *reinterpret_cast<float4*>(acc + (size_t)m * CW + 4 * qd) = seed;
+    }
+  }
+  __syncthreads();
+  if (tl < TL) {
+    const int g = ch / c;
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+      int j[4];
+      mr_targets<AK>(argmax, AK, t * C + ch, ip, k, M, j);
+      float4 direct, gm;
+      load_grad<MODE>(gin, T, t, C, ch, MODE, direct, gm);
+      if (!SELF && write_gx)
+        *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+      atomicAdd(acc + (size_t)j[0] * CW + 4 * qd + 0, gm.x);
+      atomicAdd(acc + (size_t)j[1] * CW + 4 * qd + 1, gm.y);
+      atomicAdd(acc + (size_t)j[2] * CW + 4 * qd + 2, gm.z);
+      atomicAdd(acc + (size_t)j[3] * CW + 4 * qd + 3, gm.w);
+    }
+  }
+  __syncthreads();
+  if (tl < TL) {
+    float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch0;
+    for (int m = tl; m < M; m += TL)
+      *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = *reinterpret_cast<const float4*>(acc + (size_t)m * CW + 4 * qd);
+  }
+}
+
+template <bool SELF, int MODE, int AK>
+__global__ __launch_bounds__(256) void mr_bwd_tm_scatter_i64_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                                    const uint8_t* __restrict__ argmax, float* __restrict__ gx,
+                                                                    float* __restrict__ gsrc, int B, int G, int c, int N, int M,
+                                                                    int k, int CW, int shmax) {
+  extern __shared__ long long acc64[];            // [M][CW] + control words
+  const int C = G * c;
+  const int nchunk = C / CW;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, seq = lin >> 3;        // XCD-aware map, as mr_bwd_tm_scatter_kernel
+  const int b = (seq / nchunk) * 8 + xcd;
+  if (b >= B) return;
+  const int ch0 = (seq - (seq / nchunk) * nchunk) * CW;
+  const int cw4 = CW >> 2;
+  const int tid = threadIdx.x;
+  const int qd = tid % cw4, tl = tid / cw4, TL = 256 / cw4;
+  const size_t T = (size_t)B * N;
+  const int ch = ch0 + 4 * qd;
+  unsigned* ctl = reinterpret_cast<unsigned*>(acc64 + (size_t)M * CW);
+  for (int i = tid; i < M * CW; i += 256) acc64[i] = 0;
+  if (tid == 0) ctl[0] = 0;
+  __syncthreads();
+  // ---- sweep 1: gx of the bipartite graph, and the chunk's largest |gm| bit pattern
+  unsigned mx = 0;
+  if (tl < TL) {
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      float4 direct, gm;
+      load_grad<MODE>(gin, T, t, C, ch, MODE, direct, gm);
+      if (!SELF)
+        *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+      mx = max(max(mx, __float_as_uint(gm.x) & 0x7fffffffu), max(__float_as_uint(gm.y) & 0x7fffffffu,
+               max(__float_as_uint(gm.z) & 0x7fffffffu, __float_as_uint(gm.w) & 0x7fffffffu)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if ((tid & 63) == 0) atomicMax(ctl, mx);
+  __syncthreads();
+  mx = ctl[0];
+  const int emax = (int)(mx >> 23);
+  if (emax == 255) {                              // inf / NaN somewhere in this chunk: the fp32-atomic form propagates them
+    __syncthreads();
+    mr_scatter_f32_body<SELF, MODE, AK>(reinterpret_cast<float*>(acc64), gin, nn_idx, argmax, gx, gsrc, b, G, c, N, M, k, CW, ch0, T,
+                                        false);
+    return;
+  }
+  // ---- sweep 2: exact accumulation
+  if (tl < TL && mx != 0) {
+    const int g = ch / c;
+    const int em = max(emax, 1);
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+      int j[4];
+      mr_targets<AK>(argmax, AK, t * C + ch, ip, k, M, j);
+      float4 direct, gm;
+      load_grad<MODE>(gin, T, t, C, ch, MODE, direct, gm);
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[0] * CW + 4 * qd + 0), (unsigned long long)mr_to_fixed(gm.x, em, shmax));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[1] * CW + 4 * qd + 1), (unsigned long long)mr_to_fixed(gm.y, em, shmax));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[2] * CW + 4 * qd + 2), (unsigned long long)mr_to_fixed(gm.z, em, shmax));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[3] * CW + 4 * qd + 3), (unsigned long long)mr_to_fixed(gm.w, em, shmax));
+    }
+  }
+  __syncthreads();
+  // ---- store: one rounding per element (+ the token's own seed for the self graph)
+  if (tl < TL) {
+    const int em = max(emax, 1);
+    float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch0;
+    for (int m = tl; m < M; m += TL) {
+      const long long* a = acc64 + (size_t)m * CW + 4 * qd;
+      float4 o = make_float4(mr_from_fixed(a[0], em, shmax), mr_from_fixed(a[1], em, shmax), mr_from_fixed(a[2], em, shmax),
+                             mr_from_fixed(a[3], em, shmax));
+      if (SELF) {
+        float4 direct, gm;
+        load_grad<MODE>(gin, T, (size_t)b * N + m, C, ch, MODE, direct, gm);
+        o = make_float4(o.x + (direct.x - gm.x), o.y + (direct.y - gm.y), o.z + (direct.z - gm.z), o.w + (direct.w - gm.w));
+      }
+      *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = o;
+    }
+  }
+}
+
 // Deterministic scatter (GKG_MR_DETERMINISTIC): the LDS-atomic kernel above adds the fan-in of a key in whatever order
 // its lanes arrive, so gsrc differs in the last bit from run to run (like the reference's CUDA index_put_(accumulate)).
 // Here a workgroup owns ONE channel quad of one image; each of its TL threads sweeps its own residue class of queries
@@ -726,6 +884,25 @@ static void launch_tm_lds(bool self, int mode, int ak, dim3 grid, dim3 block, si
 #undef GKG_TM_CASE
 }
 
+template <bool SELF, int MODE, int AK>
+static void launch_tm_i64_one(dim3 grid, size_t lds, hipStream_t st, const float* gin, const int64_t* nn_idx, const uint8_t* argmax,
+                              float* gx, float* gsrc, int B, int G, int c, int N, int M, int k, int CW, int shmax) {
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_scatter_i64_kernel<SELF, MODE, AK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mr_bwd_tm_scatter_i64_kernel<SELF, MODE, AK>), grid, dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, shmax);
+}
+static void launch_tm_i64(bool self, int mode, int ak, dim3 grid, size_t lds, hipStream_t st, const float* gin, const int64_t* nn_idx,
+                          const uint8_t* argmax, float* gx, float* gsrc, int B, int G, int c, int N, int M, int k, int CW, int shmax) {
+#define GKG_TM64_CASE(S, MO, A) launch_tm_i64_one<S, MO, A>(grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, shmax)
+  if (self) {
+    if (mode == 0) { if (ak) GKG_TM64_CASE(true, 0, 1); else GKG_TM64_CASE(true, 0, 0); }
+    else { if (ak) GKG_TM64_CASE(true, 1, 1); else GKG_TM64_CASE(true, 1, 0); }
+  } else {
+    if (mode == 0) { if (ak) GKG_TM64_CASE(false, 0, 1); else GKG_TM64_CASE(false, 0, 0); }
+    else { if (ak) GKG_TM64_CASE(false, 1, 1); else GKG_TM64_CASE(false, 1, 0); }
+  }
+#undef GKG_TM64_CASE
+}
+
 extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
                              int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream) {
   if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: arg_kind is 0 or 1");
@@ -742,6 +919,30 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   const int C = G * c;
   const size_t T = (size_t)B * N;
   const size_t total = T * (C / 4);
+  // Exact integer accumulation (see mr_bwd_tm_scatter_i64_kernel): the default whenever an (image, channel chunk) of 64-bit
+  // accumulators fits the LDS budget — order-independent, so it is also the deterministic form.  GKG_MR_FP32_ATOMICS keeps
+  // the fp32-atomic kernels (measurement, tests).
+  // Where it is selected (MI355X, tools/bench_mr_bwd.py, us, exact vs fp32 atomics at their best chunk widths): 18 x 18
+  // images — cfg2 21.2 vs 24.4-27.6, its label graph 9.4 vs 10.9, C = 640 39.3 vs 44.9-51.5; a tie at 36 x 36 (116.7 vs
+  // 113.5-118.2); it LOSES where the gradients stream from HBM and are swept twice (pooled 1 296-key images under 5 184 /
+  // 20 736 queries: 209 vs 164, 492 vs 425).  Rule: destination images of up to 512 rows; with GKG_MR_DETERMINISTIC wherever it
+  // fits (the private-accumulator form it replaces there is 1.6x the fp32 time).  Chunk width 8 (measured best or tied at
+  // every shape: the kernel lives on workgroups per CU), 4 when 8 does not fit.
+  if (!(flags & GKG_MR_FP32_ATOMICS) && N < (1 << 24) && (M <= 512 || (flags & GKG_MR_DETERMINISTIC))) {
+    int CW = 8;
+    const int forced = (int)((flags >> 8) & 0xff);          // measurement only: bits 8..15 force the chunk width
+    auto fits = [&](int cw, size_t budget) { return (size_t)M * cw * 8 + 16 <= budget && C % cw == 0 && c % cw == 0; };
+    if (!fits(CW, (size_t)MR_LDS_BUDGET)) CW = 4;
+    if (forced) CW = forced;
+    if (fits(CW, (size_t)MR_LDS_BUDGET) && (long)(C / CW) * (B + 7) < 0x7fffffffL) {
+      int bitsN = 0;
+      while ((1 << bitsN) <= N) ++bitsN;                  // N < 2^bitsN
+      launch_tm_i64(gsrc == nullptr, mode, arg_kind, dim3((C / CW) * ((B + 7) / 8) * 8), (size_t)M * CW * 8 + 16, st, gin, nn_idx,
+                    argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      hipError_t ei = hipGetLastError();
+      return ei == hipSuccess ? 0 : gkg_fail_hip(ei, "mr_bwd_tm_scatter_i64_kernel");
+    }
+  }
   if (flags & GKG_MR_DETERMINISTIC) {
     if (B > 65535) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd_tm: B <= 65535");
     long TL = (long)(144 * 1024) / ((long)M * 16);
@@ -764,6 +965,7 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   int CW = 64;
   while (CW > 4 && ((size_t)M * CW * 4 > (size_t)MR_LDS_BUDGET || C % CW || c % CW)) CW >>= 1;
   while (CW > 8 && (long)(C / CW) * B < 512) CW >>= 1;
+  if ((flags >> 8) & 0xff) CW = (int)((flags >> 8) & 0xff);       // measurement only
   if ((size_t)M * CW * 4 <= (size_t)MR_LDS_BUDGET && C % CW == 0 && c % CW == 0 && (long)(C / CW) * (B + 7) < 0x7fffffffL) {
     const size_t lds = (size_t)M * CW * 4;
     launch_tm_lds<false>(gsrc == nullptr, mode, arg_kind, dim3((C / CW) * ((B + 7) / 8) * 8), dim3(256), lds, st, gin, nn_idx, argmax, gx, gsrc,

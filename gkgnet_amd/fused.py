@@ -247,6 +247,13 @@ def _x6_rule(R, cin, cout, nb, kind) -> bool:
 
 
 X6_WGRAD = "x6_wgrad" not in _DISABLED
+# GKG_DISABLE=mr_i64: the aggregation backward keeps the fp32 LDS-atomic scatter instead of the exact 64-bit fixed-point
+# accumulation (csrc/gkg_mr.hip: mr_bwd_tm_scatter_i64_kernel) — A/B measurements only.
+MR_I64 = "mr_i64" not in _DISABLED
+
+
+def _mr_bwd_flags() -> int:
+    return (_lib.MR_DETERMINISTIC if DETERMINISTIC else 0) | (0 if MR_I64 else _lib.MR_FP32_ATOMICS)
 
 
 def _x6_wgrad_ok(dY, x, nb=1) -> bool:
@@ -1055,7 +1062,7 @@ class _MaxRelativeTM(torch.autograd.Function):
         gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode, ak,
-                                     _lib.MR_DETERMINISTIC if DETERMINISTIC else 0, _stream()), "gkg_mr_bwd_tm")
+                                     _mr_bwd_flags(), _stream()), "gkg_mr_bwd_tm")
         return gx, gsrc, None, None, None, None
 
 
@@ -1145,7 +1152,7 @@ class _MRGroupedLinearBNAct(torch.autograd.Function):
             gx = torch.empty((B, N, C), dtype=_F32, device=dY.device)
             gsrc = torch.empty((B, M, C), dtype=_F32, device=dY.device) if src is not None else None
             _lib.check(lib.gkg_mr_bwd_tm(_ptr(dU), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 1, 1,
-                                         _lib.MR_DETERMINISTIC if DETERMINISTIC else 0, _stream()), "gkg_mr_bwd_tm")
+                                         _mr_bwd_flags(), _stream()), "gkg_mr_bwd_tm")
         return gx, gsrc, None, None, dW, None, dgamma, dbeta, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 

@@ -156,8 +156,14 @@ int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t
  *                    argmax (B,N,C) u8
  *   gkg_mr_bwd_tm  : mode 0: gin = g (B,N,C); mode 1: gin = dU (4,B*N,C/2) (even columns = gradient reaching x
  *                    directly, odd columns = gradient of m).  gx (B,N,C) and gsrc (B,M,C)|NULL fully overwritten.
- *                    Default: LDS atomics (fan-in summed in arrival order: last-bit run-to-run differences);
- *                    flags & GKG_MR_DETERMINISTIC: per-thread private accumulators added in a fixed order.
+ *                    Default for destination images of up to 512 rows (where it measured faster; with
+ *                    GKG_MR_DETERMINISTIC wherever 8 channels of 64-bit accumulators per row fit the LDS): EXACT fixed-point
+ *                    accumulation — every gradient becomes sign * (24-bit mantissa << shift) relative to the chunk's
+ *                    largest magnitude, the fan-in is summed with 64-bit integer LDS atomics and rounded ONCE to fp32:
+ *                    independent of the arrival order (bit-identical from run to run) and at least as accurate as an
+ *                    fp32 sum; non-finite gradients fall back to fp32 atomics per chunk (inf / NaN propagate).
+ *                    flags & GKG_MR_FP32_ATOMICS: the round-1 fp32 LDS-atomic kernels (fan-in summed in arrival order);
+ *                    flags & GKG_MR_DETERMINISTIC (shapes beyond the LDS budget): private accumulators, fixed order.
  */
 int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
@@ -168,6 +174,7 @@ int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void*
                   uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind,
                   void* stream);
 #define GKG_MR_DETERMINISTIC 1u /* fixed summation order in the scatter: bit-identical results from run to run */
+#define GKG_MR_FP32_ATOMICS 2u  /* keep the fp32 LDS-atomic scatter instead of the exact integer accumulation (measurement, tests) */
 int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
                   int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream);
 

@@ -1,0 +1,125 @@
+"""The aggregation backward's exact fixed-point scatter (csrc/gkg_mr.hip: mr_bwd_tm_scatter_i64_kernel — the default LDS-image
+form since round 4; fp32 LDS atomics retire at ~170 cycles per wave instruction on gfx950, 64-bit integer ones at 30-66):
+against the C oracle's backward (oracle/c_oracle.mr_bwd, SURVEY §8a backward contract) and an fp64 evaluation, wide dynamic
+range, bit-reproducibility, the fp32-atomic form it replaces, and inf / NaN propagation (GradScaler's overflow protocol)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (B, G, C, N, M (None = self graph), k, mode)
+CASES = [(3, 4, 64, 200, None, 9, 1), (2, 2, 64, 80, 324, 9, 1), (2, 2, 32, 150, None, 5, 0), (2, 4, 320, 324, None, 9, 1),
+         (4, 4, 320, 80, 324, 9, 1), (1, 2, 80, 5000, 1296, 9, 1), (2, 8, 96, 333, 90, 18, 0)]
+
+
+def _run(x, src, idx, G, mode, g, fp32_atomics=False, det=False):
+    """``det``: GKG_DETERMINISTIC — selects the exact form wherever it fits (by default it is taken for destination images of up
+    to 512 rows, where it measured faster than the fp32 atomics)."""
+    from gkgnet_amd import fused
+    old = (fused.MR_I64, fused.DETERMINISTIC)
+    fused.MR_I64, fused.DETERMINISTIC = not fp32_atomics, det
+    try:
+        xg = x.clone().requires_grad_(True)
+        sg = None if src is None else src.clone().requires_grad_(True)
+        fused._MaxRelativeTM.apply(xg, sg, idx, G, mode).backward(g)
+        return xg.grad.clone(), None if sg is None else sg.grad.clone()
+    finally:
+        fused.MR_I64, fused.DETERMINISTIC = old
+
+
+def _oracle_bwd(x, src, idx, G, gm_tm, direct_tm):
+    """gx, gsrc (token-major) from the C oracle: forward for the argmax, then mr_bwd on the reference's (B*G, c, N) layout;
+    the identity branch ("direct": the gradient reaching x through the [x, m] interleave) is added on top."""
+    from oracle import c_oracle as O
+    B, N, C = x.shape
+    cg = C // G
+    to_ref = lambda t: t.permute(0, 2, 1).reshape(B * G, cg, t.shape[1]).cpu().numpy()
+    xc = to_ref(x)
+    sc = None if src is None else to_ref(src)
+    idn = idx.cpu().numpy()
+    _, arg = O.mr_fwd(xc, sc, idn)
+    gx, gs = O.mr_bwd(to_ref(gm_tm), idn, arg, None if src is None else src.shape[1])
+    back = lambda a, T: torch.from_numpy(a).reshape(B, C, T).permute(0, 2, 1).contiguous()
+    gx = back(gx, N) + (0 if direct_tm is None else direct_tm.cpu())
+    return gx, None if gs is None else back(gs, src.shape[1])
+
+
+@pytest.mark.parametrize("B,G,C,N,M,k,mode", CASES)
+def test_exact_scatter_matches_the_oracle_backward(B, G, C, N, M, k, mode):
+    gen = torch.Generator(device="cuda").manual_seed(C + N)
+    x = torch.randn(B, N, C, device="cuda", generator=gen)
+    src = None if M is None else torch.randn(B, M, C, device="cuda", generator=gen)
+    Mk = N if M is None else M
+    idx = torch.randint(0, min(Mk, 23), (B * G, N, k), device="cuda", generator=gen)      # heavy fan-in: few distinct keys
+    if mode == 1:
+        g = torch.randn(4, B * N, C // 2, device="cuda", generator=gen)
+        gi = g.view(4, B, N, C // 4, 2).permute(1, 2, 0, 3, 4).reshape(B, N, C, 2)
+        direct, gm = gi[..., 0].contiguous(), gi[..., 1].contiguous()
+    else:
+        g = torch.randn(B, N, C, device="cuda", generator=gen)
+        direct, gm = None, g
+    det = Mk > 512                                       # beyond the default rule: ask for the exact form explicitly
+    gx, gs = _run(x, src, idx, G, mode, g, det=det)
+    want_x, want_s = _oracle_bwd(x, src, idx, G, gm, direct)
+    # the oracle sums each key's fan-in as an fp32 chain (up to N / 23 addends here): its own rounding grows with the fan-in
+    tol = 1e-5 * max(1.0, N / 64)
+    assert torch.allclose(gx.cpu(), want_x, atol=tol, rtol=1e-5), float((gx.cpu() - want_x).abs().max())
+    if gs is not None:
+        assert torch.allclose(gs.cpu(), want_s, atol=tol, rtol=1e-5), float((gs.cpu() - want_s).abs().max())
+    # bit-identical from run to run, and equal to rounding to the fp32-atomic form it replaces
+    gx2, gs2 = _run(x, src, idx, G, mode, g, det=det)
+    assert torch.equal(gx, gx2) and (gs is None or torch.equal(gs, gs2))
+    ax, as_ = _run(x, src, idx, G, mode, g, fp32_atomics=True)
+    assert torch.allclose(gx, ax, atol=1e-4, rtol=1e-4) and (gs is None or torch.allclose(gs, as_, atol=1e-4, rtol=1e-4))
+
+
+def test_exact_scatter_is_correctly_rounded_over_a_wide_dynamic_range():
+    """Gradients spanning 12 decades inside one (image, channel chunk): every destination's sum must be within one fp32
+    rounding of the exact (fp64) total plus the documented truncation of addends below 2^-SHMAX of the chunk's largest value —
+    i.e. relative to the LARGEST magnitude of the chunk at most 2^-29 * fan-in (N = 300: SHMAX = 29)."""
+    from gkgnet_amd import _lib
+    from gkgnet_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    B, G, C, N, M, k = 2, 2, 32, 300, 40, 9
+    idx = torch.randint(0, M, (B * G, N, k), device="cuda", generator=gen)
+    arg = torch.randint(0, M, (B, N, C), device="cuda", generator=gen).to(torch.int16)         # arg kind 1: winning rows
+    mag = 10.0 ** (torch.rand(B, N, C, device="cuda", generator=gen) * 12 - 8)                 # 1e-8 .. 1e4
+    g = mag * torch.sign(torch.randn(B, N, C, device="cuda", generator=gen))
+    gx = torch.empty(B, N, C, device="cuda")
+    gsrc = torch.empty(B, M, C, device="cuda")
+    _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 0, 1, 0, _stream()),
+               "gkg_mr_bwd_tm")
+    want = torch.zeros(B, M, C, dtype=torch.float64, device="cuda")
+    want.scatter_add_(1, arg.long() & 0xffff, g.double())
+    assert torch.equal(gx, -g)                                                                  # mode 0, bipartite: gx = -gm
+    big = float(g.abs().max())
+    err = (gsrc.double() - want).abs()
+    bound = want.abs() * 2.0 ** -23 + big * 2.0 ** -29 * N
+    assert bool((err <= bound).all()), float((err / bound).max())
+    # and it beats the fp32-atomic chain on accuracy where the totals are small next to the addends
+    ax = torch.empty_like(gx); asrc = torch.empty_like(gsrc)
+    _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(idx), _ptr(arg), _ptr(ax), _ptr(asrc), B, G, C // G, N, M, k, 0, 1,
+                                 _lib.MR_FP32_ATOMICS, _stream()), "gkg_mr_bwd_tm")
+    assert float(err.max()) <= float((asrc.double() - want).abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+def test_non_finite_gradients_reach_their_destination(bad):
+    """An inf / NaN in the incoming gradient must arrive at the key it is routed to (the fp16-AMP GradScaler skips the step by
+    finding it in the parameter gradients): the chunk that sees it falls back to the fp32-atomic form; the others stay exact."""
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    B, G, C, N, k = 2, 2, 64, 120, 9
+    x = torch.randn(B, N, C, device="cuda", generator=gen)
+    idx = torch.randint(0, N, (B * G, N, k), device="cuda", generator=gen)
+    g = torch.randn(B, N, C, device="cuda", generator=gen)
+    g[1, 17, 5] = bad
+    gx, _ = _run(x, None, idx, G, 0, g)
+    col = gx[1, :, 5]
+    assert not bool(torch.isfinite(col).all())                   # it arrived somewhere in its own (image, channel) column ...
+    mask = torch.ones_like(gx, dtype=torch.bool)
+    mask[1, :, 5] = False
+    assert bool(torch.isfinite(gx[mask]).all())                  # ... and nowhere else
+    ref, _ = _run(x, None, idx, G, 0, torch.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0))
+    assert torch.allclose(gx[0], ref[0], atol=1e-5, rtol=1e-5)
