@@ -47,6 +47,18 @@ class Stem(nn.Module):
             nn.Conv2d(out_dim, out_dim, 3, stride=1, padding=1), build_norm(out_dim))
 
     def forward(self, x):
+        # channels-last convolutions hand their output over as a token-major matrix: BN (+ GELU) on the blocks' own kernels
+        if fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            x = x.contiguous(memory_format=torch.channels_last)
+            mods = list(self.convs)
+            i = 0
+            while i < len(mods):
+                conv, bn = mods[i], mods[i + 1]
+                act = mods[i + 2] if i + 2 < len(mods) and not isinstance(mods[i + 2], nn.Conv2d) else None
+                x = conv(x)
+                x = fused.bn_act(x, bn, act) if fused.bn_act_supported(bn, x, act) else (bn(x) if act is None else act(bn(x)))
+                i += 2 if act is None else 3
+            return x
         return self.convs(x)
 
 
@@ -58,6 +70,11 @@ class Downsample(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, 3, stride=2, padding=1), build_norm(out_dim))
 
     def forward(self, x):
+        if fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            y = self.conv[0](x.contiguous(memory_format=torch.channels_last))
+            if fused.bn_act_supported(self.conv[1], y, None):
+                return fused.bn_act(y, self.conv[1], None)
+            return self.conv[1](y)
         return self.conv(x)
 
 

@@ -1009,6 +1009,73 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         return dU, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 
+# ----------------------------------------------------------------------------------------------- BN (+ act) behind a library conv
+# The backbone's stem and downsample layers are 3x3 convolutions (MIOpen) followed by BN (+ GELU) (reference gkgnet.py:74-118).
+# On channels-last tensors their output IS a token-major matrix, so the BN (+ activation) runs on the same bandwidth kernels
+# as inside the blocks (statistics at 6-7 TB/s, one apply pass with the fast-erf GELU, two-pass backward) instead of
+# MIOpenBatchNorm{Fwd,Bwd}Spatial + stand-alone GELU kernels: 6.2 + 1.2 ms of the 92.7 ms GKGNet-576 train step (round 3).
+STEM_BN = "stem_bn" not in _DISABLED
+
+
+class _BNActTM(torch.autograd.Function):
+    """out (T, C) = act(BN(Y)) for a token-major matrix Y (train-mode batch statistics or eval-mode running statistics)."""
+
+    @staticmethod
+    def forward(ctx, Y, gamma, beta, bn, act):
+        lib = _lib.load()
+        R, C = Y.shape
+        a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, None, R, C, 1)
+        out = torch.empty_like(Y)
+        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, C, 1, C, 0, act, _lib.F32, None, 0, _stream()),
+                   "gkg_affine_act")
+        ctx.save_for_backward(Y, a, c, mean, invstd)
+        ctx.act, ctx.sync, ctx.gparams = act, sync, (gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        Y, a, c, mean, invstd = ctx.saved_tensors
+        if mean is None:
+            raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
+        R, C = Y.shape
+        g = dout.contiguous()
+        dY = torch.empty_like(Y)
+        gp, bp = ctx.gparams
+        dgamma = grad_view(gp, (C,)) if gp.dtype == _F32 else None
+        dbeta = grad_view(bp, (C,)) if bp.dtype == _F32 else None
+        if dgamma is None:
+            dgamma = torch.empty(C, dtype=_F32, device=Y.device)
+        if dbeta is None:
+            dbeta = torch.empty(C, dtype=_F32, device=Y.device)
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, 1, C, 0, ctx.act, ctx.sync)
+        return dY, dgamma, dbeta, None, None
+
+
+def bn_act_supported(bn, x, act_mod) -> bool:
+    """fp32 CUDA activations in channels-last memory (what a channels-last convolution returns), affine BN, GELU or no
+    activation, channel count a multiple of 4; gradients through eval-mode BN stay on the composable path."""
+    if not (ENABLED and STEM_BN and x.is_cuda and x.dim() == 4 and x.dtype == _F32 and _bn_ok(bn)):
+        return False
+    if act_mod is not None and not isinstance(act_mod, torch.nn.GELU):
+        return False
+    C = x.shape[1]
+    if C % 4 or C > 4096 or not x.permute(0, 2, 3, 1).is_contiguous():
+        return False
+    if torch.is_grad_enabled() and not bn.training and (x.requires_grad or bn.weight.requires_grad):
+        return False
+    return True
+
+
+def bn_act(x, bn, act_mod):
+    """act(BN(x)) for a channels-last (B, C, H, W) tensor, returned channels-last (same values and shape as the reference's
+    ``act(norm(x))``, gkgnet.py:81-83,109)."""
+    B, C, H, W = x.shape
+    Y = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    out = _BNActTM.apply(Y, bn.weight, bn.bias, bn, 0 if act_mod is None else 1)
+    return out.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
 # ----------------------------------------------------------------------------------------------- graph ops
 @torch.no_grad()
 def knn_graph_tm(x, y, relative_pos, k, dilation, G):

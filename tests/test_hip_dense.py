@@ -268,3 +268,39 @@ def test_affine_act_dual_writes_both_copies(act):
     _lib.check(lib.gkg_affine_act_dual(Y.data_ptr(), a.data_ptr(), c.data_ptr(), res.data_ptr(), o2.data_ptr(), o16.data_ptr(),
                                        R, C, act, scale.data_ptr(), 59, None), "gkg_affine_act_dual")
     assert torch.equal(o1, o2) and torch.equal(o16, o1.bfloat16())
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_stem_and_downsample_bn_on_own_kernels_match_torch(train):
+    """backbone.Stem / Downsample (reference gkgnet.py:74-118): 3x3 convolutions (library) + BN (+ GELU) — with the BN and the
+    activation on the blocks' token-major kernels (fused.bn_act, channels-last) against the plain torch modules on the same
+    weights: outputs, input gradient, every parameter gradient, running statistics."""
+    from gkgnet_amd import fused, layers
+    from gkgnet_amd.backbone import Downsample, Stem
+    layers.norm_cfg["type"] = "BN"
+    torch.manual_seed(11)
+    for make, shape in ((lambda: Stem(out_dim=48, act="gelu"), (3, 3, 64, 64)), (lambda: Downsample(48, 96), (3, 48, 20, 20))):
+        res = []
+        for own in (True, False):
+            torch.manual_seed(5)
+            mod = make().cuda()
+            mod.train(train)
+            x = torch.randn(*shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)).requires_grad_(train)
+            old = fused.STEM_BN
+            fused.STEM_BN = own
+            try:
+                with torch.set_grad_enabled(train):
+                    out = mod(x)
+                    if train:
+                        out.square().sum().backward()
+            finally:
+                fused.STEM_BN = old
+            res.append((out.detach(), x.grad, [p.grad for p in mod.parameters()], [b.clone() for b in mod.buffers()]))
+        (o1, g1, p1, b1), (o2, g2, p2, b2) = res
+        assert o1.shape == o2.shape and torch.allclose(o1, o2, atol=2e-4, rtol=2e-4), float((o1 - o2).abs().max())
+        if train:
+            assert torch.allclose(g1, g2, atol=2e-3, rtol=2e-3), float((g1 - g2).abs().max())
+            for a, b in zip(p1, p2):
+                assert torch.allclose(a, b, atol=2e-3 * max(1.0, float(b.abs().max())), rtol=2e-3), float((a - b).abs().max())
+        for a, b in zip(b1, b2):
+            assert torch.allclose(a.float(), b.float(), atol=1e-4, rtol=1e-4)
