@@ -63,7 +63,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_linear_bn_fwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
-           "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm")
+           "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
+           "gkg_bn_bwd_apply_from_sums")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -121,6 +122,10 @@ def load():
     lib.gkg_bn_apply_train.argtypes = [V] * 14 + [I, I, I, I, Z, I, I, V, I, F, F, V, Z, V]
     lib.gkg_bn_bwd_atomic.restype = I
     lib.gkg_bn_bwd_atomic.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, V, Z, V]
+    lib.gkg_bn_bwd_apply_from_sums.restype = I
+    lib.gkg_bn_bwd_apply_from_sums.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, V, Z, V]
+    lib.gkg_linear_dgrad_x6_bnbwd.restype = I
+    lib.gkg_linear_dgrad_x6_bnbwd.argtypes = [V, I, V, V, I, I, I] + [V] * 6 + [I, I, I, V]
     lib.gkg_bn_stats_sums.restype = I
     lib.gkg_bn_stats_sums.argtypes = [V, V, I, I, I, V, Z, V]
     lib.gkg_bn_finalize.restype = I

@@ -16,32 +16,6 @@
 
 namespace gkg {
 
-// GELU, erf form (the reference's nn.GELU(), torch_nn.py:24) and its derivative.  erf comes from Abramowitz & Stegun 7.1.26,
-// |error| <= 1.5e-7 — at the level of fp32 rounding for O(1) activations and four orders below this path's 1e-3 contract —
-// in ~15 vector instructions instead of erff's ~40 (the compile-time ablation of the fused inference kernel showed erff as
-// a quarter of its time; bn_bwd_stats<GELU> ran 2.2x slower than its plain form).  exp(-x^2) with x = z / sqrt 2 is the
-// Gaussian of the derivative as well: one exponential serves both.
-__device__ __forceinline__ void gelu_parts(float z, float& cdf, float& gauss) {
-  const float x = fabsf(z) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  gauss = __expf(-x * x);                              // exp(-z^2 / 2)
-  cdf = 0.5f * (1.0f + copysignf(1.0f - p * t * gauss, z));
-}
-__device__ __forceinline__ float gelu_f(float z) {
-  float cdf, gauss;
-  gelu_parts(z, cdf, gauss);
-  return z * cdf;
-}
-__device__ __forceinline__ float gelu_grad_f(float z) {
-  float cdf, gauss;
-  gelu_parts(z, cdf, gauss);
-  return cdf + z * 0.39894228040143267794f * gauss;
-}
-
 // Train-mode BN whose statistics came out of the projection kernel's epilogue as fp64 column sums (gkg_linear_bn_fwd* with
 // train == 2): the CONSUMER of the projection — the BN-apply pass — derives scale / shift itself instead of a one-block
 // finalize launch in between.  Every workgroup computes the coefficients of its channels once (into LDS), the first
@@ -705,6 +679,11 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
 // buffers and hands each call the region the PREVIOUS call used as `zero_buf`: every buffer is clean again before its next
 // use without a memset launch or a last-arriver ticket.  fp64 atomics: the sums are run-dependent in their last fp64 bits
 // (deterministic callers keep gkg_bn_bwd).
+static int bn_bwd_atomic_impl(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                              const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                              size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream,
+                              bool stats_pass);
+
 extern "C" int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                                  const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                                  size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream) {
@@ -713,11 +692,36 @@ extern "C" int gkg_bn_bwd_atomic(const float* dout, const float* y, const float*
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1) ||
       (zero_doubles && !zero_buf))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_atomic: bad sizes");
+  return bn_bwd_atomic_impl(dout, y, a, c, mean, invstd, dy, dgamma, dbeta, R, C, nb, ldg, dout_bstride, act, sums, zero_buf,
+                            zero_doubles, stream, true);
+}
+
+// The same backward with the statistics ALREADY in `sums` (accumulated by the epilogue of the GEMM that produced dout:
+// gkg_linear_dgrad_x6_bnbwd): only the apply pass runs.
+extern "C" int gkg_bn_bwd_apply_from_sums(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                                          const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb,
+                                          int ldg, size_t dout_bstride, int act, const double* sums, double* zero_buf,
+                                          size_t zero_doubles, void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !dy || !dgamma || !dbeta || !sums)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_apply_from_sums: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1) ||
+      (zero_doubles && !zero_buf))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_apply_from_sums: bad sizes");
+  return bn_bwd_atomic_impl(dout, y, a, c, mean, invstd, dy, dgamma, dbeta, R, C, nb, ldg, dout_bstride, act,
+                            const_cast<double*>(sums), zero_buf, zero_doubles, stream, false);
+}
+
+static int bn_bwd_atomic_impl(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                              const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                              size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream,
+                              bool stats_pass) {
   int rpb;
   const int nblk = stats_blocks(R, C, nb, &rpb);
   hipStream_t st = (hipStream_t)stream;
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
-  else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
+  if (stats_pass) {
+    if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
+    else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
+  }
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
   if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_d_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles);

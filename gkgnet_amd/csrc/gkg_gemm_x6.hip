@@ -124,9 +124,15 @@ struct X6Args {
   int NP, KC;                                           // plane geometry (padded n, k/8 chunks)
   int mtiles, ntiles;
   double* sums;  int nslots, nbatch;                    // EPI_BNSTATS: [nslots][nb][2][N] fp64, accumulated with atomics
+  // EPI_BNBWD (input-gradient GEMM): the tile it has just produced is the upstream gradient g of the BN (+ GELU) layer that
+  // made this GEMM's input in the forward.  Its backward statistics  sum dz, sum dz * yhat  (dz = g * act'(a y + c),
+  // yhat = (y - mean) * invstd) are accumulated here, from the accumulators and one read of y, instead of by a stand-alone
+  // pass over g and y.  Output column n belongs to BN group n / pco, channel n % pco; y is (pnb, M, pco).
+  const float* py; const float* pa; const float* pc; const float* pmean; const float* pinvstd;
+  double* psums;  int pco, pact;                        // psums: [pnb][2][pco] fp64 (atomics)
 };
 
-enum { X6_STORE = 0, X6_BNSTATS = 1 };
+enum { X6_STORE = 0, X6_BNSTATS = 1, X6_BNBWD = 2 };
 
 __device__ __forceinline__ void x6_chan_merge(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
   if (nb <= 0.0) return;
@@ -320,6 +326,31 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   half(0, true, nk - 1, 1);
   half(1, false, 0, 0);
 
+  // X6_BNBWD: the producer's y values of this lane's 16 rows x NI columns are fetched NOW, ahead of the tile's stores and the
+  // barrier, so that their latency is off the workgroup's tail
+  float yv[EPI == X6_BNBWD ? NI : 1][16];
+  float pav[NI], pcv[NI], pmv[NI], piv[NI];
+  if (EPI == X6_BNBWD) {
+    const int rbase = m0 + 32 * w;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + j * 32 + r;
+      pav[j] = pcv[j] = pmv[j] = piv[j] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) yv[j][q] = 0.f;
+      if (n < N) {
+        const int pq = n / g.pco, pi = n - pq * g.pco;
+        const size_t po = (size_t)pq * g.pco + pi;
+        pav[j] = g.pa[po]; pcv[j] = g.pc[po]; pmv[j] = g.pmean[po]; piv[j] = g.pinvstd[po];
+        const float* yp = g.py + ((size_t)pq * M + rbase) * (size_t)g.pco + pi;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (rbase + row < M) yv[j][q] = yp[(size_t)row * g.pco];
+        }
+      }
+    }
+  }
   // ---- epilogue.  Block j, register q: row 32 w + (q & 3) + 8 (q >> 2) + 4 h, column 32 j + r
   float* C = g.C + (size_t)z * g.c_bstride;
 #pragma unroll
@@ -332,6 +363,44 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
       const int m = m0 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h;
       if (m < M && n < N) C[(size_t)m * g.ldc + n] = acc[j][q];
     }
+  }
+  if (EPI == X6_BNBWD) {
+    // Backward statistics of the PRODUCER's BN (see X6Args): per lane the 16 rows of its column, y read with the same
+    // 128-byte row segments the tile was stored with; the two half-waves and the four waves are combined through LDS in
+    // fp64 and leave ONE atomic pair per column and tile, like the forward statistics below.
+    __syncthreads();                                   // every wave is done with the DMA rings
+    float* red = reinterpret_cast<float*>(lds);        // [4 waves][BN][2]
+    const int rbase = m0 + 32 * w;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + j * 32 + r;
+      float s0 = 0.f, s1 = 0.f;
+      if (n < N) {
+        const float av = pav[j], cv = pcv[j], mv = pmv[j], iv = piv[j];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+          float dz = rbase + row < M ? acc[j][q] : 0.f;
+          if (g.pact == 1) dz *= gelu_grad_f(__builtin_fmaf(av, yv[j][q], cv));
+          s0 += dz;
+          s1 += dz * ((yv[j][q] - mv) * iv);
+        }
+      }
+      s0 += __shfl_xor(s0, 32);
+      s1 += __shfl_xor(s1, 32);
+      if (h == 0) { float* o = red + ((w * BN) + j * 32 + r) * 2; o[0] = s0; o[1] = s1; }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { t0 += (double)red[(rg * BN + tid) * 2]; t1 += (double)red[(rg * BN + tid) * 2 + 1]; }
+      const int n = n0 + tid, pq = n / g.pco, pi = n - pq * g.pco;
+      double* sz = g.psums + (size_t)pq * 2 * g.pco + pi;
+      __hip_atomic_fetch_add(sz, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sz + g.pco, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
   }
   if (EPI != X6_BNSTATS) return;
 
@@ -962,6 +1031,30 @@ extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.M = R; a.N = cin; a.K = cout;
   hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad)");
+}
+
+// The same input gradient with the BACKWARD statistics of the producer's BN in the epilogue (X6_BNBWD): dx is the upstream
+// gradient of the layer  h = act(BN(py))  that made this projection's input; psums [pnb][2][pco] fp64 receives (atomics)
+// sum dz and sum dz * yhat per channel — what gkg_bn_bwd_atomic's statistics pass would compute from dx and py.  Un-grouped
+// projections only (nb == 1): dx (R, cin), cin == pnb * pco, py (pnb, R, pco).
+extern "C" int gkg_linear_dgrad_x6_bnbwd(const float* dy, int ldg, const void* planes_dgrad, float* dx, int R, int cin, int cout,
+                                         const float* py, const float* pa, const float* pc, const float* pmean,
+                                         const float* pinvstd, double* psums, int pnb, int pco, int pact, void* stream) {
+  if (!dy || !planes_dgrad || !dx || !py || !pa || !pc || !pmean || !pinvstd || !psums)
+    return gkg_fail(GKG_ERR_NULL, "gkg_linear_dgrad_x6_bnbwd: null pointer");
+  if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || ldg < cout || (ldg & 3) || ((size_t)dy & 15) || pnb <= 0 || pco <= 0 ||
+      (long long)pnb * pco != cin || (pact != 0 && pact != 1))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6_bnbwd: need R > 0, cin % 4 == 0, cout % 4 == 0, cin == pnb * pco, 16-byte aligned rows");
+  if ((size_t)R * ldg * 4 > 0xffffffffull) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_dgrad_x6_bnbwd: operand larger than 4 GiB");
+  X6Args a{};
+  a.A = dy; a.a_bstride = 0; a.lda = ldg;
+  a.NP = (cin + X6_NPAD - 1) / X6_NPAD * X6_NPAD; a.KC = (cout + 31) / 32 * 4;
+  a.P = (const uint4*)planes_dgrad; a.p_bstride = (size_t)3 * a.KC * a.NP;
+  a.C = dx; a.c_bstride = (size_t)R * cin; a.ldc = cin;
+  a.M = R; a.N = cin; a.K = cout;
+  a.py = py; a.pa = pa; a.pc = pc; a.pmean = pmean; a.pinvstd = pinvstd; a.psums = psums; a.pco = pco; a.pact = pact;
+  hipError_t e = x6_launch<X6_BNBWD>(a, 1, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad + BN backward statistics)");
 }
 
 // dw (nb, cout, cin) += dy^T x over the R rows; dw must be ZERO on entry (the slabs of rows are added with fp32 atomics).

@@ -793,10 +793,71 @@ def _derive_ok(bn, nb, cout, code, want16) -> bool:
             and code == _lib.F32 and not want16 and 2 * nb * cout <= _BnBwdScratch.DOUBLES)
 
 
-def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync):
+# BN backward statistics in the epilogue of the NEXT projection's input-gradient GEMM (round 4, csrc/gkg_gemm_x6.hip X6_BNBWD).
+# In h = act(BN(Y)) -> out = h W^T the gradient dh that the second layer's dgrad produces is the first layer's upstream
+# gradient: the producer layer hangs a _BnLink on the tensor it returns; a consumer whose dgrad runs on the x6 kernel finds
+# it on its input, lets the GEMM's epilogue accumulate  sum dz, sum dz yhat  (one extra read of Y, no pass over dh) and
+# leaves the scratch buffers on the link; the producer's backward then runs the apply pass only.  MEASURED neutral (round 4,
+# same-box A/B: cfg4 train step 90.0 / 90.4 ms with, 90.1 / 90.3 without; stage3 3.17-3.18 either way; cfg2 0.919 vs 0.915):
+# the 16 y rows per lane, the GELU' recompute and the reduction sit on the tail of a workgroup that lives 10-15 us, which
+# costs the GEMM what the removed pass (near the HBM roofline on its own) saved.  Opt-in: GKG_ENABLE=bn_epilogue.
+BN_EPILOGUE = "bn_epilogue" in _ENABLED
+
+
+class _BnLink:
+    __slots__ = ("Y", "a", "c", "mean", "invstd", "act", "nb", "co", "R", "ready")
+
+    def __init__(self, Y, a, c, mean, invstd, act, nb, co, R):
+        self.Y, self.a, self.c, self.mean, self.invstd, self.act, self.nb, self.co, self.R = Y, a, c, mean, invstd, act, nb, co, R
+        self.ready = None             # (data_ptr of the gradient tensor the sums belong to, cur, other, zero)
+
+
+def _bn_link(out, Y, a, c, mean, invstd, act, nb, co, R, bn, sync, scale):
+    """Hang a _BnLink on a token-major fp32 layer output (train-mode, rank-local statistics, atomics allowed)."""
+    if (BN_EPILOGUE and mean is not None and sync is None and scale is None and not DETERMINISTIC
+            and out.dtype == _F32 and 2 * nb * co <= _BnBwdScratch.DOUBLES):
+        link = _BnLink(Y, a, c, mean, invstd, act, nb, co, R)
+        out._gkg_bn_link = link
+        return link
+    return None
+
+
+def _dgrad_x6_with_link(lib, dY, pd, R, cin, cout, link):
+    """dx = dY W on the x6 kernel with the producer's BN backward statistics in the epilogue -> dx; leaves the sums on the link."""
+    scratch = _BnBwdScratch.of(dY.device)
+    cur, other, zero = scratch.acquire(lib, 2 * link.nb * link.co)
+    dx = torch.empty((R, cin), dtype=_F32, device=dY.device)
+    try:
+        _lib.check(lib.gkg_linear_dgrad_x6_bnbwd(_ptr(dY), cout, _ptr(pd), _ptr(dx), R, cin, cout, _ptr(link.Y), _ptr(link.a),
+                                                 _ptr(link.c), _ptr(link.mean), _ptr(link.invstd), _ptr(cur), link.nb, link.co,
+                                                 link.act, _stream()), "gkg_linear_dgrad_x6_bnbwd")
+    except Exception:
+        scratch.poison()
+        raise
+    link.ready = (dx.data_ptr(), cur, other, zero)
+    return dx
+
+
+def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync, link=None):
     """dY, dgamma, dbeta of out = act(BN_train(Y)) from the upstream gradient g; with ``sync`` the two column sums the
     input gradient needs are all-reduced over the ranks (dgamma/dbeta stay local, like torch's SyncBatchNorm: the
-    data-parallel gradient exchange averages them)."""
+    data-parallel gradient exchange averages them).  ``link``: this layer's _BnLink — when the consumer's dgrad epilogue has
+    left the statistics of exactly this gradient tensor on it, only the apply pass runs."""
+    if link is not None and link.ready is not None:
+        ptr, cur, other, zero = link.ready
+        link.ready = None
+        if ptr == g.data_ptr() and g_bstride == (C if nb > 1 else 0) and ldg == nb * C:
+            try:
+                _lib.check(lib.gkg_bn_bwd_apply_from_sums(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
+                                                          _ptr(dgamma), _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur),
+                                                          _ptr(other), zero, _stream()), "gkg_bn_bwd_apply_from_sums")
+            except Exception:
+                _BnBwdScratch.of(Y.device).poison()
+                raise
+            return
+        # the gradient that arrived is not the tensor the sums were taken from (autograd added another contribution):
+        # the buffer bookkeeping is off by one acquire -> start clean
+        _BnBwdScratch.of(Y.device).poison()
     if sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES:
         # two launches: statistics with fp64 atomics into one of two alternating scratch buffers, apply (which also clears
         # what the previous call left in the other buffer) — no partial rows, no second-stage reduction launch
@@ -842,6 +903,7 @@ class _LinearBNAct(torch.autograd.Function):
         R, cin = x.shape
         cout = weight.shape[0]
         W = weight.view(cout, cin)
+        prev = None if alias else getattr(x, "_gkg_bn_link", None)       # the layer that produced x (see _BnLink)
         x6f, x6d = _x6(x, weight, bn, 1, "fwd"), _x6(x, weight, bn, 1, "dgrad")
         own = x6f or _own_gemm(x, weight, bn)
         pf, pd = _planes(lib, weight, 1, cout, cin, x6f, x6d) if x6f or x6d else (None, None)
@@ -886,6 +948,8 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.pd = pd
+        ctx.prev = prev if (prev is not None and pd is not None and prev.nb * prev.co == cin and prev.R == R) else None
+        ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, 1, cout, R, bn, sync, scale) if nchw is None else None
         if alias:
             ctx.set_materialize_grads(False)
             return out, x.view_as(x)
@@ -916,10 +980,12 @@ class _LinearBNAct(torch.autograd.Function):
         dbias = None
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (cout, cin), cout, Y.device)
-        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync)
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync, ctx.link)
         W = weight.view(cout, cin)
         if not ctx.needs_input_grad[0]:
             dx = None
+        elif ctx.prev is not None and dalias is None:
+            dx = _dgrad_x6_with_link(lib, dY, ctx.pd, R, cin, cout, ctx.prev)      # + the producer's BN backward statistics
         elif ctx.pd is not None:
             dx = torch.empty((R, cin), dtype=_F32, device=dY.device)
             _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), cout, R * cout, _ptr(ctx.pd), _ptr(dx), R, cin, cout, 1, _stream()),
@@ -980,6 +1046,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
         ctx.pd = pd
+        ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, nb, co, R, bn, sync, None)
         return out
 
     @staticmethod
@@ -995,7 +1062,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (nb, co, ci), cout, Y.device)
-        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync)
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync, ctx.link)
         Wg = weight.view(nb, co, ci)
         if not ctx.needs_input_grad[0]:
             dU = None
@@ -1190,6 +1257,7 @@ class _MRGroupedLinearBNAct(torch.autograd.Function):
         ctx.meta = (B, G, C, N, M, k, act)
         ctx.gparams = (weight, gamma, beta)
         ctx.pd = pd if x6d else None
+        ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, 4, co, T, bn, None, None)
         return out
 
     @staticmethod
@@ -1201,7 +1269,7 @@ class _MRGroupedLinearBNAct(torch.autograd.Function):
         g = dout.contiguous()
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (4, co, ci), 2 * C, Y.device)
-        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, T, co, 4, 2 * C, co, act, None)
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, T, co, 4, 2 * C, co, act, None, ctx.link)
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         gx = gsrc = None
         if need_in:

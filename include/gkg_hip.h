@@ -333,6 +333,25 @@ int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float*
                         int R, int cin, int cout, int nb, void* stream);
 
 /*
+ * Input gradient of a projection with the BACKWARD statistics of the layer in front of it in its epilogue (round 4).
+ * dx (R, cin) = dy (R, cout; row pitch ldg) * w, weights as dgrad planes — like gkg_linear_dgrad_x6 with nb == 1 — where dx is
+ * at the same time the upstream gradient g of the layer  h = act(BN_train(py))  that produced this projection's input
+ * (reference: the chains fc1 -> BN -> GELU -> fc2 of FFN gkgnet.py:66-72 / FFNLabel torch_vertex.py:352-358 and
+ * BasicConv -> fc2 of Grapher torch_vertex.py:329-330).  psums [pnb][2][pco] fp64 receives, with atomics, per channel
+ *     sum_r dz   and   sum_r dz * yhat,     dz = g * act'(pa * py + pc),  yhat = (py - pmean) * pinvstd,
+ * i.e. exactly what the statistics pass of gkg_bn_bwd_atomic would compute from g and py — which then runs as
+ * gkg_bn_bwd_apply_from_sums (apply pass only).  py (pnb, R, pco) with cin == pnb * pco; column n of dx is group n / pco,
+ * channel n % pco; pact 0 none / 1 GELU.
+ */
+int gkg_linear_dgrad_x6_bnbwd(const float* dy, int ldg, const void* planes_dgrad, float* dx, int R, int cin, int cout,
+                              const float* py, const float* pa, const float* pc, const float* pmean, const float* pinvstd,
+                              double* psums, int pnb, int pco, int pact, void* stream);
+int gkg_bn_bwd_apply_from_sums(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                               const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                               size_t dout_bstride, int act, const double* sums, double* zero_buf, size_t zero_doubles,
+                               void* stream);
+
+/*
  * SURVEY §8 row g1, training / fp32 form (csrc/gkg_mrgemm_x6.hip): MRConv2d.forward's gather + max-relative + interleave
  * (torch_vertex.py:47-62) as the A-operand producer of BasicConv's grouped 1x1 convolution (torch_nn.py:57-61, bias folded
  * into the BN behind it) at the accuracy of gkg_linear_bn_fwd_x6, with the train-mode BN column sums in the epilogue: ONE

@@ -1,35 +1,35 @@
 #!/bin/bash
-# Collect the judged measurement artifacts of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r02
+# Collect the judged measurement artifacts of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r04
 # Leaves everything under gpurun_out/<tag>_*; copy into profiles/ afterwards.
 TAG=${1:-rXX}
 R=$PWD
 mkdir -p $R/gpurun_out
-# 1. the default bench line (with CPU baseline), and the two secondary workloads
+# 1. the default bench line (with CPU baseline), and every other workload through the same entry point
 python bench.py > gpurun_out/${TAG}_final_bench_cfg2.json 2> gpurun_out/${TAG}_final_bench_cfg2.err
-python bench.py --workload cfg2ref --no-cpu-baseline > gpurun_out/${TAG}_final_bench_cfg2ref.json 2>/dev/null
-python bench.py --workload stage3 --no-cpu-baseline > gpurun_out/${TAG}_final_bench_stage3.json 2>/dev/null
-# 2. rocprofv3 --kernel-trace --stats of the same command + condensed views
-bash tools/prof_run.sh ${TAG}_final --steps 20 --warmup 5 > /dev/null
-cd /tmp && export TMPDIR=/tmp
-python $R/tools/prof_graph_steps.py /tmp/${TAG}_final "knn_tile_kernel<9, true" 1100 seq > $R/gpurun_out/${TAG}_final_bench_cfg2_graph_steps.txt
-# 3. secondary configs, per kernel
-for cfg in cfg3 cfg5; do
-  rm -rf /tmp/p_$cfg
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$cfg -o run -- python $R/tools/run_configs.py $cfg > $R/gpurun_out/${TAG}_final_${cfg}.log 2>&1
-  python $R/tools/prof_detail.py /tmp/p_$cfg 30 45 > $R/gpurun_out/${TAG}_final_${cfg}_forward_per_kernel.txt
+for w in cfg2ref stage3 stage1; do
+  python bench.py --workload $w --no-cpu-baseline > gpurun_out/${TAG}_final_bench_$w.json 2>/dev/null
 done
-rm -rf /tmp/p_t4
-rocprofv3 --kernel-trace --output-format csv -d /tmp/p_t4 -o run -- python $R/tools/train_step.py --batch 32 --steps 3 --warmup 2 > $R/gpurun_out/${TAG}_final_cfg4_train_step.log 2>&1
-python $R/tools/prof_detail.py /tmp/p_t4 100 60 > $R/gpurun_out/${TAG}_final_cfg4_train_step_per_kernel.txt
+for w in cfg3 cfg5 cfg4; do
+  python bench.py --workload $w > gpurun_out/${TAG}_final_bench_$w.json 2>/dev/null
+done
+# 2. rocprofv3 --kernel-trace --stats of the default command + condensed views (both timed legs; then the library-default leg alone)
+bash tools/prof_run.sh ${TAG}_final --steps 20 --warmup 5 > /dev/null
+( cd /tmp && python $R/tools/prof_graph_steps.py /tmp/${TAG}_final "knn_tile_kernel<9, true" 1100 seq > $R/gpurun_out/${TAG}_final_bench_cfg2_graph_steps.txt )
+bash tools/prof_run.sh ${TAG}_notune --steps 20 --warmup 5 --no-tune > /dev/null
+( cd /tmp && python $R/tools/prof_graph_steps.py /tmp/${TAG}_notune "knn_tile_kernel<9, true" 1200 seq > $R/gpurun_out/${TAG}_final_bench_cfg2_graph_steps_library_default_leg.txt )
+# 3. whole-backbone configs, per kernel
+cd /tmp && export TMPDIR=/tmp
+for cfg in cfg3 cfg5 cfg4; do
+  rm -rf /tmp/p_$cfg
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$cfg -o run -- python $R/bench.py --workload $cfg --no-cpu-baseline --steps 3 --warmup 2 > $R/gpurun_out/${TAG}_final_${cfg}_prof.log 2>&1
+  win=60; [ $cfg = cfg4 ] && win=95; [ $cfg = cfg5 ] && win=110
+  python $R/tools/prof_detail.py /tmp/p_$cfg $win 60 > $R/gpurun_out/${TAG}_final_${cfg}_per_kernel.txt
+done
 cd $R
-# 4. un-profiled secondary numbers
-python tools/run_configs.py cfg3 2>&1 | tail -2 > gpurun_out/${TAG}_final_cfg3_unprofiled.txt
-python tools/run_configs.py cfg5 2>&1 | tail -2 > gpurun_out/${TAG}_final_cfg5_unprofiled.txt
-python tools/train_step.py --batch 32 --steps 6 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_final_cfg4_unprofiled.txt
-# 5. hardware counters (separate passes)
+# 4. hardware counters (separate passes)
 bash tools/pmc_refresh.sh ${TAG} > /dev/null 2>&1
-# 6. per-shape GEMM table
+bash tools/pmc_knn_run.sh > gpurun_out/${TAG}_knn_tile_sq_counters.txt 2>&1
+# 5. per-shape tables
 python tools/bench_x6.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_x6_gemm_shapes.txt
-python tools/bench_x6.py cfg4 2>&1 | grep -v amdgpu.ids >> gpurun_out/${TAG}_x6_gemm_shapes.txt
-./tools/ubench/mfma_bf16_fill > gpurun_out/${TAG}_ubench_mfma_bf16_fill.txt 2>&1
+python tools/bench_mr_bwd.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_bench_mr_bwd.txt
 cut -c1-300 gpurun_out/${TAG}_final_bench_cfg2.json
