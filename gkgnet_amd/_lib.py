@@ -64,7 +64,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
-           "gkg_bn_bwd_apply_from_sums")
+           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -174,6 +174,10 @@ def load():
     lib.gkg_mr_linear_x6.argtypes = [V] * 8 + [I] * 6 + [V]
     lib.gkg_mr_regather_tm.restype = I
     lib.gkg_mr_regather_tm.argtypes = [V] * 4 + [I] * 4 + [V]
+    lib.gkg_stem_conv3x3s2_supported.restype = I
+    lib.gkg_stem_conv3x3s2_supported.argtypes = [I, I]
+    lib.gkg_stem_conv3x3s2_fwd.restype = I
+    lib.gkg_stem_conv3x3s2_fwd.argtypes = [V] * 6 + [I] * 7 + [V]
     lib.gkg_prof_enable.restype = None
     lib.gkg_prof_enable.argtypes = [C.c_int]
     lib.gkg_prof_reset.restype = None

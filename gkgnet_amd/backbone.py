@@ -47,17 +47,37 @@ class Stem(nn.Module):
             nn.Conv2d(out_dim, out_dim, 3, stride=1, padding=1), build_norm(out_dim))
 
     def forward(self, x):
+        mods = list(self.convs)
+        conv0, bn0 = mods[0], mods[1]
+        act0 = mods[2] if not isinstance(mods[2], nn.Conv2d) else None
+        first = None
+        if fused.stem_conv_supported(conv0, x) and (act0 is None or isinstance(act0, nn.GELU)):
+            # the first convolution (3 input channels) as a direct kernel: csrc/gkg_stem.hip
+            ac16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            if (not torch.is_grad_enabled() and not bn0.training and bn0.track_running_stats and fused._bn_ok(bn0)
+                    and (ac16 or not torch.is_autocast_enabled())):
+                first = fused.stem_conv_bn_act_eval(conv0, bn0, act0, x, ac16)           # conv + BN(eval) + GELU: one launch
+                start = 3 if act0 is not None else 2
+            elif not torch.is_autocast_enabled():
+                first = fused.stem_conv(conv0, x)                                           # training: BN on the kernels below
+                start = 1
         # channels-last convolutions hand their output over as a token-major matrix: BN (+ GELU) on the blocks' own kernels
-        if fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
-            x = x.contiguous(memory_format=torch.channels_last)
-            mods = list(self.convs)
-            i = 0
+        if first is not None or (fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32
+                                 and not torch.is_autocast_enabled()):
+            if first is None:
+                x, i = x.contiguous(memory_format=torch.channels_last), 0
+            else:
+                x, i = first, start
             while i < len(mods):
-                conv, bn = mods[i], mods[i + 1]
-                act = mods[i + 2] if i + 2 < len(mods) and not isinstance(mods[i + 2], nn.Conv2d) else None
-                x = conv(x)
-                x = fused.bn_act(x, bn, act) if fused.bn_act_supported(bn, x, act) else (bn(x) if act is None else act(bn(x)))
-                i += 2 if act is None else 3
+                if isinstance(mods[i], nn.Conv2d):
+                    x = mods[i](x)
+                    i += 1
+                    continue
+                bn = mods[i]
+                act = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], nn.Conv2d) else None
+                own = x.dtype == torch.float32 and not torch.is_autocast_enabled() and fused.STEM_BN
+                x = fused.bn_act(x, bn, act) if own and fused.bn_act_supported(bn, x, act) else (bn(x) if act is None else act(bn(x)))
+                i += 1 if act is None else 2
             return x
         return self.convs(x)
 

@@ -1143,6 +1143,66 @@ def bn_act(x, bn, act_mod):
     return out.view(B, H, W, C).permute(0, 3, 1, 2)
 
 
+# ----------------------------------------------------------------------------------------------- the stem's first convolution
+# Conv2d(3 -> C1/2, 3x3, stride 2, padding 1) on the image as a direct kernel (csrc/gkg_stem.hip): MIOpen's implicit-GEMM forms
+# need 756 us (bf16 autocast) / 1 015 us (fp32) for it at B = 32, 576 x 576.  GKG_DISABLE=stem_conv keeps the library call.
+STEM_CONV = "stem_conv" not in _DISABLED
+
+
+def stem_conv_supported(conv, x) -> bool:
+    return (ENABLED and STEM_CONV and isinstance(conv, torch.nn.Conv2d) and x.is_cuda and x.dim() == 4 and x.dtype == _F32
+            and conv.weight.dtype == _F32 and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (2, 2)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and x.shape[1] == conv.in_channels
+            and bool(_lib.load().gkg_stem_conv3x3s2_supported(conv.in_channels, conv.out_channels)))
+
+
+class _StemConv(torch.autograd.Function):
+    """y = conv(x) + bias as a channels-last (B, cout, Ho, Wo) tensor; the weight / bias gradients come from the library's
+    convolution backward (the image itself needs no gradient in the backbone; it is computed when asked for)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        x = x.contiguous()
+        out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, cout), dtype=_F32, device=x.device)
+        _lib.check(lib.gkg_stem_conv3x3s2_fwd(_ptr(x), _ptr(weight.contiguous()), _ptr(bias), None, None, _ptr(out), B, cin, H, W, cout,
+                                              0, _lib.F32, _stream()), "gkg_stem_conv3x3s2_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        gx, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [2, 2], [1, 1],
+                                                         [1, 1], False, [0, 0], 1, mask)
+        return gx, gw, gb
+
+
+def stem_conv(conv, x):
+    """Training form: the plain convolution (its BN runs on the token-major kernels behind it, fused.bn_act)."""
+    return _StemConv.apply(x, conv.weight, conv.bias)
+
+
+@torch.no_grad()
+def stem_conv_bn_act_eval(conv, bn, act_mod, x, out_bf16: bool):
+    """Inference: conv + eval-mode BN (+ GELU) in ONE launch, channels-last output (bf16 under bf16 autocast, like the library
+    convolution's output there)."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    cout = conv.out_channels
+    a, c = _bn_eval_ac(lib, bn, conv.bias, cout)                      # conv bias folded into the shift
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, cout), dtype=torch.bfloat16 if out_bf16 else _F32, device=x.device)
+    _lib.check(lib.gkg_stem_conv3x3s2_fwd(_ptr(x.contiguous()), _ptr(conv.weight.contiguous()), None, _ptr(a), _ptr(c), _ptr(out), B, cin,
+                                          H, W, cout, 0 if act_mod is None else 1, _lib.BF16 if out_bf16 else _lib.F32, _stream()),
+               "gkg_stem_conv3x3s2_fwd")
+    return out.permute(0, 3, 1, 2)
+
+
 # ----------------------------------------------------------------------------------------------- graph ops
 @torch.no_grad()
 def knn_graph_tm(x, y, relative_pos, k, dilation, G):

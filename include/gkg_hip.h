@@ -372,6 +372,18 @@ int gkg_mr_linear_x6(const float* x, const float* src, const int64_t* nn_idx, co
 int gkg_mr_regather_tm(const float* x, const float* src, const void* arg, float* u, int B, int N, int M, int C, void* stream);
 
 /*
+ * The backbone's first stem convolution (reference gkgnet.py:79-81: Conv2d(3 -> C1/2, 3x3, stride 2, padding 1) on the image),
+ * as a direct kernel — with 3 input channels the library's implicit-GEMM forms run at a few TFLOP/s — writing the
+ * channels-last tensor the next convolution and the blocks' token-major kernels want; optionally the eval-mode BN (a, c:
+ * gkg_bn_eval_affine, conv bias folded) and GELU behind it (gkgnet.py:81-83) in the epilogue.
+ *   out (B, Ho, Wo, cout) = act(a * (conv(x) + bias) + c);  x (B, cin, H, W) fp32, w (cout, cin, 3, 3) fp32;
+ *   a, c both NULL: the plain convolution (+ bias);  Ho = (H + 1) / 2, Wo = (W + 1) / 2;  out_dtype GKG_F32 / GKG_BF16.
+ */
+int gkg_stem_conv3x3s2_supported(int cin, int cout);
+int gkg_stem_conv3x3s2_fwd(const float* x, const float* w, const float* bias, const float* a, const float* c, void* out, int B,
+                           int cin, int H, int W, int cout, int act, int out_dtype, void* stream);
+
+/*
  * Opt-in kernel timing (measurement only; off by default, nothing is recorded on the hot path when off).
  * When enabled, every kernel launch made by this library is bracketed by hipEventRecord on the SAME
  * stream it is launched on.  gkg_prof_read synchronises on the recorded events (so call it outside any

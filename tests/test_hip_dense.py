@@ -286,15 +286,15 @@ def test_stem_and_downsample_bn_on_own_kernels_match_torch(train):
             mod = make().cuda()
             mod.train(train)
             x = torch.randn(*shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)).requires_grad_(train)
-            old = fused.STEM_BN
-            fused.STEM_BN = own
+            old = (fused.STEM_BN, fused.STEM_CONV)
+            fused.STEM_BN = fused.STEM_CONV = own
             try:
                 with torch.set_grad_enabled(train):
                     out = mod(x)
                     if train:
                         out.square().sum().backward()
             finally:
-                fused.STEM_BN = old
+                fused.STEM_BN, fused.STEM_CONV = old
             res.append((out.detach(), x.grad, [p.grad for p in mod.parameters()], [b.clone() for b in mod.buffers()]))
         (o1, g1, p1, b1), (o2, g2, p2, b2) = res
         assert o1.shape == o2.shape and torch.allclose(o1, o2, atol=2e-4, rtol=2e-4), float((o1 - o2).abs().max())
@@ -304,3 +304,41 @@ def test_stem_and_downsample_bn_on_own_kernels_match_torch(train):
                 assert torch.allclose(a, b, atol=2e-3 * max(1.0, float(b.abs().max())), rtol=2e-3), float((a - b).abs().max())
         for a, b in zip(b1, b2):
             assert torch.allclose(a.float(), b.float(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cout", [24, 40, 48, 64])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 3, 37, 51), (3, 4, 20, 33)])
+def test_stem_first_convolution_direct_kernel(cout, shape):
+    """csrc/gkg_stem.hip against F.conv2d (reference gkgnet.py:79-81: Conv2d(3 -> C1/2, 3, stride 2, padding 1)): the plain
+    convolution with its autograd (weight / bias gradients from the library's convolution backward), and the inference form
+    with eval-mode BN + GELU folded, fp32 and bf16 outputs; odd image sizes (the last row / column of taps is padding)."""
+    import torch.nn.functional as F
+    from gkgnet_amd import fused, layers
+    layers.norm_cfg["type"] = "BN"
+    B, cin, H, W = shape
+    torch.manual_seed(cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1).cuda()
+    bn = layers.build_norm(cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    assert fused.stem_conv_supported(conv, x)
+    y = fused.stem_conv(conv, x)
+    want = F.conv2d(x, conv.weight, conv.bias, stride=2, padding=1)
+    assert y.shape == want.shape and y.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.allclose(y, want, atol=2e-5, rtol=2e-5), float((y - want).abs().max())
+    # gradients
+    cot = torch.randn_like(want)
+    y.backward(cot)
+    gw, gb = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.zero_grad()
+    F.conv2d(x, conv.weight, conv.bias, stride=2, padding=1).backward(cot)
+    assert torch.allclose(gw, conv.weight.grad, atol=1e-3, rtol=1e-3) and torch.allclose(gb, conv.bias.grad, atol=1e-3, rtol=1e-3)
+    # inference: conv + BN(eval) + GELU in one launch
+    ref = F.gelu(bn(want))
+    got32 = fused.stem_conv_bn_act_eval(conv, bn, torch.nn.GELU(), x, False)
+    assert torch.allclose(got32, ref, atol=5e-5, rtol=5e-5), float((got32 - ref).abs().max())
+    got16 = fused.stem_conv_bn_act_eval(conv, bn, torch.nn.GELU(), x, True)
+    assert got16.dtype == torch.bfloat16 and torch.allclose(got16.float(), ref, atol=2e-2, rtol=1e-2)
+    lin = fused.stem_conv_bn_act_eval(conv, bn, None, x, False)
+    assert torch.allclose(lin, bn(want), atol=5e-5, rtol=5e-5)
