@@ -10,6 +10,10 @@
 // output, which is what the next (library) convolution and the blocks' token-major kernels want — go out as 16-byte stores.
 #include "gkg_common.h"
 
+#ifndef STEM_ABL
+#define STEM_ABL 0     // measurement builds only (tools/ubench/stem_ablate.py): 1 no loads, 2 no stores, 4 one FMA group per tap
+#endif
+
 namespace gkg {
 
 typedef float st_f2 __attribute__((ext_vector_type(2)));
@@ -45,22 +49,28 @@ __global__ __launch_bounds__(256, 2) void stem_conv3x3s2_kernel(const float* __r
   const float* xb = x + (size_t)b * cin * H * W;
   const int hi0 = 2 * ho - 1, wi0 = 2 * wo0 - 1;
   int c = 0, dy = 0;
+  constexpr int NC = 2 * PX + 1;
 #pragma unroll 1
   for (int cr = 0; cr < cin * 3; ++cr) {                      // one (channel, tap row) per iteration (NOT unrolled: the compiler
-    const int hi = hi0 + dy;                                  // otherwise hoists the weights into registers and spills)
-    float col[2 * PX + 1];
-    const bool rowok = hi >= 0 && hi < H;
+    const int hi = hi0 + dy;                                  // otherwise hoists the weights into registers and spills).
+    float col[NC];                                            // Requesting the columns of iteration cr + 1 before the FMAs of
+    const bool rowok = hi >= 0 && hi < H;                     // cr measured the same (EXPERIMENTS.md) and costs 9 registers.
     const float* xr = xb + ((size_t)c * H + (rowok ? hi : 0)) * W;
 #pragma unroll
-    for (int j = 0; j < 2 * PX + 1; ++j) {
+    for (int j = 0; j < NC; ++j) {
       const int wi = wi0 + j;
+#if STEM_ABL & 1
+      col[j] = (float)(wi + cr);
+#else
       col[j] = (rowok && wi >= 0 && wi < W) ? xr[wi] : 0.f;
+#endif
     }
+    if (++dy == 3) { dy = 0; ++c; }
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const float4* wt = reinterpret_cast<const float4*>(wl + (cr * 3 + dx) * COUT);
 #pragma unroll
-      for (int k = 0; k < COUT / 4; ++k) {
+      for (int k = 0; k < ((STEM_ABL & 4) ? 1 : COUT / 4); ++k) {
         const float4 w4 = wt[k];
         const st_f2 w01 = st_f2{w4.x, w4.y}, w23 = st_f2{w4.z, w4.w};
 #pragma unroll
@@ -72,7 +82,6 @@ __global__ __launch_bounds__(256, 2) void stem_conv3x3s2_kernel(const float* __r
         }
       }
     }
-    if (++dy == 3) { dy = 0; ++c; }
   }
   const long long prow = ((long long)b * Ho + ho) * Wo;
 #pragma unroll
@@ -88,7 +97,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv3x3s2_kernel(const float* __r
           r.z = __builtin_fmaf(a[4 * k + 2], r.z, cs[4 * k + 2]); r.w = __builtin_fmaf(a[4 * k + 3], r.w, cs[4 * k + 3]);
         }
         if (act == 1) { r.x = gelu_f(r.x); r.y = gelu_f(r.y); r.z = gelu_f(r.z); r.w = gelu_f(r.w); }
+#if STEM_ABL & 2
+        if (r.x == 1.2345e-30f) stf4(o + 4 * k, r);
+#else
         stf4(o + 4 * k, r);
+#endif
       }
     }
   }
