@@ -273,6 +273,11 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
 // ================================================================================================ host side
 using namespace gkg;
 
+#ifdef KNN_TIMELINE
+static void* gkg_knn_tl_buf = nullptr;      // measurement builds only (tools/ubench/knn_timeline.py)
+extern "C" void gkg_debug_set_knn_timeline(void* buf) { gkg_knn_tl_buf = buf; }
+#endif
+
 // list sizes of the tile kernel: the lengths GKGNet's configurations use (k*d = 9, 18, 27; pvig_m k = 18: 18, 36) plus 16
 // and 64 to cover everything else (each instantiation is a kernel of its own: 6 sizes x 2 x 2 x 3 selection forms)
 static const int kListSizes[] = {9, 18, 27, 36, 64};   // k*d of GKGNet's layers + one catch-all (10..18 share the 18-entry list)
@@ -461,6 +466,9 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
   a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
+#ifdef KNN_TIMELINE
+  if (p.S == 1 && gkg_knn_tl_buf) a.part_v = (float*)gkg_knn_tl_buf;
+#endif
   a.rp_major = 0;
   // bf16 form with a positional bias at least twice the size of the keys it meets (64 x 4 B of relative_pos against
   // 2 x cp16 B of a key per (query tile, key) pair, i.e. c <= 64) and enough query tiles to spread over the XCDs: map the

@@ -8,6 +8,26 @@
 #include "gkg_knn_common.h"
 #include "gkg_topk_merge.h"
 
+// -DKNN_TIMELINE (tools/ubench/knn_timeline.py only): wave-level phase timestamps (s_memtime) of a sample of workgroups, and
+// every workgroup's start / end / placement, into the buffer the host put in a.part_v (un-split launches do not use it)
+#ifdef KNN_TIMELINE
+#define KNN_TL(p)                                                                                                  \
+  do {                                                                                                             \
+    unsigned long long* tl_ = reinterpret_cast<unsigned long long*>(a.part_v);                                     \
+    if (lane == 0 && (blockIdx.x % 97) < 3 && blockIdx.x / 97 < 8 && (p) < 32)                                      \
+      tl_[(((blockIdx.x / 97) * 3 + blockIdx.x % 97) * 8 + w) * 32 + (p)] = __builtin_readcyclecounter();           \
+    if (lane == 0 && w == 0 && blockIdx.x < 4096 && ((p) == 0 || (p) == 31)) {   /* every workgroup: start, end, where */ \
+      tl_[24 * 8 * 32 + blockIdx.x * 4 + ((p) == 0 ? 0 : 1)] = __builtin_readcyclecounter();                       \
+      if ((p) == 0) {                                                                                              \
+        tl_[24 * 8 * 32 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  /* HW_ID */ \
+        tl_[24 * 8 * 32 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); /* XCC_ID */ \
+      }                                                                                                            \
+    }                                                                                                              \
+  } while (0)
+#else
+#define KNN_TL(p) do {} while (0)
+#endif
+
 namespace gkg {
 
 // Measured on MI355X (tools/ubench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 and fp32 VALU work of the
@@ -52,6 +72,7 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // of once per query tile (measured: FETCH_SIZE 53 -> see profiles/).  Placement only affects speed.
   const int nqt = a.nqt;
   const int lin = blockIdx.x;
+  KNN_TL(0);
   if (a.wg_flags && a.wg_flags[lin] == 0) return;   // clean-up pass behind knn_pf_kernel: only the tiles it flagged
   const int xcd = lin & 7, jj = lin >> 3;
   // rp_major (launches whose positional bias outweighs their keys: narrow groups): the B*G problems of ONE query tile are
@@ -183,7 +204,9 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // floats of the staged query tile (bf16 form: 64 rows of cp16 + 8 bf16), behind which the candidate buffer lives
   const size_t qfloats = BF ? (size_t)QT * (a.cp16 + 8) / 2 : (size_t)cpad * QT;
   if (BUF > 0) smem[qfloats + (size_t)BUF * 2 * TH + tid] = INFINITY;   // ths (see below)
+  KNN_TL(1);
   __syncthreads();
+  KNN_TL(2);
 
   const int n = lane_n;
   const float* sqy = a.sqy + (size_t)bg * M;
@@ -403,6 +426,7 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
         if (FOLD) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kk ? sy32 : 1.0f, qtail0, acc0, 0, 0, 0);
       }
     }
+    KNN_TL(3 + 2 * (iv / NWV));
     // next tile's relative_pos rows and |y|^2: in flight during this tile's selection phase (bf16 form; sy32 was copied)
     if (BF && iv + NWV < TV) fetch_side(t_next);
     // ---- lane l needs all 32 keys of ITS query: v_permlane32_swap exchanges the 32-lane halves of the two
@@ -451,6 +475,7 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
       // room for the next 8 candidates?  (the stream's last group flushes unconditionally)
       if (BUF > 0 && ((g == 3 && iv + NWV >= TV) || __builtin_amdgcn_ballot_w64(bcnt > BUF - 8) != 0ull)) flush();
     }
+    KNN_TL(4 + 2 * (iv / NWV));
   }
 
   const int kd = a.kd;
@@ -478,48 +503,68 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
         }
       }
     }
+    KNN_TL(31);
     return;
   }
-  // ---- merge the 4 per-wave lists of each query through LDS
+  // ---- merge the per-wave lists of each query: EVERY wave ranks its own entries among all lists (rank = own position +
+  //      the number of smaller keys in each other list; lists are sorted, so only the first KD - j entries of another list
+  //      can keep entry j below rank KD) and writes the ones that land in the output.  The packed keys are distinct across
+  //      lists (disjoint key indices) except for empty slots (+inf, non-finite inputs only), whose duplicate ranks all write
+  //      the same 0.  Until round 4 wave 0 merged the four lists with a serial head-of-list loop (9 dependent LDS round
+  //      trips per rank) after the other waves had exited: 19 k of a cfg2 workgroup's 87 k cycles; this form takes 5 k, for
+  //      any number of waves.  The launch time at cfg2 did not move (the CU's other two workgroups filled the idle SIMDs:
+  //      tools/ubench/knn_timeline.py, profiles/r04_knn_timeline.txt).
+  KNN_TL(28);
   __syncthreads();                       // everyone is done with xs / dmat
-  float* lv = smem;                      // [NW][KD][64]
-  int* li = reinterpret_cast<int*>(smem + NW * KD * 64);
+  KNN_TL(29);
+  double* lk = reinterpret_cast<double*>(smem);      // [NWV][KD][64]
 #pragma unroll
-  for (int j = 0; j < KD; ++j) {
-    lv[(w * KD + j) * 64 + lane] = key_dist(top.key[j]);
-    li[(w * KD + j) * 64 + lane] = key_index(top.key[j]);
-  }
+  for (int j = 0; j < KD; ++j) lk[(w * KD + j) * 64 + lane] = top.key[j];
   __syncthreads();
-  if (w != 0) return;
-
-  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-  float h0 = lv[(0 * KD) * 64 + lane], h1 = lv[(1 * KD) * 64 + lane], h2 = lv[(2 * KD) * 64 + lane],
-        h3 = lv[(3 * KD) * 64 + lane];
-  int i0 = li[(0 * KD) * 64 + lane], i1 = li[(1 * KD) * 64 + lane], i2 = li[(2 * KD) * 64 + lane],
-      i3 = li[(3 * KD) * 64 + lane];
-  int next_rank = 0, outj = 0;
-  for (int j = 0; j < kd; ++j) {
-    // lexicographic (dist, idx) minimum of the four heads
-    int sel = 0; float bv = h0; int bi = i0;
-    if (h1 < bv || (h1 == bv && i1 < bi)) { sel = 1; bv = h1; bi = i1; }
-    if (h2 < bv || (h2 == bv && i2 < bi)) { sel = 2; bv = h2; bi = i2; }
-    if (h3 < bv || (h3 == bv && i3 < bi)) { sel = 3; bv = h3; bi = i3; }
-    if (sel == 0) { ++p0; h0 = p0 < KD ? lv[(0 * KD + p0) * 64 + lane] : INFINITY; i0 = p0 < KD ? li[(0 * KD + p0) * 64 + lane] : 0x7fffffff; }
-    else if (sel == 1) { ++p1; h1 = p1 < KD ? lv[(1 * KD + p1) * 64 + lane] : INFINITY; i1 = p1 < KD ? li[(1 * KD + p1) * 64 + lane] : 0x7fffffff; }
-    else if (sel == 2) { ++p2; h2 = p2 < KD ? lv[(2 * KD + p2) * 64 + lane] : INFINITY; i2 = p2 < KD ? li[(2 * KD + p2) * 64 + lane] : 0x7fffffff; }
-    else { ++p3; h3 = p3 < KD ? lv[(3 * KD + p3) * 64 + lane] : INFINITY; i3 = p3 < KD ? li[(3 * KD + p3) * 64 + lane] : 0x7fffffff; }
+  KNN_TL(30);
+  const int dil = a.dilation;
+  const unsigned magic = dil > 1 ? 0xffffffffu / (unsigned)dil + 1u : 0u;      // r / dil for r < 2^16 (r <= KD * NWV)
+  constexpr int JC = 9;                  // own entries ranked per pass (bounds the registers the ranks take next to the list)
+#pragma unroll
+  for (int j0 = 0; j0 < KD; j0 += JC) {
+    int rank[JC];
+#pragma unroll
+    for (int u = 0; u < JC; ++u) rank[u] = j0 + u;
+#pragma unroll 1
+    for (int o = 1; o < NWV; ++o) {
+      const int ww = (w + o) % NWV;
+      const double* lp = lk + (size_t)ww * KD * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < KD - j0; ++i) {
+        const double ok = lp[i * 64];
+#pragma unroll
+        for (int u = 0; u < JC; ++u)
+          if (j0 + u < KD && i < KD - (j0 + u)) rank[u] += ok < top.key[j0 + u] ? 1 : 0;
+      }
+    }
     if (n < N) {
-      if (partial) {
-        a.part_v[pbase + j] = bv;
-        a.part_i[pbase + j] = bi;
-      } else if (j == next_rank) {
-        a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;   // non-finite distances only: stay in range
-        if (a.center) a.center[obase + outj] = n;
-        ++outj;
-        next_rank += a.dilation;
+#pragma unroll
+      for (int u = 0; u < JC; ++u) {
+        if (j0 + u < KD) {
+          const int r = rank[u];
+          if (r < kd) {
+            const int bi = key_index(top.key[j0 + u]);
+            if (partial) {
+              a.part_v[pbase + r] = key_dist(top.key[j0 + u]);
+              a.part_i[pbase + r] = bi;
+            } else {
+              const int q = dil > 1 ? (int)__umulhi((unsigned)r, magic) : r;
+              if (q * dil == r) {
+                a.nn_idx[obase + q] = (unsigned)bi < (unsigned)M ? bi : 0;   // non-finite distances only: stay in range
+                if (a.center) a.center[obase + q] = n;
+              }
+            }
+          }
+        }
       }
     }
   }
+  KNN_TL(31);
 }
 
 constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 bytes each: 32 KB per workgroup)
@@ -533,6 +578,10 @@ static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStre
     lds = qbytes > merge ? qbytes : merge;
   }
   if (NWV == 1 && !BF) lds = qbytes;            // no merge area
+  if (NWV > NW && !BF) {                        // the caller sized the merge area for 4 lists
+    const size_t merge = (size_t)NWV * KD * 64 * 2 * sizeof(float);
+    if (lds < merge) lds = merge;
+  }
   if (BUF > 0) {                                // candidate buffer + the per-wave shared admission bounds behind the queries
     const size_t need = qbytes + (size_t)BUF * 64 * NWV * sizeof(float2) + NWV * 64 * sizeof(float);
     if (lds < need) lds = need;
