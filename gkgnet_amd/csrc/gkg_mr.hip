@@ -12,7 +12,26 @@
 //   bwd : grid (channel chunks, BG); LDS accumulator acc[CH][M]; all N queries of the (bg, chunk) are
 //         swept, g is added at idx[n][argmax] with ds_add_f32, then the rows are stored coalesced
 //         (gsrc / gx are fully overwritten -> no memset, no global atomics).
+#include <type_traits>
+
 #include "gkg_common.h"
+
+// measurement builds only (tools/ubench/mr_fwd_ablate.py).  MR_ABL bits: 1 gathers from 4 fixed rows, 2 synthetic indices (no
+// index loads), 4 no out stores, 8 no argmax stores.  MR_TL: wave-level s_memtime stamps of every 1009th workgroup, written
+// behind the argmax tensor (the tool allocates the room).
+#ifndef MR_ABL
+#define MR_ABL 0
+#endif
+#ifdef MR_TL
+#define MR_STAMP(p)                                                                                                     \
+  do {                                                                                                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x % 1009 == 0 && blockIdx.x / 1009 < 512)                                   \
+      reinterpret_cast<unsigned long long*>(argmax + 2 * T * C)[((blockIdx.x / 1009) * 4 + (threadIdx.x >> 6)) * 8 + (p)] = \
+          __builtin_readcyclecounter();                                                                                 \
+  } while (0)
+#else
+#define MR_STAMP(p) do {} while (0)
+#endif
 
 namespace gkg {
 
@@ -252,53 +271,95 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
   const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
   const float* sb = src + (size_t)b * M * C + ch;
   float4 xi[QP], best[QP];
-  uint32_t arg[QP];
-  int ai[QP][4];                                                  // AK == 1: winning row index per channel
+  int ai[QP][4];                                                  // winner per channel: neighbour slot j (AK == 0) / row index (AK == 1)
+  MR_STAMP(0);
 #pragma unroll
-  for (int q = 0; q < QP; ++q) { xi[q] = *reinterpret_cast<const float4*>(x + t * C + ch + 4 * q); arg[q] = 0; }
-  auto upd = [&](int q, const float4& v, int j, int row) {
-    const float d0 = v.x - xi[q].x, d1 = v.y - xi[q].y, d2 = v.z - xi[q].z, d3 = v.w - xi[q].w;
-    if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); ai[q][0] = ai[q][1] = ai[q][2] = ai[q][3] = row; return; }
-    if (AK == 1) {
-      if (takes(d0, best[q].x)) { best[q].x = d0; ai[q][0] = row; }
-      if (takes(d1, best[q].y)) { best[q].y = d1; ai[q][1] = row; }
-      if (takes(d2, best[q].z)) { best[q].z = d2; ai[q][2] = row; }
-      if (takes(d3, best[q].w)) { best[q].w = d3; ai[q][3] = row; }
-      return;
+  for (int q = 0; q < QP; ++q) xi[q] = *reinterpret_cast<const float4*>(x + t * C + ch + 4 * q);
+  // `takes` (first maximum wins, a NaN is the maximum and sticks) costs 3 compares + 2 scalar mask operations + exec-masked
+  // moves per (channel, neighbour): 420 vector + 330 scalar instructions per thread (SQ counters, profiles/r04_pmc_mr_stage1.txt).
+  // Fast chain: a plain '>' (identical to `takes` whenever no difference is NaN) while chk accumulates d * 0 — NaN as soon as
+  // any difference is NaN or infinite; a wave in which some lane's chk is NaN (non-finite inputs only) redoes its chain with
+  // `takes`.  (What bounds the kernel is neither this nor HBM nor the L2 row gathers nor the store pattern — each was
+  // removed in turn, EXPERIMENTS.md round 4 — but the in-order vector-memory pipe: a wave's stores are acknowledged 4 k cycles
+  // after issue and its first loads return after 8 k under load.)
+  auto chain = [&](auto careful, int q, const float4* v, const int* id, int kk) {
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    for (int j = 0; j < kk; ++j) {
+      const float d0 = v[j].x - xi[q].x, d1 = v[j].y - xi[q].y, d2 = v[j].z - xi[q].z, d3 = v[j].w - xi[q].w;
+      const int w = AK == 1 ? id[j] : j;
+      if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); ai[q][0] = ai[q][1] = ai[q][2] = ai[q][3] = w; }
+      else if constexpr (decltype(careful)::value) {
+        if (takes(d0, best[q].x)) { best[q].x = d0; ai[q][0] = w; }
+        if (takes(d1, best[q].y)) { best[q].y = d1; ai[q][1] = w; }
+        if (takes(d2, best[q].z)) { best[q].z = d2; ai[q][2] = w; }
+        if (takes(d3, best[q].w)) { best[q].w = d3; ai[q][3] = w; }
+      } else {
+        const bool t0 = d0 > best[q].x, t1 = d1 > best[q].y, t2 = d2 > best[q].z, t3 = d3 > best[q].w;
+        best[q].x = t0 ? d0 : best[q].x; ai[q][0] = t0 ? w : ai[q][0];
+        best[q].y = t1 ? d1 : best[q].y; ai[q][1] = t1 ? w : ai[q][1];
+        best[q].z = t2 ? d2 : best[q].z; ai[q][2] = t2 ? w : ai[q][2];
+        best[q].w = t3 ? d3 : best[q].w; ai[q][3] = t3 ? w : ai[q][3];
+      }
+      if constexpr (!decltype(careful)::value) {
+        c0 = __builtin_fmaf(d0, 0.f, c0); c1 = __builtin_fmaf(d1, 0.f, c1);
+        c2 = __builtin_fmaf(d2, 0.f, c2); c3 = __builtin_fmaf(d3, 0.f, c3);
+      }
     }
-    if (takes(d0, best[q].x)) { best[q].x = d0; arg[q] = (arg[q] & 0xffffff00u) | (uint32_t)j; }
-    if (takes(d1, best[q].y)) { best[q].y = d1; arg[q] = (arg[q] & 0xffff00ffu) | ((uint32_t)j << 8); }
-    if (takes(d2, best[q].z)) { best[q].z = d2; arg[q] = (arg[q] & 0xff00ffffu) | ((uint32_t)j << 16); }
-    if (takes(d3, best[q].w)) { best[q].w = d3; arg[q] = (arg[q] & 0x00ffffffu) | ((uint32_t)j << 24); }
+    return (c0 + c1) + (c2 + c3);
   };
   if (KS > 0) {
     int id[KS > 0 ? KS : 1];
 #pragma unroll
+#if MR_ABL & 2
+    for (int j = 0; j < KS; ++j) id[j] = (int)(((unsigned)n * 7u + (unsigned)j * 131u) % (unsigned)M);
+#else
     for (int j = 0; j < KS; ++j) id[j] = clamp_idx(ip[j], M);
+#endif
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
       float4 v[KS > 0 ? KS : 1];
 #pragma unroll
+#if MR_ABL & 1
+      for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)(id[j] & 3) * C + 4 * q);
+#else
       for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C + 4 * q);
-#pragma unroll
-      for (int j = 0; j < KS; ++j) upd(q, v[j], j, id[j]);
+#endif
+#ifdef MR_TL
+      if (v[0].x == 1.25e-33f || id[8] == -7) MR_STAMP(7);      // (forces the index loads to have arrived)
+      MR_STAMP(1);
+      if (v[8].y == 1.25e-33f && v[3].z == 1.5e-33f) MR_STAMP(7);
+      MR_STAMP(2);
+#endif
+      const float chk = chain(std::false_type{}, q, v, id, KS);
+      if (__builtin_amdgcn_ballot_w64(chk != chk) != 0ull) (void)chain(std::true_type{}, q, v, id, KS);
     }
   } else {
     for (int j = 0; j < k; ++j) {
       const int rid = clamp_idx(ip[j], M);
       const size_t row = (size_t)rid * C;
 #pragma unroll
-      for (int q = 0; q < QP; ++q) upd(q, *reinterpret_cast<const float4*>(sb + row + 4 * q), j, rid);
+      for (int q = 0; q < QP; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(sb + row + 4 * q);
+        const float d0 = v.x - xi[q].x, d1 = v.y - xi[q].y, d2 = v.z - xi[q].z, d3 = v.w - xi[q].w;
+        const int w = AK == 1 ? rid : j;
+        if (j == 0) { best[q] = make_float4(d0, d1, d2, d3); ai[q][0] = ai[q][1] = ai[q][2] = ai[q][3] = w; continue; }
+        if (takes(d0, best[q].x)) { best[q].x = d0; ai[q][0] = w; }
+        if (takes(d1, best[q].y)) { best[q].y = d1; ai[q][1] = w; }
+        if (takes(d2, best[q].z)) { best[q].z = d2; ai[q][2] = w; }
+        if (takes(d3, best[q].w)) { best[q].w = d3; ai[q][3] = w; }
+      }
     }
   }
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
     const int chq = ch + 4 * q;
-    if (argmax) {
+    if (argmax && (!(MR_ABL & 8) || best[q].x == 1.2345e-30f)) {
       if (AK == 1) *reinterpret_cast<uint2*>(argmax + 2 * (t * C + chq)) =
           make_uint2((uint32_t)ai[q][0] | ((uint32_t)ai[q][1] << 16), (uint32_t)ai[q][2] | ((uint32_t)ai[q][3] << 16));
-      else *reinterpret_cast<uint32_t*>(argmax + t * C + chq) = arg[q];
+      else *reinterpret_cast<uint32_t*>(argmax + t * C + chq) =
+          (uint32_t)ai[q][0] | ((uint32_t)ai[q][1] << 8) | ((uint32_t)ai[q][2] << 16) | ((uint32_t)ai[q][3] << 24);
     }
+    if ((MR_ABL & 4) && best[q].y != 1.2345e-30f) continue;
     if (mode == 0) {
       stf4(out + t * C + chq, best[q]);
     } else {
@@ -309,6 +370,11 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
       stf4(o + 4, make_float4(xi[q].z, best[q].z, xi[q].w, best[q].w));
     }
   }
+#ifdef MR_TL
+  MR_STAMP(3);
+  __builtin_amdgcn_s_waitcnt(0);                                 // stores acknowledged
+  MR_STAMP(4);
+#endif
 }
 
 // Backward, pass 1: gx[t][ch] = direct[t][ch] - gm[t][ch]   (mode 1: direct/gm are the even/odd columns of dU)
