@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libgkg_hip.so")
+LIB_PATH = os.environ.get("GKG_HIP_LIB") or os.path.join(PKG, "libgkg_hip.so")   # GKG_HIP_LIB: same-box A/B of two builds (tools)
 
 ABI_VERSION = 6
 F32, BF16, F16 = 0, 1, 2

@@ -52,7 +52,12 @@ __device__ __forceinline__ float pf_exact_dist(const float* __restrict__ xc, int
 // distance and, when it passes, appended to a per-lane LDS buffer of PBUF entries behind the staged queries; the lists are
 // updated in wave-uniform flushes (merge network for lists of 16+ entries, sorted inserts below).  0: every candidate goes
 // through the sorted insert (2 KDW + 6 instructions).
-template <int KD, int KDW, bool HAS_RP, int PBUF = 0>
+// SB — the whole contraction is ONE batch of key operands (cp16 <= 64: narrow groups, pvig_s stage 1, pvig_m): the MFMAs read
+// the prefetched batch in place and the next tile's batch is requested behind them, instead of copying the batch aside and
+// prefetching at once — 32 registers less, which pays for fetching relative_pos one tile AHEAD at three waves per SIMD.
+// Measured before (tools/ubench/knn_timeline.py, pvig_s stage 1): every tile spent 4-5 k of its 10 k cycles between its top
+// and its first MFMA result, waiting for the bias it had just requested; 1 670 -> 1 500 us.
+template <int KD, int KDW, bool HAS_RP, int PBUF = 0, bool SB = false>
 __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs a) {
   extern __shared__ float smem[];
   typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const int xcd = lin & 7, jj = lin >> 3;
   const int bg = (jj / nqt) * 8 + xcd;               // XCD-aware map, as knn_tile_kernel
   if (bg >= a.BG) return;
+  KNN_TL(0);
   const int n0 = (jj % nqt) * QT;
   const int N = a.N, M = a.M, cpad = a.cpad, cp16 = a.cp16, S16 = cp16 >> 4;
   const int lane_n = n0 + lane;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
     }
   }
   __syncthreads();
+  KNN_TL(2);
 
   const float* sqy = a.sqy + (size_t)bg * M;
   const bool two_blocks = n0 + 32 < N;               // wave-uniform
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   // AHEAD: those of the NEXT tile are fetched during this tile's selection phase (see knn_tile_kernel's bf16 form) — only
   // where the 32 extra live registers are free (lists >= 18: already 2 waves per SIMD; measured 438 -> 416 us at pvig_s
   // stage 3).  With 12-entry lists they cost the third wave per SIMD and the kernel loses (stage 1 2230 -> 2450 us).
-  constexpr bool AHEAD = KDW > 16;
+  constexpr bool AHEAD = KDW > 16 || SB;
   float4 rq0[4], rq1[4];
   float sy_n = MASKED_SQ;
   const size_t rp_row0 = (size_t)min(n0, N - 1) * M;
@@ -214,6 +221,37 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       const char* xl0 = xq_lo + l31 * qpitch + 16 * kk;
       const char* xh1 = xh0 + 32 * qpitch;
       const char* xl1 = xl0 + 32 * qpitch;
+      if constexpr (SB) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (u < S16) {
+            const bf16x8_t kh = __builtin_bit_cast(bf16x8_t, bh_[u]);
+            const bf16x8_t kl = __builtin_bit_cast(bf16x8_t, bl_[u]);
+            const bf16x8_t qh0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh0 + 32 * u));
+            const bf16x8_t ql0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl0 + 32 * u));
+            if (two_blocks) {
+              const bf16x8_t qh1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh1 + 32 * u));
+              const bf16x8_t ql1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl1 + 32 * u));
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh1, acc1, 0, 0, 0);
+            } else {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh0, acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // the next tile's batch: behind the MFMAs that read this one
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          bh_[u] = u < S16 ? ynh[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
+          bl_[u] = u < S16 ? ynl[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
+        }
+      } else
       for (int s0 = 0; s0 < S16; s0 += KB) {
         const bool last = s0 + KB >= S16;                         // uniform: prefetch the NEXT tile's first batch
         uint4 ah[KB], al[KB];
@@ -251,6 +289,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
         }
       }
     }
+    if (iv / NW < 10) KNN_TL(3 + 2 * (iv / NW));
     if (AHEAD && iv + NW < ktiles) fetch_side(t_next); // in flight during the selection below
     // ---- lane l <- all 32 keys of query n0 + l (permlane swap as in knn_tile_kernel); approximate distance (without the
     //      query's own |x|^2, a per-query constant) = acc + |y|^2, keys past M masked by MASKED_SQ
@@ -283,10 +322,15 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       }
       if (PBUF > 0 && ((g == 3 && iv + NW >= ktiles) || __builtin_amdgcn_ballot_w64(bcnt > PBUF - 8) != 0ull)) flush();
     }
+    if (iv / NW < 10) KNN_TL(4 + 2 * (iv / NW));
   }
 
-  // ---- the 4 per-wave lists -> LDS; wave 0 merges them per query and collects the survivors
+  // ---- the 4 per-wave lists -> LDS; wave 0 merges them per query and collects the survivors.  (A rank-counting merge on all
+  //      four waves, as in knn_tile_kernel, measured the same launch time here: it trades wave 0's LDS latency, which the
+  //      CU's other workgroups fill, for vector work — and vector issue is what this kernel is short of.)
+  KNN_TL(28);
   __syncthreads();                       // everyone is done with the staged queries
+  KNN_TL(29);
   float* lv = smem;                      // [NW][KDW][64]
   int* li = reinterpret_cast<int*>(smem + NW * KDW * 64);
   int* sidx = li + NW * KDW * 64;        // [SMAX][64] survivor key indices (ascending prefilter distance)
@@ -369,7 +413,9 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       }
     }
   }
+  KNN_TL(30);
   __syncthreads();
+  KNN_TL(25);
 
   // ---- exact contract distance of the pairs that need it: one thread per pair, dense over the workgroup
   const float* xcb = a.xh + (size_t)bg * cpad * N;
@@ -386,7 +432,9 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       keys[sv * 64 + q] = d == d && d < INFINITY ? pack_key(d, m) : (double)INFINITY;   // NaN / +inf never enter a list
     }
   }
+  KNN_TL(26);
   __syncthreads();
+  KNN_TL(27);
   if (w != 0) return;
 
   // ---- wave 0: rank the survivors by their keys (a flagged tile writes nothing: the clean-up launch owns it)
@@ -413,6 +461,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       }
     }
   }
+  KNN_TL(31);
 }
 
 }  // namespace gkg
@@ -420,14 +469,17 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
 using namespace gkg;
 
 // prefilter + exact re-rank (knn_pf_kernel): un-split, normalised, fp32-contract problems
-template <int KD, int KDW, bool HAS_RP, int PBUF>
+template <int KD, int KDW, bool HAS_RP, int PBUF, bool SB = false>
 static hipError_t launch_pf_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if constexpr (KDW <= 16 && HAS_RP && !SB) {                     // single-batch form (see the kernel): narrow groups
+    if (a.cp16 <= 64) return launch_pf_v<KD, KDW, HAS_RP, PBUF, true>(a, grid, lds, st);
+  }
   if (lds > 64 * 1024) {
-    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, HAS_RP, PBUF>),
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pf_kernel<KD, KDW, HAS_RP, PBUF, SB>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
   }
-  hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, HAS_RP, PBUF>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((knn_pf_kernel<KD, KDW, HAS_RP, PBUF, SB>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -8,25 +8,6 @@
 #include "gkg_knn_common.h"
 #include "gkg_topk_merge.h"
 
-// -DKNN_TIMELINE (tools/ubench/knn_timeline.py only): wave-level phase timestamps (s_memtime) of a sample of workgroups, and
-// every workgroup's start / end / placement, into the buffer the host put in a.part_v (un-split launches do not use it)
-#ifdef KNN_TIMELINE
-#define KNN_TL(p)                                                                                                  \
-  do {                                                                                                             \
-    unsigned long long* tl_ = reinterpret_cast<unsigned long long*>(a.part_v);                                     \
-    if (lane == 0 && (blockIdx.x % 97) < 3 && blockIdx.x / 97 < 8 && (p) < 32)                                      \
-      tl_[(((blockIdx.x / 97) * 3 + blockIdx.x % 97) * 8 + w) * 32 + (p)] = __builtin_readcyclecounter();           \
-    if (lane == 0 && w == 0 && blockIdx.x < 4096 && ((p) == 0 || (p) == 31)) {   /* every workgroup: start, end, where */ \
-      tl_[24 * 8 * 32 + blockIdx.x * 4 + ((p) == 0 ? 0 : 1)] = __builtin_readcyclecounter();                       \
-      if ((p) == 0) {                                                                                              \
-        tl_[24 * 8 * 32 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  /* HW_ID */ \
-        tl_[24 * 8 * 32 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); /* XCC_ID */ \
-      }                                                                                                            \
-    }                                                                                                              \
-  } while (0)
-#else
-#define KNN_TL(p) do {} while (0)
-#endif
 
 namespace gkg {
 

@@ -61,12 +61,14 @@ def main():
     lib = build()
     torch.manual_seed(0)
     flags0 = 1
-    for name, BG, c, N, M, rp in (("cfg2 grapher", 128, 80, 324, 324, True), ("cfg2 label", 128, 80, 80, 324, False)):
+    for name, BG, c, N, M, rp in (("cfg2 grapher", 128, 80, 324, 324, True), ("cfg2 label", 128, 80, 80, 324, False),
+                                  ("pvig_s stage 1 (prefilter kernel)", 64, 40, 20736, 1296, "xy"), ("pvig_s stage 3 d=2 (prefilter kernel)", 64, 200, 1296, 1296, "d2")):
         x = torch.randn(BG, c, N, device="cuda")
-        y = None if rp else torch.randn(BG, c, M, device="cuda")
+        y = None if rp in (True, "d2") else torch.randn(BG, c, M, device="cuda")
         r = -torch.rand(N, M, device="cuda") if rp else None
+        dil = 2 if rp == "d2" else 1
         flags = flags0 | (64 if rp else 0)
-        nb = lib.gkg_knn_workspace_bytes(BG, c, N, M, 9, 1, 0, flags)
+        nb = lib.gkg_knn_workspace_bytes(BG, c, N, M, 9, dil, 0, flags)
         ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
         idx = torch.empty(BG, N, 9, dtype=torch.int64, device="cuda")
         tl = torch.zeros(24 * 8 * 32 + 4096 * 4, dtype=torch.int64, device="cuda")
@@ -75,7 +77,7 @@ def main():
             tl.zero_()
             torch.cuda.synchronize()
             rc = lib.gkg_knn_fwd(x.data_ptr(), None if y is None else y.data_ptr(), None if r is None else r.data_ptr(), idx.data_ptr(),
-                                 None, BG, c, N, M, 9, 1, 0, flags, ws.data_ptr(), nb, None)
+                                 None, BG, c, N, M, 9, dil, 0, flags, ws.data_ptr(), nb, None)
             assert rc == 0
             torch.cuda.synchronize()
         full = tl.cpu().numpy()
@@ -84,12 +86,13 @@ def main():
         t0 = t[t > 0].min()
         print(f"== {name}: BG={BG} c={c} N={N} M={M}; stamps in us after the launch's first stamp (100 MHz s_memtime assumed: /100)")
         print("   phases: 0 start, 1 queries staged, 2 barrier, 3/4 5/6 7/8.. tile contraction / selection done, 28 loop done, 29 barrier, 30 lists in LDS, 31 end")
+        print("   (prefilter kernel: 2 staged, 28 stream done, 29 barrier, 30 merge + survivors done, 25 barrier, 26 exact pairs done, 27 barrier, 31 end)")
         for wg in range(24):
             for w in range(8):
                 row = t[wg, w]
                 if row[0] == 0:
                     continue
-                s = " ".join(f"{p}:{(row[p] - t0) / 100.0:6.2f}" for p in range(32) if row[p] > 0)
+                s = " ".join(f"{p}:{int(row[p] - row[0])}" for p in sorted(range(32), key=lambda q: row[q]) if row[p] > 0)
                 print(f"   wg {wg // 3 * 97 + wg % 3:4d} wave {w}: {s}")
 
 

@@ -14,7 +14,7 @@ VARIANTS = {"full": 0, "no_gather": 1, "no_mfma": 2, "no_gelu": 4, "no_idx": 8, 
 
 def build(bits):
     so = f"/tmp/libmg_{bits}.so"
-    srcs = [os.path.join(CS, f) for f in ("gkg_mrgemm.hip", "gkg_api.hip")]
+    srcs = [os.path.join(CS, f) for f in (os.environ.get("MRGEMM_SRC", "gkg_mrgemm.hip"), "gkg_api.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                            f"-DMG_ABL={bits}", "-I" + os.path.join(ROOT, "include"), "-I" + CS, "-o", so] + srcs)
     lib = C.CDLL(so)
@@ -42,6 +42,8 @@ def main():
         data[name] = (x, src, idx, planes, a, c, out, B, G, Cc // G, N, Mk, k)
     res = {n: {} for n in SHAPES}
     for vname, bits in VARIANTS.items():
+        if len(sys.argv) > 1 and vname not in sys.argv[1:]:
+            continue
         lib = build(bits)
         for name, (x, src, idx, planes, a, c, out, B, G, cg, N, Mk, k) in data.items():
             def call():
