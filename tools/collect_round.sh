@@ -32,4 +32,8 @@ bash tools/pmc_knn_run.sh > gpurun_out/${TAG}_knn_tile_sq_counters.txt 2>&1
 # 5. per-shape tables
 python tools/bench_x6.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_x6_gemm_shapes.txt
 python tools/bench_mr_bwd.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_bench_mr_bwd.txt
+python tools/bench_mr_fwd.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_bench_mr_fwd.txt
+python tools/bench_knn_model_inputs.py cfg3 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_knn_kernels_on_model_inputs_cfg3.txt
+python tools/bench_stem.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_bench_stem.txt
+python tools/ubench/hbm_rate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_hbm_rate.txt
 cut -c1-300 gpurun_out/${TAG}_final_bench_cfg2.json
