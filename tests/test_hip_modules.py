@@ -195,7 +195,11 @@ def test_autocast_bf16_label_module_and_ffn_inference():
     assert (r16 - r32).abs().max().item() < 5e-2 * r32.abs().max().item()
 
 
-def test_cfg2_full_size_grapher_and_label_vs_oracle():
+FLIP_BOUND = (20, 10)        # label graph vs the oracle's own: index slots / neighbour sets that may differ (MI355X, round 4: 0 / 0)
+REPLAY_FLIP_BOUND = 40       # per k-NN call, HIP k-NN on the oracle's tensors vs the HIP run's graphs (round 4: 1 of 41 472, 0 of 10 240)
+
+
+def test_cfg2_full_size_grapher_and_label_vs_oracle(record_property):
     """BASELINE config 2 at FULL size (B=32, C=320, 18x18, k=9, G=4, +80 label tokens): fused fwd+bwd on the GPU against
     the CPU oracle with the same weights and inputs.
 
@@ -256,12 +260,15 @@ def test_cfg2_full_size_grapher_and_label_vs_oracle():
     # (the two runs' fc1 outputs differ by ~1e-6, which moves a few dozen of the 41k 9th/10th-neighbour boundaries).
     real_knn = R.knn_graph
     replay = iter(recorded)
+    replay_flips = []                    # per k-NN call: (neighbour sets that differ, sets)
 
     def replay_knn(xq, yk, rp, kk, dd=1, normalize=True):
         edge = next(replay)
         hip = ops.knn_graph(xq.cuda(), None if yk is None else yk.cuda(), None if rp is None else rp.cuda(), kk, dd,
                             normalize).cpu()
-        assert (hip[0].sort(-1).values == edge[0].sort(-1).values).all(-1).float().mean().item() > 0.995
+        same = (hip[0].sort(-1).values == edge[0].sort(-1).values).all(-1)
+        replay_flips.append((int((~same).sum()), same.numel()))
+        assert same.float().mean().item() > 0.995
         return edge
 
     R.knn_graph = replay_knn
@@ -282,7 +289,21 @@ def test_cfg2_full_size_grapher_and_label_vs_oracle():
             dirty = int((bad > 0).sum())
             assert dirty <= (0 if name in ("out", "labels") else 3), (name, bad.tolist(), float((a_ - b_).abs().max()))
             assert bad.sum().item() / a_.numel() < 0.01, (name, bad.tolist())
-    # (1) oracle's own graph: near-tie flips only
+    # (1) oracle's own graph: near-tie flips only.  The COUNTS are printed (pytest -s / the junit properties) and bounded in
+    # absolute terms, so a drift shows up as a number: slots of the (2, B*G, N, k) index tensor that differ, and
+    # neighbour SETS that differ (a flip inside the list reorders two equal-distance neighbours; a set flip exchanges the
+    # 9th and the 10th).  Measured on MI355X, round 4: see the bound below.
+    slot_flips = int((got[2] != own[2]).sum())
+    set_flips = int((got[2][0].sort(-1).values != own[2][0].sort(-1).values).any(-1).sum())
+    print(f"cfg2 full size vs the oracle's own graphs: {slot_flips} of {got[2].numel()} index slots differ, "
+          f"{set_flips} of {got[2][0].sort(-1).values.shape[:-1].numel()} neighbour sets differ")
+    print("HIP k-NN on the ORACLE's fc1 outputs vs the graphs of the HIP run (Grapher, label): "
+          + ", ".join(f"{a} of {b} neighbour sets differ" for a, b in replay_flips))
+    record_property("cfg2_replay_set_flips", [a for a, _ in replay_flips])
+    assert all(a <= REPLAY_FLIP_BOUND for a, _ in replay_flips), replay_flips
+    record_property("cfg2_index_slot_flips", slot_flips)
+    record_property("cfg2_neighbour_set_flips", set_flips)
+    assert slot_flips <= FLIP_BOUND[0] and set_flips <= FLIP_BOUND[1], (slot_flips, set_flips)
     assert (got[2] == own[2]).float().mean().item() > 0.999
     close = lambda a_, b_: ((a_ - b_).abs() <= 1e-3 + 1e-3 * b_.abs()).float().mean().item()
     assert close(got[0], own[0]) > 0.9995 and (got[0] - own[0]).abs().median().item() < 1e-5
