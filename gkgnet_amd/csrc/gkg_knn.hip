@@ -523,7 +523,11 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     e = launch_knn_tile_bf(a, grid, lds, p.KD, wbuf, solo && wbuf > 0, st);
   } else {
     // fp32 contract forms: direct (guarded / guard-less for short streams) or buffered selection — gkg_knn_f32.hip
-    e = launch_knn_tile_f32(a, grid, lds, p.KD, buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0), st);
+    // single-wave workgroups for the narrowest groups (pvig_m stage 1: c = 12, 36 864 queries x 2 304 keys, k*d = 18): one list
+    // per query instead of four quarter-stream lists — measured on the model's activations 9 045 -> 7 872 us per launch; no
+    // gain at c = 24 / 48 (2 748 -> 2 761, 1 225 -> 1 238 us), where the per-wave query image costs occupancy
+    const bool solo32 = buffered && !pf && p.S == 1 && (size_t)a.nqt * BG >= 2048 && lds_q <= 4 * 1024;
+    e = launch_knn_tile_f32(a, grid, lds, p.KD, solo32 ? 5 : (buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0)), st);
   }
   if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");
   if (p.S > 1) {

@@ -15,6 +15,9 @@ static hipError_t launch_tile_f32(const KnnArgs& a, dim3 grid, size_t lds, int m
   // the catch-all 64-entry list has no buffered form: its list (128 registers) + the 16-entry batch + the merge network's
   // temporaries spilled 100-400 VGPRs to scratch in every such instantiation; the guarded direct insert fits
   if constexpr (KD <= 36) {
+    // mode 5: buffered selection with ONE wave per workgroup (the wave streams all keys of its 64 queries: one list per query
+    // instead of four quarter-stream lists, no merge) — launches with enough query tiles to fill the chip that way
+    if (mode == 5) return deep ? launch_tile_v<KD, HAS_RP, 8, false, KNN_BUF, false, 1>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF, false, 1>(a, grid, lds, st);
     if (mode == 2) return deep ? launch_tile_v<KD, HAS_RP, 8, false, KNN_BUF>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF>(a, grid, lds, st);
   }
   if constexpr (KD == 9) {

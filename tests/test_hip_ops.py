@@ -45,6 +45,8 @@ KNN_SHAPES = [
     (1, 8, 50, 70, 32, 2, False),        # kd = 64 (largest list)
     (5, 200, 130, None, 9, 2, True),     # stage-3-like c=200, kd=18
     (1, 4, 40, 30000, 9, 1, False),      # keys beyond the LDS-resident row budget: gather / atomic fallbacks
+    (16, 12, 8200, 1100, 18, 1, True),   # pvig_m stage-1-like narrow groups, 2 064 query tiles: single-wave buffered form
+    (32, 8, 4100, 700, 9, 1, False),     # the same form with the 9-entry list, ragged last query / key tiles
 ]
 
 
