@@ -59,7 +59,7 @@ class Stem(nn.Module):
                 first = fused.stem_conv_bn_act_eval(conv0, bn0, act0, x, ac16)           # conv + BN(eval) + GELU: one launch
                 start = 3 if act0 is not None else 2
             elif not torch.is_autocast_enabled():
-                first = fused.stem_conv(conv0, x)                                           # training: BN on the kernels below
+                first = fused.stem_conv(conv0, x, bn0)                                        # training: BN on the kernels below
                 start = 1
         # channels-last convolutions hand their output over as a token-major matrix: BN (+ GELU) on the blocks' own kernels
         if first is not None or (fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32
@@ -70,7 +70,7 @@ class Stem(nn.Module):
                 x, i = first, start
             while i < len(mods):
                 if isinstance(mods[i], nn.Conv2d):
-                    x = mods[i](x)
+                    x = fused.conv_before_bn(mods[i], mods[i + 1], x) if i + 1 < len(mods) else mods[i](x)
                     i += 1
                     continue
                 bn = mods[i]
@@ -91,7 +91,7 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         if fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
-            y = self.conv[0](x.contiguous(memory_format=torch.channels_last))
+            y = fused.conv_before_bn(self.conv[0], self.conv[1], x.contiguous(memory_format=torch.channels_last))
             if fused.bn_act_supported(self.conv[1], y, None):
                 return fused.bn_act(y, self.conv[1], None)
             return self.conv[1](y)
@@ -179,7 +179,7 @@ class GKGNet(nn.Module):
 
     def forward(self, inputs):
         labels = self.label_lt(self.label_input.to(inputs.device).repeat(inputs.size(0), 1))   # (B, n_classes, C1)
-        x = self.stem(inputs) + self.pos_embed
+        x = fused.add_pos_embed(self.stem(inputs), self.pos_embed)
         stage = 0
         edge_index = None
         # the fused blocks pass channels-last activations through without transposing (fused.CHANNELS_LAST): convert once
