@@ -75,128 +75,7 @@ _ENABLED = _env_list("GKG_ENABLE")
 KNN_BF16 = "knn_bf16" in _ENABLED
 
 
-class _WeightPlanes:
-    """bf16 hi / mid / lo planes (forward and dgrad orientation) of every projection weight that went through the x6
-    kernels on one device.  The planes are a function of the parameter values only, so they are refreshed when a
-    parameter's version counter moves (an optimiser step) — ALL registered weights in ONE launch (gkg_x6_prep_weights).
-    Inside a hipGraph capture the host cannot see later in-place updates, so the first projection of each capture emits
-    the refresh unconditionally: a captured training step re-splits the weights once per replay.  Once ANY capture has
-    gone through this registry the version counters prove nothing on the eager side either — a replay (with an in-graph
-    optimiser step) moves the weights after its own re-split and bumps no counter — so from then on (``captured`` is
-    sticky) every eager projection re-splits ITS OWN weight right before use (a one-descriptor launch)."""
-
-    def __init__(self, device):
-        self.device = device
-        self.entries = {}            # id(weight) -> dict
-        self.descs = None            # device copy of the descriptor table
-        self.solo = None             # the same descriptors, each numbered from unit 0 (single-weight launches)
-        self.unit_ends = []
-        self.capture_id = 0
-        self.captured = False
-
-    def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None):
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.GkgError("x6 projection: a weight was first seen inside a hipGraph capture; run one eager "
-                                "warm-up step before capturing")
-        same = (old is not None and old["ref"]() is weight and old["ptr"] == weight.data_ptr()
-                and (old["nb"], old["cout"], old["cin"]) == (nb, cout, cin))
-        e = dict(ref=weakref.ref(weight), nb=nb, cout=cout, cin=cin, ptr=weight.data_ptr(), version=-1,
-                 pf=old["pf"] if same else None, pd=old["pd"] if same else None)
-        if need_f and e["pf"] is None:
-            e["pf"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device=self.device)
-        if need_d and e["pd"] is None:
-            e["pd"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device=self.device)
-        self.entries[id(weight)] = e
-        self.descs = None
-        return e
-
-    def _build_descs(self, lib):
-        live = {k: e for k, e in self.entries.items() if e["ref"]() is not None}
-        self.entries = live
-        size = lib.gkg_x6_prep_desc_bytes()
-        host = ctypes.create_string_buffer(size * max(1, len(live)))
-        units = 0
-        self.unit_ends = []
-        for i, e in enumerate(live.values()):
-            if i % 256 == 0:
-                units = 0                                             # unit numbering restarts with every launch's table
-            units = lib.gkg_x6_prep_desc_fill(host, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"], e["nb"],
-                                              units)
-            if units < 0:
-                raise _lib.GkgError("gkg_x6_prep_desc_fill rejected a weight")
-            self.unit_ends.append(units)
-        self.descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
-        solo = ctypes.create_string_buffer(size * max(1, len(live)))
-        for i, e in enumerate(live.values()):
-            e["slot"] = i
-            e["solo_units"] = lib.gkg_x6_prep_desc_fill(solo, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"],
-                                                        e["nb"], 0)
-        self.solo = torch.frombuffer(bytearray(solo.raw), dtype=torch.uint8).to(self.device)
-
-    def refresh_one(self, lib, e):
-        """Re-split one registered weight (eager use after a capture: see the class docstring)."""
-        if self.descs is None:
-            self._build_descs(lib)
-        size = lib.gkg_x6_prep_desc_bytes()
-        _lib.check(lib.gkg_x6_prep_weights(self.solo.data_ptr() + e["slot"] * size, 1, e["solo_units"], _stream()),
-                   "gkg_x6_prep_weights")
-
-    def refresh(self, lib):
-        """Re-split every registered weight (one launch)."""
-        if self.descs is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.GkgError("x6 weight planes: descriptor table is stale inside a capture; run a warm-up step first")
-            self._build_descs(lib)
-        if not self.entries:
-            return
-        n = len(self.entries)
-        size = lib.gkg_x6_prep_desc_bytes()
-        for i0 in range(0, n, 256):                                   # at most 256 descriptors per launch
-            i1 = min(n, i0 + 256)
-            _lib.check(lib.gkg_x6_prep_weights(self.descs.data_ptr() + i0 * size, i1 - i0, self.unit_ends[i1 - 1], _stream()),
-                       "gkg_x6_prep_weights")
-        for e in self.entries.values():
-            w = e["ref"]()
-            e["version"] = -1 if w is None else w._version
-
-    def get(self, lib, weight, nb, cout, cin, need_f=True, need_d=True):
-        e = self.entries.get(id(weight))
-        if (e is None or e["ref"]() is not weight or e["ptr"] != weight.data_ptr()
-                or (e["nb"], e["cout"], e["cin"]) != (nb, cout, cin) or (need_f and e["pf"] is None)
-                or (need_d and e["pd"] is None)):
-            e = self._register(lib, weight, nb, cout, cin, need_f, need_d, e)
-        cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
-        if cap:
-            self.captured = True
-            if cap != self.capture_id:
-                self.capture_id = cap
-                self.refresh(lib)
-        elif e["version"] != weight._version:
-            self.refresh(lib)                    # eager call, stale by the version counter (an eager optimiser step)
-        elif self.captured:
-            # graphs exist: any replay since the last eager call may have moved this weight (a captured optimiser step)
-            # without a counter moving, and it may do so again between any two eager calls
-            self.refresh_one(lib, e)
-        return e["pf"], e["pd"]
-
-
-_PLANES = {}
-
-
-def _planes(lib, weight, nb, cout, cin, need_f=True, need_d=True):
-    key = (weight.device.type, weight.device.index)
-    reg = _PLANES.get(key)
-    if reg is None:
-        reg = _PLANES[key] = _WeightPlanes(weight.device)
-    return reg.get(lib, weight, nb, cout, cin, need_f, need_d)
-
-
-def refresh_weight_planes(device=None):
-    """Re-split the registered projection weights now (normally automatic: see _WeightPlanes)."""
-    lib = _lib.load()
-    for key, reg in _PLANES.items():
-        if device is None or key == (torch.device(device).type, torch.device(device).index):
-            reg.refresh(lib)
+from .planes import _WeightPlanes, _PLANES, _planes, refresh_weight_planes      # noqa: E402,F401  (x6 weight planes: planes.py)
 
 
 def _vendor_tuned() -> bool:
@@ -480,8 +359,7 @@ def _mm_t(x, W, W16=None):
     return Y if Y.dtype == _F32 else Y.float()
 
 
-def _tm_dtype(lowp: bool):
-    return (torch.bfloat16, _lib.BF16) if lowp else (_F32, _lib.F32)
+from .layout import _tm_dtype, _TokenMajorToCL, _ToTokenMajor, _BlockEntry      # noqa: E402  (layout Functions: layout.py)
 
 
 # ----------------------------------------------------------------------------------------------- layout
@@ -497,26 +375,6 @@ def is_channels_last(x) -> bool:
     return (CHANNELS_LAST and x.dim() == 4 and x.dtype == _F32 and x.shape[1] > 1 and x.shape[2] * x.shape[3] > 1
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
 
-
-class _TokenMajorToCL(torch.autograd.Function):
-    """(B*H*W, C) token-major -> logical (B, C, H, W) in channels-last memory (a view).  The backward accepts either
-    memory format: a channels-last gradient is a view again, an NCHW one goes through the layout kernel."""
-
-    @staticmethod
-    def forward(ctx, t, B, H, W):
-        ctx.dims = (B, H, W)
-        return t.view(B, H, W, t.shape[1]).permute(0, 3, 1, 2)
-
-    @staticmethod
-    def backward(ctx, g):
-        B, H, W = ctx.dims
-        C = g.shape[1]
-        if g.dtype == _F32 and g.permute(0, 2, 3, 1).is_contiguous():
-            return g.permute(0, 2, 3, 1).reshape(B * H * W, C), None, None, None
-        g = g.float().contiguous()
-        out = torch.empty((B * H * W, C), dtype=_F32, device=g.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(g), _ptr(out), B, C, H * W, _lib.F32, None, _stream()), "gkg_nchw_to_tm")
-        return out, None, None, None
 
 
 def _cl_out(out_tm, B, H, W):
@@ -545,62 +403,10 @@ def _block_entry(x, lp):
     return xt, xr, False
 
 
-class _ToTokenMajor(torch.autograd.Function):
-    """(B, C, *spatial) -> (B*N, C)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        B, C = x.shape[:2]
-        N = x[0, 0].numel()
-        x = x.contiguous()
-        out = torch.empty((B * N, C), dtype=_F32, device=x.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, _lib.F32, None, _stream()), "gkg_nchw_to_tm")
-        ctx.shape = tuple(x.shape)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        B, C = ctx.shape[:2]
-        N = g.shape[0] // B
-        g = g.contiguous()
-        out = torch.empty(ctx.shape, dtype=_F32, device=g.device)
-        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g), None, None, None, _ptr(out), B, C, N, None, _stream()),
-                   "gkg_tm_affine_to_nchw")
-        return out
-
 
 def to_token_major(x):
     return _ToTokenMajor.apply(x)
 
-
-class _BlockEntry(torch.autograd.Function):
-    """x (B, C, *spatial) -> (x_tm (B*N, C), x): a block's token-major input and its residual branch leave ONE
-    autograd node, so the backward receives both incoming gradients together and adds them inside the layout
-    kernel (instead of a separate layout pass followed by autograd's elementwise accumulation)."""
-
-    @staticmethod
-    def forward(ctx, x, lowp=False):
-        B, C = x.shape[:2]
-        N = x[0, 0].numel()
-        dt, code = _tm_dtype(lowp)
-        out = torch.empty((B * N, C), dtype=dt, device=x.device)
-        _lib.check(_lib.load().gkg_nchw_to_tm(_ptr(x), _ptr(out), B, C, N, code, None, _stream()), "gkg_nchw_to_tm")
-        ctx.shape = tuple(x.shape)
-        ctx.set_materialize_grads(False)
-        return out, x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g_tm, g_res):
-        if g_tm is None:
-            return g_res, None
-        B, C = ctx.shape[:2]
-        N = g_tm.shape[0] // B
-        res = None if g_res is None else g_res.contiguous()
-        out = torch.empty(ctx.shape, dtype=_F32, device=g_tm.device)
-        g_tm = g_tm.contiguous()                 # named: the copy must outlive the launch that reads it
-        _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g_tm), None, None, _ptr(res), _ptr(out), B, C, N, None,
-                                                     _stream()), "gkg_tm_affine_to_nchw")
-        return out, None
 
 
 # ----------------------------------------------------------------------------------------------- BN helpers
@@ -677,78 +483,7 @@ def _bn_forward_params(lib, Y, bn, bias, R, C, nb):
     return a, c, None, None, None
 
 
-class _BnBwdScratch:
-    """Two fp64 column-sum buffers per device for gkg_bn_apply_train / gkg_bn_bwd_atomic, used alternately: a call accumulates into the clean one
-    and its apply pass clears what the previous call left in the other (stream-ordered, single stream: like _stats_scratch).
-    ``dirty[i]``: doubles of buffer i that hold sums.
-
-    hipGraph captures make the host-side bookkeeping blind (a replay runs its calls without this object seeing them), so:
-    the FIRST call of every capture clears both buffers inside the capture (one memset pair per replay: the replayed
-    sequence is self-contained), and once any capture exists every EAGER call clears both buffers first (correct after any
-    interleaving of replays and eager calls; only mixed capture / eager use pays for it).
-
-    Streams: the pair is shared by every stream of the device.  Eager calls from a stream other than the previous
-    eager caller's first wait for that stream (``wait_stream``: everything the previous user enqueued, its apply pass
-    included, completes before this call's atomics start), so blocks driven from two streams by ONE host thread — a
-    side-stream evaluation during training — serialise on the pair instead of mixing their sums.  Concurrent host THREADS
-    are not supported (like the rest of the fused path's per-device scratch).  A failed launch between acquire() and the
-    apply pass leaves sums behind that the bookkeeping calls clean: callers report it through ``poison()`` and the next
-    acquire() clears both buffers."""
-    DOUBLES = 2 * 4096 * 4
-    _inst = {}
-
-    def __init__(self, device):
-        self.store = torch.zeros((2, self.DOUBLES), dtype=torch.float64, device=device)
-        self.bufs = [self.store[0], self.store[1]]
-        self.cur = 0
-        self.dirty = [0, 0]
-        self.capture_id = 0
-        self.captured = False
-        self.poisoned = False
-        self.last_stream = None
-
-    @classmethod
-    def of(cls, device):
-        key = (device.type, device.index)
-        inst = cls._inst.get(key)
-        if inst is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.GkgError("BN scratch first used inside a hipGraph capture; run one eager warm-up step first")
-            inst = cls._inst[key] = cls(device)
-        return inst
-
-    def acquire(self, lib, n):
-        """-> (buffer to accumulate into: clean, buffer to clear, doubles to clear); the caller's kernels do the clearing."""
-        cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
-        if cap:
-            self.captured = True
-            if cap != self.capture_id:
-                self.capture_id = cap
-                self._reset()
-        else:
-            here = torch.cuda.current_stream(self.store.device)
-            if self.last_stream is not None and self.last_stream != here:
-                here.wait_stream(self.last_stream)
-            self.last_stream = here
-            if self.captured or self.poisoned:
-                self._reset()
-        cur, other = self.bufs[self.cur], self.bufs[self.cur ^ 1]
-        zero = self.dirty[self.cur ^ 1]
-        self.dirty[self.cur], self.dirty[self.cur ^ 1] = n, 0
-        self.cur ^= 1
-        return cur, other, zero
-
-    def _reset(self):
-        self.store.fill_(0.0)            # ONE elementwise launch (a captured memset node measured far slower than a kernel node)
-        self.dirty = [0, 0]
-        self.poisoned = False
-
-    def poison(self):
-        """A launch between acquire() and its apply pass failed: the buffers' contents are unknown."""
-        self.poisoned = True
-
-
-_BnFwdScratch = _BnBwdScratch       # forward and backward calls alternate through the SAME pair (one reset per capture)
+from .bn_scratch import _BnBwdScratch, _BnFwdScratch      # noqa: E402  (fp64 column-sum scratch of the two-launch BN passes)
 
 
 def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale,
@@ -1149,6 +884,9 @@ def bn_act(x, bn, act_mod):
 STEM_CONV = "stem_conv" not in _DISABLED
 
 
+from .stem import _StemConv, _ConvBeforeBN, _AddPosEmbed      # noqa: E402  (autograd Functions of the stem path: stem.py)
+
+
 def stem_conv_supported(conv, x) -> bool:
     return (ENABLED and STEM_CONV and isinstance(conv, torch.nn.Conv2d) and x.is_cuda and x.dim() == 4 and x.dtype == _F32
             and conv.weight.dtype == _F32 and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (2, 2)
@@ -1157,40 +895,6 @@ def stem_conv_supported(conv, x) -> bool:
             and bool(_lib.load().gkg_stem_conv3x3s2_supported(conv.in_channels, conv.out_channels)))
 
 
-class _StemConv(torch.autograd.Function):
-    """y = conv(x) + bias as a channels-last (B, cout, Ho, Wo) tensor; the weight / bias gradients come from the library's
-    convolution backward (the image itself needs no gradient in the backbone; it is computed when asked for)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, bn_behind=False):
-        lib = _lib.load()
-        B, cin, H, W = x.shape
-        cout = weight.shape[0]
-        ctx.bn_behind = bool(bn_behind)
-        x = x.contiguous()
-        out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, cout), dtype=_F32, device=x.device)
-        _lib.check(lib.gkg_stem_conv3x3s2_fwd(_ptr(x), _ptr(weight.contiguous()), _ptr(bias), None, None, _ptr(out), B, cin, H, W, cout,
-                                              0, _lib.F32, _stream()), "gkg_stem_conv3x3s2_fwd")
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return out.permute(0, 3, 1, 2)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        # the gradient arrives channels-last (the BN kernels behind the convolution are token-major): the image is laid out the
-        # same way for the library's backward (127 MB at GKGNet-576 / B = 32) instead of the library copying the gradient
-        # (425 MB, 1.0 ms) to the image's layout
-        if g.is_contiguous(memory_format=torch.channels_last) and not g.is_contiguous():
-            x = x.contiguous(memory_format=torch.channels_last)
-        bias_grad = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.bn_behind
-        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], bias_grad]
-        gx, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [2, 2], [1, 1],
-                                                         [1, 1], False, [0, 0], 1, mask)
-        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.bn_behind:
-            gb = torch.zeros(weight.shape[0], dtype=g.dtype, device=g.device)     # exactly zero behind a train-mode BN (_ConvBeforeBN)
-        return gx, gw, gb, None
-
 
 def stem_conv(conv, x, bn=None):
     """Training form: the plain convolution (its BN runs on the token-major kernels behind it, fused.bn_act).  ``bn``: the
@@ -1198,30 +902,6 @@ def stem_conv(conv, x, bn=None):
     bn_behind = (STEM_BN and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and (bn.training or not bn.track_running_stats))
     return _StemConv.apply(x, conv.weight, conv.bias, bn_behind)
 
-
-class _ConvBeforeBN(torch.autograd.Function):
-    """A library convolution whose output goes straight into a TRAIN-mode BatchNorm: channels-last operands on both sides of
-    the backward (no layout copy of the incoming gradient), and no bias-gradient reduction — the BN removes the per-channel
-    mean, so the bias gradient is exactly zero in exact arithmetic (the library spends a 0.6 TB/s reduction over the whole
-    output on it: 340 us per stem convolution at GKGNet-576, B = 32); a zero tensor is returned for it."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding):
-        xc = x.contiguous(memory_format=torch.channels_last)
-        y = torch.ops.aten.convolution(xc, weight, bias, stride, padding, [1, 1], False, [0, 0], 1)
-        ctx.save_for_backward(xc, weight)
-        ctx.conf = (stride, padding, None if bias is None else bias.shape[0])
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        xc, weight = ctx.saved_tensors
-        stride, padding, nbias = ctx.conf
-        g = g.contiguous(memory_format=torch.channels_last)
-        gx, gw, _ = torch.ops.aten.convolution_backward(g, xc, weight, None, stride, padding, [1, 1], False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        gb = None if nbias is None or not ctx.needs_input_grad[2] else torch.zeros(nbias, dtype=g.dtype, device=g.device)
-        return gx, gw, gb, None, None
 
 
 def conv_before_bn(conv, bn, x):
@@ -1234,27 +914,6 @@ def conv_before_bn(conv, bn, x):
         return _ConvBeforeBN.apply(x, conv.weight, conv.bias, list(conv.stride), list(conv.padding))
     return conv(x)
 
-
-class _AddPosEmbed(torch.autograd.Function):
-    """x (B, C, H, W) channels-last + pos_embed (1, C, H, W): the broadcast add against an NCHW parameter runs at 0.76 TB/s
-    through the generic strided kernel and its backward (sum over the batch of a channels-last gradient) at 0.63 TB/s; with
-    the parameter laid out like x both are plain streaming passes."""
-
-    @staticmethod
-    def forward(ctx, x, pos):
-        ctx.pos_shape = pos.shape
-        return x + pos.contiguous(memory_format=torch.channels_last)
-
-    @staticmethod
-    def backward(ctx, g):
-        gp = None
-        if ctx.needs_input_grad[1]:
-            B, C, H, W = g.shape
-            gl = g.permute(0, 2, 3, 1)                                   # channels-last gradient: a contiguous (B, H*W*C) matrix
-            if not gl.is_contiguous():
-                gl = gl.contiguous()
-            gp = gl.reshape(B, -1).sum(0).view(1, H, W, C).permute(0, 3, 1, 2)
-        return g, gp
 
 
 def add_pos_embed(x, pos):

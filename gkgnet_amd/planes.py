@@ -1,0 +1,135 @@
+"""bf16 operand planes of the projection weights for the split-bf16 (x6) GEMM kernels: one registry per device, refreshed when
+a parameter's version counter moves, or once per hipGraph capture (csrc/gkg_gemm_x6.hip: x6_prep_kernel)."""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream
+
+
+class _WeightPlanes:
+    """bf16 hi / mid / lo planes (forward and dgrad orientation) of every projection weight that went through the x6
+    kernels on one device.  The planes are a function of the parameter values only, so they are refreshed when a
+    parameter's version counter moves (an optimiser step) — ALL registered weights in ONE launch (gkg_x6_prep_weights).
+    Inside a hipGraph capture the host cannot see later in-place updates, so the first projection of each capture emits
+    the refresh unconditionally: a captured training step re-splits the weights once per replay.  Once ANY capture has
+    gone through this registry the version counters prove nothing on the eager side either — a replay (with an in-graph
+    optimiser step) moves the weights after its own re-split and bumps no counter — so from then on (``captured`` is
+    sticky) every eager projection re-splits ITS OWN weight right before use (a one-descriptor launch)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}            # id(weight) -> dict
+        self.descs = None            # device copy of the descriptor table
+        self.solo = None             # the same descriptors, each numbered from unit 0 (single-weight launches)
+        self.unit_ends = []
+        self.capture_id = 0
+        self.captured = False
+
+    def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None):
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.GkgError("x6 projection: a weight was first seen inside a hipGraph capture; run one eager "
+                                "warm-up step before capturing")
+        same = (old is not None and old["ref"]() is weight and old["ptr"] == weight.data_ptr()
+                and (old["nb"], old["cout"], old["cin"]) == (nb, cout, cin))
+        e = dict(ref=weakref.ref(weight), nb=nb, cout=cout, cin=cin, ptr=weight.data_ptr(), version=-1,
+                 pf=old["pf"] if same else None, pd=old["pd"] if same else None)
+        if need_f and e["pf"] is None:
+            e["pf"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device=self.device)
+        if need_d and e["pd"] is None:
+            e["pd"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device=self.device)
+        self.entries[id(weight)] = e
+        self.descs = None
+        return e
+
+    def _build_descs(self, lib):
+        live = {k: e for k, e in self.entries.items() if e["ref"]() is not None}
+        self.entries = live
+        size = lib.gkg_x6_prep_desc_bytes()
+        host = ctypes.create_string_buffer(size * max(1, len(live)))
+        units = 0
+        self.unit_ends = []
+        for i, e in enumerate(live.values()):
+            if i % 256 == 0:
+                units = 0                                             # unit numbering restarts with every launch's table
+            units = lib.gkg_x6_prep_desc_fill(host, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"], e["nb"],
+                                              units)
+            if units < 0:
+                raise _lib.GkgError("gkg_x6_prep_desc_fill rejected a weight")
+            self.unit_ends.append(units)
+        self.descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+        solo = ctypes.create_string_buffer(size * max(1, len(live)))
+        for i, e in enumerate(live.values()):
+            e["slot"] = i
+            e["solo_units"] = lib.gkg_x6_prep_desc_fill(solo, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"],
+                                                        e["nb"], 0)
+        self.solo = torch.frombuffer(bytearray(solo.raw), dtype=torch.uint8).to(self.device)
+
+    def refresh_one(self, lib, e):
+        """Re-split one registered weight (eager use after a capture: see the class docstring)."""
+        if self.descs is None:
+            self._build_descs(lib)
+        size = lib.gkg_x6_prep_desc_bytes()
+        _lib.check(lib.gkg_x6_prep_weights(self.solo.data_ptr() + e["slot"] * size, 1, e["solo_units"], _stream()),
+                   "gkg_x6_prep_weights")
+
+    def refresh(self, lib):
+        """Re-split every registered weight (one launch)."""
+        if self.descs is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GkgError("x6 weight planes: descriptor table is stale inside a capture; run a warm-up step first")
+            self._build_descs(lib)
+        if not self.entries:
+            return
+        n = len(self.entries)
+        size = lib.gkg_x6_prep_desc_bytes()
+        for i0 in range(0, n, 256):                                   # at most 256 descriptors per launch
+            i1 = min(n, i0 + 256)
+            _lib.check(lib.gkg_x6_prep_weights(self.descs.data_ptr() + i0 * size, i1 - i0, self.unit_ends[i1 - 1], _stream()),
+                       "gkg_x6_prep_weights")
+        for e in self.entries.values():
+            w = e["ref"]()
+            e["version"] = -1 if w is None else w._version
+
+    def get(self, lib, weight, nb, cout, cin, need_f=True, need_d=True):
+        e = self.entries.get(id(weight))
+        if (e is None or e["ref"]() is not weight or e["ptr"] != weight.data_ptr()
+                or (e["nb"], e["cout"], e["cin"]) != (nb, cout, cin) or (need_f and e["pf"] is None)
+                or (need_d and e["pd"] is None)):
+            e = self._register(lib, weight, nb, cout, cin, need_f, need_d, e)
+        cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
+        if cap:
+            self.captured = True
+            if cap != self.capture_id:
+                self.capture_id = cap
+                self.refresh(lib)
+        elif e["version"] != weight._version:
+            self.refresh(lib)                    # eager call, stale by the version counter (an eager optimiser step)
+        elif self.captured:
+            # graphs exist: any replay since the last eager call may have moved this weight (a captured optimiser step)
+            # without a counter moving, and it may do so again between any two eager calls
+            self.refresh_one(lib, e)
+        return e["pf"], e["pd"]
+
+
+_PLANES = {}
+
+
+def _planes(lib, weight, nb, cout, cin, need_f=True, need_d=True):
+    key = (weight.device.type, weight.device.index)
+    reg = _PLANES.get(key)
+    if reg is None:
+        reg = _PLANES[key] = _WeightPlanes(weight.device)
+    return reg.get(lib, weight, nb, cout, cin, need_f, need_d)
+
+
+def refresh_weight_planes(device=None):
+    """Re-split the registered projection weights now (normally automatic: see _WeightPlanes)."""
+    lib = _lib.load()
+    for key, reg in _PLANES.items():
+        if device is None or key == (torch.device(device).type, torch.device(device).index):
+            reg.refresh(lib)
