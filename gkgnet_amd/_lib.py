@@ -64,7 +64,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
-           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd")
+           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -138,6 +138,8 @@ def load():
     lib.gkg_linear_stats_doubles.restype = I
     lib.gkg_linear_stats_doubles.argtypes = []
     lib.gkg_linear_bn_fwd.argtypes = [V, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V]
+    lib.gkg_affine_act_bf16in.restype = I
+    lib.gkg_affine_act_bf16in.argtypes = [V, V, V, V, V, I, I, I, V]
     lib.gkg_affine_act_dual.restype = I
     lib.gkg_affine_act_dual.argtypes = [V, V, V, V, V, V, I, I, I, V, I, V]
     lib.gkg_edge_stats.restype = I

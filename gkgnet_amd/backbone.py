@@ -61,6 +61,23 @@ class Stem(nn.Module):
             elif not torch.is_autocast_enabled():
                 first = fused.stem_conv(conv0, x, bn0)                                        # training: BN on the kernels below
                 start = 1
+        # inference: every remaining conv -> BN (-> GELU) unit is the library convolution + ONE own pass (fused.conv_bn_act_eval)
+        if not torch.is_grad_enabled():
+            units, i, ok = [], (start if first is not None else 0), True
+            while i < len(mods) and ok:
+                conv = mods[i]
+                bn = mods[i + 1] if i + 1 < len(mods) else None
+                act = mods[i + 2] if i + 2 < len(mods) and not isinstance(mods[i + 2], nn.Conv2d) else None
+                ok = isinstance(conv, nn.Conv2d) and bn is not None and not isinstance(bn, nn.Conv2d)
+                units.append((conv, bn, act))
+                i += 2 if act is None else 3
+            cur = first if first is not None else x
+            if ok and units and all(fused.conv_bn_act_eval_supported(cv, b, a_, cur) for cv, b, a_ in units):
+                for j, (cv, b, a_) in enumerate(units):
+                    last = j == len(units) - 1
+                    cur = fused.conv_bn_act_eval(cv, b, a_, cur, want32=last or not torch.is_autocast_enabled(),
+                                                 want16=not last and torch.is_autocast_enabled())
+                return cur
         # channels-last convolutions hand their output over as a token-major matrix: BN (+ GELU) on the blocks' own kernels
         if first is not None or (fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32
                                  and not torch.is_autocast_enabled()):
@@ -90,6 +107,9 @@ class Downsample(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_dim, out_dim, 3, stride=2, padding=1), build_norm(out_dim))
 
     def forward(self, x):
+        if fused.conv_bn_act_eval_supported(self.conv[0], self.conv[1], None, x):
+            # inference: convolution + ONE pass (eval BN + bias) -> fp32 channels-last, its bf16 rounding riding along under autocast
+            return fused.conv_bn_act_eval(self.conv[0], self.conv[1], None, x, want32=True, want16=torch.is_autocast_enabled())
         if fused.STEM_BN and fused.ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
             y = fused.conv_before_bn(self.conv[0], self.conv[1], x.contiguous(memory_format=torch.channels_last))
             if fused.bn_act_supported(self.conv[1], y, None):

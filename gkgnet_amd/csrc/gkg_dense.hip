@@ -431,6 +431,38 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   }
 }
 
+// The same apply pass for a bf16 input matrix (the output of a library convolution under bf16 autocast, channels-last =
+// token-major): out32 (fp32) and / or out16 (its bf16 rounding), 8 values per thread and step.
+template <int ACT>
+__global__ __launch_bounds__(256) void affine_act_bf16in_kernel(const uint16_t* __restrict__ y, const float* __restrict__ a,
+                                                                const float* __restrict__ cs, float* __restrict__ out32,
+                                                                uint16_t* __restrict__ out16, size_t total8, int C) {
+  const int C8 = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % C8);
+    const uint4 v = *reinterpret_cast<const uint4*>(y + 8 * i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float o[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      o[2 * u] = __uint_as_float(w[u] << 16);
+      o[2 * u + 1] = __uint_as_float(w[u] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      o[u] = __builtin_fmaf(a[8 * cg + u], o[u], cs[8 * cg + u]);
+      if (ACT == 1) o[u] = gelu_f(o[u]);
+    }
+    if (out32) {
+      stf4(out32 + 8 * i, make_float4(o[0], o[1], o[2], o[3]));
+      stf4(out32 + 8 * i + 4, make_float4(o[4], o[5], o[6], o[7]));
+    }
+    if (out16)
+      *reinterpret_cast<uint4*>(out16 + 8 * i) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                                             pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  }
+}
+
 // dy[r][c] = a[c] * (dz - sdz[c]/R - yhat*sdzy[c]/R), dz = dout*act'(a*y+c).  dout may be strided (ldg).
 // fp64-sums form of the apply pass (gkg_bn_bwd_atomic): reads the column sums the statistics pass accumulated with atomics,
 // its first workgroup of every group also emits dbeta / dgamma and clears `zero_buf` (the OTHER scratch buffer: what the
@@ -626,6 +658,22 @@ extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, co
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");
+}
+
+// out = act(a * y + c) for a BF16 matrix y (R, C) with C % 8 == 0 — the output of a library convolution under bf16 autocast
+// viewed token-major (channels-last) with the eval-mode BN (+ conv bias) folded into a / c (reference gkgnet.py:79-118 in
+// eval mode): out_f32 (fp32, the residual stream) and / or out_bf16 (the next GEMM / convolution operand); at least one.
+extern "C" int gkg_affine_act_bf16in(const void* y_bf16, const float* a, const float* c, float* out_f32, void* out_bf16, int R,
+                                     int C, int act, void* stream) {
+  if (!y_bf16 || !a || !c || (!out_f32 && !out_bf16)) return gkg_fail(GKG_ERR_NULL, "gkg_affine_act_bf16in: null pointer");
+  if (R <= 0 || C <= 0 || (C & 7) || (act != 0 && act != 1)) return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act_bf16in: bad sizes (C % 8 == 0)");
+  const size_t total8 = (size_t)R * (C >> 3);
+  const int blocks = (int)((total8 + 255) / 256 > 4096 ? 4096 : (total8 + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == 1) hipLaunchKernelGGL((affine_act_bf16in_kernel<1>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)y_bf16, a, c, out_f32, (uint16_t*)out_bf16, total8, C);
+  else hipLaunchKernelGGL((affine_act_bf16in_kernel<0>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)y_bf16, a, c, out_f32, (uint16_t*)out_bf16, total8, C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_bf16in_kernel");
 }
 
 // gkg_affine_act (one batch, contiguous rows) writing the result twice: fp32 (the residual stream) and its bf16 rounding

@@ -884,6 +884,64 @@ def bn_act(x, bn, act_mod):
 STEM_CONV = "stem_conv" not in _DISABLED
 
 
+def conv_bn_act_eval_supported(conv, bn, act_mod, x) -> bool:
+    """Inference form of a stem / downsample unit: library convolution (channels-last, no bias) + ONE own pass with the
+    eval-mode BN, the conv bias (+ GELU) folded in (fp32, or bf16 autocast)."""
+    if not (ENABLED and STEM_BN and x.is_cuda and x.dim() == 4 and not torch.is_grad_enabled()):
+        return False
+    if not (isinstance(conv, torch.nn.Conv2d) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and not isinstance(conv.padding, str) and conv.out_channels % 8 == 0 and conv.weight.dtype == _F32):
+        return False
+    if not (_bn_ok(bn) and not bn.training and bn.track_running_stats and bn.running_mean is not None):
+        return False
+    if act_mod is not None and not isinstance(act_mod, torch.nn.GELU):
+        return False
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype in (_F32, torch.bfloat16)
+    return x.dtype == _F32
+
+
+@torch.no_grad()
+def conv_bn_act_eval(conv, bn, act_mod, x, want32=True, want16=False):
+    """-> channels-last (B, Cout, Ho, Wo): the fp32 result (want32; with the bf16 rounding riding along as ``_gkg_bf16`` for
+    the next block's entry when want16) or only its bf16 rounding (want16 alone: the next convolution's operand).  The
+    library's separate bias add, its BN kernel, the stand-alone GELU and the layout / cast copies around them (1.4 ms of
+    the 22.7 ms GKGNet-576 forward, tools/prof_backbone_ops.py cfg3) become one streaming pass per unit."""
+    lib = _lib.load()
+    cout = conv.out_channels
+    a, c = _bn_eval_ac(lib, bn, conv.bias, cout)
+    ac16 = torch.is_autocast_enabled()
+    dt = torch.bfloat16 if ac16 else _F32
+    xin = x if (x.dtype == dt and x.is_contiguous(memory_format=torch.channels_last)) else \
+        x.to(dtype=dt, memory_format=torch.channels_last)
+    w = _w16_of(conv) if ac16 else conv.weight
+    with torch.autocast("cuda", enabled=False):
+        y = torch.ops.aten.convolution(xin, w, None, list(conv.stride), list(conv.padding), list(conv.dilation), False, [0, 0], 1)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    B, _, Ho, Wo = y.shape
+    R = B * Ho * Wo
+    act = 0 if act_mod is None else 1
+    o32 = torch.empty((B, Ho, Wo, cout), dtype=_F32, device=y.device) if want32 else None
+    o16 = torch.empty((B, Ho, Wo, cout), dtype=torch.bfloat16, device=y.device) if want16 else None
+    if ac16:
+        _lib.check(lib.gkg_affine_act_bf16in(_ptr(y), _ptr(a), _ptr(c), _ptr(o32), _ptr(o16), R, cout, act, _stream()),
+                   "gkg_affine_act_bf16in")
+    elif want32 and want16:
+        _lib.check(lib.gkg_affine_act_dual(_ptr(y), _ptr(a), _ptr(c), None, _ptr(o32), _ptr(o16), R, cout, act, None, 0, _stream()),
+                   "gkg_affine_act_dual")
+    else:
+        out = o32 if want32 else o16
+        _lib.check(lib.gkg_affine_act(_ptr(y), _ptr(a), _ptr(c), None, _ptr(out), R, cout, 1, cout, 0, act,
+                                      _lib.F32 if want32 else _lib.BF16, None, 0, _stream()), "gkg_affine_act")
+    if want32:
+        res = o32.permute(0, 3, 1, 2)
+        if want16:
+            res._gkg_bf16 = (res._version, o16.view(R, cout))
+        return res
+    return o16.permute(0, 3, 1, 2)
+
+
 from .stem import _StemConv, _ConvBeforeBN, _AddPosEmbed      # noqa: E402  (autograd Functions of the stem path: stem.py)
 
 

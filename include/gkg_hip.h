@@ -229,6 +229,12 @@ int gkg_affine_act(const float* y, const float* a, const float* c, const float* 
  * rounding (the next projection's operand in bf16 inference) — no stand-alone cast pass between blocks. */
 int gkg_affine_act_dual(const float* y, const float* a, const float* c, const float* res, float* out_f32, void* out_bf16,
                         int R, int C, int act, const float* row_scale, int rows_per_scale, void* stream);
+
+/* out = act(a * y + c) for a BF16 matrix y (R, C), C % 8 == 0: the output of a library convolution under bf16 autocast viewed
+ * token-major (channels-last), eval-mode BN (+ conv bias) folded into a / c (reference gkgnet.py:79-118 in eval mode).  Writes
+ * out_f32 (fp32: the residual stream) and / or out_bf16 (the next operand); at least one must be non-null.  act: 0 / 1 (GELU). */
+int gkg_affine_act_bf16in(const void* y_bf16, const float* a, const float* c, float* out_f32, void* out_bf16, int R, int C,
+                          int act, void* stream);
 /* Backward of out = act(BN_train(y)): dy, dgamma, dbeta from dout (row pitch ldg, batch stride dout_bstride). */
 int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,

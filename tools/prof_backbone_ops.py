@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Which aten / autograd operators of a GKGNet-576 training step (forward + backward of the backbone, fp32) launch the torch-side
+"""Which aten / autograd operators of a GKGNet-576 training step (cfg4: forward + backward of the backbone, fp32) or inference
+forward (cfg3: eval, bf16 autocast) launch the torch-side
 glue kernels (strided elementwise, adds, reductions, copies): torch.profiler, one eager step; per kernel-name pattern the CPU
-operators above the launches, with counts and total time.     python tools/prof_backbone_ops.py [pattern ...]"""
+operators above the launches, with counts and total time.     python tools/prof_backbone_ops.py [cfg3|cfg4] [pattern ...]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,13 +11,22 @@ from gkgnet_amd.backbone import GKGNet
 from torch.profiler import profile, ProfilerActivity
 
 pats = sys.argv[1:] or ["elementwise_kernel_manual_unroll", "CUDAFunctor_add", "reduce_kernel", "Memcpy", "vectorized_elementwise"]
-spec = bench.BACKBONE_WORKLOADS["cfg4"]
+MODE = "cfg3" if "cfg3" in sys.argv else "cfg4"
+pats = [a for a in pats if a not in ("cfg3", "cfg4")] or ["elementwise_kernel_manual_unroll", "CUDAFunctor_add", "reduce_kernel", "Memcpy", "vectorized_elementwise", "copy_kernel", "transpose", "MIOpen"]
+spec = bench.BACKBONE_WORKLOADS[MODE]
 torch.manual_seed(0)
-net = GKGNet(**dict(spec["kw"])).cuda().train()
-img = torch.randn(spec["B"], 3, 576, 576, device="cuda").contiguous(memory_format=torch.channels_last)
+net = GKGNet(**dict(spec["kw"])).cuda()
+net = net.eval() if MODE == "cfg3" else net.train()
+img = torch.randn(spec["B"], 3, 576, 576, device="cuda")
+if MODE == "cfg4":
+    img = img.contiguous(memory_format=torch.channels_last)
 
 
 def step():
+    if MODE == "cfg3":                       # the bench's forward: eval, bf16 autocast
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            net(img)
+        return
     out = net(img)
     outs = out if isinstance(out, (tuple, list)) else (out,)
     sum(o.float().sum() for o in outs if torch.is_tensor(o)).backward()
