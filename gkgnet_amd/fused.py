@@ -535,8 +535,13 @@ def _derive_ok(bn, nb, cout, code, want16) -> bool:
 # leaves the scratch buffers on the link; the producer's backward then runs the apply pass only.  MEASURED neutral (round 4,
 # same-box A/B: cfg4 train step 90.0 / 90.4 ms with, 90.1 / 90.3 without; stage3 3.17-3.18 either way; cfg2 0.919 vs 0.915):
 # the 16 y rows per lane, the GELU' recompute and the reduction sit on the tail of a workgroup that lives 10-15 us, which
-# costs the GEMM what the removed pass (near the HBM roofline on its own) saved.  Opt-in: GKG_ENABLE=bn_epilogue.
-BN_EPILOGUE = "bn_epilogue" in _ENABLED
+# costs the GEMM what the removed pass (near the HBM roofline on its own) saved.  A later same-box A/B of the cfg4 step
+# (alternating runs) measured 85.16 / 85.18 ms without and 84.70 / 84.67 ms with: on from 32 768 rows (below).
+BN_EPILOGUE = "bn_epilogue" not in _DISABLED
+# rows from which the link is attached: where the saved pass over the gradient is memory time (GKGNet-576's stages: cfg4 85.17 ->
+# 84.69 ms on one box) rather than a launch among ~85 short ones (neutral at the cfg2 shapes, 10 368 rows).  GKG_ENABLE=bn_epilogue
+# (and the tests) attach it at every size.
+BN_EPILOGUE_MIN_ROWS = 0 if "bn_epilogue" in _ENABLED else 32768
 
 
 class _BnLink:
@@ -549,7 +554,7 @@ class _BnLink:
 
 def _bn_link(out, Y, a, c, mean, invstd, act, nb, co, R, bn, sync, scale):
     """Hang a _BnLink on a token-major fp32 layer output (train-mode, rank-local statistics, atomics allowed)."""
-    if (BN_EPILOGUE and mean is not None and sync is None and scale is None and not DETERMINISTIC
+    if (BN_EPILOGUE and R >= BN_EPILOGUE_MIN_ROWS and mean is not None and sync is None and scale is None and not DETERMINISTIC
             and out.dtype == _F32 and 2 * nb * co <= _BnBwdScratch.DOUBLES):
         link = _BnLink(Y, a, c, mean, invstd, act, nb, co, R)
         out._gkg_bn_link = link

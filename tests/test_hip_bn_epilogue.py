@@ -36,6 +36,7 @@ def test_ffn_block_takes_the_epilogue_and_matches_the_two_pass_backward(monkeypa
     res = []
     for on in (True, False):
         monkeypatch.setattr(fused, "BN_EPILOGUE", on)
+        monkeypatch.setattr(fused, "BN_EPILOGUE_MIN_ROWS", 0)
         torch.manual_seed(4)
         ffn = FFN(C, 4 * C, act="gelu").cuda().train()
         x = xin.clone().requires_grad_(True)
@@ -61,6 +62,7 @@ def test_grapher_block_grouped_producer_and_label_branch(monkeypatch):
     res = []
     for on in (True, False):
         monkeypatch.setattr(fused, "BN_EPILOGUE", on)
+        monkeypatch.setattr(fused, "BN_EPILOGUE_MIN_ROWS", 0)
         torch.manual_seed(6)
         g = Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, drop_path=0.0, relative_pos=True,
                     use_multi_group=True, num_group=G).cuda().train()
@@ -83,6 +85,7 @@ def test_a_second_consumer_of_the_activation_falls_back_cleanly(monkeypatch):
     from gkgnet_amd import fused, layers
     layers.norm_cfg["type"] = "BN"
     monkeypatch.setattr(fused, "BN_EPILOGUE", True)
+    monkeypatch.setattr(fused, "BN_EPILOGUE_MIN_ROWS", 0)
     R, C = 10368, 64
     gen = torch.Generator(device="cuda").manual_seed(8)
     x0 = torch.randn(R, C, device="cuda", generator=gen)
