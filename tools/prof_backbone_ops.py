@@ -11,19 +11,19 @@ from gkgnet_amd.backbone import GKGNet
 from torch.profiler import profile, ProfilerActivity
 
 pats = sys.argv[1:] or ["elementwise_kernel_manual_unroll", "CUDAFunctor_add", "reduce_kernel", "Memcpy", "vectorized_elementwise"]
-MODE = "cfg3" if "cfg3" in sys.argv else "cfg4"
-pats = [a for a in pats if a not in ("cfg3", "cfg4")] or ["elementwise_kernel_manual_unroll", "CUDAFunctor_add", "reduce_kernel", "Memcpy", "vectorized_elementwise", "copy_kernel", "transpose", "MIOpen"]
+MODE = "cfg3" if "cfg3" in sys.argv else ("cfg5" if "cfg5" in sys.argv else "cfg4")
+pats = [a for a in pats if a not in ("cfg3", "cfg4", "cfg5")] or ["elementwise_kernel_manual_unroll", "CUDAFunctor_add", "reduce_kernel", "Memcpy", "vectorized_elementwise", "copy_kernel", "transpose", "MIOpen"]
 spec = bench.BACKBONE_WORKLOADS[MODE]
 torch.manual_seed(0)
 net = GKGNet(**dict(spec["kw"])).cuda()
-net = net.eval() if MODE == "cfg3" else net.train()
-img = torch.randn(spec["B"], 3, 576, 576, device="cuda")
+net = net.eval() if MODE != "cfg4" else net.train()
+img = torch.randn(spec["B"], 3, spec["kw"]["size"], spec["kw"]["size"], device="cuda")
 if MODE == "cfg4":
     img = img.contiguous(memory_format=torch.channels_last)
 
 
 def step():
-    if MODE == "cfg3":                       # the bench's forward: eval, bf16 autocast
+    if MODE != "cfg4":                       # the bench's forward: eval, bf16 autocast
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             net(img)
         return
