@@ -64,7 +64,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
-           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in")
+           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -122,6 +122,8 @@ def load():
     lib.gkg_bn_apply_train.argtypes = [V] * 14 + [I, I, I, I, Z, I, I, V, I, F, F, V, Z, V]
     lib.gkg_bn_bwd_atomic.restype = I
     lib.gkg_bn_bwd_atomic.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, V, Z, V]
+    lib.gkg_bn_bwd_atomic_scaled.restype = I
+    lib.gkg_bn_bwd_atomic_scaled.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, V, Z, V, I, V]
     lib.gkg_bn_bwd_apply_from_sums.restype = I
     lib.gkg_bn_bwd_apply_from_sums.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, V, Z, V]
     lib.gkg_linear_dgrad_x6_bnbwd.restype = I

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ part, int R, int C, int rows_per_block,
                                                            int ldg, size_t g_bstride, float* __restrict__ dz_out,
-                                                           double* __restrict__ asums = nullptr) {
+                                                           double* __restrict__ asums = nullptr,
+                                                           const float* __restrict__ row_scale = nullptr, int rows_per_scale = 1) {
   __shared__ float red[2][ST_RL][4 * ST_CG];
   const int tid = threadIdx.x;
   const int cg = tid & (ST_CG - 1), rl = tid >> 4;
@@ -225,6 +226,10 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
       const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)r * ldg + 4 * cgi);
       const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + 4 * cgi);
       float4 dz = g;
+      if (row_scale) {                                // DropPath: the branch output was scaled per image, so is its gradient
+        const float sc = row_scale[r / rows_per_scale];
+        dz.x *= sc; dz.y *= sc; dz.z *= sc; dz.w *= sc;
+      }
       if (ACT == 1) {
         dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
         dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
@@ -474,7 +479,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_d_kernel(const float* dout, 
                                                              const double* __restrict__ dsums, float* dy,
                                                              size_t total4, int C, int R, int ldg, size_t g_bstride,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             double* __restrict__ zero_buf, size_t zero_doubles) {
+                                                             double* __restrict__ zero_buf, size_t zero_doubles,
+                                                             const float* __restrict__ row_scale = nullptr, int rows_per_scale = 1) {
   const int C4 = C >> 2;
   const float invR = 1.0f / (float)R;
   const int q = blockIdx.y;
@@ -502,6 +508,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_d_kernel(const float* dout, 
     const float4 s4 = make_float4((float)sa.x, (float)sa.y, (float)sb.x, (float)sb.y);
     const float4 q4 = make_float4((float)qa.x, (float)qa.y, (float)qb.x, (float)qb.y);
     float4 dz = g;
+    if (row_scale) {
+      const float sc = row_scale[r / (size_t)rows_per_scale];
+      dz.x *= sc; dz.y *= sc; dz.z *= sc; dz.w *= sc;
+    }
     if (ACT == 1) {
       dz.x *= gelu_grad_f(__builtin_fmaf(a4.x, v.x, c4.x)); dz.y *= gelu_grad_f(__builtin_fmaf(a4.y, v.y, c4.y));
       dz.z *= gelu_grad_f(__builtin_fmaf(a4.z, v.z, c4.z)); dz.w *= gelu_grad_f(__builtin_fmaf(a4.w, v.w, c4.w));
@@ -730,7 +740,7 @@ extern "C" int gkg_bn_bwd(const float* dout, const float* y, const float* a, con
 static int bn_bwd_atomic_impl(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                               const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                               size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream,
-                              bool stats_pass);
+                              bool stats_pass, const float* row_scale = nullptr, int rows_per_scale = 1);
 
 extern "C" int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                                  const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
@@ -742,6 +752,21 @@ extern "C" int gkg_bn_bwd_atomic(const float* dout, const float* y, const float*
     return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_atomic: bad sizes");
   return bn_bwd_atomic_impl(dout, y, a, c, mean, invstd, dy, dgamma, dbeta, R, C, nb, ldg, dout_bstride, act, sums, zero_buf,
                             zero_doubles, stream, true);
+}
+
+// gkg_bn_bwd_atomic for a branch whose OUTPUT was scaled per image (DropPath, torch_vertex.py:332,355,402): the incoming
+// gradient is multiplied by row_scale[row / rows_per_scale] inside both passes instead of by a separate elementwise launch.
+extern "C" int gkg_bn_bwd_atomic_scaled(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                                        const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb,
+                                        int ldg, size_t dout_bstride, int act, double* sums, double* zero_buf,
+                                        size_t zero_doubles, const float* row_scale, int rows_per_scale, void* stream) {
+  if (!dout || !y || !a || !c || !mean || !invstd || !dy || !dgamma || !dbeta || !sums || !row_scale)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_bwd_atomic_scaled: null pointer");
+  if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldg < C || (ldg & 3) || (dout_bstride & 3) || (act != 0 && act != 1) ||
+      (zero_doubles && !zero_buf) || rows_per_scale <= 0)
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_bwd_atomic_scaled: bad sizes");
+  return bn_bwd_atomic_impl(dout, y, a, c, mean, invstd, dy, dgamma, dbeta, R, C, nb, ldg, dout_bstride, act, sums, zero_buf,
+                            zero_doubles, stream, true, row_scale, rows_per_scale);
 }
 
 // The same backward with the statistics ALREADY in `sums` (accumulated by the epilogue of the GEMM that produced dout:
@@ -762,18 +787,18 @@ extern "C" int gkg_bn_bwd_apply_from_sums(const float* dout, const float* y, con
 static int bn_bwd_atomic_impl(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                               const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                               size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream,
-                              bool stats_pass) {
+                              bool stats_pass, const float* row_scale, int rows_per_scale) {
   int rpb;
   const int nblk = stats_blocks(R, C, nb, &rpb);
   hipStream_t st = (hipStream_t)stream;
   if (stats_pass) {
-    if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
-    else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums);
+    if (act == 1) hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums, row_scale, rows_per_scale);
+    else hipLaunchKernelGGL((bn_bwd_stats_kernel<0>), dim3(nblk, stats_tiles(C), nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, (float*)nullptr, R, C, rpb, ldg, dout_bstride, (float*)nullptr, sums, row_scale, rows_per_scale);
   }
   const size_t total4 = (size_t)R * (C >> 2);
   const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_d_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles);
-  else hipLaunchKernelGGL((bn_bwd_apply_d_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles);
+  if (act == 1) hipLaunchKernelGGL((bn_bwd_apply_d_kernel<1>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles, row_scale, rows_per_scale);
+  else hipLaunchKernelGGL((bn_bwd_apply_d_kernel<0>), dim3(blocks, nb), dim3(256), 0, st, dout, y, a, c, mean, invstd, sums, dy, total4, C, R, ldg, dout_bstride, dgamma, dbeta, zero_buf, zero_doubles, row_scale, rows_per_scale);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_bwd_atomic");
 }

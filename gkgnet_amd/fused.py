@@ -578,7 +578,17 @@ def _dgrad_x6_with_link(lib, dY, pd, R, cin, cout, link):
     return dx
 
 
-def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync, link=None):
+DROPPATH_FOLD = "droppath_fold" not in _DISABLED
+
+
+def _bn_scale_in_kernel(sync, nb, C) -> bool:
+    """Whether _bn_backward will take the two-launch fp64-atomic form, whose kernels can apply a per-image gradient scale
+    (DropPath) themselves instead of a separate elementwise launch in front of them (22 launches, 0.6 ms of the cfg4 step)."""
+    return DROPPATH_FOLD and sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES
+
+
+def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync, link=None, row_scale=None,
+                 rows_per_scale=0):
     """dY, dgamma, dbeta of out = act(BN_train(Y)) from the upstream gradient g; with ``sync`` the two column sums the
     input gradient needs are all-reduced over the ranks (dgamma/dbeta stay local, like torch's SyncBatchNorm: the
     data-parallel gradient exchange averages them).  ``link``: this layer's _BnLink — when the consumer's dgrad epilogue has
@@ -604,9 +614,14 @@ def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg
         scratch = _BnBwdScratch.of(Y.device)
         cur, other, zero = scratch.acquire(lib, 2 * nb * C)
         try:
-            _lib.check(lib.gkg_bn_bwd_atomic(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
-                                             _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), zero, _stream()),
-                       "gkg_bn_bwd_atomic")
+            if row_scale is not None:
+                _lib.check(lib.gkg_bn_bwd_atomic_scaled(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
+                                                        _ptr(dgamma), _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other),
+                                                        zero, _ptr(row_scale), rows_per_scale, _stream()), "gkg_bn_bwd_atomic_scaled")
+            else:
+                _lib.check(lib.gkg_bn_bwd_atomic(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY), _ptr(dgamma),
+                                                 _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur), _ptr(other), zero, _stream()),
+                           "gkg_bn_bwd_atomic")
         except Exception:
             scratch.poison()
             raise
@@ -705,11 +720,15 @@ class _LinearBNAct(torch.autograd.Function):
         R, cin = x.shape
         cout = weight.shape[0]
         dres = dout if has_res else None
+        row_scale = None
         if nchw is not None:
             g = torch.empty((R, cout), dtype=_F32, device=dout.device)
             dout_c = dout.contiguous()           # named: the copy must outlive the launch that reads it
             _lib.check(lib.gkg_nchw_to_tm(_ptr(dout_c), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32,
                                           _ptr(ctx.scale[0]), _stream()), "gkg_nchw_to_tm")      # DropPath: g * mask / keep
+        elif ctx.scale[0] is not None and _bn_scale_in_kernel(ctx.sync, 1, cout) and (ctx.link is None or ctx.link.ready is None):
+            g = dout.contiguous()                # DropPath: the BN-backward kernels scale the gradient per image themselves
+            row_scale = (ctx.scale[0].contiguous().float(), ctx.scale[1])
         elif ctx.scale[0] is not None:
             g = (dout.view(-1, ctx.scale[1], cout) * ctx.scale[0].view(-1, 1, 1)).view(R, cout)
         else:
@@ -720,7 +739,8 @@ class _LinearBNAct(torch.autograd.Function):
         dbias = None
         dY = torch.empty_like(Y)
         dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (cout, cin), cout, Y.device)
-        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync, ctx.link)
+        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, cout, 1, cout, 0, act, ctx.sync, ctx.link,
+                     *(row_scale if row_scale is not None else (None, 0)))
         W = weight.view(cout, cin)
         if not ctx.needs_input_grad[0]:
             dx = None

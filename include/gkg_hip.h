@@ -261,6 +261,13 @@ int gkg_bn_apply_train(const float* y, const double* sums, const float* gamma, c
 int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                       const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                       size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream);
+
+/* gkg_bn_bwd_atomic for a branch whose output was scaled per image (DropPath: torch_vertex.py:332,355,402): the incoming
+ * gradient is multiplied by row_scale[row / rows_per_scale] inside both passes. */
+int gkg_bn_bwd_atomic_scaled(const float* dout, const float* y, const float* a, const float* c, const float* mean,
+                             const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
+                             size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles,
+                             const float* row_scale, int rows_per_scale, void* stream);
 /* Cross-rank batch statistics (the reference's SyncBatchNorm under DDP, torch_nn.py:37 / mmcv build_norm_layer):
  * gkg_bn_train_stats and gkg_bn_bwd split where the ranks exchange statistics.  Forward: gkg_bn_stats_sums ->
  * caller all-reduces `sums` [nb][2][C] (column sum, sum of squares) and the row count over the ranks ->
