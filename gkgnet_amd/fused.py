@@ -359,7 +359,7 @@ def _mm_t(x, W, W16=None):
     return Y if Y.dtype == _F32 else Y.float()
 
 
-from .layout import _tm_dtype, _TokenMajorToCL, _ToTokenMajor, _BlockEntry      # noqa: E402  (layout Functions: layout.py)
+from .layout import _tm_dtype, _TokenMajorToCL, _ToTokenMajor, _BlockEntry, _AvgPoolTM      # noqa: E402  (layout Functions: layout.py)
 
 
 # ----------------------------------------------------------------------------------------------- layout
@@ -1308,8 +1308,7 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     x1b = x1.view(B, N, C)
     yb = None
     if gc.r > 1:                                                    # pooled keys (torch_vertex.py:194-196)
-        pooled = F.avg_pool2d(x1.view(B, H, W, C).permute(0, 3, 1, 2), gc.r, gc.r)
-        yb = pooled.permute(0, 2, 3, 1).reshape(B, -1, C)
+        yb = _AvgPoolTM.apply(x1.view(B, H, W, C), gc.r).reshape(B, -1, C)
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
     a2 = _aggregate_project(x1b, yb, edge[0], groups, gc.gconv.nn, C, lp)   # row g1: aggregation = the projection's operand producer
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last

@@ -87,3 +87,30 @@ class _BlockEntry(torch.autograd.Function):
         _lib.check(_lib.load().gkg_tm_affine_to_nchw(_ptr(g_tm), None, None, _ptr(res), _ptr(out), B, C, N, None,
                                                      _stream()), "gkg_tm_affine_to_nchw")
         return out, None
+
+
+class _AvgPoolTM(torch.autograd.Function):
+    """avg_pool2d(r, r) of a token-major feature map x (B, H, W, C) -> (B, H/r, W/r, C) (the pooled key set of the reference,
+    torch_vertex.py:194-196).  Forward: the library's channels-last pooling on a view.  Backward: every pooled gradient goes
+    to its r x r window divided by r^2 — one broadcast copy; the library's NHWC backward ran at 0.87 TB/s (243 us per
+    GKGNet-576 stage-1 block, B = 32)."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        ctx.r = r
+        ctx.hw = (x.shape[1], x.shape[2])
+        y = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), r, r)
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.r
+        B, Hr, Wr, C = g.shape
+        H, W = ctx.hw
+        gs = (g * (1.0 / (r * r))).view(B, Hr, 1, Wr, 1, C).expand(B, Hr, r, Wr, r, C)
+        if Hr * r == H and Wr * r == W:
+            return gs.reshape(B, H, W, C), None
+        out = g.new_zeros((B, H, W, C))                 # floor mode: rows / columns past the last full window get no gradient
+        out[:, :Hr * r, :Wr * r] = gs.reshape(B, Hr * r, Wr * r, C)
+        return out, None
+
