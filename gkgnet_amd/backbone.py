@@ -198,7 +198,18 @@ class GKGNet(nn.Module):
         return None
 
     def forward(self, inputs):
-        labels = self.label_lt(self.label_input.to(inputs.device).repeat(inputs.size(0), 1))   # (B, n_classes, C1)
+        # (B, n_classes, C1) label queries: label_input is arange(n_classes), so the embedding lookup of the reference
+        # (gkgnet.py:218) is the weight itself, broadcast over the batch — its backward is then a batch sum instead of the
+        # library's sort-based embedding backward (153 us per step at B = 32)
+        if getattr(self, "_lt_identity", None) is None:
+            li = self.label_input.reshape(-1)
+            self._lt_identity = bool(self.label_lt.max_norm is None and self.label_lt.padding_idx is None
+                                     and li.numel() == self.label_lt.num_embeddings
+                                     and torch.equal(li.cpu(), torch.arange(li.numel())))
+        if self._lt_identity:
+            labels = self.label_lt.weight.unsqueeze(0).expand(inputs.size(0), -1, -1)
+        else:
+            labels = self.label_lt(self.label_input.to(inputs.device).repeat(inputs.size(0), 1))
         x = fused.add_pos_embed(self.stem(inputs), self.pos_embed)
         stage = 0
         edge_index = None
