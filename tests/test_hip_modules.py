@@ -324,16 +324,22 @@ def _droppath_block(kind):
     return FFN(64, 256, act="gelu", drop_path=0.4)
 
 
-@pytest.mark.parametrize("kind", ["grapher", "label", "ffn"])
+@pytest.mark.parametrize("kind", ["grapher", "label", "ffn", "grapher_cl", "ffn_cl"])
 def test_fused_path_covers_active_droppath(kind):
     """The reference's real training config runs stochastic depth (configs/gkgnet/gkgnet_coco_576.py:15 drop_path=0.1;
     gkgnet.py:181,235-237; torch_vertex.py:332): the fused block folds the per-image keep / (1 - p) factor into its last
     BN-apply kernel (and into the layout kernel of the backward).  Same RNG state -> same mask -> the fused and the
     composable per-op paths must agree, forward and backward."""
     from gkgnet_amd import fused
+    # "_cl": channels-last feature map (what the in-repo backbone hands its blocks): the token-major path, where the per-image
+    # scale of the incoming gradient is applied inside the BN-backward kernels (gkg_bn_bwd_atomic_scaled)
+    cl = kind.endswith("_cl")
+    kind = kind[:-3] if cl else kind
     mod = _droppath_block(kind).cuda().train()
     B = 6
     x = torch.randn(B, 64, 10, 10, device="cuda")
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
     e = torch.randn(B, 20, 64, device="cuda")
     outs = []
     calls = {"n": 0}
@@ -350,7 +356,7 @@ def test_fused_path_covers_active_droppath(kind):
             fused.ENABLED = enabled
             mod.zero_grad(set_to_none=True)
             torch.manual_seed(1234)                                   # identical Bernoulli draws on both paths
-            xg, eg = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+            xg, eg = x.clone(memory_format=torch.preserve_format).requires_grad_(True), e.clone().requires_grad_(True)
             if kind == "label":
                 out = mod(eg, xg)[0]
             else:
