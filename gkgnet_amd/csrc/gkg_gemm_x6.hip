@@ -152,6 +152,18 @@ __device__ __forceinline__ void x6_dma16(const void* sbase, unsigned voff, unsig
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+// -DX6_TIMELINE (tools/ubench/x6_timeline.py only): phase timestamps (s_memtime) of every 16th workgroup's first wave
+#ifdef X6_TIMELINE
+__device__ long long* x6_tl_buf;
+#define X6_TL(p)                                                                                                      \
+  do {                                                                                                                \
+    if (x6_tl_buf && tid == 0 && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < 4096)                                 \
+      x6_tl_buf[(blockIdx.x >> 4) * 8 + (p)] = (long long)__builtin_readcyclecounter();                               \
+  } while (0)
+#else
+#define X6_TL(p) do {} while (0)
+#endif
+
 template <int NI, int EPI>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   constexpr int BM = 128, BN = 32 * NI, BK = 32, SA = 3;
@@ -165,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
   const int tn = slot % g.ntiles, tm = (slot / g.ntiles) * 8 + xcd;
   if (tm >= g.mtiles) return;
+  X6_TL(0);
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = g.M, N = g.N, K = g.K;
   const float* A = g.A + (size_t)z * g.a_bstride;
@@ -306,10 +319,12 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   dma_a(0); dma_b(0);
   if (nk > 1) { dma_a(1); dma_b(1); }
   if (nk > 2) dma_a(2);
+  X6_TL(1);
   if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + BI_MIN) : "memory");
   else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + BI_MIN) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  X6_TL(2);
   read_raw(0, 0); read_b(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 44; ++i) op(i);
@@ -325,6 +340,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   }
   half(0, true, nk - 1, 1);
   half(1, false, 0, 0);
+  X6_TL(3);
 
   // X6_BNBWD: the producer's y values of this lane's 16 rows x NI columns are fetched NOW, ahead of the tile's stores and the
   // barrier, so that their latency is off the workgroup's tail
@@ -364,6 +380,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
       if (m < M && n < N) C[(size_t)m * g.ldc + n] = acc[j][q];
     }
   }
+  X6_TL(4);
+#ifdef X6_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  X6_TL(5);
+#endif
   if (EPI == X6_BNBWD) {
     // Backward statistics of the PRODUCER's BN (see X6Args): per lane the 16 rows of its column, y read with the same
     // 128-byte row segments the tile was stored with; the two half-waves and the four waves are combined through LDS in
@@ -939,6 +960,12 @@ inline size_t x6_plane_units(int n, int k, int nb) {       // uint4 units of one
 
 }  // namespace gkg
 using namespace gkg;
+
+#ifdef X6_TIMELINE
+extern "C" int gkg_debug_set_x6_timeline(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(x6_tl_buf), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad) {
   if (x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0) return 0;

@@ -15,7 +15,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "cfg4":        # GKGNet-576 (pvig_s) sta
     SHAPES = [(663552, 80, 80, 1), (663552, 160, 80, 1), (663552, 80, 320, 1), (663552, 320, 80, 1), (165888, 160, 160, 1),
               (165888, 320, 160, 1), (165888, 160, 640, 1), (165888, 640, 160, 1), (41472, 400, 400, 1), (41472, 800, 400, 1),
               (41472, 400, 1600, 1), (41472, 1600, 400, 1), (10368, 640, 640, 1), (10368, 1280, 640, 1)]
+if len(sys.argv) > 1 and sys.argv[1] == "coltiles":    # one vs two column tiles at the stage-1 row count
+    SHAPES = [(663552, 80, 64, 1), (663552, 80, 80, 1), (663552, 80, 128, 1), (663552, 160, 64, 1), (663552, 160, 80, 1),
+              (663552, 160, 128, 1), (663552, 320, 64, 1), (663552, 320, 80, 1), (663552, 64, 320, 1), (663552, 80, 320, 1)]
 WGRAD_ONLY = len(sys.argv) > 1 and sys.argv[1] == "wgrad"
+X6_ONLY = bool(os.environ.get("X6_ONLY"))               # forward / dgrad of the own kernels only (A/B of two library builds)
 if WGRAD_ONLY:                                         # every weight gradient of the cfg2 step (Grapher rows 10 368, label rows 2 560)
     SHAPES = [(10368, 320, 320, 1), (10368, 160, 160, 4), (10368, 640, 320, 1), (10368, 320, 1280, 1), (10368, 1280, 320, 1),
               (2560, 320, 320, 1), (2560, 160, 160, 4), (2560, 640, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1)]
@@ -60,13 +64,15 @@ for R, cin, cout, nb in SHAPES:
     pf, pd = planes(w, nb, cout, cin)
     stats = fused._stats_scratch(x.device)
     dw = torch.zeros(nb, cout, cin, device="cuda")
-    vw = timeit(lambda: fused._wgrad(dy[0], x[0]) if nb == 1 else fused._wgrad_grouped(dy, x))
+    vw = 0.0 if X6_ONLY else timeit(lambda: fused._wgrad(dy[0], x[0]) if nb == 1 else fused._wgrad_grouped(dy, x))
     xw = timeit(lambda: (dw.zero_(), lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(),
                                                               R, cin, cout, nb, st())))
     print(f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: wgrad vendor (split-K bmm) {vw:6.1f}  x6 (incl. memset) {xw:6.1f}", flush=True)
     if WGRAD_ONLY:
         continue
-    line = f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: vendor fwd {timeit(lambda: torch.bmm(x, w.transpose(1, 2), out=y)):6.1f} dgrad {timeit(lambda: torch.bmm(dy, w, out=dx)):6.1f} |"
+    line = f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}:"
+    if not X6_ONLY:
+        line += f" vendor fwd {timeit(lambda: torch.bmm(x, w.transpose(1, 2), out=y)):6.1f} dgrad {timeit(lambda: torch.bmm(dy, w, out=dx)):6.1f} |"
     for ni in ("auto",):
         f = timeit(lambda: lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 0,
                                                     *([None] * 10), 0.0, 0.0, None, st()))
