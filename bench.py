@@ -335,6 +335,9 @@ def run_backbone(args):
         params = [p for p in list(net.parameters()) + list(head.parameters()) if p.requires_grad]
         bucket = parallel.GradBucket(params)
         opt = build_optimizer([net, head])
+        if args.foreach_optimizer:               # A/B: the multi-tensor (foreach) clip + AdamW passes
+            opt = torch.optim.AdamW([dict(params=g["params"], weight_decay=g["weight_decay"]) for g in opt.param_groups],
+                                    lr=1e-4, betas=(0.9, 0.999), eps=1e-8, fused=False, foreach=True)
         tgt = (torch.rand(B, kw["n_classes"], generator=gen) < 0.04).float().to(dev)
         bucket.install_overlap_hooks()       # chunk all-reduces start during the backward (the reference's DDP reducer)
 
@@ -343,7 +346,10 @@ def run_backbone(args):
             losses = head.forward_train(net(img), tgt)
             (losses["bce_loss"] + losses["asy_loss"]).backward()
             bucket.wait()
-            torch.nn.utils.clip_grad_norm_(params, 5.0)
+            if args.foreach_optimizer:
+                torch.nn.utils.clip_grad_norm_(params, 5.0)
+            else:
+                bucket.clip_grad_norm_(5.0)          # the same clipping as a norm + a scale launch on the flat buffer
             opt.step()
         el = timed(train_step)
         kernels, work = profile(train_step, 1)
@@ -423,6 +429,7 @@ def main():
                          "backbone hands over: the blocks then chain without layout kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="keep the GEMM library's default kernel selection")
+    ap.add_argument("--foreach-optimizer", action="store_true", help="cfg4: torch's multi-tensor clip_grad_norm_ + foreach AdamW instead of the flat-buffer clip + fused AdamW")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--knn", default="both", choices=["both", "exact", "bf16"],
                     help="cfg3 / cfg5 (bf16 autocast): which k-NN legs to time — exact (the bit-exact index contract, same graphs as "

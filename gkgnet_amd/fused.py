@@ -75,7 +75,8 @@ _ENABLED = _env_list("GKG_ENABLE")
 KNN_BF16 = "knn_bf16" in _ENABLED
 
 
-from .planes import _WeightPlanes, _PLANES, _planes, refresh_weight_planes      # noqa: E402,F401  (x6 weight planes: planes.py)
+from .planes import (_WeightPlanes, _PLANES, _planes, refresh_weight_planes, param_version,      # noqa: E402,F401  (x6 weight
+                     mark_parameters_updated)                                                 # planes + staleness: planes.py)
 
 
 def _vendor_tuned() -> bool:
@@ -305,8 +306,8 @@ def _w16_of(conv) -> torch.Tensor:
     whenever the parameter is updated in place or replaced."""
     w = conv.weight
     ent = getattr(conv, "_gkg_w16", None)
-    if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
-        ent = (w._version, w.data_ptr(), w.detach().to(torch.bfloat16))
+    if ent is None or ent[0] != param_version(w) or ent[1] != w.data_ptr():
+        ent = (param_version(w), w.data_ptr(), w.detach().to(torch.bfloat16))
         conv._gkg_w16 = ent
     return ent[2]
 
@@ -322,7 +323,7 @@ def _folded_of(conv, bn):
     # the running statistics can change behind the version counters (layers._StatsEpoch): norm layers without the epoch
     # counter are never cached
     epoch = getattr(bn, "_gkg_epoch", None)
-    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps, epoch)
+    key = tuple((param_version(t), t.data_ptr()) for t in srcs) + (bn.eps, epoch)
     ent = getattr(conv, "_gkg_fold", None)
     if ent is None or ent[0] != key or epoch is None:
         with torch.no_grad():
@@ -430,7 +431,7 @@ def _bn_eval_ac(lib, bn, bias, n):
     small kernel) only when one of the tensors it derives from changed — an inference forward launched it per layer."""
     srcs = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([bias] if bias is not None else [])
     epoch = getattr(bn, "_gkg_epoch", None)
-    key = tuple((t._version, t.data_ptr()) for t in srcs) + (bn.eps, n, epoch)
+    key = tuple((param_version(t), t.data_ptr()) for t in srcs) + (bn.eps, n, epoch)
     ent = getattr(bn, "_gkg_eval_ac", None)
     if ent is None or ent[0] != key or epoch is None or torch.is_grad_enabled():
         a = torch.empty(n, dtype=_F32, device=bn.weight.device)
@@ -1194,14 +1195,14 @@ def _mr_planes_of(conv) -> torch.Tensor:
     (include/gkg_hip.h), cached on the module and rebuilt when the parameter changes."""
     w = conv.weight
     ent = getattr(conv, "_gkg_mrplanes", None)
-    if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
+    if ent is None or ent[0] != param_version(w) or ent[1] != w.data_ptr():
         co, ci = w.shape[0] // 4, w.shape[1]
         ci_pad, co_pad = (ci + 15) // 16 * 16, (co + 31) // 32 * 32
         W = torch.zeros((4, co_pad, ci_pad), dtype=torch.bfloat16, device=w.device)
         W[:, :co, :ci] = w.detach().reshape(4, co, ci).to(torch.bfloat16)
         planes = W.view(4, co_pad, ci_pad // 8, 8).permute(0, 2, 1, 3).contiguous()
         assert planes.numel() * 2 == _lib.load().gkg_mr_linear_planes_bytes(4 * ci // 2)
-        ent = (w._version, w.data_ptr(), planes)
+        ent = (param_version(w), w.data_ptr(), planes)
         conv._gkg_mrplanes = ent
     return ent[2]
 

@@ -185,6 +185,15 @@ class GradBucket:
                     self._zero.difference_update(id(q) for q in plist)
             self._issued += 1
 
+    def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6):
+        """``torch.nn.utils.clip_grad_norm_(params, max_norm)`` (the reference's ``grad_clip`` of the optimizer hook,
+        configs/gkgnet/gkgnet_coco_576.py:126) over every gradient of the bucket, as a norm and a scale launch on the flat
+        buffer instead of multi-tensor passes over ~300 parameters.  Call after :meth:`pack` / :meth:`wait` (all gradients
+        resident; slots of parameters without a gradient hold zeros).  Returns the total norm (a 0-d tensor)."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + eps), max=1.0))
+        return total
+
     def all_reduce(self, async_op: bool = False):
         """Average over ranks with ONE collective over the whole buffer.  No-op in a single process."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

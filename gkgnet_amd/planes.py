@@ -11,6 +11,33 @@ from . import _lib
 from .ops import _ptr, _stream
 
 
+# Parameter updates that move no version counter — torch.optim's fused=True kernels (measured: AdamW(fused=True).step()
+# leaves p._version where it was), updates through p.data, third-party fused optimisers — would leave every cache that is
+# keyed on ._version stale (weight planes, bf16 / BN-folded weight copies).  A process-wide optimiser-step counter is part
+# of those keys: every torch.optim step bumps it through the global post-step hook; anything else that rewrites
+# parameters behind autograd's back calls mark_parameters_updated().
+_STEP = [0]
+
+
+def _on_optimizer_step(*_args, **_kwargs):
+    _STEP[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook      # noqa: E402
+
+_register_step_hook(_on_optimizer_step)
+
+
+def mark_parameters_updated():
+    """Tell the library that parameters were modified in a way autograd's version counters did not see."""
+    _STEP[0] += 1
+
+
+def param_version(t):
+    """Staleness token of a parameter-derived cache: (version counter, optimiser-step counter)."""
+    return (t._version, _STEP[0])
+
+
 class _WeightPlanes:
     """bf16 hi / mid / lo planes (forward and dgrad orientation) of every projection weight that went through the x6
     kernels on one device.  The planes are a function of the parameter values only, so they are refreshed when a
@@ -93,7 +120,7 @@ class _WeightPlanes:
                        "gkg_x6_prep_weights")
         for e in self.entries.values():
             w = e["ref"]()
-            e["version"] = -1 if w is None else w._version
+            e["version"] = -1 if w is None else param_version(w)
 
     def get(self, lib, weight, nb, cout, cin, need_f=True, need_d=True):
         e = self.entries.get(id(weight))
@@ -107,8 +134,8 @@ class _WeightPlanes:
             if cap != self.capture_id:
                 self.capture_id = cap
                 self.refresh(lib)
-        elif e["version"] != weight._version:
-            self.refresh(lib)                    # eager call, stale by the version counter (an eager optimiser step)
+        elif e["version"] != param_version(weight):
+            self.refresh(lib)                    # eager call, stale by the version / step counters (an eager optimiser step)
         elif self.captured:
             # graphs exist: any replay since the last eager call may have moved this weight (a captured optimiser step)
             # without a counter moving, and it may do so again between any two eager calls

@@ -279,3 +279,26 @@ def test_release_prezero_marks_slots_clean_once():
     bucket.release()                                    # no pre-zero: the view is not marked (its contents are stale)
     b = grad_view(w)
     assert b is not None and not getattr(b, "_gkg_zero", False)
+
+
+def test_bucket_clip_grad_norm_matches_torch():
+    """GradBucket.clip_grad_norm_ (norm + scale on the flat buffer) against torch.nn.utils.clip_grad_norm_ on a copy:
+    clipping and non-clipping thresholds, with one parameter that receives no gradient."""
+    import copy
+    from gkgnet_amd.parallel import GradBucket
+    for max_norm in (0.05, 1e6):
+        torch.manual_seed(3)
+        net = _net()
+        ref = copy.deepcopy(net)
+        x = torch.randn(5, 4, 3, 3)
+        bucket = GradBucket(net.parameters())
+        bucket.release()
+        net[:4](x).square().mean().backward()               # the last conv stays unused: its slots hold zeros
+        bucket.pack()
+        total = bucket.clip_grad_norm_(max_norm)
+        ref[:4](x).square().mean().backward()
+        used = [p for p in ref.parameters() if p.grad is not None]
+        want = torch.nn.utils.clip_grad_norm_(used, max_norm)
+        torch.testing.assert_close(total, want, rtol=1e-6, atol=0)
+        for p, q in zip(net.parameters(), ref.parameters()):
+            torch.testing.assert_close(p.grad, q.grad if q.grad is not None else torch.zeros_like(q), rtol=1e-6, atol=1e-12)
