@@ -164,9 +164,15 @@ __device__ long long* x6_tl_buf;
 #define X6_TL(p) do {} while (0)
 #endif
 
-template <int NI, int EPI>
+// BN: columns per tile — 32 NI, or 80 with NI = 3 (the last 32-column block is half used).  Every GKGNet width is a multiple of
+// 80, so 80-column tiles cover 80 / 160 outputs with one / two workgroups per row block where 64-column tiles need two / three:
+// at the short-K stage-1 / stage-2 shapes the launch time follows the number of requests (A is fetched once per column tile,
+// B once per tile and K-step), not the arithmetic (profiles/r04_x6_one_vs_two_column_tiles.txt).
+template <int NI, int EPI, int BN = 32 * NI>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
-  constexpr int BM = 128, BN = 32 * NI, BK = 32, SA = 3;
+  static_assert(BN <= 32 * NI && BN > 32 * (NI - 1) && BN % 16 == 0 && (12 * BN * 16) % 1024 == 0, "tile width");
+  constexpr int BM = 128, BK = 32, SA = 3;
+  constexpr bool PARTIAL = BN != 32 * NI;                // lanes r >= BN - 32 (NI - 1) of the last block hold no column
   constexpr int A_STAGE = 4 * 4096, B_STAGE = 12 * BN * 16, B_BASE = SA * A_STAGE;
   constexpr int PIECES = 12 * BN * 16 / 1024;            // 1-KiB pieces of one B stage image
   constexpr int BI = (PIECES + 3) / 4;                   // ... per wave per K-step (wave w: pieces w, w+4, ...), and the
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
       pav[j] = pcv[j] = pmv[j] = piv[j] = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) yv[j][q] = 0.f;
-      if (n < N) {
+      if (n < N && (!PARTIAL || j * 32 + r < BN)) {
         const int pq = n / g.pco, pi = n - pq * g.pco;
         const size_t po = (size_t)pq * g.pco + pi;
         pav[j] = g.pa[po]; pcv[j] = g.pc[po]; pmv[j] = g.pmean[po]; piv[j] = g.pinvstd[po];
@@ -374,10 +380,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] += accs[j][q];
     const int n = n0 + j * 32 + r;
+    const bool mine = n < N && (!PARTIAL || j * 32 + r < BN);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = m0 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (m < M && n < N) C[(size_t)m * g.ldc + n] = acc[j][q];
+      if (m < M && mine) C[(size_t)m * g.ldc + n] = acc[j][q];
     }
   }
   X6_TL(4);
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + j * 32 + r;
       float s0 = 0.f, s1 = 0.f;
-      if (n < N) {
+      if (n < N && (!PARTIAL || j * 32 + r < BN)) {
         const float av = pav[j], cv = pcv[j], mv = pmv[j], iv = piv[j];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
       }
       s0 += __shfl_xor(s0, 32);
       s1 += __shfl_xor(s1, 32);
-      if (h == 0) { float* o = red + ((w * BN) + j * 32 + r) * 2; o[0] = s0; o[1] = s1; }
+      if (h == 0 && (!PARTIAL || j * 32 + r < BN)) { float* o = red + ((w * BN) + j * 32 + r) * 2; o[0] = s0; o[1] = s1; }
     }
     __syncthreads();
     if (tid < BN && n0 + tid < N) {
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
       m2 += rbase + (q & 3) + 8 * (q >> 2) + 4 * h < M ? d * d : 0.f;
     }
     m2 += __shfl_xor(m2, 32);
-    if (h == 0) { float* o = red + ((w * BN) + j * 32 + r) * 2; o[0] = mean; o[1] = m2; }
+    if (h == 0 && (!PARTIAL || j * 32 + r < BN)) { float* o = red + ((w * BN) + j * 32 + r) * 2; o[0] = mean; o[1] = m2; }
   }
   __syncthreads();
   if (tid < BN && n0 + tid < N) {
@@ -462,23 +469,23 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   }
 }
 
-template <int NI, int EPI>
+template <int NI, int EPI, int BN = 32 * NI>
 static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
-  constexpr int BN = 32 * NI;
   a.mtiles = (a.M + 127) / 128;
   a.ntiles = (a.N + BN - 1) / BN;
-  const size_t sh = 3 * 4 * 4096 + 2 * 12 * BN * 16;
+  // A ring + two B stages (+ slack: the unused lanes of a partial last block read past their image row)
+  const size_t sh = 3 * 4 * 4096 + 2 * 12 * BN * 16 + (BN != 32 * NI ? 512 : 0);
   // the attribute is per DEVICE (a per-process guard left a second GPU of the same process without it — ADVICE r3)
   static bool once[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !once[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_x6_kernel<NI, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_x6_kernel<NI, EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) once[dev] = true;
   }
   const int groups = (a.mtiles + 7) / 8;
-  hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
+  hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI, BN>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
   return hipGetLastError();
 }
 
@@ -491,6 +498,13 @@ static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_GEMM_X6, st, 2.0 * a.M * a.N * a.K * nb);
   const int mt = (a.M + 127) / 128;
   int ni = (long long)mt * ((a.N + 63) / 64) * nb < 160 ? 1 : 2;
+  // 80 output columns on many rows (GKGNet-576 stage 1): ONE 80-column tile per row block instead of a full and a quarter
+  // 64-column tile — 663 552 rows: 80 -> 80 171 -> 133 us, + statistics 208 -> 161, 320 -> 80 345 -> 279, dgrad 320 <- 80
+  // 351 -> 279.  Wider outputs measured equal or slower on 80-column tiles (160: +-3 %, 320 / 400 / 640: 3-8 % slower:
+  // profiles/r04_x6_80_column_tiles_ab.txt); the BN-backward epilogue's registers do not fit two waves per SIMD there.
+  if constexpr (EPI != X6_BNBWD) {
+    if (a.N == 80 && ni == 2) return x6_launch_ni<3, EPI, 80>(a, nb, st);
+  }
   if (ni == 1) return x6_launch_ni<1, EPI>(a, nb, st);
   return x6_launch_ni<2, EPI>(a, nb, st);
 }

@@ -29,7 +29,10 @@ def _rel(a, ref, scale):
 
 # (R, cin, cout, nb): cfg2's layers, ragged rows, K not a multiple of 32 (36, 400), N below one tile, grouped (nb = 4)
 SHAPES = [(10368, 320, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1), (10368, 160, 160, 4), (777, 36, 40, 1),
-          (4100, 400, 400, 1), (129, 64, 8, 2), (19, 16, 8, 1), (128, 32, 64, 1)]
+          (4100, 400, 400, 1), (129, 64, 8, 2), (19, 16, 8, 1), (128, 32, 64, 1),
+          # 80 output columns on >= 10 240 rows: the 80-column tile form (forward of cout = 80, dgrad of cin = 80), ragged rows,
+          # K = 100 (tail step), grouped
+          (10368, 80, 80, 1), (12001, 160, 80, 1), (10300, 80, 320, 1), (11000, 100, 80, 1), (10250, 80, 80, 2)]
 
 
 @pytest.mark.parametrize("R,cin,cout,nb", SHAPES)
@@ -118,10 +121,14 @@ def test_column_slices_and_row_pitch():
 
 def test_train_statistics_epilogue():
     """train = 1: BN scale / shift / saved statistics / running statistics from the epilogue's fp64 column sums."""
+    _check_train_statistics(3001, 96, 72)
+    _check_train_statistics(12001, 96, 80)                           # the 80-column tile form
+
+
+def _check_train_statistics(R, cin, cout):
     from gkgnet_amd import _lib, fused
     lib = _lib.load()
     torch.manual_seed(5)
-    R, cin, cout = 3001, 96, 72
     x = torch.randn(R, cin, device="cuda") + 3.0                     # a large mean against the spread
     w = torch.randn(cout, cin, device="cuda") * 0.1
     pf, _ = _planes(lib, w, 1, cout, cin)
