@@ -226,6 +226,10 @@ def run_backbone(args):
     kind = spec["kind"]
     layers.norm_cfg["type"] = "SyncBN" if (args.sync_bn and world > 1 and kind == "train") else "BN"
     if not args.no_tune:                 # library GEMM selection per shape, tuned during the warm-up passes
+        # ... and the library CONVOLUTION selection (the backbone's 3x3 stem / downsample layers run on MIOpen): the
+        # reference's own `cudnn_benchmark` config switch (tools/train.py:105-107, tools/test.py:141-143) — MIOpen times its
+        # applicable solvers per shape on first use.  cfg3 21.6 -> 19.3 ms, cfg4 86.8 -> 82.5 ms on one box.
+        torch.backends.cudnn.benchmark = True
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(True)
@@ -394,6 +398,8 @@ def run_backbone(args):
                                knn=("index-exact contract (library default; same graphs as fp32)" if headline != "bf16" else
                                     "bf16 contraction (opt-in GKG_KNN_BF16_CONTRACT)"),
                                gemm_selection="library default" if args.no_tune else "TunableOp pass in the warm-up",
+                               conv_selection=("library default (immediate mode)" if args.no_tune else
+                                               "MIOpen find in the warm-up (cudnn.benchmark, the reference's cudnn_benchmark switch)"),
                                grad_allreduce=("n/a (inference)" if kind == "forward" else
                                                ("none (1 GPU)" if world == 1 else
                                                 f"chunked {'RCCL' if backend == 'nccl' else backend} all-reduces started from "
@@ -428,7 +434,7 @@ def main():
                          "layers hand to a dropped-in Grapher) or channels_last (what the preceding block of gkgnet_amd's "
                          "backbone hands over: the blocks then chain without layout kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tune", action="store_true", help="keep the GEMM library's default kernel selection")
+    ap.add_argument("--no-tune", action="store_true", help="keep the GEMM (and, for the backbone workloads, convolution) libraries' default kernel selection")
     ap.add_argument("--foreach-optimizer", action="store_true", help="cfg4: torch's multi-tensor clip_grad_norm_ + foreach AdamW instead of the flat-buffer clip + fused AdamW")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--knn", default="both", choices=["both", "exact", "bf16"],
