@@ -358,6 +358,25 @@ def run_backbone(args):
         el = timed(train_step)
         kernels, work = profile(train_step, 1)
         legs["train"] = (el, kernels, work)
+        if args.amp != "none":
+            # Extra leg: the recipe the reference ships (configs/gkgnet/gkgnet_coco_576.py:146, fp16 AMP with a dynamic loss
+            # scale: mmcls/core/fp16/hooks.py) — forward + loss under autocast, scaled backward, unscale, clip, step.
+            # The graph kernels, BN statistics and every backward GEMM stay fp32 (tests/test_hip_autocast_trainstep.py, F17).
+            amp_dtype = torch.float16 if args.amp == "fp16" else torch.bfloat16
+            scaler = torch.amp.GradScaler("cuda", enabled=args.amp == "fp16")
+
+            def amp_step():
+                bucket.release(prezero=True)
+                with torch.autocast("cuda", dtype=amp_dtype):
+                    losses = head.forward_train(net(img), tgt)
+                    loss = losses["bce_loss"] + losses["asy_loss"]
+                scaler.scale(loss).backward()
+                bucket.wait()
+                scaler.unscale_(opt)
+                bucket.clip_grad_norm_(5.0)
+                scaler.step(opt)
+                scaler.update()
+            legs["amp"] = (timed(amp_step), None, None)
         headline = "train"
         step_desc = "forward + ASL x10 + smoothed BCE + backward + grad all-reduce + clip 5.0 + AdamW"
         dtype = "f32"
@@ -406,6 +425,8 @@ def run_backbone(args):
                                                 f"post-accumulate hooks during backward"))),
                    roofline=roof, roofline_hbm=roof_hbm, hip_kernels=kernels,
                    peak_mem_GiB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), model_build_s=round(build_s, 1))
+        if "amp" in legs:
+            res[f"ms_per_step_amp_{args.amp}"] = round(1e3 * legs["amp"][0] / steps, 3)
         if kind == "forward":
             for name, (e2, k2, w2) in legs.items():
                 res[f"ms_per_step_knn_{name}"] = round(1e3 * e2 / steps, 3)
@@ -435,6 +456,8 @@ def main():
                          "backbone hands over: the blocks then chain without layout kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="keep the GEMM (and, for the backbone workloads, convolution) libraries' default kernel selection")
+    ap.add_argument("--amp", choices=["none", "fp16", "bf16"], default="none",
+                    help="cfg4: also time the train step under autocast (fp16 with a dynamic loss scale = the reference's shipped recipe); reported beside the fp32 value")
     ap.add_argument("--foreach-optimizer", action="store_true", help="cfg4: torch's multi-tensor clip_grad_norm_ + foreach AdamW instead of the flat-buffer clip + fused AdamW")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--knn", default="both", choices=["both", "exact", "bf16"],
