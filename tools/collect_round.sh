@@ -21,7 +21,8 @@ bash tools/prof_run.sh ${TAG}_notune --steps 20 --warmup 5 --no-tune > /dev/null
 cd /tmp && export TMPDIR=/tmp
 for cfg in cfg3 cfg5 cfg4; do
   rm -rf /tmp/p_$cfg
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$cfg -o run -- python $R/bench.py --workload $cfg --no-cpu-baseline --steps 3 --warmup 2 > $R/gpurun_out/${TAG}_final_${cfg}_prof.log 2>&1
+  knn=""; [ $cfg != cfg4 ] && knn="--knn exact"          # the forward workloads: the default (index-exact) leg only, eager launches
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$cfg -o run -- python $R/bench.py --workload $cfg --no-cpu-baseline --steps 3 --warmup 2 --no-graph $knn > $R/gpurun_out/${TAG}_final_${cfg}_prof.log 2>&1
   win=60; [ $cfg = cfg4 ] && win=95; [ $cfg = cfg5 ] && win=110
   python $R/tools/prof_detail.py /tmp/p_$cfg $win 60 > $R/gpurun_out/${TAG}_final_${cfg}_per_kernel.txt
 done
