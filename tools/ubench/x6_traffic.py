@@ -34,6 +34,14 @@ def run():
             flush.add_(1.0)                  # evict the operands (L2 + memory-side cache)
             _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, 1, 0,
                                                 *([None] * 10), 0.0, 0.0, None, None), "fwd")
+        # the weight gradient of the same layer: dW = dY^T X over the R rows (reads both activations, writes a few KB)
+        dy = torch.randn(R, cout, device="cuda")
+        dw = torch.zeros(cout, cin, device="cuda")
+        for _ in range(3):
+            flush.add_(1.0)
+            dw.zero_()
+            _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin, cout,
+                                               1, None), "wgrad")
         torch.cuda.synchronize()
 
 
@@ -60,6 +68,12 @@ def report(dfetch, dwrite):
             vals = [v for n, g, v in x6[3 * i:3 * i + 3]]
             if vals:
                 out.setdefault((R, cin, cout), {})[counter] = vals[-1] * 1024 * k
+        wg = [(n, g, v) for _, n, g, v in rows if "wgrad_x6" in n and "wgrad_x6_kernel" not in n]      # the main (DMA) launch of each call
+        for i, (R, cin, cout) in enumerate(SHAPES):
+            vals = [v for n, g, v in wg[3 * i:3 * i + 3]]
+            if vals and counter == "FETCH_SIZE":
+                print(f"   wgrad R={R:6d} {cin:3d}x{cout:3d}: fetched {vals[-1] * 1024 * k / 1e6:7.1f} MB, algorithmic {R * (cin + cout) * 4 / 1e6:7.1f} "
+                      f"-> {vals[-1] * 1024 * k / (R * (cin + cout) * 4):.2f}")
     for (R, cin, cout), v in out.items():
         rd, wr = v.get("FETCH_SIZE", float("nan")), v.get("WRITE_SIZE", float("nan"))
         print(f"R={R:6d} {cin:3d}->{cout:3d}: fetched {rd / 1e6:7.1f} MB (algorithmic {R * cin * 4 / 1e6:6.1f} + planes), written {wr / 1e6:7.1f} MB "
