@@ -469,7 +469,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
 #ifdef KNN_TIMELINE
   if (p.S == 1 && gkg_knn_tl_buf) a.part_v = (float*)gkg_knn_tl_buf;
 #endif
-  a.rp_major = 0;
+  a.rp_major = 0; a.rp_group = 1;
   // bf16 form with a positional bias at least twice the size of the keys it meets (64 x 4 B of relative_pos against
   // 2 x cp16 B of a key per (query tile, key) pair, i.e. c <= 64) and enough query tiles to spread over the XCDs: map the
   // workgroups relative_pos-major (see the kernel).  Measured (tools/bench_knn_bf.py, us): pvig_m stages 1-2 6031 -> 5101,
@@ -477,6 +477,18 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   if (bf && relpos && !pf && a.nqt >= 64 && BG >= 8 && (size_t)QT * 4 >= (size_t)cp16 * 2 * 2) {
     a.rp_major = 1;
     grid = dim3((unsigned)(((a.nqt + 7) / 8) * 8 * BG), 1, p.S);
+  }
+  // Exact forms (fp32 tile kernel, prefilter kernel) with a positional bias that is far beyond an L2 (>= 8 MB: GKGNet-576
+  // stage 1: 107 MB, stage 2: 27 MB; pvig_m stage 1: 340 MB): problem-major order streams the WHOLE bias once per problem
+  // (counters, pvig_s stage 1: 7.5 GB of L2 misses per launch at B*G = 64 — the launch ran at the speed of that stream).
+  // Interleave the XCD's problems in groups whose key sets stay in the L2 (<= 2 MB): the bias is fetched once per group.
+  if (relpos && a.rp_major == 0 && p.S == 1 && BG >= 16 && (size_t)N * M * 4 >= ((size_t)8 << 20)) {
+    const size_t key_bytes = (size_t)M * (pf ? (size_t)cp16 * 4 : (size_t)p.cpad * 4);
+    const int bpx = (BG + 7) / 8;
+    int g = (int)(((size_t)2 << 20) / (key_bytes ? key_bytes : 1));
+    g = g > bpx ? bpx : g;
+    while (g >= 2 && bpx % g) --g;               // a divisor of the XCD's problem count: the grid (and the flag array) keep their size
+    if (g >= 2) { a.rp_major = 2; a.rp_group = g; }
   }
   if (pf) {
     a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;

@@ -124,7 +124,9 @@ struct KnnArgs {
   int BG, cpad, N, M, k, dilation, kd;
   int splits, tiles_per_split;
   int nqt;              // query tiles per problem
-  int rp_major;         // workgroup -> (problem, query tile) map: 1 = all problems of one query tile adjacent on one XCD
+  int rp_major;         // workgroup -> (problem, query tile) map (knn_map): 0 problem-major, 1 = all problems of one query
+                        // tile adjacent on one XCD, 2 = groups of rp_group problems of an XCD interleaved per query tile
+  int rp_group;
   const uint16_t* xb;   // BF mode: (BG, N, cp16) / (BG, M, cp16) normalised bf16 token-major copies (prefilter: hi planes)
   const uint16_t* yb;
   int cp16;
@@ -136,6 +138,34 @@ struct KnnArgs {
                           // tile it cannot settle; knn_tile_kernel: when non-null, only flagged workgroups run (clean-up pass)
 };
 
+
+// XCD-aware workgroup -> (problem bg, query tile qt) map shared by knn_tile_kernel and knn_pf_kernel (the clean-up pass of the
+// latter reads the flags the former wrote per workgroup id, so both must agree).  Workgroups are dealt round-robin over the 8
+// XCDs, each with its own L2; lin & 7 is the XCD, jj = lin >> 3 the position in that XCD's dispatch order.
+//   0  problem-major: the query tiles of ONE problem are adjacent — its keys enter that L2 once, every problem streams the whole
+//      (N, M) positional bias again (B*G x its size per launch: fine while the bias is small);
+//   1  bias-major: ALL problems of one query tile are adjacent — the tile's 64 rows of bias enter the L2 once, the keys of every
+//      problem re-enter per query tile (narrow groups with a huge bias: pvig_m stage 1, bf16 form);
+//   2  interleaved: an XCD owns the problems bg = xcd (mod 8) as in 0, but walks them in groups of rp_group — for every query
+//      tile the group's problems are adjacent.  The bias rows are fetched once per group instead of once per problem, and the
+//      group's keys (rp_group key sets, sized to stay in the L2) are still reused across the query tiles.
+// Returns false for the padding workgroups of the grid.  Placement only affects speed.
+__device__ __forceinline__ bool knn_map(const KnnArgs& a, int lin, int& bg, int& qt) {
+  const int xcd = lin & 7, jj = lin >> 3, nqt = a.nqt;
+  if (a.rp_major == 1) {
+    bg = jj % a.BG;
+    qt = (jj / a.BG) * 8 + xcd;
+  } else if (a.rp_major == 2) {
+    const int g = a.rp_group, per = nqt * g;
+    const int grp = jj / per, rem = jj - grp * per;
+    qt = rem / g;
+    bg = (grp * g + (rem - qt * g)) * 8 + xcd;
+  } else {
+    bg = (jj / nqt) * 8 + xcd;
+    qt = jj % nqt;
+  }
+  return bg < a.BG && qt < nqt;
+}
 
 // gkg_knn_pf.hip: launches knn_pf_kernel for list size KD (9, 16, 18, 27 or 36)
 hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t st);

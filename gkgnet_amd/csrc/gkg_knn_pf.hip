@@ -67,11 +67,10 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqt = a.nqt;
   const int lin = blockIdx.x;
-  const int xcd = lin & 7, jj = lin >> 3;
-  const int bg = (jj / nqt) * 8 + xcd;               // XCD-aware map, as knn_tile_kernel
-  if (bg >= a.BG) return;
+  int bg, qt;
+  if (!knn_map(a, lin, bg, qt)) return;              // XCD-aware map shared with knn_tile_kernel (gkg_knn_common.h)
   KNN_TL(0);
-  const int n0 = (jj % nqt) * QT;
+  const int n0 = qt * QT;
   const int N = a.N, M = a.M, cpad = a.cpad, cp16 = a.cp16, S16 = cp16 >> 4;
   const int lane_n = n0 + lane;
   const int nc = lane_n < N ? lane_n : N - 1;

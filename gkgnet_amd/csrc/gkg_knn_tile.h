@@ -55,14 +55,10 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   const int lin = blockIdx.x;
   KNN_TL(0);
   if (a.wg_flags && a.wg_flags[lin] == 0) return;   // clean-up pass behind knn_pf_kernel: only the tiles it flagged
-  const int xcd = lin & 7, jj = lin >> 3;
-  // rp_major (launches whose positional bias outweighs their keys: narrow groups): the B*G problems of ONE query tile are
-  // adjacent on one XCD instead — its 64 rows of relative_pos (64 x M x 4 B, the same for every problem) enter that L2 once
-  // instead of once per problem (pvig_m stage 1: 43.5 GB of relative_pos per launch from the MALL -> 0.34 GB, against
-  // 5.4 GB of keys that now re-enter per query tile)
-  const int bg = a.rp_major ? jj % a.BG : (jj / nqt) * 8 + xcd;
-  const int qt = a.rp_major ? (jj / a.BG) * 8 + xcd : jj % nqt;
-  if (bg >= a.BG || qt >= nqt) return;          // grid is padded to a multiple of 8 problems / query tiles (uniform exit)
+  // the map (gkg_knn_common.h): problem-major, bias-major (pvig_m stage 1, bf16 form: 43.5 GB of relative_pos per launch from
+  // the MALL -> 0.34 GB, against 5.4 GB of keys that now re-enter per query tile) or interleaved
+  int bg, qt;
+  if (!knn_map(a, lin, bg, qt)) return;         // the grid is padded (uniform exit)
   const int split = blockIdx.z;
   const int n0 = qt * QT;
   const int N = a.N, M = a.M, cpad = a.cpad;
