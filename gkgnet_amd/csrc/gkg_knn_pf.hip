@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqt = a.nqt;
   const int lin = blockIdx.x;
   int bg, qt;
   if (!knn_map(a, lin, bg, qt)) return;              // XCD-aware map shared with knn_tile_kernel (gkg_knn_common.h)

@@ -51,7 +51,6 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // its own L2; all query tiles of one (b,g) problem stream the SAME keys, so they are given linear ids that are
   // congruent mod 8 (same XCD) and adjacent in dispatch order: the keys are then fetched into one L2 once instead
   // of once per query tile (measured: FETCH_SIZE 53 -> see profiles/).  Placement only affects speed.
-  const int nqt = a.nqt;
   const int lin = blockIdx.x;
   KNN_TL(0);
   if (a.wg_flags && a.wg_flags[lin] == 0) return;   // clean-up pass behind knn_pf_kernel: only the tiles it flagged
