@@ -10,7 +10,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GKG_HIP_LIB") or os.path.join(PKG, "libgkg_hip.so")   # GKG_HIP_LIB: same-box A/B of two builds (tools)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 KNN_BF16_CONTRACT = 2
@@ -64,10 +64,17 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
-           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled")
+           "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
+           "gkg_linear_wgrad_x6_batch")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
+
+
+class WgradProblem(C.Structure):
+    """include/gkg_hip.h GkgWgradProblem"""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("g_bstride", C.c_size_t), ("x_bstride", C.c_size_t),
+                ("ldg", C.c_int), ("ldx", C.c_int), ("R", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("nb", C.c_int)]
 
 
 class GkgError(RuntimeError):
@@ -168,6 +175,8 @@ def load():
     lib.gkg_linear_dgrad_x6.argtypes = [V, I, Z, V, V, I, I, I, I, V]
     lib.gkg_linear_wgrad_x6.restype = I
     lib.gkg_linear_wgrad_x6.argtypes = [V, I, Z, V, I, Z, V, I, I, I, I, V]
+    lib.gkg_linear_wgrad_x6_batch.restype = I
+    lib.gkg_linear_wgrad_x6_batch.argtypes = [C.POINTER(WgradProblem), I, I, V]
     lib.gkg_mr_linear_planes_bytes.restype = Z
     lib.gkg_mr_linear_planes_bytes.argtypes = [I]
     lib.gkg_mr_linear_bf16.restype = I

@@ -130,6 +130,11 @@ struct X6Args {
   // pass over g and y.  Output column n belongs to BN group n / pco, channel n % pco; y is (pnb, M, pco).
   const float* py; const float* pa; const float* pc; const float* pmean; const float* pinvstd;
   double* psums;  int pco, pact;                        // psums: [pnb][2][pco] fp64 (atomics)
+  // split-K (ksplit > 1): workgroup (tile, ks) contracts K-steps [ks * kper, (ks + 1) * kper) and leaves its 128 x BN partial
+  // in part[(z * tiles + tile) * ksplit + ks]; the LAST of a tile's ksplit workgroups to arrive (cnt[z * tiles + tile], reset
+  // by it) adds the partials in split order — the same bits whoever arrives last — and runs the epilogue on the sum.
+  int ksplit, kper;
+  float* part;  unsigned* cnt;
 };
 
 enum { X6_STORE = 0, X6_BNSTATS = 1, X6_BNBWD = 2 };
@@ -181,13 +186,16 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int z = blockIdx.y;
   const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-  const int tn = slot % g.ntiles, tm = (slot / g.ntiles) * 8 + xcd;
+  // the column tiles and the K splits of one 128-row block run back to back on one XCD
+  const int per_row = g.ntiles * g.ksplit, inner = slot % per_row;
+  const int tn = inner % g.ntiles, ks = inner / g.ntiles, tm = (slot / per_row) * 8 + xcd;
   if (tm >= g.mtiles) return;
   X6_TL(0);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int M = g.M, N = g.N, K = g.K;
-  const float* A = g.A + (size_t)z * g.a_bstride;
-  const uint4* P = g.P + (size_t)z * g.p_bstride;
+  const int M = g.M, N = g.N;
+  const int K = g.ksplit > 1 ? min(g.K - ks * g.kper * BK, g.kper * BK) : g.K;       // this workgroup's share of the contraction
+  const float* A = g.A + (size_t)z * g.a_bstride + (size_t)ks * g.kper * BK;
+  const uint4* P = g.P + (size_t)z * g.p_bstride + (size_t)ks * g.kper * 4 * g.NP;
   const unsigned lds0 = (unsigned)(size_t)lds;
   const int nk = (K + BK - 1) / BK;
   const bool ktail = (K & (BK - 1)) != 0;
@@ -376,9 +384,39 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   // ---- epilogue.  Block j, register q: row 32 w + (q & 3) + 8 (q >> 2) + 4 h, column 32 j + r
   float* C = g.C + (size_t)z * g.c_bstride;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
+  for (int j = 0; j < NI; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] += accs[j][q];
+  if (g.ksplit > 1) {
+    // split-K: the partial goes out in register order (element (j, q) of thread tid at (j * 16 + q) * 256 + tid: every store
+    // instruction of a wave is one 256-byte run); release, count, and all but the last arrival are done
+    const size_t tile_id = ((size_t)z * g.mtiles + tm) * g.ntiles + tn;
+    float* mine = g.part + (tile_id * g.ksplit + ks) * (size_t)(NI * 16 * 256);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) mine[(j * 16 + q) * 256 + tid] = acc[j][q];
+    __threadfence();
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(lds);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(g.cnt + tile_id, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(g.ksplit - 1)) return;
+    __threadfence();
+    if (tid == 0) __hip_atomic_store(g.cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+    const float* all = g.part + tile_id * g.ksplit * (size_t)(NI * 16 * 256);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float t = 0.f;
+        for (int s2 = 0; s2 < g.ksplit; ++s2)
+          t += __builtin_nontemporal_load(all + (size_t)s2 * (NI * 16 * 256) + (j * 16 + q) * 256 + tid);
+        acc[j][q] = t;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
     const int n = n0 + j * 32 + r;
     const bool mine = n < N && (!PARTIAL || j * 32 + r < BN);
 #pragma unroll
@@ -527,6 +565,8 @@ struct X6WgradArgs {
   int M, N, K;
   int mtiles, ntiles, splits, rows_per_split;        // rows_per_split % 128 == 0
   int swap;                                          // wide kernel: A / B roles exchanged, C written transposed
+  int share, rot;                                    // workgroup -> (slab, tile) map of batched launches (x6w_map); 0, 0 otherwise
+  int ubase, urem;                                   // LDS-DMA kernels: slab s = ubase + (s < urem) units of 128 rows (K = 128 * units)
 };
 
 typedef unsigned x6_u32x4 __attribute__((ext_vector_type(4)));
@@ -672,19 +712,35 @@ __global__ __launch_bounds__(256) void wgrad_x6_kernel(X6WgradArgs g) {
 // it copied itself.  Requires every row of the launch to be inside the tensor (the host gives the ragged remainder to the
 // register-load kernel) and 16-byte aligned rows; columns past M / N are read from a clamped address and zeroed after the
 // LDS read.  Step s issues the DMA of step s + 4, waits until step s + 2 has landed (counted vmcnt) and reads it.
-__global__ __launch_bounds__(256) void wgrad_x6_dma_kernel(X6WgradArgs g) {
+// (split, tile) of workgroup `lin` of a weight-gradient launch.  Default map: slab s runs with ALL its tiles on XCD s % 8 (lin & 7
+// is the XCD the hardware dispatches workgroup lin to).  g.share = t > 1 (batched launches of few-slab problems, splits * t == 8):
+// t XCDs share a slab and take every t-th tile of it each, so that a problem of 1 / 2 / 4 slabs still spreads over all 8 XCDs
+// with no idle workgroup ids.  `rot` rotates the XCD assignment (batched launches: consecutive problems start on different XCDs).
+__device__ __forceinline__ bool x6w_map(const X6WgradArgs& g, int lin, int& split, int& tile) {
+  const int ntile = g.mtiles * g.ntiles;
+  const int xcd = (lin + g.rot) & 7, slot = lin >> 3;
+  if (g.share > 1) {
+    split = xcd / g.share;
+    tile = slot * g.share + xcd % g.share;
+    return split < g.splits && tile < ntile;
+  }
+  split = (slot / ntile) * 8 + xcd;
+  tile = slot % ntile;
+  return split < g.splits;
+}
+
+__device__ __forceinline__ void wgrad_x6_dma_body(const X6WgradArgs& g, const int lin, const int z) {
   extern __shared__ float wlds[];               // [4 waves][4 stages][2 operands][16 rows][64 cols], then reused for the reduce
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int z = blockIdx.y;
-  const int ntile = g.mtiles * g.ntiles;
-  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-  const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
-  if (split >= g.splits) return;
+  int split, tile;
+  if (!x6w_map(g, lin, split, tile)) return;
   const int m0 = (tile / g.ntiles) * 64, n0 = (tile % g.ntiles) * 64;
   const int r = lane & 31, h = lane >> 5;
   // the last slab may be shorter (whole 128-row units: 4 waves x 2 steps x 16 rows)
-  const long long slab0 = (long long)split * g.rows_per_split;
-  const int rows_here = (int)min((long long)g.rows_per_split, (long long)g.K - slab0);
+  // balanced slabs of whole 128-row units: the first g.urem slabs hold one unit more (a fixed slab length left the last slab
+  // — and, with slab s on XCD s % 8, one XCD — with as little as a third of the others' rows)
+  const long long slab0 = 128ll * ((long long)split * g.ubase + min(split, g.urem));
+  const int rows_here = 128 * (g.ubase + (split < g.urem ? 1 : 0));
   const int rows_per_wave = rows_here >> 2;
   const long long k_begin = slab0 + (long long)w * rows_per_wave;
   const int T = rows_per_wave >> 4;
@@ -791,6 +847,8 @@ __global__ __launch_bounds__(256) void wgrad_x6_dma_kernel(X6WgradArgs g) {
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_x6_dma_kernel(X6WgradArgs g) { wgrad_x6_dma_body(g, blockIdx.x, blockIdx.y); }
+
 // ---- wide form: 64 x 128 output tile per workgroup --------------------------------------------------------------------
 // Same decomposition (a workgroup = one tile of dW x one slab of rows, its 4 waves a quarter of the slab each, private LDS
 // rings filled by DMA, no barriers in the loop), but a wave owns 2 x 4 blocks of 32 x 32: six fragments per 16-row step feed
@@ -840,19 +898,18 @@ __device__ __forceinline__ void x6ww_slots(const X6WFragW& fc, X6WFragW& fn, x6_
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_x6_wide_kernel(X6WgradArgs g) {
+__device__ __forceinline__ void wgrad_x6_wide_body(const X6WgradArgs& g, const int lin, const int z) {
   extern __shared__ float wlds[];               // [4 waves][3 stages][16 x 64 | 16 x 128], then reused for the reduce
   constexpr int STAGE_BYTES = 16 * 192 * 4, STAGE_F = 16 * 192;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int z = blockIdx.y;
-  const int ntile = g.mtiles * g.ntiles;
-  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-  const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
-  if (split >= g.splits) return;
+  int split, tile;
+  if (!x6w_map(g, lin, split, tile)) return;
   const int m0 = (tile / g.ntiles) * 64, n0 = (tile % g.ntiles) * 128;
   const int r = lane & 31, h = lane >> 5;
-  const long long slab0 = (long long)split * g.rows_per_split;
-  const int rows_here = (int)min((long long)g.rows_per_split, (long long)g.K - slab0);
+  // balanced slabs of whole 128-row units: the first g.urem slabs hold one unit more (a fixed slab length left the last slab
+  // — and, with slab s on XCD s % 8, one XCD — with as little as a third of the others' rows)
+  const long long slab0 = 128ll * ((long long)split * g.ubase + min(split, g.urem));
+  const int rows_here = 128 * (g.ubase + (split < g.urem ? 1 : 0));
   const int rows_per_wave = rows_here >> 2;
   const long long k_begin = slab0 + (long long)w * rows_per_wave;
   const int T = rows_per_wave >> 4;              // even, >= 2
@@ -965,6 +1022,35 @@ __global__ __launch_bounds__(256) void wgrad_x6_wide_kernel(X6WgradArgs g) {
       __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_x6_wide_kernel(X6WgradArgs g) { wgrad_x6_wide_body(g, blockIdx.x, blockIdx.y); }
+
+// ---- batched form: the weight gradients of SEVERAL layers in one launch ------------------------------------------------
+// A weight gradient is off the backward's critical path (nothing downstream reads dW), and at this path's sizes each one is
+// a launch of 50-400 workgroups on 256 CUs that lives 12-40 us: ten of them per Grapher + GrapherLabel step, a fifth of the
+// step.  The host side queues them while the backward runs and issues ONE launch at its end: workgroup ids [begin[i],
+// begin[i+1]) belong to problem i (begin[] in multiples of 8, so lin & 7 stays the XCD inside a problem), which runs the
+// 64 x 64 or the 64 x 128 body above exactly as its own launch would.  The descriptors travel in the kernel arguments (a
+// hipGraph node keeps them by value).
+constexpr int X6W_BATCH = 16;
+struct X6WgradBatch {
+  int n;
+  int begin[X6W_BATCH + 1];
+  int gridx[X6W_BATCH];                         // workgroups per group z of the problem (a multiple of 8)
+  int wide[X6W_BATCH];
+  X6WgradArgs p[X6W_BATCH];
+};
+
+__global__ __launch_bounds__(256) void wgrad_x6_batch_kernel(X6WgradBatch b) {
+  const int bid = blockIdx.x;
+  int i = 0;
+  while (i + 1 < b.n && bid >= b.begin[i + 1]) ++i;
+  const int local = bid - b.begin[i], gx = b.gridx[i];
+  const int z = local / gx, lin = local - z * gx;
+  const X6WgradArgs g = b.p[i];
+  if (b.wide[i]) wgrad_x6_wide_body(g, lin, z);
+  else wgrad_x6_dma_body(g, lin, z);
 }
 
 inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
@@ -1100,8 +1186,41 @@ extern "C" int gkg_linear_dgrad_x6_bnbwd(const float* dy, int ldg, const void* p
 
 // dw (nb, cout, cin) += dy^T x over the R rows; dw must be ZERO on entry (the slabs of rows are added with fp32 atomics).
 // dy (nb, R, cout) row pitch ldg / batch stride g_bstride, x (nb, R, cin) row pitch ldx / batch stride x_bstride (floats).
-extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride,
-                                   float* dw, int R, int cin, int cout, int nb, void* stream) {
+namespace gkg {
+struct X6WgradPlan {
+  X6WgradArgs main;              // the LDS-DMA launch over the whole 128-row units (main.K rows; 0: none)
+  bool wide;
+  int grid_x;                    // workgroups per group of the main launch
+  X6WgradArgs rest;              // the register-load launch over the ragged remainder (rest.K rows; 0: none)
+  int rest_grid_x;
+};
+
+static int x6_wgrad_set_attr(bool wide) {
+  // the attribute is per DEVICE: the guard is indexed by the current device (a per-process guard left a second GPU of the
+  // same process without it — ADVICE r3)
+  static bool once[3][64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t sh_w = (size_t)4 * 3 * 16 * 192 * 4, sh_d = (size_t)4 * 4 * 8192;
+  if (dev < 0 || dev >= 64 || !once[wide][dev]) {
+    hipError_t e = hipFuncSetAttribute(wide ? (const void*)wgrad_x6_wide_kernel : (const void*)wgrad_x6_dma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wide ? sh_w : sh_d));
+    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel (attribute)");
+    if (dev >= 0 && dev < 64) once[wide][dev] = true;
+  }
+  if (dev < 0 || dev >= 64 || !once[2][dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_x6_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w);
+    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 batch kernel (attribute)");
+    if (dev >= 0 && dev < 64) once[2][dev] = true;
+  }
+  return 0;
+}
+
+// Tile shape, operand roles and row slabs of one weight gradient.  `batched` > 0: the launch shares the chip with other
+// problems (gkg_linear_wgrad_x6_batch) — slabs of ~`batched` units whatever the tile count, few-slab problems spread over the
+// XCDs by tiles.
+static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride, float* dw, int R,
+                         int cin, int cout, int nb, int batched, X6WgradPlan& pl) {
   if (!dy || !x || !dw) return gkg_fail(GKG_ERR_NULL, "gkg_linear_wgrad_x6: null pointer");
   if (R <= 0 || cin <= 0 || cout <= 0 || nb <= 0 || nb > 64 || ldg < cout || ldx < cin)
     return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6: need R, cin, cout > 0, 1 <= nb <= 64, pitches >= widths");
@@ -1112,8 +1231,6 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
   a.M = cout; a.N = cin; a.K = R;
   a.mtiles = (cout + 63) / 64; a.ntiles = (cin + 63) / 64;
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipSuccess;
   // whole 128-row units go through an LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and everything,
   // when they are not) through the register-load kernel
   const bool aligned = (cin & 3) == 0 && (cout & 3) == 0 && (ldg & 3) == 0 && (ldx & 3) == 0 && (g_bstride & 3) == 0 &&
@@ -1128,14 +1245,24 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   const bool swap = wide && padm < padn;
   const int main_mtiles = !wide ? a.mtiles : (swap ? a.ntiles : a.mtiles);
   const int main_ntiles = !wide ? a.ntiles : (swap ? (cout + 127) / 128 : (cin + 127) / 128);
-  // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 / 144 KiB of LDS rings) and
-  // slab s runs with all its tiles on XCD s % 8 (its rows are fetched into that L2 once), so an XCD's 32 CUs work in rounds
-  // over tiles x ceil(slabs / 8) workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost), the
-  // fixed cost (ring fill, LDS reduction, the tile's atomics) being worth about 6 units of streaming.  (Counting rounds over
-  // the whole chip instead put 36 workgroups on two XCDs at 6 tiles x 42 slabs: 245 -> 393 us at 663 552 x 160 -> 80.)
   const int tiles = main_mtiles * main_ntiles * nb, units = R / 128;
-  int splits = 1;
-  {
+  int splits = 1, share = 0;
+  if (batched) {
+    // ~`batched` (default 12) units of 128 rows per workgroup (its fixed cost — ring fill, LDS reduction, the tile's atomics — is worth about 6):
+    // 1 / 2 / 4 slabs shared by 8 / 4 / 2 XCDs each, or a multiple of 8 slabs on one XCD each
+    const int want = (units + batched - 1) / batched;
+    if (want <= 1) splits = 1;
+    else if (want <= 2) splits = 2;
+    else if (want <= 5) splits = 4;
+    else splits = (want + 7) / 8 * 8;
+    if (splits > units) splits = units > 0 ? units : 1;
+    if (splits < 8) { while (8 % splits) --splits; share = 8 / splits; }
+  } else {
+    // Slabs of whole 128-row units (4 waves x 2 steps x 16 rows).  One workgroup per CU fits (128 / 144 KiB of LDS rings) and
+    // slab s runs with all its tiles on XCD s % 8 (its rows are fetched into that L2 once), so an XCD's 32 CUs work in rounds
+    // over tiles x ceil(slabs / 8) workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost), the
+    // fixed cost (ring fill, LDS reduction, the tile's atomics) being worth about 6 units of streaming.  (Counting rounds over
+    // the whole chip instead put 36 workgroups on two XCDs at 6 tiles x 42 slabs: 245 -> 393 us at 663 552 x 160 -> 80.)
     long long best = -1;
     for (int sp = 1; sp <= units && sp <= 4096; ++sp) {
       const long long per_xcd = (long long)tiles * ((sp + 7) / 8);
@@ -1146,6 +1273,10 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   }
   a.rows_per_split = units > 0 ? (units + splits - 1) / splits * 128 : 128;
   const int main_rows = aligned ? units * 128 : 0;
+  pl.wide = wide;
+  pl.main = a;
+  pl.main.K = 0;
+  pl.grid_x = 0;
   if (main_rows > 0) {
     X6WgradArgs m = a;
     m.mtiles = main_mtiles; m.ntiles = main_ntiles;
@@ -1154,26 +1285,20 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
       m.B = dy; m.b_bstride = g_bstride; m.ldb = ldg; m.N = cout;
       m.swap = 1;
     }
-    m.K = main_rows; m.splits = (main_rows + a.rows_per_split - 1) / a.rows_per_split;
-    const size_t sh = wide ? (size_t)4 * 3 * 16 * 192 * 4 : (size_t)4 * 4 * 8192;
-    // the attribute is per DEVICE: the guard is indexed by the current device (a per-process guard left a second GPU of the
-    // same process without it — ADVICE r3)
-    static bool once[2][64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const void* fn = wide ? (const void*)wgrad_x6_wide_kernel : (const void*)wgrad_x6_dma_kernel;
-    if (dev < 0 || dev >= 64 || !once[wide][dev]) {
-      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel (attribute)");
-      if (dev >= 0 && dev < 64) once[wide][dev] = true;
+    m.K = main_rows; m.splits = splits < units ? splits : units;
+    m.ubase = units / m.splits; m.urem = units % m.splits;
+    if (share > 1 && m.splits * share == 8) {
+      m.share = share;
+      pl.grid_x = (m.mtiles * m.ntiles + share - 1) / share * 8;
+    } else {
+      pl.grid_x = (m.splits + 7) / 8 * 8 * m.mtiles * m.ntiles;
     }
-    const dim3 grid((m.splits + 7) / 8 * 8 * m.mtiles * m.ntiles, nb);
-    if (wide) hipLaunchKernelGGL(wgrad_x6_wide_kernel, grid, dim3(256), sh, st, m);
-    else hipLaunchKernelGGL(wgrad_x6_dma_kernel, grid, dim3(256), sh, st, m);
-    e = hipGetLastError();
-    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel");
+    pl.main = m;
   }
   const int done = main_rows, rest = R - done;
+  pl.rest = a;
+  pl.rest.K = 0;
+  pl.rest_grid_x = 0;
   if (rest > 0) {
     X6WgradArgs t = a;
     t.A = dy + (size_t)done * ldg; t.B = x + (size_t)done * ldx; t.K = rest;
@@ -1181,8 +1306,81 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
     int ts = splits > tunits ? tunits : splits;
     t.rows_per_split = (tunits + ts - 1) / ts * 128;
     t.splits = (rest + t.rows_per_split - 1) / t.rows_per_split;
-    hipLaunchKernelGGL(wgrad_x6_kernel, dim3((t.splits + 7) / 8 * 8 * a.mtiles * a.ntiles, nb), dim3(256), 0, st, t);
+    pl.rest = t;
+    pl.rest_grid_x = (t.splits + 7) / 8 * 8 * a.mtiles * a.ntiles;
+  }
+  return 0;
+}
+}  // namespace gkg
+
+extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride,
+                                   float* dw, int R, int cin, int cout, int nb, void* stream) {
+  X6WgradPlan pl;
+  int rc = x6_wgrad_plan(dy, ldg, g_bstride, x, ldx, x_bstride, dw, R, cin, cout, nb, 0, pl);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  if (pl.main.K > 0) {
+    if ((rc = x6_wgrad_set_attr(pl.wide))) return rc;
+    const size_t sh = pl.wide ? (size_t)4 * 3 * 16 * 192 * 4 : (size_t)4 * 4 * 8192;
+    const dim3 grid(pl.grid_x, nb);
+    if (pl.wide) hipLaunchKernelGGL(wgrad_x6_wide_kernel, grid, dim3(256), sh, st, pl.main);
+    else hipLaunchKernelGGL(wgrad_x6_dma_kernel, grid, dim3(256), sh, st, pl.main);
+    e = hipGetLastError();
+    if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6 DMA kernel");
+  }
+  if (pl.rest.K > 0) {
+    hipLaunchKernelGGL(wgrad_x6_kernel, dim3(pl.rest_grid_x, nb), dim3(256), 0, st, pl.rest);
     e = hipGetLastError();
   }
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "wgrad_x6_kernel");
+}
+
+// The weight gradients of n layers in ONE launch per 16 problems (wgrad_x6_batch_kernel): problem i is what
+// gkg_linear_wgrad_x6(p[i].dy, ..., p[i].nb) would compute — every dw ZERO on entry.  Problems whose rows are not whole
+// 128-row units / 16-byte aligned fall back to their own launches.  Largest problems first (the tail of the launch is made of
+// the short ones).
+extern "C" int gkg_linear_wgrad_x6_batch(const GkgWgradProblem* p, int n, int units_per_slab, void* stream) {
+  if (!p || n <= 0) return gkg_fail(GKG_ERR_NULL, "gkg_linear_wgrad_x6_batch: no problems");
+  if (units_per_slab < 0 || units_per_slab > 4096) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6_batch: units_per_slab out of range");
+  if (units_per_slab == 0) units_per_slab = 12;
+  hipStream_t st = (hipStream_t)stream;
+  int order[256];
+  if (n > 256) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6_batch: at most 256 problems per call");
+  for (int i = 0; i < n; ++i) order[i] = i;
+  auto work = [&](int i) { return (double)p[i].R * p[i].cin * p[i].cout * p[i].nb; };
+  for (int i = 1; i < n; ++i)                     // insertion sort, descending work
+    for (int j = i; j > 0 && work(order[j]) > work(order[j - 1]); --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  X6WgradBatch b{};
+  int rot = 0;
+  auto flush = [&]() -> int {
+    if (b.n == 0) return 0;
+    int rc = x6_wgrad_set_attr(true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_x6_batch_kernel, dim3(b.begin[b.n]), dim3(256), (size_t)4 * 3 * 16 * 192 * 4, st, b);
+    hipError_t e = hipGetLastError();
+    b.n = 0;
+    return e == hipSuccess ? 0 : gkg_fail_hip(e, "wgrad_x6_batch_kernel");
+  };
+  for (int oi = 0; oi < n; ++oi) {
+    const GkgWgradProblem& q = p[order[oi]];
+    X6WgradPlan pl;
+    int rc = x6_wgrad_plan(q.dy, q.ldg, q.g_bstride, q.x, q.ldx, q.x_bstride, q.dw, q.R, q.cin, q.cout, q.nb, units_per_slab, pl);
+    if (rc) return rc;
+    if (pl.main.K > 0) {
+      const int i = b.n;
+      pl.main.rot = rot;
+      rot = (rot + (pl.main.share > 1 ? 0 : pl.main.splits)) & 7;
+      b.p[i] = pl.main; b.wide[i] = pl.wide ? 1 : 0; b.gridx[i] = pl.grid_x;
+      b.begin[i + 1] = b.begin[i] + pl.grid_x * q.nb;
+      b.n = i + 1;
+      if (b.n == X6W_BATCH && (rc = flush())) return rc;
+    }
+    if (pl.rest.K > 0) {
+      hipLaunchKernelGGL(wgrad_x6_kernel, dim3(pl.rest_grid_x, q.nb), dim3(256), 0, st, pl.rest);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return gkg_fail_hip(e, "wgrad_x6_kernel");
+    }
+  }
+  return flush();
 }

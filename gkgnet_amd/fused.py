@@ -164,6 +164,74 @@ def _x6_wgrad_ok(dY, x, nb=1) -> bool:
     return R >= 8192 or (R >= 2048 and tiles <= 64)
 
 
+# ---- batched weight gradients (round 5) ---------------------------------------------------------------------------------
+# Nothing downstream of a backward pass reads a weight gradient, so the projections' dW launches are taken OFF the chain of
+# dependent launches: while the backward runs they are only queued (operands kept alive), and ONE launch at the end of the
+# backward pass (an autograd engine callback) computes all of them (csrc/gkg_gemm_x6.hip wgrad_x6_batch_kernel).  At the cfg2
+# shapes the ten weight gradients were ten launches of 50-400 workgroups on 256 CUs, 12-40 us each (195 of 981 us, six of them
+# vendor kernels); together they fill the chip.  Queued only when the gradient has a slot in a GradBucket (the kernel writes
+# there; autograd adopts the returned view as ``p.grad``) — a caller without a bucket gets its dW from this node's own launch,
+# as before, because autograd consumes the returned tensor at once.  GradBucket flushes the queue before it reads a gradient
+# (all_reduce / chunk all-reduce / clip / pack).  GKG_DISABLE=wgrad_batch: every weight gradient in its own launch.
+WGRAD_BATCH = "wgrad_batch" not in _DISABLED
+WGRAD_UNITS = int(os.environ.get("GKG_WGRAD_UNITS", "0"))      # rows per workgroup of the batched launch / 128 (0: library default)
+
+
+class _WgradQueue:
+    MAX = 192
+
+    def __init__(self):
+        self.items, self.keep, self.task = [], [], -1
+
+
+_WQ = _WgradQueue()
+
+
+def flush_wgrads():
+    """Launch every queued weight gradient (no-op when the queue is empty)."""
+    q = _WQ
+    if not q.items:
+        q.keep, q.task = [], -1
+        return
+    items, q.items, q.task = q.items, [], -1
+    try:
+        arr = (_lib.WgradProblem * len(items))(*items)
+        _lib.check(_lib.load().gkg_linear_wgrad_x6_batch(arr, len(items), WGRAD_UNITS, _stream()), "gkg_linear_wgrad_x6_batch")
+    finally:
+        q.keep = []                      # the launch is stream-ordered behind the operands' producers and ahead of their reuse
+
+
+from . import parallel as _parallel      # noqa: E402
+_parallel._FLUSH.append(flush_wgrads)
+
+
+def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs) -> bool:
+    """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
+    if not (WGRAD_BATCH and not DETERMINISTIC and X6_WGRAD and GEMM_MATH in ("x6", "x6all") and OWN_GEMM != "none"
+            and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
+            and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
+            and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
+        return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False                     # not inside a backward pass: nobody would flush
+    q = _WQ
+    if q.task != task:
+        q.items, q.keep = [], []         # leftovers of a backward pass that raised before its callback
+        q.task = task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    if not getattr(out, "_gkg_zero", False):
+        out.zero_()
+    q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb))
+    q.keep.append((dY, x))
+    if len(q.items) >= q.MAX:
+        items, q.items = q.items, []
+        arr = (_lib.WgradProblem * len(items))(*items)
+        _lib.check(_lib.load().gkg_linear_wgrad_x6_batch(arr, len(items), WGRAD_UNITS, _stream()), "gkg_linear_wgrad_x6_batch")
+        q.keep = []
+    return True
+
+
 def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
     """dW (Cout, Cin) = dY^T (Cout x R) @ x (R x Cin).  The output is tiny and the contraction long (R = B*N),
     so a single GEMM leaves most CUs idle; split R into S slabs with a batched GEMM and add the S partials.
@@ -171,6 +239,9 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
     R = x.shape[0]
     if out is not None and out.dtype != dY.dtype:
         out = None
+    if (dY.stride(1) == 1 and x.stride(1) == 1
+            and _wgrad_defer(dY, x, out, R, x.shape[1], dY.shape[1], 1, dY.stride(0), 0, x.stride(0), 0)):
+        return out
     if _x6_wgrad_ok(dY, x) and dY.stride(1) == 1 and x.stride(1) == 1 and dY.stride(0) % 4 == 0 and x.stride(0) % 4 == 0:
         cout, cin = dY.shape[1], x.shape[1]
         if out is None:
@@ -196,6 +267,9 @@ def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None) -> torch.Tensor:
     S = 4
     if out is not None and (out.dtype != dY.dtype or not out.is_contiguous()):
         out = None
+    if (dY.stride(2) == 1 and U.stride(2) == 1
+            and _wgrad_defer(dY, U, out, R, ci, co, nb, dY.stride(1), dY.stride(0), U.stride(1), U.stride(0))):
+        return out
     if (_x6_wgrad_ok(dY, U, nb) and dY.stride(2) == 1 and U.stride(2) == 1
             and all(t.stride(d) % 4 == 0 for t in (dY, U) for d in (0, 1))):
         if out is None:

@@ -35,6 +35,14 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+_FLUSH = []          # callables that complete gradients still queued for a batched launch (fused.flush_wgrads registers itself)
+
+
+def flush_pending_grads():
+    for f in _FLUSH:
+        f()
+
+
 class GradBucket:
     """Flat gradient storage for a set of parameters + the gradient all-reduce(avg) of the step.
 
@@ -143,6 +151,7 @@ class GradBucket:
         """Bring every gradient into the flat bucket: gradients the fused kernels already wrote in place are left alone,
         the others are copied with one batched copy; parameters without a gradient get zeros.  Re-points ``p.grad`` at
         the bucket views."""
+        flush_pending_grads()
         src, dst, zero = [], [], []
         for p in self.params:
             if self._resident(p):
@@ -171,6 +180,8 @@ class GradBucket:
         (chunk i only after chunks 0..i-1), whatever order the hooks fired in — ranks whose backward completes the
         chunks in different orders (unused parameters on some ranks) still issue identical collective sequences."""
         while self._issued < len(self.chunks) and (upto_all or self._issued in self._complete):
+            if world > 1:
+                flush_pending_grads()             # weight gradients queued for the batched launch: this chunk is about to be read
             start, end, plist = self.chunks[self._issued]
             for q in plist:                                      # gradients not written in place: copy this chunk now
                 if not self._resident(q):
@@ -190,12 +201,14 @@ class GradBucket:
         configs/gkgnet/gkgnet_coco_576.py:126) over every gradient of the bucket, as a norm and a scale launch on the flat
         buffer instead of multi-tensor passes over ~300 parameters.  Call after :meth:`pack` / :meth:`wait` (all gradients
         resident; slots of parameters without a gradient hold zeros).  Returns the total norm (a 0-d tensor)."""
+        flush_pending_grads()
         total = torch.linalg.vector_norm(self.flat)
         self.flat.mul_(torch.clamp(max_norm / (total + eps), max=1.0))
         return total
 
     def all_reduce(self, async_op: bool = False):
         """Average over ranks with ONE collective over the whole buffer.  No-op in a single process."""
+        flush_pending_grads()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         self.flat.div_(dist.get_world_size())
@@ -252,6 +265,7 @@ def grad_view(p: torch.nn.Parameter, shape=None):
     flat, o = b
     v = flat[o:o + p.numel()]
     v = v.view(p.shape if shape is None else shape)
+    v._gkg_slot = True                            # a bucket slot: kernels may fill it after the backward node has returned it
     if getattr(p, "_gkg_clean", False):           # zeroed by release(prezero=True) and not written since
         p._gkg_clean = False
         v._gkg_zero = True

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 6
+#define GKG_ABI_VERSION 7
 
 /* dtype codes */
 #define GKG_F32 0
@@ -344,6 +344,21 @@ int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* 
  * split-K GEMM).  x (nb, R, cin) with row pitch ldx / batch stride x_bstride (floats).  Any cin, cout >= 1. */
 int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride, float* dw,
                         int R, int cin, int cout, int nb, void* stream);
+/* The weight gradients of SEVERAL layers in one launch (round 5).  Nothing downstream of a backward pass reads a dW, so the
+ * host side may queue the weight gradients of every projection (reference torch_vertex.py:290-306, :334-360, torch_nn.py:57-69
+ * backward) while the input gradients run and issue them together when the backward ends: at this path's sizes each of them
+ * alone is a launch of 50-400 workgroups on 256 CUs.  Problem i is exactly gkg_linear_wgrad_x6(dy, ldg, g_bstride, x, ldx,
+ * x_bstride, dw, R, cin, cout, nb): every dw ZERO on entry, accumulated with fp32 atomics.  At most 256 problems per call
+ * (16 per launch); operands must stay valid until the launch has run.  units_per_slab: rows per workgroup in units of 128
+ * (0: the library's default, 12). */
+typedef struct GkgWgradProblem {
+  const float* dy;
+  const float* x;
+  float* dw;
+  size_t g_bstride, x_bstride;
+  int ldg, ldx, R, cin, cout, nb;
+} GkgWgradProblem;
+int gkg_linear_wgrad_x6_batch(const GkgWgradProblem* problems, int n, int units_per_slab, void* stream);
 
 /*
  * Input gradient of a projection with the BACKWARD statistics of the layer in front of it in its epilogue (round 4).
