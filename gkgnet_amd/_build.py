@@ -35,6 +35,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    # objects are only as good as the flags they were compiled with (GKG_BUILD_FLAGS adds -D ablation switches: no stores, no
+    # loads ...): a stamp of the flag list sits beside them, and a different list rebuilds everything
+    stamp = os.path.join(objdir, ".flags")
+    flags_now = " ".join(FLAGS)
+    try:
+        flags_then = open(stamp).read()
+    except OSError:
+        flags_then = None
+    if flags_then != flags_now:
+        force = force or flags_then is not None or bool(os.environ.get("GKG_BUILD_FLAGS", "").split())
+        with open(stamp, "w") as fh:
+            fh.write(flags_now)
     jobs = []
     objs = []
     for s in SOURCES:

@@ -65,7 +65,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
-           "gkg_linear_wgrad_x6_batch")
+           "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -175,6 +175,12 @@ def load():
     lib.gkg_linear_dgrad_x6.argtypes = [V, I, Z, V, V, I, I, I, I, V]
     lib.gkg_linear_wgrad_x6.restype = I
     lib.gkg_linear_wgrad_x6.argtypes = [V, I, Z, V, I, Z, V, I, I, I, I, V]
+    lib.gkg_x6_splitk_workspace_bytes.restype = Z
+    lib.gkg_x6_splitk_workspace_bytes.argtypes = []
+    lib.gkg_linear_bn_fwd_x6_sk.restype = I
+    lib.gkg_linear_bn_fwd_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V, Z, V]
+    lib.gkg_linear_dgrad_x6_sk.restype = I
+    lib.gkg_linear_dgrad_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, V, V, Z, V]
     lib.gkg_linear_wgrad_x6_batch.restype = I
     lib.gkg_linear_wgrad_x6_batch.argtypes = [C.POINTER(WgradProblem), I, I, V]
     lib.gkg_mr_linear_planes_bytes.restype = Z

@@ -37,6 +37,8 @@ class _BnBwdScratch:
         self.captured = False
         self.poisoned = False
         self.last_stream = None
+        self.pending = None             # a _BnLink whose consumer has accumulated into a buffer while the clear of the other one
+                                        # waits for the producer's apply pass (fused._dgrad_x6_with_link)
 
     @classmethod
     def of(cls, device):
@@ -63,6 +65,14 @@ class _BnBwdScratch:
             self.last_stream = here
             if self.captured or self.poisoned:
                 self._reset()
+        if self.pending is not None:
+            # an acquire between a consumer's dgrad epilogue and its producer's apply pass (another ready BN backward node was
+            # scheduled in between, or the producer's backward never ran: autograd.grad stopping at the activation): the
+            # deferred clear has not happened and the bookkeeping calls that buffer clean -> start clean, and the
+            # producer falls back to its own statistics pass
+            self.pending.ready = None
+            self.pending = None
+            self._reset()
         cur, other = self.bufs[self.cur], self.bufs[self.cur ^ 1]
         zero = self.dirty[self.cur ^ 1]
         self.dirty[self.cur], self.dirty[self.cur ^ 1] = n, 0
@@ -73,6 +83,9 @@ class _BnBwdScratch:
         self.store.fill_(0.0)            # ONE elementwise launch (a captured memset node measured far slower than a kernel node)
         self.dirty = [0, 0]
         self.poisoned = False
+        if self.pending is not None:
+            self.pending.ready = None
+            self.pending = None
 
     def poison(self):
         """A launch between acquire() and its apply pass failed: the buffers' contents are unknown."""

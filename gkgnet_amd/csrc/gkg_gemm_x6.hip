@@ -135,6 +135,7 @@ struct X6Args {
   // by it) adds the partials in split order — the same bits whoever arrives last — and runs the epilogue on the sum.
   int ksplit, kper;
   float* part;  unsigned* cnt;
+  const float* add;                                     // X6_STORE: C = A B^T + add (same shape and pitch as C), or null
 };
 
 enum { X6_STORE = 0, X6_BNSTATS = 1, X6_BNBWD = 2 };
@@ -389,31 +390,39 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
     for (int q = 0; q < 16; ++q) acc[j][q] += accs[j][q];
   if (g.ksplit > 1) {
     // split-K: the partial goes out in register order (element (j, q) of thread tid at (j * 16 + q) * 256 + tid: every store
-    // instruction of a wave is one 256-byte run); release, count, and all but the last arrival are done
+    // instruction of a wave is one 256-byte run).  Hand-off without cache-wide fences (an agent-scope release writes the whole
+    // L2 back: measured 57-150 us per launch in this place): every payload store is write-through (relaxed agent-scope atomic
+    // store = sc1), every storing wave drains its stores, the workgroup meets, ONE lane counts the arrival; the last arrival
+    // reads all partials with sc1 loads (they bypass this CU's L1, the only cache that could hold a stale copy).
     const size_t tile_id = ((size_t)z * g.mtiles + tm) * g.ntiles + tn;
-    float* mine = g.part + (tile_id * g.ksplit + ks) * (size_t)(NI * 16 * 256);
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    gfloat* mine = (gfloat*)(g.part + (tile_id * g.ksplit + ks) * (size_t)(NI * 16 * 256));
+    gu32* cnt = (gu32*)(g.cnt + tile_id);
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) mine[(j * 16 + q) * 256 + tid] = acc[j][q];
-    __threadfence();
+      for (int q = 0; q < 16; ++q) __hip_atomic_store(mine + (j * 16 + q) * 256 + tid, acc[j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(lds);
-    if (tid == 0) *flag = __hip_atomic_fetch_add(g.cnt + tile_id, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*flag != (unsigned)(g.ksplit - 1)) return;
-    __threadfence();
-    if (tid == 0) __hip_atomic_store(g.cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
-    const float* all = g.part + tile_id * g.ksplit * (size_t)(NI * 16 * 256);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // no instruction: keeps the loads below the count
+    if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+    const gfloat* all = (const gfloat*)(g.part + tile_id * g.ksplit * (size_t)(NI * 16 * 256));
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float t = 0.f;
-        for (int s2 = 0; s2 < g.ksplit; ++s2)
-          t += __builtin_nontemporal_load(all + (size_t)s2 * (NI * 16 * 256) + (j * 16 + q) * 256 + tid);
-        acc[j][q] = t;
-      }
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    for (int s2 = 0; s2 < g.ksplit; ++s2) {                         // range order: the same bits whoever arrives last
+      const gfloat* ps = all + (size_t)s2 * (NI * 16 * 256) + tid;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] += __hip_atomic_load(ps + (j * 16 + q) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -422,7 +431,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = m0 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (m < M && mine) C[(size_t)m * g.ldc + n] = acc[j][q];
+      if (m < M && mine) {
+        float v = acc[j][q];
+        if (EPI == X6_STORE && g.add) v += g.add[(size_t)z * g.c_bstride + (size_t)m * g.ldc + n];
+        C[(size_t)m * g.ldc + n] = v;
+      }
     }
   }
   X6_TL(4);
@@ -511,6 +524,7 @@ template <int NI, int EPI, int BN = 32 * NI>
 static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
   a.mtiles = (a.M + 127) / 128;
   a.ntiles = (a.N + BN - 1) / BN;
+  if (a.ksplit < 1) a.ksplit = 1;
   // A ring + two B stages (+ slack: the unused lanes of a partial last block read past their image row)
   const size_t sh = 3 * 4 * 4096 + 2 * 12 * BN * 16 + (BN != 32 * NI ? 512 : 0);
   // the attribute is per DEVICE (a per-process guard left a second GPU of the same process without it — ADVICE r3)
@@ -523,7 +537,7 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
     if (dev >= 0 && dev < 64) once[dev] = true;
   }
   const int groups = (a.mtiles + 7) / 8;
-  hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI, BN>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
+  hipLaunchKernelGGL((gemm_x6_kernel<NI, EPI, BN>), dim3(groups * 8 * a.ntiles * a.ksplit, nb), dim3(256), sh, st, a);
   return hipGetLastError();
 }
 
@@ -531,11 +545,33 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
 // VALU-bound, NI = 2 about balanced) but leave fewer workgroups: NI = 2, and NI = 1 when that leaves the chip under-filled
 // (few rows: the label branch).  Measured cold-cache per shape with tools/bench_x6.py; NI = 5 (160 columns, one
 // workgroup per CU) was tried and is slower everywhere (cfg2 fc1 25.8 vs 22.9 us).
+// Split-K workspace (caller-owned, gkg_x6_splitk_workspace_bytes()): [1024 tile counters, zero between launches][partials].
+constexpr size_t X6_SK_CNT_BYTES = 4096, X6_SK_MAX_WG = 512;
+constexpr size_t X6_SK_BYTES = X6_SK_CNT_BYTES + X6_SK_MAX_WG * (size_t)(2 * 16 * 256 * 4);
+
 template <int EPI>
-static hipError_t x6_launch(X6Args a, int nb, hipStream_t st) {
+static hipError_t x6_launch(X6Args a, int nb, hipStream_t st, void* sk_ws = nullptr, size_t sk_bytes = 0) {
   GkgProfScope prof(GKG_PROF_GEMM_X6, st, 2.0 * a.M * a.N * a.K * nb);
   const int mt = (a.M + 127) / 128;
-  int ni = (long long)mt * ((a.N + 63) / 64) * nb < 160 ? 1 : 2;
+  // Few rows under a long contraction (the label branch: 2 560 x 1280 -> 320 is 100 workgroups of 40 K-steps on 256 CUs): the
+  // contraction is cut into ksplit ranges so that the launch fills the chip's 512 workgroup slots, at least 4 K-steps each
+  // (the pipeline's fill is worth about two).  The last arrival per tile sums the partials in split order (deterministic) and
+  // runs the normal epilogue, BN statistics included.
+  const long long base2 = (long long)mt * ((a.N + 63) / 64) * nb;
+  const int nk_total = (a.K + 31) / 32;
+  if (sk_ws && sk_bytes >= X6_SK_BYTES && base2 < 320 && base2 <= 1024 && nk_total >= 8 && EPI != X6_BNBWD) {
+    int ks = (int)(X6_SK_MAX_WG / base2);
+    if (ks > nk_total / 4) ks = nk_total / 4;
+    if (ks > 8) ks = 8;
+    if (ks >= 2) {
+      a.kper = (nk_total + ks - 1) / ks;
+      a.ksplit = (nk_total + a.kper - 1) / a.kper;               // no empty range
+      a.cnt = reinterpret_cast<unsigned*>(sk_ws);
+      a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_ws) + X6_SK_CNT_BYTES);
+      return x6_launch_ni<2, EPI>(a, nb, st);
+    }
+  }
+  int ni = base2 < 160 ? 1 : 2;
   // 80 output columns on many rows (GKGNet-576 stage 1): ONE 80-column tile per row block instead of a full and a quarter
   // 64-column tile — 663 552 rows: 80 -> 80 171 -> 133 us, + statistics 208 -> 161, 320 -> 80 345 -> 279, dgrad 320 <- 80
   // 351 -> 279.  Wider outputs measured equal or slower on 80-column tiles (160: +-3 %, 320 / 400 / 640: 3-8 % slower:
@@ -1101,11 +1137,13 @@ extern "C" int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long t
 
 // gkg_linear_bn_fwd with the weights given as forward planes (gkg_x6_prep_weights).  x (nb, R, cin) with row pitch ldx and
 // batch stride x_bstride (floats); y (nb, R, cout) contiguous.  Same `train` modes and outputs as gkg_linear_bn_fwd.
-extern "C" int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
-                                    int cin, int cout, int nb, int train, const float* gamma, const float* beta,
-                                    const float* bias, float* running_mean, float* running_var,
-                                    long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
-                                    float* bn_invstd, float momentum, float eps, double* stats, void* stream) {
+extern "C" size_t gkg_x6_splitk_workspace_bytes(void) { return X6_SK_BYTES; }
+
+static int x6_fwd_impl(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
+                       int cin, int cout, int nb, int train, const float* gamma, const float* beta,
+                       const float* bias, float* running_mean, float* running_var,
+                       long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
+                       float* bn_invstd, float momentum, float eps, double* stats, void* sk_ws, size_t sk_bytes, void* stream) {
   if (!x || !planes_fwd || !y) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: null pointer");
   if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || nb > 64 || ldx < cin || (ldx & 3) || (x_bstride & 3) ||
       ((size_t)x & 15))
@@ -1131,20 +1169,43 @@ extern "C" int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, c
     const int fit = gkg_linear_stats_doubles() / (nb * 2 * cout), want = (R + 127) / 128 / 64;
     a.nslots = train == 2 ? 1 : (want < 1 ? 1 : (want > 16 ? 16 : want));
     if (a.nslots > fit) a.nslots = fit;
-    e = x6_launch<X6_BNSTATS>(a, nb, st);
+    e = x6_launch<X6_BNSTATS>(a, nb, st, sk_ws, sk_bytes);
     if (e == hipSuccess && train != 2) {
       e = launch_bn_sums_finalize(stats, R, cout, nb, gamma, beta, bias, running_mean, running_var, bn_a, bn_c, bn_mean,
                                   bn_invstd, momentum, eps, num_batches_tracked, st, a.nslots);
     }
   } else {
-    e = x6_launch<X6_STORE>(a, nb, st);
+    e = x6_launch<X6_STORE>(a, nb, st, sk_ws, sk_bytes);
   }
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (forward)");
 }
 
+extern "C" int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
+                                    int cin, int cout, int nb, int train, const float* gamma, const float* beta,
+                                    const float* bias, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
+                                    float* bn_invstd, float momentum, float eps, double* stats, void* stream) {
+  return x6_fwd_impl(x, ldx, x_bstride, planes_fwd, y, R, cin, cout, nb, train, gamma, beta, bias, running_mean, running_var,
+                     num_batches_tracked, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, stats, nullptr, 0, stream);
+}
+
+// The same call with a split-K workspace (gkg_x6_splitk_workspace_bytes() bytes, its first 4 KiB ZERO before the first use;
+// every launch leaves them zero again): few-row / long-contraction shapes then run as several K ranges per tile.
+extern "C" int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
+                                       int cin, int cout, int nb, int train, const float* gamma, const float* beta,
+                                       const float* bias, float* running_mean, float* running_var,
+                                       long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
+                                       float* bn_invstd, float momentum, float eps, double* stats, void* splitk_ws,
+                                       size_t splitk_bytes, void* stream) {
+  if (splitk_ws && (splitk_bytes < X6_SK_BYTES || ((size_t)splitk_ws & 15)))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_bn_fwd_x6_sk: need a 16-byte aligned workspace of gkg_x6_splitk_workspace_bytes() bytes (or NULL: no split)");
+  return x6_fwd_impl(x, ldx, x_bstride, planes_fwd, y, R, cin, cout, nb, train, gamma, beta, bias, running_mean, running_var,
+                     num_batches_tracked, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, stats, splitk_ws, splitk_bytes, stream);
+}
+
 // dx (nb, R, cin) = dy (nb, R, cout; row pitch ldg, batch stride g_bstride) * w, the weights given as dgrad planes.
-extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
-                                   int cin, int cout, int nb, void* stream) {
+static int x6_dgrad_impl(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
+                         int cin, int cout, int nb, const float* residual, void* sk_ws, size_t sk_bytes, void* stream) {
   if (!dy || !planes_dgrad || !dx) return gkg_fail(GKG_ERR_NULL, "gkg_linear_dgrad_x6: null pointer");
   if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || nb > 64 || ldg < cout || (ldg & 3) || (g_bstride & 3) ||
       ((size_t)dy & 15))
@@ -1156,8 +1217,24 @@ extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, c
   a.P = (const uint4*)planes_dgrad; a.p_bstride = (size_t)3 * a.KC * a.NP;
   a.C = dx; a.c_bstride = (size_t)R * cin; a.ldc = cin;
   a.M = R; a.N = cin; a.K = cout;
-  hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream);
+  a.add = residual;
+  hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream, sk_ws, sk_bytes);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad)");
+}
+
+extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
+                                   int cin, int cout, int nb, void* stream) {
+  return x6_dgrad_impl(dy, ldg, g_bstride, planes_dgrad, dx, R, cin, cout, nb, nullptr, nullptr, 0, stream);
+}
+
+// `residual` (nb, R, cin) contiguous or null: dx = dy w + residual — the gradient that reaches the layer's input along a
+// skip connection (reference torch_vertex.py:331,354,402 `+ _tmp`), added in the epilogue instead of by a stand-alone kernel.
+extern "C" int gkg_linear_dgrad_x6_sk(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
+                                      int cin, int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes,
+                                      void* stream) {
+  if (splitk_ws && (splitk_bytes < X6_SK_BYTES || ((size_t)splitk_ws & 15)))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6_sk: need a 16-byte aligned workspace of gkg_x6_splitk_workspace_bytes() bytes (or NULL: no split)");
+  return x6_dgrad_impl(dy, ldg, g_bstride, planes_dgrad, dx, R, cin, cout, nb, residual, splitk_ws, splitk_bytes, stream);
 }
 
 // The same input gradient with the BACKWARD statistics of the producer's BN in the epilogue (X6_BNBWD): dx is the upstream
@@ -1241,14 +1318,24 @@ static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float
   // 20 % padding 22.3 -> 24.3); the 128-wide side is cin, or — roles of the operands exchanged, dW written transposed — cout
   const long long padn = (long long)((cin + 127) / 128) * 128 * 100 / ((long long)a.ntiles * 64);
   const long long padm = (long long)((cout + 127) / 128) * 128 * 100 / ((long long)a.mtiles * 64);
-  const bool wide = aligned && (padn <= 110 || padm <= 110);
-  const bool swap = wide && padm < padn;
+  bool wide = aligned && (padn <= 110 || padm <= 110);
+  bool swap = wide && padm < padn;
+  if (batched > 0 && aligned) {
+    // inside a batched launch the tile count of ONE problem no longer decides how well the chip is filled, only the matrix
+    // time does: the 64 x 128 body runs at about its MFMA time, the 64 x 64 body at ~1.5x (7.3 vs 5.5 split instructions per
+    // MFMA) — padding up to 128 pays until it costs that much (160 x 160: 3 x 2 wide tiles against 3 x 3; 320 x 320: 5 x 3
+    // against 5 x 5)
+    const long long c64 = (long long)a.mtiles * a.ntiles * 36;
+    const long long cwn = (long long)a.mtiles * ((cin + 127) / 128) * 48, cwm = (long long)a.ntiles * ((cout + 127) / 128) * 48;
+    wide = (cwn < cwm ? cwn : cwm) <= c64;
+    swap = wide && cwm < cwn;
+  }
   const int main_mtiles = !wide ? a.mtiles : (swap ? a.ntiles : a.mtiles);
   const int main_ntiles = !wide ? a.ntiles : (swap ? (cout + 127) / 128 : (cin + 127) / 128);
   const int tiles = main_mtiles * main_ntiles * nb, units = R / 128;
   int splits = 1, share = 0;
   if (batched) {
-    // ~`batched` (default 12) units of 128 rows per workgroup (its fixed cost — ring fill, LDS reduction, the tile's atomics — is worth about 6):
+    // ~`batched` (default 20) units of 128 rows per workgroup (its fixed cost — ring fill, LDS reduction, the tile's atomics — is worth about 6):
     // 1 / 2 / 4 slabs shared by 8 / 4 / 2 XCDs each, or a multiple of 8 slabs on one XCD each
     const int want = (units + batched - 1) / batched;
     if (want <= 1) splits = 1;
@@ -1343,7 +1430,7 @@ extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, c
 extern "C" int gkg_linear_wgrad_x6_batch(const GkgWgradProblem* p, int n, int units_per_slab, void* stream) {
   if (!p || n <= 0) return gkg_fail(GKG_ERR_NULL, "gkg_linear_wgrad_x6_batch: no problems");
   if (units_per_slab < 0 || units_per_slab > 4096) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6_batch: units_per_slab out of range");
-  if (units_per_slab == 0) units_per_slab = 12;
+  if (units_per_slab == 0) units_per_slab = 20;
   hipStream_t st = (hipStream_t)stream;
   int order[256];
   if (n > 256) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6_batch: at most 256 problems per call");

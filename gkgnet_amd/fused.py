@@ -40,11 +40,10 @@ def _env_list(name):
 # ---- run-time switches (all of them; INTEGRATION.md has the table) ---------------------------------------------------
 # GKG_GEMM_MATH — arithmetic of the fp32 projection GEMMs:
 #   "x6" (default)  bf16 matrix cores with every fp32 operand split exactly into three bf16 terms, six cross products, fp32
-#                   accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 3-4x below an fp32 fma chain) for the forward and
-#                   input-gradient GEMMs where it measured faster inside the cfg2 step (rule in _x6), the fp32-MFMA forward
-#                   kernel with BN-statistics epilogue (csrc/gkg_gemm.hip) on the short label-branch matrices, the vendor
-#                   GEMM library for the rest (weight gradients);
-#   "x6all"         every eligible projection on the x6 kernels, weight gradient included;
+#                   accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 3-4x below an fp32 fma chain) for every forward, input-
+#                   gradient and weight-gradient GEMM of the blocks (round 5: split-K forms for the label branch's short
+#                   matrices, the weight gradients of a backward pass batched into one launch) — no vendor GEMM in the step;
+#   "x6all"         the same (kept as a spelling: rounds 2-4 applied a per-shape rule under "x6");
 #   "f32"           own fp32-MFMA forward kernels under the row-count rule of _own_gemm, vendor GEMMs otherwise;
 #   "vendor"        vendor GEMM library + stand-alone BN passes everywhere.
 GEMM_MATH = os.environ.get("GKG_GEMM_MATH", "x6")
@@ -90,12 +89,7 @@ def _vendor_tuned() -> bool:
 
 def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     """This projection GEMM (kind "fwd": y = x W^T, "dgrad": dx = dy W) runs on the x6 kernels.  Eligible: fp32 operands
-    outside autocast, batch statistics local to the rank, 16-byte aligned rows.  GKG_GEMM_MATH=x6 then applies the rule
-    measured inside the cfg2 step on MI355X (tools/prof_graph_steps.py, x6 vs the vendor / fp32-MFMA kernel it replaces):
-    x6 wins on the long un-grouped projections (R >= 8192: fc2 31.6 vs 37.4 us, its dgrad 31.8 vs 36.4, fc1 dgrads 18.4
-    vs 20.6) and on wide outputs (label FFN fc1 320 -> 1280: 20.3 vs 27.5); it loses where a 128-row tile grid leaves the
-    chip under-filled over a long contraction (2560 x 1280 -> 320: 31.8 vs 21.1) and on the grouped K = 160 products
-    (28.5 vs 21.4: five K-steps do not amortise the pipeline fill).  GKG_GEMM_MATH=x6all: every eligible projection."""
+    outside autocast, batch statistics local to the rank, 16-byte aligned rows, the C entry points' size limits (_x6_rule)."""
     if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none":
         return False
     if not (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None
@@ -113,17 +107,14 @@ def _x6_rule(R, cin, cout, nb, kind) -> bool:
     if (cout % 4 or nb > 64 or R * max(cin, cout) * 4 > 0xffffffff
             or nb * 2 * cout > _lib.load().gkg_linear_stats_doubles()):
         return False
-    if GEMM_MATH == "x6all":
-        return True
-    if nb != 1:
-        # grouped K = 160 forward at cfg2: x6 + statistics epilogue 33.5 us against vendor GEMM + statistics passes
-        # 23.7 + 11 us with a TunableOp-selected kernel (tie) but 32.9 + 11 us with the library's default selection:
-        # measured in the step, x6 here costs the tuned leg 12 us and saves the untuned leg 20 us
-        # (the grouped input gradient likewise: 28.5 us against 23.8 tuned / 34.2 untuned)
-        # ... and from 32 768 rows up (GKGNet-576 stages 1-3) x6 is ahead of the tuned kernels too: --workload stage3
-        # 3.39 -> 3.28 ms/step, cfg4 train step 97.9 -> 97.2 ms (same box)
-        return R >= 8192 and (not _vendor_tuned() or R >= 32768)
-    return R >= 8192 or (kind == "fwd" and cout >= 4 * cin)
+    # Round 5: every eligible projection runs on the x6 kernels.  The per-shape rule of rounds 2-4 (vendor GEMMs under TunableOp
+    # for the grouped K = 160 products and the label branch's 2 560-row matrices, the fp32-MFMA kernel for its short forwards)
+    # went away with the split-K forms, the residual epilogue and the batched weight gradients: measured inside the cfg2 step
+    # (profiles/r05_x6all_vs_rule_launch_sequences.txt, us, vendor or fp32-MFMA -> x6): 2 560 x 1280 -> 320 forward + statistics
+    # 34.7 -> 27.3, its input gradient 25.5 + 5.3 (copy) -> 25.6 (+ residual in the epilogue), 2 560 x 320 -> 1280 input gradient
+    # 24.8 -> 19.1, grouped 2 560 x 4 x (160 -> 160) input gradient 16.1 -> 10.9, 2 560 x 320 -> 640 16.0 -> 14.7, the three short
+    # forwards 12.2 / 11.8 / 21.2 -> 13.2 / 12.9 / 20.9 — and the step no longer depends on a TunableOp pass.
+    return True
 
 
 X6_WGRAD = "x6_wgrad" not in _DISABLED
@@ -303,6 +294,30 @@ def _stats_scratch(device) -> torch.Tensor:
     return t
 
 
+_SK = {}
+
+
+SPLIT_K = "splitk" not in _DISABLED      # GKG_DISABLE=splitk: the short-matrix projections as one K range per tile (A/B, tests)
+
+
+def _sk_ws(device) -> torch.Tensor:
+    """Split-K workspace of the x6 projection kernels (tile counters + partial tiles; include/gkg_hip.h): one per device,
+    counters zero between launches, stream-ordered reuse."""
+    key = (device.type, device.index)
+    t = _SK.get(key)
+    if t is None:
+        t = torch.zeros(_lib.load().gkg_x6_splitk_workspace_bytes(), dtype=torch.uint8, device=device)
+        _SK[key] = t
+    return t
+
+
+def _dgrad_x6(lib, dY, ldg, g_bs, pd, dx, R, cin, cout, nb, residual=None):
+    """dx = dY W (+ residual: the skip connection's gradient, added in the epilogue) on the x6 kernel."""
+    ws = _sk_ws(dY.device) if SPLIT_K else None
+    _lib.check(lib.gkg_linear_dgrad_x6_sk(_ptr(dY), ldg, g_bs, _ptr(pd), _ptr(dx), R, cin, cout, nb, _ptr(residual), _ptr(ws),
+                                          ws.numel() if SPLIT_K else 0, _stream()), "gkg_linear_dgrad_x6")
+
+
 def _own_gemm(x, weight, bn) -> bool:
     """fp32 operands outside autocast and batch statistics local to this rank: the projection's FORWARD runs on the library's
     own fp32 matrix-core kernel with the BN statistics in its epilogue (csrc/gkg_gemm.hip).  bf16 autocast and cross-rank
@@ -342,7 +357,9 @@ def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, planes=None):
     dev = x.device
     if planes is not None:
         def fwd(xp, wp, yp, R_, cin_, cout_, nb_, *rest):
-            return lib.gkg_linear_bn_fwd_x6(xp, cin_, R_ * cin_, _ptr(planes), yp, R_, cin_, cout_, nb_, *rest)
+            ws = _sk_ws(dev) if SPLIT_K else None
+            return lib.gkg_linear_bn_fwd_x6_sk(xp, cin_, R_ * cin_, _ptr(planes), yp, R_, cin_, cout_, nb_, *rest[:-1], _ptr(ws),
+                                               ws.numel() if SPLIT_K else 0, rest[-1])
     else:
         fwd = lib.gkg_linear_bn_fwd
     Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
@@ -575,8 +592,9 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
         if launch is not None:
             rc = launch(Y, cur)
         elif planes is not None:
-            rc = lib.gkg_linear_bn_fwd_x6(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
-                                          _ptr(cur), _stream())
+            ws = _sk_ws(dev) if SPLIT_K else None
+            rc = lib.gkg_linear_bn_fwd_x6_sk(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
+                                             _ptr(cur), _ptr(ws), ws.numel() if SPLIT_K else 0, _stream())
         else:
             rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
         _lib.check(rc, "gkg_linear_bn_fwd (statistics only)")
@@ -620,11 +638,11 @@ BN_EPILOGUE_MIN_ROWS = 0 if "bn_epilogue" in _ENABLED else 32768
 
 
 class _BnLink:
-    __slots__ = ("Y", "a", "c", "mean", "invstd", "act", "nb", "co", "R", "ready")
+    __slots__ = ("Y", "a", "c", "mean", "invstd", "act", "nb", "co", "R", "ready", "__weakref__")
 
     def __init__(self, Y, a, c, mean, invstd, act, nb, co, R):
         self.Y, self.a, self.c, self.mean, self.invstd, self.act, self.nb, self.co, self.R = Y, a, c, mean, invstd, act, nb, co, R
-        self.ready = None             # (data_ptr of the gradient tensor the sums belong to, cur, other, zero)
+        self.ready = None             # (the gradient tensor the sums belong to, its version, cur, other, zero)
 
 
 def _bn_link(out, Y, a, c, mean, invstd, act, nb, co, R, bn, sync, scale):
@@ -649,7 +667,11 @@ def _dgrad_x6_with_link(lib, dY, pd, R, cin, cout, link):
     except Exception:
         scratch.poison()
         raise
-    link.ready = (dx.data_ptr(), cur, other, zero)
+    # the tensor ITSELF and its version: holding it keeps autograd from accumulating another consumer's gradient
+    # into it in place (use_count > 1 -> a fresh sum is allocated), and a changed version or another object means the sums on
+    # the link do not describe the gradient the producer receives
+    link.ready = (dx, dx._version, cur, other, zero)
+    scratch.pending = link               # the other buffer's clear is deferred to the producer's apply pass (bn_scratch.acquire)
     return dx
 
 
@@ -669,9 +691,12 @@ def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg
     data-parallel gradient exchange averages them).  ``link``: this layer's _BnLink — when the consumer's dgrad epilogue has
     left the statistics of exactly this gradient tensor on it, only the apply pass runs."""
     if link is not None and link.ready is not None:
-        ptr, cur, other, zero = link.ready
+        dxr, ver, cur, other, zero = link.ready
         link.ready = None
-        if ptr == g.data_ptr() and g_bstride == (C if nb > 1 else 0) and ldg == nb * C:
+        scr = _BnBwdScratch.of(Y.device)
+        if scr.pending is link:
+            scr.pending = None
+        if g is dxr and g._version == ver and g_bstride == (C if nb > 1 else 0) and ldg == nb * C:
             try:
                 _lib.check(lib.gkg_bn_bwd_apply_from_sums(_ptr(g), _ptr(Y), _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd), _ptr(dY),
                                                           _ptr(dgamma), _ptr(dbeta), R, C, nb, ldg, g_bstride, act, _ptr(cur),
@@ -823,8 +848,10 @@ class _LinearBNAct(torch.autograd.Function):
             dx = _dgrad_x6_with_link(lib, dY, ctx.pd, R, cin, cout, ctx.prev)      # + the producer's BN backward statistics
         elif ctx.pd is not None:
             dx = torch.empty((R, cin), dtype=_F32, device=dY.device)
-            _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), cout, R * cout, _ptr(ctx.pd), _ptr(dx), R, cin, cout, 1, _stream()),
-                       "gkg_linear_dgrad_x6")
+            res = dalias.contiguous() if (dalias is not None and dalias.dtype == _F32 and dalias.shape == dx.shape) else None
+            _dgrad_x6(lib, dY, cout, R * cout, ctx.pd, dx, R, cin, cout, 1, res)
+            if res is not None:
+                dalias = None
         elif dalias is not None and dalias.dtype == dY.dtype:
             dx = torch.addmm(dalias, dY, W)                # the residual-path gradient rides in the GEMM epilogue
             dalias = None
@@ -903,8 +930,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
             dU = None
         elif ctx.pd is not None:
             dU = torch.empty((nb, R, ci), dtype=_F32, device=dY.device)
-            _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), co, R * co, _ptr(ctx.pd), _ptr(dU), R, ci, co, nb, _stream()),
-                       "gkg_linear_dgrad_x6")
+            _dgrad_x6(lib, dY, co, R * co, ctx.pd, dU, R, ci, co, nb)
         else:
             dU = torch.bmm(dY, Wg)
         dW = _wgrad_grouped(dY, U, dWv).view_as(weight)
@@ -1228,8 +1254,7 @@ class _MRGroupedLinearBNAct(torch.autograd.Function):
         if need_in:
             if ctx.pd is not None:
                 dU = torch.empty((4, T, ci), dtype=_F32, device=dY.device)
-                _lib.check(lib.gkg_linear_dgrad_x6(_ptr(dY), co, T * co, _ptr(ctx.pd), _ptr(dU), T, ci, co, 4, _stream()),
-                           "gkg_linear_dgrad_x6")
+                _dgrad_x6(lib, dY, co, T * co, ctx.pd, dU, T, ci, co, 4)
             else:
                 dU = torch.bmm(dY, weight.view(4, co, ci))
         if U is None:                                   # the weight gradient's operand, rebuilt from the saved winning rows

@@ -339,6 +339,21 @@ int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* 
                          float* bn_mean, float* bn_invstd, float momentum, float eps, double* stats, void* stream);
 int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R, int cin,
                         int cout, int nb, void* stream);
+/* Split-K forms (round 5) for few rows under a long contraction (the label branch's 2 560-row matrices: 100 workgroups of 40
+ * K-steps on 256 CUs): the same calls with a caller-owned workspace of gkg_x6_splitk_workspace_bytes() bytes (NULL: never
+ * split) whose first 4 KiB (tile counters) are ZERO before the first use — every launch leaves them zero again.  The library cuts the contraction
+ * into up to 8 ranges when that fills the chip (shapes it does not split run exactly as without the workspace); the last
+ * workgroup to arrive at a tile adds the partial tiles in range order (run-to-run identical bits) and runs the normal
+ * epilogue, BN statistics included.  gkg_linear_dgrad_x6_sk: `residual` (nb, R, cin) contiguous or NULL is added to dx in
+ * the epilogue (the skip connection's gradient, reference torch_vertex.py:331,354,402). */
+size_t gkg_x6_splitk_workspace_bytes(void);
+int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R, int cin,
+                            int cout, int nb, int train, const float* gamma, const float* beta, const float* bias,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* bn_a, float* bn_c,
+                            float* bn_mean, float* bn_invstd, float momentum, float eps, double* stats, void* splitk_ws,
+                            size_t splitk_bytes, void* stream);
+int gkg_linear_dgrad_x6_sk(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R, int cin,
+                           int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes, void* stream);
 /* dw (nb, cout, cin) += dy^T x over the R rows (both operands split in registers; no LDS staging, each wave streams its own
  * rows).  dw must be ZERO on entry: slabs of rows are added with fp32 atomics (run-dependent summation order, like a
  * split-K GEMM).  x (nb, R, cin) with row pitch ldx / batch stride x_bstride (floats).  Any cin, cout >= 1. */
@@ -350,7 +365,7 @@ int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float*
  * alone is a launch of 50-400 workgroups on 256 CUs.  Problem i is exactly gkg_linear_wgrad_x6(dy, ldg, g_bstride, x, ldx,
  * x_bstride, dw, R, cin, cout, nb): every dw ZERO on entry, accumulated with fp32 atomics.  At most 256 problems per call
  * (16 per launch); operands must stay valid until the launch has run.  units_per_slab: rows per workgroup in units of 128
- * (0: the library's default, 12). */
+ * (0: the library's default, 20). */
 typedef struct GkgWgradProblem {
   const float* dy;
   const float* x;

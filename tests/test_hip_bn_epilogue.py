@@ -90,14 +90,19 @@ def test_a_second_consumer_of_the_activation_falls_back_cleanly(monkeypatch):
     gen = torch.Generator(device="cuda").manual_seed(8)
     x0 = torch.randn(R, C, device="cuda", generator=gen)
     res = []
-    for extra in (True, False):
+    # "before": the second use of h is created BEFORE the x6 consumer, so the consumer's dx arrives first and autograd would add
+    # the other gradient into it IN PLACE (same data_ptr, other values) unless the link holds the tensor
+    for extra in ("after", "before", False):
         torch.manual_seed(9)
         s1 = torch.nn.Sequential(torch.nn.Conv2d(C, C, 1), layers.build_norm(C)).cuda().train()
         s2 = torch.nn.Sequential(torch.nn.Conv2d(C, C, 1), layers.build_norm(C)).cuda().train()
         x = x0.clone().requires_grad_(True)
         h = fused._lin(x, s1, act=1)
+        side = (h * 0.5).sum() if extra == "before" else 0
         out = fused._lin(h, s2)
-        loss = out.square().sum() + ((h * 0.5).sum() if extra else 0)       # a second use of h: autograd sums two gradients
+        if extra == "after":
+            side = (h * 0.5).sum()                                           # a second use of h: autograd sums two gradients
+        loss = out.square().sum() + side
         loss.backward()
         # reference: the same with the epilogue off
         monkeypatch.setattr(fused, "BN_EPILOGUE", False)

@@ -394,3 +394,58 @@ def test_non_finite_inputs_poison_only_their_rows():
                                         *([None] * 10), 0.0, 0.0, None, None), "fwd")
     bad = ~torch.isfinite(y[0]).all(dim=1)
     assert bad.nonzero().flatten().tolist() == [17, 200, 201]
+
+
+# ---- split-K forms (round 5): few rows under a long contraction.  (R, cin, cout, nb): the label branch's products, ragged rows,
+# a contraction that is not a multiple of 32 (its last range ends in a tail step), grouped, and one shape the rule does not split
+SK_SHAPES = [(2560, 1280, 320, 1), (2560, 640, 320, 1), (2560, 320, 320, 1), (2560, 320, 640, 1), (300, 2048, 64, 2),
+             (1000, 1000, 100, 1), (777, 516, 40, 3), (2560, 320, 1280, 1)]
+
+
+@pytest.mark.parametrize("R,cin,cout,nb", SK_SHAPES)
+def test_split_k_forward_statistics_and_dgrad(R, cin, cout, nb):
+    """gkg_linear_bn_fwd_x6_sk / gkg_linear_dgrad_x6_sk against fp64 at the fp32 bar, run-to-run identical bits (the partials
+    are added in range order by the last arrival), BN column sums from the summed tile, counters left zero."""
+    from gkgnet_amd import _lib, fused
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(R + cin + cout)
+    x = torch.randn(nb, R, cin, device="cuda", generator=gen) * 2 + 0.5
+    w = torch.randn(nb, cout, cin, device="cuda", generator=gen) * 0.1
+    dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
+    pf, pd = _planes(lib, w, nb, cout, cin)
+    ws = torch.zeros(lib.gkg_x6_splitk_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros(lib.gkg_linear_stats_doubles(), dtype=torch.float64, device="cuda")
+    ys, dxs = [], []
+    for rep in range(2):
+        y = torch.full((nb, R, cout), float("nan"), device="cuda")
+        stats.zero_()
+        _lib.check(lib.gkg_linear_bn_fwd_x6_sk(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
+                                               *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), None), "fwd sk")
+        dx = torch.full((nb, R, cin), float("nan"), device="cuda")
+        res = torch.randn(nb, R, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+        _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
+                                              res.data_ptr(), ws.data_ptr(), ws.numel(), None), "dgrad sk")
+        torch.cuda.synchronize()
+        ys.append(y)
+        dxs.append(dx)
+        assert int(ws[:4096].view(torch.int32).abs().max()) == 0                     # every tile counter re-armed
+    assert torch.equal(ys[0], ys[1]) and torch.equal(dxs[0], dxs[1])
+    y, dx = ys[0], dxs[0]
+    ref_y = torch.bmm(x.double(), w.double().transpose(1, 2))
+    ref_dx = torch.bmm(dy.double(), w.double()) + res.double()                      # the residual rides in the epilogue
+    mag_y = torch.bmm(x.double().abs(), w.double().abs().transpose(1, 2)) + 1e-30
+    mag_dx = torch.bmm(dy.double().abs(), w.double().abs()) + res.double().abs() + 1e-30
+    e_y, e_dx = _rel(y, ref_y, mag_y), _rel(dx, ref_dx, mag_dx)
+    f_y = _rel(torch.bmm(x, w.transpose(1, 2)), ref_y, mag_y)
+    f_dx = _rel(torch.baddbmm(res, dy, w), ref_dx, mag_dx)
+    assert e_y <= max(f_y, 1.2e-7) and e_dx <= max(f_dx, 1.2e-7), (e_y, f_y, e_dx, f_dx)
+    assert e_y < 2e-7 and e_dx < 2e-7
+    # the epilogue's column sums [nb][2][cout]: sum y, sum y^2
+    sums = stats[:nb * 2 * cout].view(nb, 2, cout)
+    assert torch.allclose(sums[:, 0], ref_y.sum(1), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(sums[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
+    # the same bits as the unsplit kernel would be a coincidence (different summation tree); the same VALUES to fp32 accuracy
+    y1 = torch.empty_like(y)
+    _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y1.data_ptr(), R, cin, cout, nb, 0,
+                                        *([None] * 10), 0.0, 0.0, None, None), "fwd")
+    assert float(((y1.double() - y.double()).abs() / mag_y).max()) < 3e-7

@@ -53,6 +53,7 @@ def test_real_shape_blocks_fused_vs_composable_and_autocast_forward(cfg):
     for stage, c in enumerate(ch):
         shapes[c] = hw
         hw //= 2
+    torch.manual_seed(1234)
     for name, g in _block_pairs(net):
         g.train()
         C = g.channels
@@ -88,10 +89,15 @@ def test_real_shape_blocks_fused_vs_composable_and_autocast_forward(cfg):
             g.zero_grad(set_to_none=True)
         (o1, d1), (o2, d2) = res
         assert torch.allclose(o1, o2, atol=1e-3, rtol=1e-3), (name, float((o1 - o2).abs().max()))
-        # a near-tie inside max_k(x_j - x_i) (two neighbours equal in one channel to ~1e-7) may still route single
-        # gradient elements to the other neighbour: element-wise for >= 99.9 %, bounded in norm
-        okg = ((d1 - d2).abs() <= 2e-3 + 2e-3 * d2.abs()).float().mean().item()
-        assert okg >= 0.999 and ((d1 - d2).norm() / d2.norm()).item() < 2e-2, (name, okg)
+        # a near-tie inside max_k(x_j - x_i) (two neighbours equal in one channel to ~1e-6: the two paths' fc1 outputs differ
+        # by that much) routes ONE gradient element to the other neighbour — which fc1's input gradient then spreads over all C
+        # channels of the (up to three) tokens involved.  So the comparison is per TOKEN: all but a handful of tokens agree in
+        # every channel (expected flips ~1e-6 per (token, channel) maximum), and the difference is bounded in norm.  (Round 5:
+        # the former element-wise ">= 99.9 %" bar counted one flip at B = 2 as 0.3 % of the elements.)
+        bad_tok = ((d1 - d2).abs() > 2e-3 + 2e-3 * d2.abs()).any(dim=1)                 # (B, H, W)
+        flips_allowed = 2 + int(3e-6 * d1.numel())
+        assert int(bad_tok.sum()) <= 3 * flips_allowed, (name, int(bad_tok.sum()), flips_allowed)
+        assert ((d1 - d2).norm() / d2.norm()).item() < 2e-2, name
     # ---- (2) the config's own mode: eval, bf16 autocast, every graph layer on the fused HIP path — and the graphs it builds
     # there are the CONTRACT's, index for index: the first k-NN call of every distinct (queries, keys, channels, list) shape
     # is re-evaluated by the C oracle on the very tokens the kernel saw ("bit-exact neighbor indices" in
