@@ -65,7 +65,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
-           "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk")
+           "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
+           "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -115,6 +116,12 @@ def load():
     lib.gkg_nchw_to_tm.argtypes = [V, V, I, I, I, I, V, V]
     lib.gkg_tm_affine_to_nchw.restype = I
     lib.gkg_tm_affine_to_nchw.argtypes = [V] * 5 + [I, I, I, V, V]
+    lib.gkg_tm_affine_to_nchw_dual.restype = I
+    lib.gkg_tm_affine_to_nchw_dual.argtypes = [V] * 6 + [I, I, I, V]
+    lib.gkg_nchw_to_tm_add.restype = I
+    lib.gkg_nchw_to_tm_add.argtypes = [V, V, V, I, I, I, V]
+    lib.gkg_bn_apply_train_dual.restype = I
+    lib.gkg_bn_apply_train_dual.argtypes = [V] * 15 + [I, I, I, F, F, V, Z, V]
     lib.gkg_bn_workspace_bytes.restype = Z
     lib.gkg_bn_workspace_bytes.argtypes = [I, I, I]
     lib.gkg_bn_train_stats.restype = I

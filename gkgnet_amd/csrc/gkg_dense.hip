@@ -53,7 +53,8 @@ __device__ __forceinline__ void bn_derive_channel(const BnDerive& d, size_t o, d
 // (B, C, N) channel-major -> (B*N, C) token-major through a padded 32x32 LDS tile (coalesced both sides).
 template <typename OutT>
 __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict__ x, OutT* __restrict__ out,
-                                                         int C, int N, const float* __restrict__ img_scale) {
+                                                         int C, int N, const float* __restrict__ img_scale,
+                                                         const float* __restrict__ add_tm = nullptr) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
@@ -67,7 +68,12 @@ __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, ch = c0 + tx;
-    if (ch < C && n < N) stf(out + ((size_t)b * N + n) * C + ch, img_scale ? tile[tx][ty + 8 * i] * sc : tile[tx][ty + 8 * i]);
+    if (ch < C && n < N) {
+      const size_t o = ((size_t)b * N + n) * C + ch;
+      float v = tile[tx][ty + 8 * i];
+      if (add_tm) v += add_tm[o];                 // a second gradient of the same tensor that arrives token-major
+      stf(out + o, img_scale ? v * sc : v);
+    }
   }
 }
 
@@ -75,7 +81,12 @@ __global__ __launch_bounds__(256) void nchw_to_tm_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ a,
                                                                 const float* __restrict__ cs, const float* __restrict__ res,
                                                                 float* __restrict__ out, int C, int N,
-                                                                const float* __restrict__ img_scale, BnDerive d) {
+                                                                const float* __restrict__ img_scale, BnDerive d,
+                                                                const float* __restrict__ res_tm = nullptr,
+                                                                float* __restrict__ out_tm = nullptr) {
+  // res_tm / out_tm (round 5): the residual given token-major (the block's own token-major copy of its input) and the result
+  // written token-major as well — what a GrapherLabel behind this block reads as keys / values (torch_vertex.py:392-403) —
+  // from the pass that writes the NCHW tensor anyway.
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -97,8 +108,14 @@ __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __r
     const int n = n0 + ty + 8 * i, ch = c0 + tx;
     float v = 0.f;
     if (ch < C && n < N) {
-      v = y[((size_t)b * N + n) * C + ch];
+      const size_t ot = ((size_t)b * N + n) * C + ch;
+      v = y[ot];
       if (affine) v = __builtin_fmaf(av, v, cv);
+      if (res_tm) {
+        if (img_scale) v *= img_scale[b];
+        v += res_tm[ot];
+        if (out_tm) out_tm[ot] = v;
+      }
     }
     tile[ty + 8 * i][tx] = v;
   }
@@ -109,8 +126,10 @@ __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __r
     if (ch < C && n < N) {
       const size_t o = ((size_t)b * C + ch) * N + n;
       float v = tile[tx][ty + 8 * i];
-      if (img_scale) v *= img_scale[b];             // DropPath (reference torch_vertex.py:332): branch * mask / keep
-      if (res) v += res[o];
+      if (!res_tm) {
+        if (img_scale) v *= img_scale[b];           // DropPath (reference torch_vertex.py:332): branch * mask / keep
+        if (res) v += res[o];
+      }
       out[o] = v;
     }
   }
@@ -603,6 +622,29 @@ extern "C" int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, in
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "nchw_to_tm_kernel");
 }
 
+// (B,C,N) + token-major addend -> token-major fp32: the upstream gradient of a block output that was handed out in BOTH
+// layouts (gkg_tm_affine_to_nchw_dual), summed while it is re-laid out.
+extern "C" int gkg_nchw_to_tm_add(const float* x, const float* add_tm, float* out, int B, int C, int N, void* stream) {
+  if (!x || !add_tm || !out) return gkg_fail(GKG_ERR_NULL, "gkg_nchw_to_tm_add: null pointer");
+  if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_nchw_to_tm_add: bad sizes");
+  dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(nchw_to_tm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, N, (const float*)nullptr, add_tm);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "nchw_to_tm_kernel (add)");
+}
+
+// gkg_tm_affine_to_nchw with the residual given token-major and the result written in both layouts.
+extern "C" int gkg_tm_affine_to_nchw_dual(const float* y, const float* a, const float* c, const float* res_tm, float* out,
+                                          float* out_tm, int B, int C, int N, void* stream) {
+  if (!y || !out || !res_tm || !out_tm || ((a == nullptr) != (c == nullptr))) return gkg_fail(GKG_ERR_NULL, "gkg_tm_affine_to_nchw_dual: null pointer");
+  if (B <= 0 || C <= 0 || N <= 0 || B > 65535) return gkg_fail(GKG_ERR_SHAPE, "gkg_tm_affine_to_nchw_dual: bad sizes");
+  dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, a, c, (const float*)nullptr, out, C, N,
+                     (const float*)nullptr, BnDerive{}, res_tm, out_tm);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "tm_affine_to_nchw_kernel (dual)");
+}
+
 extern "C" int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
                                      int B, int C, int N, const float* img_scale, void* stream) {
   if (!y || !out || ((a == nullptr) != (c == nullptr))) return gkg_fail(GKG_ERR_NULL, "gkg_tm_affine_to_nchw: null pointer");
@@ -841,6 +883,26 @@ extern "C" int gkg_bn_apply_train(const float* y, const double* sums, const floa
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_apply_train");
+}
+
+// gkg_bn_apply_train's channel-major form with the residual given token-major and the result written in both layouts
+// (gkg_tm_affine_to_nchw_dual with the coefficients derived from the projection's column sums).
+extern "C" int gkg_bn_apply_train_dual(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked, float* a,
+                                       float* c, float* mean, float* invstd, const float* res_tm, float* out, float* out_tm,
+                                       int B, int C, int N, float momentum, float eps, double* zero_buf, size_t zero_doubles,
+                                       void* stream) {
+  if (!y || !sums || !gamma || !beta || !a || !c || !mean || !invstd || !out || !res_tm || !out_tm)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train_dual: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train_dual: running stats come in pairs");
+  if (B <= 0 || B > 65535 || N <= 0 || bad_c(C) || (zero_doubles && !zero_buf)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train_dual: bad sizes");
+  BnDerive d{sums, gamma, beta, bias, running_mean, running_var, num_batches_tracked, a, c, mean, invstd, B * N, momentum, eps,
+             zero_buf, zero_doubles};
+  dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(tm_affine_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, out, C, N, (const float*)nullptr, d, res_tm, out_tm);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_apply_train (dual)");
 }
 
 // ------------------------------------------------------------------------------------------ cross-rank (SyncBN) halves

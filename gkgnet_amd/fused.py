@@ -579,7 +579,7 @@ from .bn_scratch import _BnBwdScratch, _BnFwdScratch      # noqa: E402  (fp64 co
 
 
 def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale,
-                           launch=None):
+                           launch=None, out_tm=None):
     """Projection (statistics in its epilogue) -> BN-apply straight from the fp64 sums: two launches, no finalize kernel.
     Returns (Y, a, c, mean, invstd).  ``launch(Y, sums) -> rc``: a caller-supplied producer of Y and its column sums (the
     fused aggregation + projection kernel) instead of the plain projection of ``x``."""
@@ -602,12 +602,20 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
         c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
         track = bn.training and bn.track_running_stats
         _touch_stats(bn, track)
-        _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
-                                          _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
-                                          _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd),
-                                          _ptr(res), _ptr(out), R, cout, nb, ldo, obs, act, nchw_B, _ptr(scale), rows_per_scale,
-                                          float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
-                   "gkg_bn_apply_train")
+        if out_tm is not None:           # channel-major AND token-major result, residual token-major (gkg_bn_apply_train_dual)
+            _lib.check(lib.gkg_bn_apply_train_dual(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                                   _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                                   _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
+                                                   _ptr(invstd), _ptr(res), _ptr(out), _ptr(out_tm), nchw_B, cout, R // nchw_B,
+                                                   float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
+                       "gkg_bn_apply_train_dual")
+        else:
+            _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                              _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                              _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd),
+                                              _ptr(res), _ptr(out), R, cout, nb, ldo, obs, act, nchw_B, _ptr(scale), rows_per_scale,
+                                              float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
+                       "gkg_bn_apply_train")
     except Exception:
         scratch.poison()                 # sums may sit in a buffer the bookkeeping calls clean: cleared at the next acquire
         raise
@@ -749,11 +757,13 @@ class _LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None, scale=None,
-                rows_per_scale=0, want16=False, alias=False):
+                rows_per_scale=0, want16=False, alias=False, dual=False):
         """``alias``: also return ``x`` itself as a second output (a view).  A caller that uses the layer's input again
         as the residual of a later layer takes the alias for that: both gradient contributions then arrive at THIS node
         and the input-gradient GEMM adds the residual one in its epilogue (``addmm``), instead of autograd summing two
-        tensors with a stand-alone add kernel."""
+        tensors with a stand-alone add kernel.
+        ``dual`` (with ``nchw``, fp32, no DropPath scale): ``residual`` is given TOKEN-MAJOR (R, cout) and the result is
+        returned in both layouts, ``(out (B, C, H, W), out_tm (R, cout))`` — see DUAL_LAYOUT below."""
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
@@ -774,10 +784,15 @@ class _LinearBNAct(torch.autograd.Function):
         if own:
             x = x.contiguous()
         sync = None
+        out_tm = None
+        if dual:
+            assert nchw is not None and scale is None and res is not None and res.shape == (R, cout) and res.dtype == _F32
+            out_tm = torch.empty((R, cout), dtype=_F32, device=x.device)
         fused_apply = own and _derive_ok(bn, 1, cout, code, want16)
         if fused_apply:                               # projection (statistics epilogue) -> apply from the sums: 2 launches
             Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, pf, res, out,
-                                                           cout, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale)
+                                                           cout, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale,
+                                                           out_tm=out_tm)
         elif own:                                     # projection kernel with the BN statistics in its epilogue
             Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
         else:
@@ -794,10 +809,14 @@ class _LinearBNAct(torch.autograd.Function):
         elif nchw is None:
             _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
                                           code, _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act")
+        elif dual:
+            _lib.check(lib.gkg_tm_affine_to_nchw_dual(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), _ptr(out_tm), nchw[0], cout,
+                                                      R // nchw[0], _stream()), "gkg_tm_affine_to_nchw_dual")
         else:
             _lib.check(lib.gkg_tm_affine_to_nchw(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), nchw[0], cout,
                                                  R // nchw[0], _ptr(scale), _stream()), "gkg_tm_affine_to_nchw")
         ctx.save_for_backward(x, weight, Y, a, c, mean, invstd)
+        ctx.dual = dual
         ctx.meta = (act, nchw, residual is not None, bias is not None)
         ctx.scale = (scale, rows_per_scale)
         ctx.gparams = (weight, gamma, beta)
@@ -808,6 +827,9 @@ class _LinearBNAct(torch.autograd.Function):
         if alias:
             ctx.set_materialize_grads(False)
             return out, x.view_as(x)
+        if dual:
+            ctx.set_materialize_grads(False)
+            return out, out_tm
         return out
 
     @staticmethod
@@ -815,13 +837,34 @@ class _LinearBNAct(torch.autograd.Function):
         lib = _lib.load()
         x, weight, Y, a, c, mean, invstd = ctx.saved_tensors
         act, nchw, has_res, has_bias = ctx.meta
-        if dout is None:                                   # only the alias was used downstream
-            return (dalias,) + (None,) * 14
+        dtm = None
+        if ctx.dual:
+            dtm, dalias = dalias, None
+            if dout is None and dtm is None:
+                return (None,) * 16
+        elif dout is None:                                 # only the alias was used downstream
+            return (dalias,) + (None,) * 15
         R, cin = x.shape
         cout = weight.shape[0]
         dres = dout if has_res else None
         row_scale = None
-        if nchw is not None:
+        if ctx.dual:
+            # the output went out in both layouts: its two upstream gradients are summed while the NCHW one is re-laid out, and
+            # the (token-major) residual's gradient is that very sum
+            if dout is None:
+                g = dtm.contiguous()
+            elif dtm is None:
+                g = torch.empty((R, cout), dtype=_F32, device=dout.device)
+                dout_c = dout.contiguous()
+                _lib.check(lib.gkg_nchw_to_tm(_ptr(dout_c), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32, None, _stream()),
+                           "gkg_nchw_to_tm")
+            else:
+                g = torch.empty((R, cout), dtype=_F32, device=dout.device)
+                dout_c, dtm_c = dout.contiguous(), dtm.contiguous()
+                _lib.check(lib.gkg_nchw_to_tm_add(_ptr(dout_c), _ptr(dtm_c), _ptr(g), nchw[0], cout, R // nchw[0], _stream()),
+                           "gkg_nchw_to_tm_add")
+            dres = g
+        elif nchw is not None:
             g = torch.empty((R, cout), dtype=_F32, device=dout.device)
             dout_c = dout.contiguous()           # named: the copy must outlive the launch that reads it
             _lib.check(lib.gkg_nchw_to_tm(_ptr(dout_c), _ptr(g), nchw[0], cout, R // nchw[0], _lib.F32,
@@ -862,7 +905,7 @@ class _LinearBNAct(torch.autograd.Function):
         elif dalias is not None:
             dx = dalias
         dW = _wgrad(dY, x, dWv).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -1362,7 +1405,8 @@ def fused_supported(mod, x, groups: int) -> bool:
     return ENABLED
 
 
-def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False, alias=False):
+def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False, alias=False,
+         dual=False):
     """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
     output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402).
     ``alias``: returns ``(out, x')`` with ``x'`` the input again, to be used as a later layer's residual (see
@@ -1390,7 +1434,19 @@ def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, ro
         return torch.addmm(_folded_shift32(conv, bn), x, wf.t(), out_dtype=_F32)
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
     return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
-                              rows_per_scale, want16)
+                              rows_per_scale, want16, False, dual)
+
+
+# ---- a block output in both layouts (round 5) ---------------------------------------------------------------------------
+# A Grapher that takes and returns NCHW (the drop-in case: reference torch_vertex.py:325-333) in front of a GrapherLabel, which
+# reads the feature map token-major as keys / values (torch_vertex.py:392-403): the label branch paid nchw_to_tm in its forward
+# and, in the backward, token-major gradient -> NCHW, autograd's add with the other gradient, -> token-major again (8 + 25 of
+# 981 us at cfg2).  Instead the block's last kernel writes its result token-major as well (the residual read from the block's
+# own token-major copy of the input), the label branch takes that companion (``features._gkg_tm``), and the node's backward
+# sums the two upstream gradients while it re-lays out the NCHW one.  Adaptive: a GrapherLabel that has to convert a feature
+# map marks the block that produced it (``_gkg_producer``), which emits the companion from its next call on — blocks nobody
+# reads token-major never pay the second store.  GKG_DISABLE=dual_layout: off.
+DUAL_LAYOUT = "dual_layout" not in _DISABLED
 
 
 def _drop_scale(drop_path, batch, device):
@@ -1404,7 +1460,13 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     gc = mod.graph_conv
     lp = lowp_inference()
     xt, x, cl = _block_entry(x, lp)                                 # (T, C) and the residual branch
-    x1 = _lin(xt, mod.fc1)                                          # fc1 + BN
+    scale = _drop_scale(mod.drop_path, B, x.device)
+    dual = (DUAL_LAYOUT and not cl and not lp and scale is None and torch.is_grad_enabled() and xt.dtype == _F32
+            and getattr(mod, "_gkg_want_tm", False))
+    if dual:
+        x1, xt_r = _lin(xt, mod.fc1, alias=True)                    # xt_r: xt again, the (token-major) residual of fc2
+    else:
+        x1 = _lin(xt, mod.fc1)                                      # fc1 + BN
     x1b = x1.view(B, N, C)
     yb = None
     if gc.r > 1:                                                    # pooled keys (torch_vertex.py:194-196)
@@ -1412,10 +1474,15 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
     a2 = _aggregate_project(x1b, yb, edge[0], groups, gc.gconv.nn, C, lp)   # row g1: aggregation = the projection's operand producer
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
-        out = _lin(a2, mod.fc2, residual=x, scale=_drop_scale(mod.drop_path, B, x.device), rows_per_scale=N, want16=lp)
+        out = _lin(a2, mod.fc2, residual=x, scale=scale, rows_per_scale=N, want16=lp)
         return _cl_out(out, B, H, W), edge
-    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W),          # ... back to NCHW
-               scale=_drop_scale(mod.drop_path, B, x.device))
+    if dual:
+        out, out_tm = _lin(a2, mod.fc2, residual=xt_r, nchw=(B, C, H, W), dual=True)
+        out._gkg_tm = (out._version, out_tm)                        # the token-major companion (grapher_label_forward)
+        return out, edge
+    out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W), scale=scale)      # ... back to NCHW
+    if DUAL_LAYOUT:
+        out._gkg_producer = weakref.ref(mod)
     return out, edge
 
 
@@ -1423,9 +1490,16 @@ def grapher_label_forward(mod, e, features, groups: int):
     """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
     B, L, C = e.shape
     gc = mod.graph_conv
+    ent = getattr(features, "_gkg_tm", None)
     if is_channels_last(features):                                           # keys / values (B, HW, C): a view
         ft = features.permute(0, 2, 3, 1).reshape(B, -1, C)
+    elif (DUAL_LAYOUT and ent is not None and ent[0] == features._version and features.dim() == 4 and features.dtype == _F32
+          and ent[1].shape == (B * features.shape[2] * features.shape[3], C)):
+        ft = ent[1].view(B, -1, C)                                           # the producing block's token-major companion
     else:
+        prod = getattr(features, "_gkg_producer", None)
+        if prod is not None and prod() is not None:
+            prod()._gkg_want_tm = True                                       # ... which it emits from its next call on
         ft = to_token_major(features.float().contiguous()).view(B, -1, C)
     e2 = e.float().reshape(B * L, C).contiguous()
     x1, e2r = _lin(e2, mod.fc1, alias=True)                          # e2r: e2 again, for the residual of fc2 (one gradient node)

@@ -208,6 +208,15 @@ int gkg_nchw_to_tm(const float* x, void* out, int B, int C, int N, int out_dtype
  * img_scale is the reference's DropPath (torch_vertex.py:332, timm): per-image Bernoulli keep mask / keep probability. */
 int gkg_tm_affine_to_nchw(const float* y, const float* a, const float* c, const float* res, float* out,
                           int B, int C, int N, const float* img_scale, void* stream);
+/* Round 5: a block output handed out in BOTH layouts.  A Grapher that takes and returns NCHW (reference torch_vertex.py:325-333)
+ * in front of a GrapherLabel (torch_vertex.py:392-403, which reads the feature map token-major as keys / values) used to pay a
+ * layout pass in the label branch's forward and three in its backward (token-major gradient -> NCHW, + the other gradient,
+ * -> token-major again).  gkg_tm_affine_to_nchw_dual: out(B,C,N) and out_tm(B*N,C) = a*y + c + res_tm, the residual given
+ * token-major (the block's own token-major copy of its input).  gkg_nchw_to_tm_add: out(B*N,C) = x(B,C,N)^T + add_tm — the two
+ * upstream gradients of such an output summed while the NCHW one is re-laid out. */
+int gkg_tm_affine_to_nchw_dual(const float* y, const float* a, const float* c, const float* res_tm, float* out, float* out_tm,
+                               int B, int C, int N, void* stream);
+int gkg_nchw_to_tm_add(const float* x, const float* add_tm, float* out, int B, int C, int N, void* stream);
 size_t gkg_bn_workspace_bytes(int R, int C, int nb);
 /* Train-mode batch statistics of y (R,C) (conv bias NOT included in y; it is folded: it cancels in the output and
  * is added to running_mean).  Writes scale a, shift c (out = a*y + c), saved mean / invstd; updates running stats
@@ -253,6 +262,11 @@ int gkg_bn_apply_train(const float* y, const double* sums, const float* gamma, c
                        float* mean, float* invstd, const float* res, float* out, int R, int C, int nb, int ldo,
                        size_t out_bstride, int act, int nchw_B, const float* row_scale, int rows_per_scale, float momentum,
                        float eps, double* zero_buf, size_t zero_doubles, void* stream);
+/* gkg_bn_apply_train's channel-major form as gkg_tm_affine_to_nchw_dual: residual token-major, result in both layouts. */
+int gkg_bn_apply_train_dual(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
+                            float* mean, float* invstd, const float* res_tm, float* out, float* out_tm, int B, int C, int N,
+                            float momentum, float eps, double* zero_buf, size_t zero_doubles, void* stream);
 /* gkg_bn_bwd in two launches instead of three: the statistics pass accumulates its column sums into `sums` (fp64,
  * 2 * nb * C doubles, ZERO on entry) with atomics, the apply pass reads them, writes dgamma / dbeta and clears `zero_buf`
  * (`zero_doubles` doubles; NULL / 0: nothing).  The caller alternates between two scratch buffers and passes the region the
