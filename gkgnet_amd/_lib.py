@@ -66,7 +66,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
-           "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual")
+           "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
+           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -108,6 +109,10 @@ def load():
     V, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
     lib.gkg_knn_fwd_tm.restype = I
     lib.gkg_knn_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V, Z, V]
+    lib.gkg_knn_mr_fused_supported.restype = I
+    lib.gkg_knn_mr_fused_supported.argtypes = [I] * 9 + [C.c_uint]
+    lib.gkg_knn_mr_fwd_tm.restype = I
+    lib.gkg_knn_mr_fwd_tm.argtypes = [V] * 8 + [I] * 7 + [C.c_uint, V, Z, V]
     lib.gkg_mr_fwd_tm.restype = I
     lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 9 + [V]
     lib.gkg_mr_bwd_tm.restype = I

@@ -399,16 +399,31 @@ static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int 
   return hipGetLastError();
 }
 
+// Fused aggregation request of gkg_knn_mr_fwd_tm (token-major fp32 callers): outputs of knn_tile_kernel<..., MRF = true>.
+struct KnnMrFuse {
+  float* out;             // (4, B * N, C / 2)
+  uint16_t* arg;          // (B, N, C)
+  uint16_t* nn16;         // (B * G, N, k) or null
+};
+
+// The launch-plan part of the eligibility of the fused form (the caller checks dtype / channel alignment): the fp32 tile
+// kernel with merged per-wave lists — no key splits, no prefilter, no single-wave form — and lists of at most 36 entries.
+static bool knn_mr_plan_ok(const KnnPlan& p, int c, int N, int M, int k, bool pf, bool solo32) {
+  return p.S == 1 && !pf && !solo32 && p.KD <= 36 && k <= 18 && M <= 65536 && (c & 3) == 0 &&
+         (size_t)NW * p.KD * 64 * 8 + (size_t)k * 64 * 4 <= 150 * 1024;
+}
+
 static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                         int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
-                        void* workspace, size_t workspace_bytes, void* stream, int G_tm) {
-  if (!x || !nn_idx || !workspace) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
+                        void* workspace, size_t workspace_bytes, void* stream, int G_tm, const KnnMrFuse* mr = nullptr,
+                        bool probe_only = false) {
+  if (!probe_only && (!x || (!nn_idx && !mr) || !workspace)) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
   if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32, GKG_BF16 or GKG_F16");
   KnnPlan p;
   int rc = make_plan(BG, c, N, M, k, dilation, y != nullptr, &p);
   if (rc == GKG_ERR_SHAPE) return gkg_fail(rc, "gkg_knn_fwd: bad sizes (need >0, k*dilation <= M, M == N for the self graph)");
   if (rc != 0) return gkg_fail(rc, "gkg_knn_fwd: unsupported size (k*dilation <= 64, c <= 600, BG <= 65535)");
-  if (workspace_bytes < p.total) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_knn_fwd: workspace too small (see gkg_knn_workspace_bytes)");
+  if (!probe_only && workspace_bytes < p.total) return gkg_fail(GKG_ERR_WORKSPACE, "gkg_knn_fwd: workspace too small (see gkg_knn_workspace_bytes)");
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   float* xh = (float*)(ws + p.off_xh);
@@ -445,6 +460,28 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   const bool rp_ok = !relpos || (flags & GKG_KNN_RELPOS_UNIT);
   const bool pf = !bf && norm && p.S == 1 && c >= 16 && p.KD <= 36 && !(flags & GKG_KNN_NO_PREFILTER) && rp_ok
                   && pf_stage <= 150 * 1024 && (pf_pays || (flags & GKG_KNN_FORCE_PREFILTER));
+  size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
+  size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
+  size_t lds = lds_q > lds_m ? lds_q : lds_m;
+  const bool short_stream = p.tps < 10 * NW;
+  // Selection mode.  Buffered selection (see the kernel) wins where the per-candidate insert dominates and its 32 KB
+  // buffer does not cost occupancy — measured on MI355X (tools/bench_ops.py, direct -> buffered): pvig_m@768 k=18
+  // stage 1 (c=12, kd=18) 15.97 -> 10.61 ms, stage 2 4.46 -> 3.13 ms, stage 3 (c=48, kd=36) 2.59 -> 1.55 ms; pvig_s@576
+  // stage 1 2.52 -> 2.42 ms, stage 2 0.96 -> 0.89 ms, label graph over 20 736 keys 250 -> 214 us; it LOSES with wide groups
+  // (c=200: query tile 51 KB + buffer -> one workgroup per CU, 607 -> 876 us) and on short streams with 9-entry lists
+  // (cfg2 label graph 24.6 -> 31.5 us).  The GKG_KNN_SELECT_DIRECT / _BUFFERED flags override the rule (measurement / tests).
+  const int force = (flags & GKG_KNN_SELECT_BUFFERED) ? 2 : ((flags & GKG_KNN_SELECT_DIRECT) ? 1 : 0);
+  const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 + NW * 64 * 4 <= 150 * 1024;
+  const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
+  const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));
+  // fp32 contract forms: single-wave workgroups for the narrowest groups (see the launch below)
+  const int nqt_ = (N + QT - 1) / QT;
+  const bool solo32 = buffered && !pf && p.S == 1 && (size_t)nqt_ * BG >= 2048 && lds_q <= 4 * 1024;
+  if (mr || probe_only) {
+    const bool ok = !bf && dtype == GKG_F32 && G_tm > 0 && knn_mr_plan_ok(p, c, N, M, k, pf, solo32);
+    if (probe_only) return ok ? 0 : GKG_ERR_UNSUPPORTED;
+    if (!ok) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_mr_fwd_tm: this shape does not take the fused form (gkg_knn_mr_fused_supported)");
+  }
   uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
   uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
   const PrepSet sx{x, xh, sqx, N, strides(N), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), cp16,
@@ -465,6 +502,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.nqt = (N + QT - 1) / QT;
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
   a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
+  a.mr_x = a.mr_src = nullptr; a.mr_out = nullptr; a.mr_arg = nullptr; a.nn16 = nullptr; a.mr_G = 1; a.mr_c = c;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
 #ifdef KNN_TIMELINE
   if (p.S == 1 && gkg_knn_tl_buf) a.part_v = (float*)gkg_knn_tl_buf;
@@ -504,20 +542,6 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     // fall through: the fp32 tile kernel below runs as the clean-up pass over the tiles the prefilter flagged
     // (a.wg_flags != null: every other workgroup exits at once)
   }
-  size_t lds_q = (size_t)p.cpad * QT * sizeof(float);
-  size_t lds_m = (size_t)NW * p.KD * 64 * 2 * sizeof(float);
-  size_t lds = lds_q > lds_m ? lds_q : lds_m;
-  const bool short_stream = p.tps < 10 * NW;
-  // Selection mode.  Buffered selection (see the kernel) wins where the per-candidate insert dominates and its 32 KB
-  // buffer does not cost occupancy — measured on MI355X (tools/bench_ops.py, direct -> buffered): pvig_m@768 k=18
-  // stage 1 (c=12, kd=18) 15.97 -> 10.61 ms, stage 2 4.46 -> 3.13 ms, stage 3 (c=48, kd=36) 2.59 -> 1.55 ms; pvig_s@576
-  // stage 1 2.52 -> 2.42 ms, stage 2 0.96 -> 0.89 ms, label graph over 20 736 keys 250 -> 214 us; it LOSES with wide groups
-  // (c=200: query tile 51 KB + buffer -> one workgroup per CU, 607 -> 876 us) and on short streams with 9-entry lists
-  // (cfg2 label graph 24.6 -> 31.5 us).  The GKG_KNN_SELECT_DIRECT / _BUFFERED flags override the rule (measurement / tests).
-  const int force = (flags & GKG_KNN_SELECT_BUFFERED) ? 2 : ((flags & GKG_KNN_SELECT_DIRECT) ? 1 : 0);
-  const bool lds_ok = lds_q + (size_t)KNN_BUF * 256 * 8 + NW * 64 * 4 <= 150 * 1024;
-  const bool pays = lds_q <= 24 * 1024 && p.tps >= 2 * NW && (p.tps >= 4 * NW || p.KD >= 18 || p.S > 1);
-  const bool buffered = lds_ok && (force == 2 || (force == 0 && pays));
   // enough query tiles to fill the chip with single-wave workgroups (2+ waves per SIMD) and the keys not split: one list per query
   // (measured, bf16 form, 4 waves -> 1: pvig_s stage 1 1353 -> 1257 us, pvig_m stages 1-3 6661 -> 6051, 1697 -> 1592,
   // 801 -> 731; it loses when the per-wave query image costs occupancy: stage 2, c = 80, 458 -> 540)
@@ -538,8 +562,13 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     // single-wave workgroups for the narrowest groups (pvig_m stage 1: c = 12, 36 864 queries x 2 304 keys, k*d = 18): one list
     // per query instead of four quarter-stream lists — measured on the model's activations 9 045 -> 7 872 us per launch; no
     // gain at c = 24 / 48 (2 748 -> 2 761, 1 225 -> 1 238 us), where the per-wave query image costs occupancy
-    const bool solo32 = buffered && !pf && p.S == 1 && (size_t)a.nqt * BG >= 2048 && lds_q <= 4 * 1024;
-    e = launch_knn_tile_f32(a, grid, lds, p.KD, solo32 ? 5 : (buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0)), st);
+    if (mr) {
+      a.mr_x = (const float*)x; a.mr_src = (const float*)(y ? y : x);
+      a.mr_out = mr->out; a.mr_arg = mr->arg; a.nn16 = mr->nn16; a.mr_G = G_tm; a.mr_c = c;
+      e = launch_knn_tile_f32_mr(a, grid, lds, p.KD, buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0), st);
+    } else {
+      e = launch_knn_tile_f32(a, grid, lds, p.KD, solo32 ? 5 : (buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0)), st);
+    }
   }
   if (e != hipSuccess) return gkg_fail_hip(e, "knn_tile_kernel");
   if (p.S > 1) {
@@ -568,4 +597,32 @@ extern "C" int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos,
   if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm: bad B / G");
   return knn_fwd_impl(x, y, relpos, nn_idx, center, B * G, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
                       stream, G);
+}
+
+// Row g2: k-NN + max-relative aggregation in one kernel (knn_tile_kernel<..., MRF = true>) for token-major fp32 callers.
+// x (B, N, C = G c), y (B, M, C) or NULL (self graph), relative_pos (N, M) or NULL -> the graph of gkg_knn_fwd_tm (same
+// contract, same bits) is built and consumed on the spot: u_out (4, B N, C / 2) = the grouped projection's interleaved
+// operand of gkg_mr_fwd_tm mode 1, arg_out (B, N, C) u16 = the winning neighbour rows of gkg_mr_fwd_tm arg_kind 1,
+// nn16_out (B G, N, k) u16 = the neighbour lists (optional); nn_idx_out / center_out (B G, N, k) int64 = gkg_knn_fwd_tm's outputs
+// for callers that return the graph (GrapherLabel), optional — otherwise no int64 index tensor and no centre plane exist.
+extern "C" int gkg_knn_mr_fused_supported(int B, int G, int c, int N, int M, int k, int dilation, int has_y, int has_relpos,
+                                          unsigned flags) {
+  if (B <= 0 || G <= 0 || c <= 0 || ((G * c) & 15)) return 0;
+  static const float dummy = 0.f;
+  return knn_fwd_impl(nullptr, has_y ? &dummy : nullptr, has_relpos ? &dummy : nullptr, nullptr, nullptr, B * G, c, N, M, k,
+                      dilation, GKG_F32, flags, nullptr, 0, nullptr, G, nullptr, true) == 0 ? 1 : 0;
+}
+
+extern "C" int gkg_knn_mr_fwd_tm(const float* x, const float* y, const float* relpos, float* u_out, uint16_t* arg_out,
+                                 uint16_t* nn16_out, int64_t* nn_idx_out, int64_t* center_out, int B, int G, int c, int N, int M,
+                                 int k, int dilation, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: bad B / G");
+  if (!u_out || !arg_out) return gkg_fail(GKG_ERR_NULL, "gkg_knn_mr_fwd_tm: null output");
+  if ((G * c) & 15) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: C = G * c must be a multiple of 16");
+  if (((size_t)x & 15) || ((size_t)y & 15) || ((size_t)u_out & 15) || ((size_t)arg_out & 7))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: 16-byte aligned rows");
+  const KnnMrFuse mr{u_out, arg_out, nn16_out};
+  if (center_out && !nn_idx_out) return gkg_fail(GKG_ERR_NULL, "gkg_knn_mr_fwd_tm: center_out without nn_idx_out");
+  return knn_fwd_impl(x, y, relpos, nn_idx_out, center_out, B * G, c, N, M, k, dilation, GKG_F32, flags, workspace, workspace_bytes,
+                      stream, G, &mr);
 }

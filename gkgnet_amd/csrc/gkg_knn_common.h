@@ -136,7 +136,17 @@ struct KnnArgs {
   float margin;           // 2 * eps: eps bounds |prefilter distance - contract distance| (see knn_pf_kernel)
   int* wg_flags;          // [gridDim.x] or null.  knn_pf_kernel: sets [blockIdx.x] = 1 (and writes no output) for a query
                           // tile it cannot settle; knn_tile_kernel: when non-null, only flagged workgroups run (clean-up pass)
+  // fused aggregation (knn_tile_kernel<..., MRF = true>): token-major fp32 centre / source rows, outputs (see the kernel)
+  const float* mr_x;      // (B, N, G * mr_c)
+  const float* mr_src;    // (B, M, G * mr_c)
+  float* mr_out;          // (4, B * N, G * mr_c / 2) interleaved [x, m]: the grouped projection's operand
+  uint16_t* mr_arg;       // (B, N, G * mr_c) winning neighbour rows
+  uint16_t* nn16;         // (BG, N, k) compact neighbour lists, or null
+  int mr_G, mr_c;
 };
+
+// the aggregation's maximum rule (gkg_mr.hip `takes`): the first maximum wins, a NaN is the maximum and sticks
+__device__ __forceinline__ bool mr_takes(float v, float best) { return v > best || (v != v && best == best); }
 
 
 // XCD-aware workgroup -> (problem bg, query tile qt) map shared by knn_tile_kernel and knn_pf_kernel (the clean-up pass of the
@@ -173,5 +183,7 @@ hipError_t launch_knn_prefilter(const KnnArgs& a, dim3 grid, int KD, hipStream_t
 hipError_t launch_knn_tile_bf(const KnnArgs& a, dim3 grid, size_t lds, int KD, int wbuf, bool solo, hipStream_t st);
 // gkg_knn_f32.hip: the tile kernel's fp32-contract forms (mode 0 direct + guard, 1 direct without it, 2 buffered)
 hipError_t launch_knn_tile_f32(const KnnArgs& a, dim3 grid, size_t lds, int KD, int mode, hipStream_t st);
+// gkg_knn_f32_mr.hip: the same forms with the max-relative aggregation in the epilogue (modes 0-2, lists up to 36 entries)
+hipError_t launch_knn_tile_f32_mr(const KnnArgs& a, dim3 grid, size_t lds, int KD, int mode, hipStream_t st);
 
 }  // namespace gkg

@@ -1,0 +1,4 @@
+// fp32-contract k-NN tile kernel with the max-relative aggregation in its epilogue (row g2), positional-bias forms: a
+// parallel-build unit of gkg_knn_f32.hip.
+#define GKG_KNN_MR_PART 1
+#include "gkg_knn_f32.hip"

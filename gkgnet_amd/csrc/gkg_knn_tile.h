@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gkg_knn_common.h"
 #include "gkg_topk_merge.h"
@@ -39,8 +40,19 @@ namespace gkg {
 // keys for its 64 queries — one list per query instead of four quarter-stream lists, i.e. k·d·(1 + ln(M / k·d)) expected
 // admissions instead of 4·k·d·(1 + ln(M / 4·k·d)) (k·d = 9, M = 1296: 54 vs 164), no merge, no barrier after the staging.
 // Same result bit for bit (the k·d smallest (distance, index) keys do not depend on how the stream was cut up).
-template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false, int NWV = NW>
-__global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD <= 12 ? 4 : (KD <= 27 ? 3 : 2))) void knn_tile_kernel(KnnArgs a) {
+// MRF (round 5, SURVEY §8 row g2: "the k-NN + gather kernel") — the max-relative aggregation in the epilogue.  After the merge
+// the workgroup holds the final lists of its 64 queries: they go to LDS (no int64 index tensor, no centre plane, unless the
+// caller asks for the compact u16 list), and the 256 threads gather the k neighbour rows of every query from the token-major
+// source (one thread = one query x 4 channels, k float4 row-segment loads + the centre, all issued before the max chain:
+// mr_fwd_tm_kernel's arithmetic, same bits) and write the grouped projection's interleaved operand U[q][t][2i] = x,
+// U[q][t][2i+1] = max_j (x_j - x_i) and the winning rows (u16) the backward scatters from.  Replaces the launch pair
+// knn_tile_kernel -> mr_fwd_tm_kernel (reference torch_edge.py:164-176 -> torch_vertex.py:49-61); while one workgroup of a
+// CU gathers, the CU's other two or three are in their matrix phase.
+template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false, int NWV = NW, bool MRF = false>
+__global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD <= 12 ? (MRF ? 3 : 4) : (KD <= 27 ? 3 : 2))) void knn_tile_kernel(KnnArgs a) {
+  // (MRF with the 9-entry list: three workgroups per SIMD instead of four — at 128 registers the gather's k float4 rows next to
+  // the bias row of the matrix phase spilled 11-15 registers; the 18 x 18 stages it serves launch three workgroups per CU)
+  static_assert(!MRF || (NWV > 1 && !BF), "fused aggregation: the merged-list forms of the fp32 contract");
   extern __shared__ float smem[];
   constexpr int TH = 64 * NWV;                  // threads
   constexpr int RPS = TH / 16;                  // query-staging rows per pass
@@ -496,6 +508,10 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   double* lk = reinterpret_cast<double*>(smem);      // [NWV][KD][64]
 #pragma unroll
   for (int j = 0; j < KD; ++j) lk[(w * KD + j) * 64 + lane] = top.key[j];
+  int* nbr = reinterpret_cast<int*>(lk + (size_t)NWV * KD * 64);      // MRF: [k][64] final neighbour rows of the 64 queries
+  if constexpr (MRF) {
+    for (int i = tid; i < a.k * 64; i += TH) nbr[i] = 0;               // ranks no finite candidate claims (non-finite inputs)
+  }
   __syncthreads();
   KNN_TL(30);
   const int dil = a.dilation;
@@ -531,7 +547,14 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
             } else {
               const int q = dil > 1 ? (int)__umulhi((unsigned)r, magic) : r;
               if (q * dil == r) {
-                a.nn_idx[obase + q] = (unsigned)bi < (unsigned)M ? bi : 0;   // non-finite distances only: stay in range
+                const int bc = (unsigned)bi < (unsigned)M ? bi : 0;          // non-finite distances only: stay in range
+                if constexpr (MRF) {
+                  nbr[q * 64 + lane] = bc;
+                  if (a.nn16) a.nn16[obase + q] = (uint16_t)bc;
+                  if (a.nn_idx) a.nn_idx[obase + q] = bc;
+                } else {
+                  a.nn_idx[obase + q] = bc;
+                }
                 if (a.center) a.center[obase + q] = n;
               }
             }
@@ -540,12 +563,100 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
       }
     }
   }
+  if constexpr (MRF) {
+    __syncthreads();
+    const int G = a.mr_G, c = a.mr_c, C = G * c, k = a.k;
+    const int b = bg / G, g = bg - b * G;
+    const int f4n = c >> 2;                                    // float4 columns of a query's group segment
+    const int nq = min(QT, N - n0);
+    const size_t T = (size_t)(a.BG / G) * N;
+    const float* xrow0 = a.mr_x + ((size_t)b * N + n0) * C + (size_t)g * c;
+    const float* sb = a.mr_src + (size_t)b * M * C + (size_t)g * c;
+    const int Cq = C >> 2;                                     // original channels per conv group (reference torch_nn.py:61)
+    // Two (query, 4-channel) tasks per thread at a time: all 2 (k + 1) row-segment loads are issued before the first maximum
+    // chain (the gather is latency-bound: one task at a time measured +20 us on the cfg2 launch against 14.7 us for the
+    // stand-alone aggregation kernel it replaces).
+    const int ntask = nq * f4n;
+    auto run = [&](auto careful, auto ks, int f4, const float4& xi, const int* id, const float4* v, float4& best, int (&ai)[4]) {
+      constexpr int KS = decltype(ks)::value;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        if (j < k) {
+          const float d0 = v[j].x - xi.x, d1 = v[j].y - xi.y, d2 = v[j].z - xi.z, d3 = v[j].w - xi.w;
+          const int wv = id[j];
+          if (j == 0) { best = make_float4(d0, d1, d2, d3); ai[0] = ai[1] = ai[2] = ai[3] = wv; }
+          else if constexpr (decltype(careful)::value) {
+            if (mr_takes(d0, best.x)) { best.x = d0; ai[0] = wv; }
+            if (mr_takes(d1, best.y)) { best.y = d1; ai[1] = wv; }
+            if (mr_takes(d2, best.z)) { best.z = d2; ai[2] = wv; }
+            if (mr_takes(d3, best.w)) { best.w = d3; ai[3] = wv; }
+          } else {
+            const bool t0 = d0 > best.x, t1 = d1 > best.y, t2 = d2 > best.z, t3 = d3 > best.w;
+            best.x = t0 ? d0 : best.x; ai[0] = t0 ? wv : ai[0];
+            best.y = t1 ? d1 : best.y; ai[1] = t1 ? wv : ai[1];
+            best.z = t2 ? d2 : best.z; ai[2] = t2 ? wv : ai[2];
+            best.w = t3 ? d3 : best.w; ai[3] = t3 ? wv : ai[3];
+          }
+          if constexpr (!decltype(careful)::value) {
+            c0 = __builtin_fmaf(d0, 0.f, c0); c1 = __builtin_fmaf(d1, 0.f, c1);
+            c2 = __builtin_fmaf(d2, 0.f, c2); c3 = __builtin_fmaf(d3, 0.f, c3);
+          }
+        }
+      }
+      return (c0 + c1) + (c2 + c3);
+    };
+    auto pass = [&](auto ks) {
+      constexpr int KS = decltype(ks)::value;
+      constexpr int TU = KS <= 9 ? 2 : 1;                      // tasks in flight per thread
+      for (int task0 = tid; task0 < ntask; task0 += TU * TH) {
+        int q[TU], f4[TU], id[TU][KS];
+        float4 xi[TU], v[TU][KS];
+        bool on[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const int task = task0 + u * TH;
+          on[u] = task < ntask;
+          const int tk = on[u] ? task : task0;
+          q[u] = tk / f4n; f4[u] = tk - q[u] * f4n;
+#pragma unroll
+          for (int j = 0; j < KS; ++j) id[u][j] = nbr[(j < k ? j : 0) * 64 + q[u]];
+          xi[u] = *reinterpret_cast<const float4*>(xrow0 + (size_t)q[u] * C + 4 * f4[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int j = 0; j < KS; ++j) v[u][j] = *reinterpret_cast<const float4*>(sb + (size_t)id[u][j] * C + 4 * f4[u]);
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          float4 best;
+          int ai[4];
+          // mr_fwd_tm_kernel's chain: a plain '>' (first maximum wins) while chk accumulates d * 0 — NaN as soon as a difference
+          // is NaN or infinite; such a lane (non-finite inputs only) redoes the chain with `takes` (a NaN is the maximum and sticks)
+          const float chk = run(std::false_type{}, ks, f4[u], xi[u], id[u], v[u], best, ai);
+          if (chk != chk) (void)run(std::true_type{}, ks, f4[u], xi[u], id[u], v[u], best, ai);
+          if (on[u]) {
+            const size_t t = (size_t)b * N + n0 + q[u];
+            const int chq = g * c + 4 * f4[u];
+            *reinterpret_cast<uint2*>(a.mr_arg + t * C + chq) =
+                make_uint2((uint32_t)ai[0] | ((uint32_t)ai[1] << 16), (uint32_t)ai[2] | ((uint32_t)ai[3] << 16));
+            const int qc = chq / Cq, il = chq - qc * Cq;       // 4 channels never straddle a conv group (C % 16 == 0)
+            float* o = a.mr_out + ((size_t)qc * T + t) * (size_t)(2 * Cq) + 2 * il;
+            *reinterpret_cast<float4*>(o) = make_float4(xi[u].x, best.x, xi[u].y, best.y);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(xi[u].z, best.z, xi[u].w, best.w);
+          }
+        }
+      }
+    };
+    if (KD <= 9 || k <= 9) pass(std::integral_constant<int, 9>{});          // a 9-entry list holds k <= 9 neighbours
+    else if constexpr (KD > 9) pass(std::integral_constant<int, 18>{});
+  }
   KNN_TL(31);
 }
 
 constexpr int KNN_BUF = 16;        // buffered selection: entries per lane (8 bytes each: 32 KB per workgroup)
 
-template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false, int NWV = NW>
+template <int KD, bool HAS_RP, int KU, bool GUARD = true, int BUF = 0, bool BF = false, int NWV = NW, bool MRF = false>
 static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   // staged query tile: fp32 [cpad][64], or (bf16 form) 64 rows of cp16 + 8 bf16
   const size_t qbytes = BF ? (size_t)QT * (a.cp16 + 8) * 2 : (size_t)a.cpad * QT * sizeof(float);
@@ -562,12 +673,16 @@ static hipError_t launch_tile_v(const KnnArgs& a, dim3 grid, size_t lds, hipStre
     const size_t need = qbytes + (size_t)BUF * 64 * NWV * sizeof(float2) + NWV * 64 * sizeof(float);
     if (lds < need) lds = need;
   }
+  if (MRF) {                                    // the final lists of the 64 queries behind the merge area
+    const size_t need = (size_t)NWV * KD * 64 * 2 * sizeof(float) + (size_t)a.k * 64 * sizeof(int);
+    if (lds < need) lds = need;
+  }
   if (lds > 64 * 1024) {
-    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF, NWV>),
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF, NWV, MRF>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
   }
-  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF, NWV>), grid, dim3(64 * NWV), lds, st, a);
+  hipLaunchKernelGGL((knn_tile_kernel<KD, HAS_RP, KU, GUARD, BUF, BF, NWV, MRF>), grid, dim3(64 * NWV), lds, st, a);
   return hipGetLastError();
 }
 

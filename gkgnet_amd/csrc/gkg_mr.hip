@@ -972,14 +972,16 @@ static void launch_tm_i64(bool self, int mode, int ak, dim3 grid, size_t lds, hi
 extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
                              int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream) {
   if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: arg_kind is 0 or 1");
-  if (!gin || !nn_idx || !argmax || !gx) return gkg_fail(GKG_ERR_NULL, "gkg_mr_bwd_tm: gin, nn_idx, argmax and gx must be non-null");
+  // arg_kind 1: the saved winning ROWS are the scatter targets — the index tensor is not read and may be null (the fused
+  // k-NN + aggregation forward, gkg_knn_mr_fwd_tm, never materialises one)
+  if (!gin || (!nn_idx && arg_kind != 1) || !argmax || !gx) return gkg_fail(GKG_ERR_NULL, "gkg_mr_bwd_tm: gin, argmax, gx (and nn_idx unless arg_kind == 1) must be non-null");
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 255 || (c & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: bad sizes");
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode is 0 or 1");
   if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: mode 1 needs C % 16 == 0");
   if (!gsrc && M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: self graph needs M == N");
   hipStream_t st = (hipStream_t)stream;
-  // algorithmic bytes (SURVEY §8d "MR bwd"): g + int64 indices + argmax + gx (+ gsrc)
-  const double work = 4.0 * B * (double)G * c * N + 8.0 * B * (double)G * N * k + 1.0 * B * (double)G * c * N
+  // algorithmic bytes (SURVEY §8d "MR bwd"): g + int64 indices + argmax + gx (+ gsrc); arg_kind 1: u16 winning rows, no indices
+  const double work = 4.0 * B * (double)G * c * N + (arg_kind == 1 ? 0.0 : 8.0 * B * (double)G * N * k) + (arg_kind == 1 ? 2.0 : 1.0) * B * (double)G * c * N
                       + 4.0 * B * (double)G * c * N + (gsrc ? 4.0 * B * (double)G * c * M : 0.0);
   GkgProfScope prof(GKG_PROF_MR_BWD, st, work);
   const int C = G * c;

@@ -1190,6 +1190,9 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
     return edge
 
 
+_KNN_GRAPH_TM = knn_graph_tm             # the library's own function (tests patch ``fused.knn_graph_tm`` to record / force graphs)
+
+
 class _MaxRelativeTM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, src, nn_idx, G, mode, out_lowp=False):
@@ -1220,6 +1223,75 @@ class _MaxRelativeTM(torch.autograd.Function):
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode, ak,
                                      _mr_bwd_flags(), _stream()), "gkg_mr_bwd_tm")
         return gx, gsrc, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- row g2: k-NN + aggregation
+# ONE kernel builds the graph and consumes it (csrc/gkg_knn_tile.h, MRF): the workgroup that has merged the lists of its 64
+# queries gathers their neighbour rows and writes the grouped projection's interleaved operand and the winning rows; no
+# (2, B*G, N, k) int64 edge_index, no centre plane, no mr_fwd launch (reference torch_edge.py:164-176 -> torch_vertex.py:49-61).
+# Taken for fp32 training / inference blocks whose graph runs on the fp32 tile kernel with merged per-wave lists
+# (gkg_knn_mr_fused_supported: the 18 x 18 stages and the label graphs over them; key-split and prefilter shapes keep the two
+# launches) — and only while ``fused.knn_graph_tm`` is the library's own function: tests that record or force graphs patch
+# it and thereby select the two-launch form.  GKG_DISABLE=knn_mr: off.
+KNN_MR = "knn_mr" not in _DISABLED
+
+
+class _KnnMaxRelativeTM(torch.autograd.Function):
+    """(U (4, B*N, C/2), edge_index (2, B*G, N, k) | empty) = aggregation over the k-NN graph of x (B, N, C) [keys / values src (B, M, C)]."""
+
+    @staticmethod
+    def forward(ctx, x, src, relative_pos, k, d, G, want_nn):
+        lib = _lib.load()
+        B, N, C = x.shape
+        M = N if src is None else src.shape[1]
+        c = C // G
+        flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags()
+        rp = None
+        if relative_pos is not None:
+            rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
+            if tuple(rp.shape) != (N, M):
+                raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+            flags |= _lib.relpos_flags(relative_pos)
+        U = torch.empty((4, B * N, C // 2), dtype=_F32, device=x.device)
+        arg = torch.empty((B, N, C), dtype=torch.int16, device=x.device)
+        # the (2, B*G, N, k) int64 edge_index only for callers that return the graph (GrapherLabel / tests): written by the kernel
+        edge = torch.empty((2, B * G, N, k) if want_nn else (0,), dtype=torch.int64, device=x.device)
+        ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), x.device)
+        _lib.check(lib.gkg_knn_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(rp), _ptr(U), _ptr(arg), None,
+                                         edge[0].data_ptr() if want_nn else None, edge[1].data_ptr() if want_nn else None, B, G, c,
+                                         N, M, k, d, flags, _ptr(ws), ws.numel(), _stream()), "gkg_knn_mr_fwd_tm")
+        ctx.save_for_backward(arg)
+        ctx.meta = (B, G, C, N, M, k, src is not None)
+        ctx.mark_non_differentiable(edge)
+        return U, edge
+
+    @staticmethod
+    def backward(ctx, g, _gnn=None):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        B, G, C, N, M, k, has_src = ctx.meta
+        g = g.contiguous()
+        gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
+        gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
+        _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), None, _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 1, 1, _mr_bwd_flags(),
+                                     _stream()), "gkg_mr_bwd_tm")
+        return gx, gsrc, None, None, None, None, None
+
+
+def _knn_mr_ok(x, src, relative_pos, k, d, G, nn_, lp) -> bool:
+    """The fused k-NN + aggregation kernel applies (see KNN_MR)."""
+    if not (KNN_MR and not lp and knn_graph_tm is _KNN_GRAPH_TM and x.dtype == _F32 and x.is_contiguous()
+            and (src is None or (src.dtype == _F32 and src.is_contiguous())) and not MR_X6):
+        return False
+    if KNN_BF16 and torch.is_autocast_enabled():
+        return False
+    B, N, C = x.shape
+    M = N if src is None else src.shape[1]
+    if C % 16 or M > 65536 or len(nn_) != 3:
+        return False
+    flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
+    return bool(_lib.load().gkg_knn_mr_fused_supported(B, G, C // G, N, M, k, d, 0 if src is None else 1,
+                                                       0 if relative_pos is None else 1, flags))
 
 
 # ----------------------------------------------------------------------------------------------- row g1 (training / fp32)
@@ -1453,8 +1525,21 @@ def _drop_scale(drop_path, batch, device):
     return drop_path.sample_scale(batch, device) if hasattr(drop_path, "sample_scale") else None
 
 
-def grapher_forward(mod, x, relative_pos, groups: int):
-    """Fused Grapher.forward (reference torch_vertex.py:325-333).  Returns (out (B,C,H,W), edge_index)."""
+def _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge):
+    """DyGraphConv2d.forward on token-major tensors (torch_vertex.py:191-205): -> (BasicConv output (T, 2C), edge_index | None)."""
+    nn_ = gc.gconv.nn
+    N = x1b.shape[1]
+    if _knn_mr_ok(x1b, yb, relative_pos, gc.k, gc.d, groups, nn_, lp):      # row g2: graph + aggregation in one kernel
+        U, edge = _KnnMaxRelativeTM.apply(x1b, yb, relative_pos, gc.k, gc.d, groups, want_edge)
+        a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, False, None)
+        return a2, (edge if want_edge else None)
+    edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
+    return _aggregate_project(x1b, yb, edge[0], groups, nn_, C, lp), edge      # row g1: aggregation = the projection's operand producer
+
+
+def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
+    """Fused Grapher.forward (reference torch_vertex.py:325-333).  Returns (out (B,C,H,W), edge_index); ``want_edge=False``
+    (Grapher.forward, which discards the graph like the reference, torch_vertex.py:330): edge_index may be None."""
     B, C, H, W = x.shape
     N = H * W
     gc = mod.graph_conv
@@ -1471,8 +1556,7 @@ def grapher_forward(mod, x, relative_pos, groups: int):
     yb = None
     if gc.r > 1:                                                    # pooled keys (torch_vertex.py:194-196)
         yb = _AvgPoolTM.apply(x1.view(B, H, W, C), gc.r).reshape(B, -1, C)
-    edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
-    a2 = _aggregate_project(x1b, yb, edge[0], groups, gc.gconv.nn, C, lp)   # row g1: aggregation = the projection's operand producer
+    a2, edge = _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge)
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
         out = _lin(a2, mod.fc2, residual=x, scale=scale, rows_per_scale=N, want16=lp)
         return _cl_out(out, B, H, W), edge
@@ -1504,9 +1588,8 @@ def grapher_label_forward(mod, e, features, groups: int):
     e2 = e.float().reshape(B * L, C).contiguous()
     x1, e2r = _lin(e2, mod.fc1, alias=True)                          # e2r: e2 again, for the residual of fc2 (one gradient node)
     x1b = x1.view(B, L, C)
-    edge = knn_graph_tm(x1b, ft, None, gc.k, gc.d, groups)
     lp = lowp_inference()
-    a2 = _aggregate_project(x1b, ft, edge[0], groups, gc.gconv.nn, C, lp)
+    a2, edge = _graph_and_project(x1b, ft.contiguous(), None, gc, groups, C, lp, True)      # GrapherLabel returns its graph
     h2 = _lin(a2, mod.fc2, residual=e2r, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
     f1, h2r = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp, alias=True)
     out = _lin(f1, mod.ffn.fc2, residual=h2r, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)

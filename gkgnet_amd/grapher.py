@@ -46,7 +46,7 @@ class Grapher(nn.Module):
         relative_pos = self._get_relative_pos(self.relative_pos, H, W)
         groups = self.graph_conv.num_head
         if fused.fused_supported(self, x, groups):
-            return fused.grapher_forward(self, x, relative_pos, groups)[0]
+            return fused.grapher_forward(self, x, relative_pos, groups, want_edge=False)[0]
         shortcut = x
         x = self.fc1(x)
         x, _ = self.graph_conv(x, relative_pos)

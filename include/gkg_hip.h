@@ -168,6 +168,25 @@ int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t
 int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Row g2 (round 5): the k-NN graph AND the max-relative aggregation over it in ONE kernel, for token-major fp32 callers — the
+ * reference chain DenseDilatedKnnGraph.forward (torch_edge.py:164-176) -> MRConv2d.forward's two batched_index_select + max
+ * (torch_vertex.py:49-61) without the (2, B*G, N, k) int64 edge_index in between.  x (B, N, C = G*c), y (B, M, C) or NULL (self
+ * graph), relative_pos (N, M) or NULL; flags as gkg_knn_fwd (GKG_KNN_NORMALIZE ...).  The graph is the one gkg_knn_fwd_tm
+ * builds (same contract, same bits); it is consumed by the workgroup that built it:
+ *   u_out   (4, B*N, C/2) fp32  the grouped projection's interleaved operand, exactly gkg_mr_fwd_tm(mode 1)'s output
+ *   arg_out (B, N, C)     u16   the winning neighbour ROW per channel, exactly gkg_mr_fwd_tm(arg_kind 1)'s argmax (the
+ *                                backward gkg_mr_bwd_tm(arg_kind 1) scatters from it and needs no index tensor)
+ *   nn16_out (B*G, N, k)  u16   the neighbour lists, or NULL (M <= 65536)
+ *   nn_idx_out, center_out (B*G, N, k) int64   gkg_knn_fwd_tm's outputs, or NULL: only for callers that RETURN the graph
+ *                                (GrapherLabel.forward, torch_vertex.py:403); a Grapher never materialises them
+ * gkg_knn_mr_fused_supported: 1 when this shape takes the fused form — the fp32 tile kernel with merged per-wave lists (no
+ * key splits, no prefilter, lists of <= 36 entries, k <= 18, c % 4 == 0, C % 16 == 0); otherwise call gkg_knn_fwd_tm and
+ * gkg_mr_fwd_tm.  Workspace: gkg_knn_workspace_bytes. */
+int gkg_knn_mr_fused_supported(int B, int G, int c, int N, int M, int k, int dilation, int has_y, int has_relpos, unsigned flags);
+int gkg_knn_mr_fwd_tm(const float* x, const float* y, const float* relative_pos, float* u_out, uint16_t* arg_out,
+                      uint16_t* nn16_out, int64_t* nn_idx_out, int64_t* center_out, int B, int G, int c, int N, int M, int k,
+                      int dilation, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 /* arg_kind: what `argmax` holds — 0: (B,N,C) u8, the winning slot j (as gkg_mr_fwd); 1: (B,N,C) u16, the winning
  * neighbour's row index itself (M <= 65536), which lets the backward scatter without looking the index row up again. */
 int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out /* out_dtype elements */,

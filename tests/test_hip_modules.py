@@ -37,6 +37,7 @@ def test_grapher_forward_backward(name, path):
     real_fused = fused.grapher_forward
 
     def spy(*args, **kw):                     # the fused path bypasses graph_conv: capture its edge_index here
+        kw["want_edge"] = True                # (Grapher.forward itself discards the graph, like the reference)
         out = real_fused(*args, **kw)
         cap.update(edge=out[1].detach(), fused_calls=cap.get("fused_calls", 0) + 1)
         return out
