@@ -294,6 +294,16 @@ int gkg_bn_apply_train_dual(const float* y, const double* sums, const float* gam
 int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                       const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                       size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream);
+/* Round 5, opt-in: gkg_bn_set_flags(2) lets gkg_bn_bwd_atomic (and its _scaled form) run as ONE launch — statistics, a grid
+ * barrier, apply from registers — while the grid fits 3 workgroups of 128 rows x 64 channels per CU.  Built, tested and
+ * measured: faster only at ~100 workgroups (8.4-9.0 vs 10.9-11.7 us), slower from ~240 up (a grid barrier of hundreds of
+ * workgroups costs more than a kernel boundary on this chip), neutral for the cfg2 step — so the default (flags 0) keeps the
+ * two launches everywhere.  Same results up to the summation order of the fp64 atomics.
+ * gkg_debug_barrier_timeouts: non-zero if a workgroup ever gave up waiting at the barrier (~0.1 s; only possible when
+ * something else holds the chip's workgroup slots) — the results of that call are then wrong, the GPU does not hang. */
+void gkg_bn_set_flags(unsigned flags);
+int gkg_debug_barrier_timeouts(void);
+
 
 /* gkg_bn_bwd_atomic for a branch whose output was scaled per image (DropPath: torch_vertex.py:332,355,402): the incoming
  * gradient is multiplied by row_scale[row / rows_per_scale] inside both passes. */
