@@ -695,7 +695,12 @@ def main():
                     with open(pmc_path) as fh:
                         pj = json.load(fh)
                     traffic = pj["knn_tile_per_step_traffic_bytes"] / pj.get("knn_tile_launches_per_step", 2)   # per launch
-                    traffic_source = f"{os.path.relpath(pmc_path, ROOT)} @ {pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
+                    from gkgnet_amd._build import csrc_sha16
+                    same = pj.get("csrc_sha16") == csrc_sha16()
+                    traffic_source = (f"{os.path.relpath(pmc_path, ROOT)} @ {pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      f"passes, not this run); collected on " +
+                                      ("the kernel sources this run uses (csrc hash matches)" if same else
+                                       "OTHER kernel sources than this run's (csrc hash differs: stale)"))
                     break
                 except Exception:
                     continue

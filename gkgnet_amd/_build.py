@@ -16,6 +16,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
         os.environ.get("GKG_BUILD_FLAGS", "").split()          # measurement builds (-D switches of the ablation tools)
 
 
+def csrc_sha16() -> str:
+    """First 16 hex digits of a SHA-256 over the kernel sources (csrc/*.hip, csrc/*.h, include/gkg_hip.h, sorted by name): the
+    identity of the kernels a measurement was taken on, computable wherever the sources are (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(INCLUDE, "gkg_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

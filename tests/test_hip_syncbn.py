@@ -58,7 +58,18 @@ def _worker(rank, world, store_path, result_path, backend="gloo"):
         fused.grapher_forward = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
         B = x.shape[0]
         sl = slice(rank * B // world, (rank + 1) * B // world)
-        got = _run(g, gl, x[sl], e[sl], cx[sl], ce[sl])
+        # exactly TWO collectives per BN layer and step — the forward's statistics and the backward's two column sums — so that
+        # the first real RCCL run has a known-good count to compare with (GKGNet-576: 86 SyncBN layers -> 172 per step,
+        # reference mmcls/apis/train.py:117-125 + torch_nn.py:37)
+        n_bn = sum(isinstance(m, torch.nn.SyncBatchNorm) for mod in (g, gl) for m in mod.modules())
+        counted = []
+        real_ar = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (counted.append(1), real_ar(*a, **k))[1]
+        try:
+            got = _run(g, gl, x[sl], e[sl], cx[sl], ce[sl])
+        finally:
+            dist.all_reduce = real_ar
+        assert n_bn == 8 and len(counted) == 2 * n_bn, (n_bn, len(counted))
         fused.grapher_forward = real
         assert calls, "SyncBatchNorm across ranks was expected to stay on the fused path"
         tol = dict(atol=2e-4, rtol=1e-3)

@@ -29,11 +29,20 @@ def main():
                 v = v[len(v) // 2:]
                 acc[k][c] = round(sum(v) / len(v), 1)
                 acc[k]["dispatches"] = len(v)
-    try:
-        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
-    except Exception:
-        commit = "unknown (gpurun snapshot has no .git; see the commit that adds this file)"
-    res = {"note": __doc__.strip().split("\n\n")[0], "commit": commit, "kernels": acc}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gkgnet_amd._build import csrc_sha16
+    # which kernels these counters belong to: the hash of the kernel sources they were collected on (the GPU box has no .git);
+    # bench.py recomputes it and says whether the `traffic` it quotes was taken on the kernels it is running
+    commit = os.environ.get("GKG_COMMIT", "")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "log", "-1", "--format=%h", "--", "gkgnet_amd/csrc"], text=True,
+                                             stderr=subprocess.DEVNULL).strip()
+        except Exception:
+            commit = ""
+    res = {"note": __doc__.strip().split("\n\n")[0], "commit": commit or "n/a (no .git on the GPU box): see csrc_sha16",
+           "csrc_sha16": csrc_sha16(), "kernels": acc}
     # calibration on the layout kernel of the Grapher entry: reads B*C*N*4 = 13 271 040 bytes at cfg2
     cal = [v for k, v in acc.items() if k.startswith("nchw_to_tm_kernel") and "FETCH_SIZE" in v]
     if cal:
