@@ -44,8 +44,10 @@ def test_companion_is_emitted_from_the_second_call_and_changes_nothing(monkeypat
         ob, eb, ib, gxb, geb, pb = b[step]
         assert torch.equal(ia, ib)                                       # same graphs
         assert torch.allclose(oa, ob, atol=1e-5, rtol=1e-5) and torch.allclose(ea, eb, atol=1e-5, rtol=1e-5)
+        # (conv biases in front of train-mode BN have an exactly zero gradient: what arrives there is rounding noise of ~1e-5
+        # on both sides — hence the absolute floor)
         for u, v in [(gxa, gxb), (gea, geb)] + list(zip(pa, pb)):
-            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-6, float((u - v).abs().max())
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-5, float((u - v).abs().max())
 
 
 def test_only_one_of_the_two_outputs_used(monkeypatch):
