@@ -513,10 +513,12 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_kernel(const float* __r
 //            largest value keeps 24 + SHMAX bits, the sum of up to N of them fits 62 bits, values down to 2^-SHMAX of the
 //            largest keep their FULL mantissa (29 binary orders at N = 324, 23 at N = 20 736; below that the low bits are
 //            truncated — against a total that is then >= 2^24 times larger); one ds_add_u64 per value;
-//   store    acc * 2^(e_max - 150 - SHMAX) rounded ONCE to fp32 (+ the token's own "direct - gm" seed for self graphs).
+//   store    acc * 2^(e_max - 150 - SHMAX) converted to fp32 at the end — through a double (53 bits), so the 62-bit total is
+//            rounded twice, not once, and the self graphs' "direct - gm" seed is one more fp32 add.
 // Integer addition is associative: the result does not depend on the order the lanes arrive in — bit-identical from run
-// to run (this form also serves GKG_MR_DETERMINISTIC) — and every sum is correctly rounded from an exact total where an
-// fp32 atomic chain rounds after every addend.  Non-finite gradients (the GradScaler overflow protocol needs inf / NaN
+// to run (this form also serves GKG_MR_DETERMINISTIC) — and the sum carries the rounding of its conversion only (plus the
+// truncation of addends more than 2^-SHMAX below the chunk's largest), where an fp32 atomic chain rounds after every addend:
+// deterministic and at least as accurate as the fp32 sum, not "correctly rounded".  Non-finite gradients (the GradScaler overflow protocol needs inf / NaN
 // to reach the parameters) show up as e_max = 255: the workgroup then re-runs the fp32-atomic form on the same LDS.
 __device__ __forceinline__ long long mr_to_fixed(float v, int emax, int shmax) {
   const unsigned bits = __float_as_uint(v);
