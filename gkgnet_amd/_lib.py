@@ -67,7 +67,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
-           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts")
+           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts", "gkg_x6_set_flags")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -139,6 +139,8 @@ def load():
     lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_apply_train.restype = I
     lib.gkg_bn_apply_train.argtypes = [V] * 14 + [I, I, I, I, Z, I, I, V, I, F, F, V, Z, V]
+    lib.gkg_x6_set_flags.restype = None
+    lib.gkg_x6_set_flags.argtypes = [C.c_uint]
     lib.gkg_bn_set_flags.restype = None
     lib.gkg_bn_set_flags.argtypes = [C.c_uint]
     lib.gkg_debug_barrier_timeouts.restype = I
@@ -223,6 +225,8 @@ def load():
     v = lib.gkg_version()
     if v != ABI_VERSION:
         raise GkgError(f"libgkg_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    if "x6_ks" in {t.strip() for t in os.environ.get("GKG_DISABLE", "").split(",")}:
+        lib.gkg_x6_set_flags(1)             # GKG_DISABLE=x6_ks: short matrices on gemm_x6_kernel (+ cross-workgroup split-K) again
     if "bn_fused" in {t.strip() for t in os.environ.get("GKG_ENABLE", "").split(",")}:
         lib.gkg_bn_set_flags(2)             # GKG_ENABLE=bn_fused: the one-launch (grid barrier) BN backward where the grid fits
     _lib = lib

@@ -545,6 +545,193 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
 // VALU-bound, NI = 2 about balanced) but leave fewer workgroups: NI = 2, and NI = 1 when that leaves the chip under-filled
 // (few rows: the label branch).  Measured cold-cache per shape with tools/bench_x6.py; NI = 5 (160 columns, one
 // workgroup per CU) was tried and is slower everywhere (cfg2 fc1 25.8 vs 22.9 us).
+// ---- few rows: the waves of a workgroup split K, not M (round 5) --------------------------------------------------------
+// gemm_x6_kernel has a floor of ~10 us per launch whatever the size (2.4 us of prologue DMA issue for three 16 KB A stages and
+// two B stages per workgroup, a barrier per K-step, a 128-row epilogue) and needed a cross-workgroup split-K seam (5-13 us) to
+// fill the chip with the label branch's 2 560-row matrices: ten launches of 13-28 us per cfg2 step.  Here a workgroup owns
+// 32 rows x 64 columns and its four waves take a QUARTER OF THE CONTRACTION each: every wave streams its own A rows through a
+// private 3 x 4 KB LDS ring (LDS-DMA, as above), reads its B fragments straight from the weight planes (they are stored in
+// MFMA operand order: one 16-byte load per lane and product, L2-resident, one K-step ahead in registers), and never meets
+// another wave before the end — no barrier in the loop, no partial tiles through global memory.  The four 32 x 64 partials
+// are added through LDS in wave order (deterministic), and the workgroup stores its tile (+ residual) and, EPI_BNSTATS, adds
+// the tile's centred column statistics to the fp64 sums like the kernel above.  2 560 x 320 -> 320: 400 workgroups of
+// 3 + 3 + 2 + 2 K-steps.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
+  constexpr int NI = 2, BN = 64, BM = 32, BK = 32, SA = 3;
+  extern __shared__ uint4 lds[];                       // [4 waves][SA][4 KB] A rings; then [4][32][64] fp32 partials (aliased)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.y;
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int tn = slot % g.ntiles, tm = (slot / g.ntiles) * 8 + xcd;      // the column tiles of a row block on one XCD
+  if (tm >= g.mtiles) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = g.M, N = g.N, K = g.K;
+  const int nk_total = (K + BK - 1) / BK;
+  const int kbase = nk_total >> 2, krem = nk_total & 3;
+  const int cnt = kbase + (w < krem ? 1 : 0);                            // this wave's K-steps
+  const int kt0 = w * kbase + min(w, krem);
+  const bool ktail = (K & (BK - 1)) != 0;
+  const float* A = g.A + (size_t)z * g.a_bstride;
+  const uint4* P = g.P + (size_t)z * g.p_bstride;
+  const unsigned lds0 = (unsigned)(size_t)lds + w * (SA * 4096);
+  const char* ring = (const char*)lds + w * (SA * 4096);
+
+  // A pieces (as gemm_x6_kernel): LDS slot L = 64 i + lane of the 32 x 128-B image holds chunk (L & 7) ^ ((row >> 1) & 7) of row L >> 3
+  unsigned aoff[4];
+  int achunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int L = 64 * i + lane, row = L >> 3, chunk = (L & 7) ^ ((row >> 1) & 7);
+    const int gr = min(m0 + row, M - 1);
+    aoff[i] = (unsigned)((size_t)gr * g.lda + chunk * 4) * 4u;
+    achunk[i] = chunk;
+  }
+  auto dma_a = [&](int k) {                                              // k: this wave's step index
+    const int kt = kt0 + k;
+    const char* base = (const char*)A + (size_t)kt * (BK * 4);
+    const unsigned dst = lds0 + (k % SA) * 4096;
+    const bool last = ktail && kt == nk_total - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned o = aoff[i];
+      if (last && kt * BK + achunk[i] * 4 >= K) o -= achunk[i] * 16;    // past K: a valid address, masked after the read
+      x6_dma16(base, o, dst + i * 1024);
+    }
+  };
+  const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+  const size_t plane = (size_t)g.KC * g.NP;                              // uint4 units
+  auto load_b = [&](uint4 (&b)[NI][3], int k, int s2) {                  // the 6 operand fragments of half s2 of K-step k
+    const uint4* base = P + ((size_t)(kt0 + k) * 4 + h + 2 * s2) * g.NP + n0 + r;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[j][p] = base[p * plane + j * 32];
+  };
+  x6_f32x16 acc[NI], accs[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[j][q] = 0.f; accs[j][q] = 0.f; }
+
+  uint4 b0f[NI][3], b1f[NI][3], bnx[NI][3];           // halves 0 / 1 of the current K-step, half 0 of the next one
+  // issue order per wave: A0 A1 A2 B0.0 B0.1 | B(k+1).0 (wait A(k), B(k)) step k, B(k+1).1, A(k+3) | ...
+  if (cnt > 0) dma_a(0);
+  if (cnt > 1) dma_a(1);
+  if (cnt > 2) dma_a(2);
+  if (cnt > 0) { load_b(b0f, 0, 0); load_b(b1f, 0, 1); }
+  auto mma = [&](const char* ab, int s2, bool last, int kglob, const uint4 (&bq)[NI][3]) {
+    const float4 f0 = *(const float4*)(ab + r * 128 + (((4 * s2 + 2 * h) ^ sw) << 4));
+    const float4 f1 = *(const float4*)(ab + r * 128 + (((4 * s2 + 2 * h + 1) ^ sw) << 4));
+    float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    if (last) {
+      const int kb = kglob * BK + 16 * s2 + 8 * h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = kb + e < K ? f[e] : 0.f;
+    }
+    uint4 ah, am, al;
+    x6_split2(f[0], f[1], ah.x, am.x, al.x); x6_split2(f[2], f[3], ah.y, am.y, al.y);
+    x6_split2(f[4], f[5], ah.z, am.z, al.z); x6_split2(f[6], f[7], ah.w, am.w, al.w);
+    const x6_bf16x8 a0 = __builtin_bit_cast(x6_bf16x8, ah), a1 = __builtin_bit_cast(x6_bf16x8, am), a2 = __builtin_bit_cast(x6_bf16x8, al);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const x6_bf16x8 b0 = __builtin_bit_cast(x6_bf16x8, bq[j][0]), b1 = __builtin_bit_cast(x6_bf16x8, bq[j][1]),
+                      b2 = __builtin_bit_cast(x6_bf16x8, bq[j][2]);
+      // small terms first, the hi*hi product into its own accumulator (gemm_x6_kernel's order)
+      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, accs[j], 0, 0, 0);
+      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, accs[j], 0, 0, 0);
+      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, accs[j], 0, 0, 0);
+      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, accs[j], 0, 0, 0);
+      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, accs[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+    }
+  };
+  for (int k = 0; k < cnt; ++k) {
+    const bool more = k + 1 < cnt;
+    if (more) load_b(bnx, k + 1, 0);
+    // A(k) and both halves of B(k) have landed once at most the operations issued AFTER B(k).1 are outstanding: A(k+2) (issued
+    // right behind B(k).1 at the end of step k-1; k == 0: A1, A2 are OLDER than B0) and the 6 loads just issued.  (The
+    // compiler's own waits cover the plain loads it can see; this asm wait is for the LDS-DMA pieces it cannot.)
+    const int after = (more ? 6 : 0) + ((k >= 1 && k + 2 < cnt) ? 4 : 0);
+    if (after == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (after == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (after == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* ab = ring + (k % SA) * 4096;
+    const bool last = ktail && kt0 + k == nk_total - 1;
+    mma(ab, 0, last, kt0 + k, b0f);
+    mma(ab, 1, last, kt0 + k, b1f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the ring slot's reads are in registers: it may be refilled
+    if (more) {
+      // first the copy (its wait sees only B(k+1).0, a whole step old), then the new loads: behind them the compiler's count of
+      // outstanding loads would be short by the DMA pieces and its wait for the copy would stall on the loads just issued
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b0f[j][p] = bnx[j][p];
+      asm volatile("" ::: "memory");
+      load_b(b1f, k + 1, 1);
+    }
+    asm volatile("" ::: "memory");                                        // (keeps the order: B(k+1).1, then A(k+3))
+    if (k + SA < cnt) dma_a(k + SA);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                       // every wave is done with its ring
+  float* red = reinterpret_cast<float*>(lds);                            // [4][32][64]
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+      red[(w * BM + row) * BN + j * 32 + r] = acc[j][q] + accs[j][q];
+    }
+  __syncthreads();
+  float* C = g.C + (size_t)z * g.c_bstride;
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+    v[u] = ((red[e] + red[BM * BN + e]) + red[2 * BM * BN + e]) + red[3 * BM * BN + e];      // wave order: the same bits every run
+    const int m = m0 + row, n = n0 + col;
+    if (m < M && n < N) {
+      float o = v[u];
+      if (EPI == X6_STORE && g.add) o += g.add[(size_t)z * g.c_bstride + (size_t)m * g.ldc + n];
+      C[(size_t)m * g.ldc + n] = o;
+    }
+  }
+  if (EPI != X6_BNSTATS) return;
+  // train-mode BN statistics of the tile's columns: the summed tile back into LDS, one thread per column takes the centred
+  // (mean, M2) over the tile's valid rows, ONE fp64 atomic pair per column and tile:  S += n mean,  Q += M2 + n mean^2
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) red[tid + 256 * u] = v[u];
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    const int rows = max(0, min(BM, M - m0));
+    float sum = 0.f;
+    for (int row = 0; row < rows; ++row) sum += red[row * BN + tid];
+    const float mean = rows > 0 ? sum / (float)rows : 0.f;
+    float m2 = 0.f;
+    for (int row = 0; row < rows; ++row) { const float d = red[row * BN + tid] - mean; m2 += d * d; }
+    const double nd = (double)rows, md = (double)mean;
+    double* sz = g.sums + ((size_t)(tm % g.nslots) * g.nbatch + z) * 2 * N + n0 + tid;
+    __hip_atomic_fetch_add(sz, nd * md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sz + N, (double)m2 + nd * md * md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+static unsigned gkg_x6_flags = 0;       // gkg_x6_set_flags: bit 0 = never take the K-split-in-workgroup form, bit 1 = wherever it applies (A/B, tests)
+
+template <int EPI>
+static hipError_t x6_launch_ks(X6Args a, int nb, hipStream_t st) {
+  a.mtiles = (a.M + 31) / 32;
+  a.ntiles = (a.N + 63) / 64;
+  const size_t sh = 4 * 3 * 4096;                    // 48 KB of A rings (the 32 KB of partials alias them)
+  const int groups = (a.mtiles + 7) / 8;
+  hipLaunchKernelGGL((gemm_x6_ks_kernel<EPI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
+  return hipGetLastError();
+}
+
 // Split-K workspace (caller-owned, gkg_x6_splitk_workspace_bytes()): [1024 tile counters, zero between launches][partials].
 constexpr size_t X6_SK_CNT_BYTES = 4096, X6_SK_MAX_WG = 512;
 constexpr size_t X6_SK_BYTES = X6_SK_CNT_BYTES + X6_SK_MAX_WG * (size_t)(2 * 16 * 256 * 4);
@@ -559,6 +746,19 @@ static hipError_t x6_launch(X6Args a, int nb, hipStream_t st, void* sk_ws = null
   // runs the normal epilogue, BN statistics included.
   const long long base2 = (long long)mt * ((a.N + 63) / 64) * nb;
   const int nk_total = (a.K + 31) / 32;
+  // Few rows (<= 4 096: the label branch): the waves of a workgroup split K instead of M (gemm_x6_ks_kernel) — taken by the _sk
+  // entry points, i.e. by callers that asked for the short-matrix forms
+  // Where it pays (measured inside the cfg2 step, same box, us, this body vs gemm_x6_kernel with cross-workgroup split-K:
+  // profiles/r05_x6_ks_vs_tile_kernel.txt): 2 560 x 320 -> 320 11.0 vs 13.1 (input gradient + residual 11.7 vs 20.7), 640 -> 320
+  // 15.2 vs 21.2, 1280 -> 320 24.3 vs 29.6 (input gradient of 320 -> 1280: 25.4 vs 36.5); a tie at 320 -> 640 (16.4); it LOSES
+  // where every 32-row workgroup re-reads a wide B (320 -> 1280: 30.0 vs 22.4, its transpose 27.3 vs 21.3: 196 MB of plane
+  // traffic) and on the grouped 4 x (160 -> 160) products (15.5 vs 13.5).  Rule: un-grouped, at most 640 output columns.
+  // gkg_x6_set_flags(2) forces it for every short matrix (tests).
+  if constexpr (EPI != X6_BNBWD) {
+    if (sk_ws && !(gkg_x6_flags & 1u) && a.M <= 4096 && (long long)((a.M + 31) / 32) * ((a.N + 63) / 64) * nb <= 65535 * 8 &&
+        ((gkg_x6_flags & 2u) || (nb == 1 && a.N <= 640)))
+      return x6_launch_ks<EPI>(a, nb, st);
+  }
   if (sk_ws && sk_bytes >= X6_SK_BYTES && base2 < 320 && base2 <= 1024 && nk_total >= 8 && EPI != X6_BNBWD) {
     int ks = (int)(X6_SK_MAX_WG / base2);
     if (ks > nk_total / 4) ks = nk_total / 4;
@@ -1138,6 +1338,7 @@ extern "C" int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long t
 // gkg_linear_bn_fwd with the weights given as forward planes (gkg_x6_prep_weights).  x (nb, R, cin) with row pitch ldx and
 // batch stride x_bstride (floats); y (nb, R, cout) contiguous.  Same `train` modes and outputs as gkg_linear_bn_fwd.
 extern "C" size_t gkg_x6_splitk_workspace_bytes(void) { return X6_SK_BYTES; }
+extern "C" void gkg_x6_set_flags(unsigned flags) { gkg_x6_flags = flags; }
 
 static int x6_fwd_impl(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
                        int cin, int cout, int nb, int train, const float* gamma, const float* beta,

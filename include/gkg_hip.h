@@ -390,6 +390,12 @@ int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, const void* 
  * epilogue, BN statistics included.  gkg_linear_dgrad_x6_sk: `residual` (nb, R, cin) contiguous or NULL is added to dx in
  * the epilogue (the skip connection's gradient, reference torch_vertex.py:331,354,402). */
 size_t gkg_x6_splitk_workspace_bytes(void);
+/* With a workspace the _sk entry points run matrices of at most 4 096 rows on a body whose four waves split K inside the
+ * workgroup (32-row x 64-column tiles, private LDS rings, B fragments straight from the weight planes, no barrier in the loop,
+ * no cross-workgroup hand-off: csrc/gkg_gemm_x6.hip gemm_x6_ks_kernel) — the cross-workgroup split-K form above then only
+ * serves what that body does not.  Taken for un-grouped projections of at most 640 output columns (where it measured faster:
+ * a 32-row workgroup re-reads all of B).  gkg_x6_set_flags: bit 0 = never take it, bit 1 = for every short matrix (A/B, tests). */
+void gkg_x6_set_flags(unsigned flags);
 int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R, int cin,
                             int cout, int nb, int train, const float* gamma, const float* beta, const float* bias,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* bn_a, float* bn_c,

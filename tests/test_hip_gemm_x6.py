@@ -449,3 +449,55 @@ def test_split_k_forward_statistics_and_dgrad(R, cin, cout, nb):
     _lib.check(lib.gkg_linear_bn_fwd_x6(x.data_ptr(), cin, R * cin, pf.data_ptr(), y1.data_ptr(), R, cin, cout, nb, 0,
                                         *([None] * 10), 0.0, 0.0, None, None), "fwd")
     assert float(((y1.double() - y.double()).abs() / mag_y).max()) < 3e-7
+
+
+# ---- few rows: the waves of a workgroup split K (gemm_x6_ks_kernel, round 5).  The _sk entry points take it for <= 4 096 rows.
+KS_SHAPES = [(2560, 320, 320, 1), (2560, 1280, 320, 1), (2560, 320, 1280, 1), (2560, 160, 160, 4), (2560, 640, 320, 1),
+             (777, 36, 40, 1), (129, 64, 8, 2), (19, 16, 8, 1), (4096, 100, 72, 1), (33, 2048, 64, 3), (300, 72, 200, 2)]
+
+
+@pytest.mark.parametrize("R,cin,cout,nb", KS_SHAPES)
+def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb):
+    """Forward (+ BN column sums), input gradient (+ residual) on the K-split-in-workgroup body against fp64 at the fp32 bar and
+    against gemm_x6_kernel (flags 1) on the same operands; run-to-run identical bits (partials are added in wave order)."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(R * 5 + cin + cout)
+    x = torch.randn(nb, R, cin, device="cuda", generator=gen) * 2 + 0.5
+    w = torch.randn(nb, cout, cin, device="cuda", generator=gen) * 0.1
+    dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
+    res = torch.randn(nb, R, cin, device="cuda", generator=gen)
+    pf, pd = _planes(lib, w, nb, cout, cin)
+    ws = torch.zeros(lib.gkg_x6_splitk_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros(lib.gkg_linear_stats_doubles(), dtype=torch.float64, device="cuda")
+    out = {}
+    try:
+        for flags in (2, 2, 1):                      # the K-split body (forced for every short matrix) twice, gemm_x6_kernel once
+            lib.gkg_x6_set_flags(flags)
+            y = torch.full((nb, R, cout), float("nan"), device="cuda")
+            stats.zero_()
+            _lib.check(lib.gkg_linear_bn_fwd_x6_sk(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
+                                                   *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), None), "fwd")
+            dx = torch.full((nb, R, cin), float("nan"), device="cuda")
+            _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
+                                                  res.data_ptr(), ws.data_ptr(), ws.numel(), None), "dgrad")
+            torch.cuda.synchronize()
+            out.setdefault(flags, []).append((y, dx, stats[:nb * 2 * cout].clone()))
+    finally:
+        lib.gkg_x6_set_flags(0)
+    (y, dx, st), (y_b, dx_b, _), (y_ref, dx_ref, st_ref) = out[2][0], out[2][1], out[1][0]
+    assert torch.equal(y, y_b) and torch.equal(dx, dx_b)
+    ref_y = torch.bmm(x.double(), w.double().transpose(1, 2))
+    ref_dx = torch.bmm(dy.double(), w.double()) + res.double()
+    mag_y = torch.bmm(x.double().abs(), w.double().abs().transpose(1, 2)) + 1e-30
+    mag_dx = torch.bmm(dy.double().abs(), w.double().abs()) + res.double().abs() + 1e-30
+    e_y, e_dx = _rel(y, ref_y, mag_y), _rel(dx, ref_dx, mag_dx)
+    f_y = _rel(torch.bmm(x, w.transpose(1, 2)), ref_y, mag_y)
+    f_dx = _rel(torch.baddbmm(res, dy, w), ref_dx, mag_dx)
+    assert e_y <= max(f_y, 1.2e-7) and e_dx <= max(f_dx, 1.2e-7), (e_y, f_y, e_dx, f_dx)
+    assert e_y < 2e-7 and e_dx < 2e-7
+    sums = st.view(nb, 2, cout)
+    assert torch.allclose(sums[:, 0], ref_y.sum(1), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(sums[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
+    assert float(((y_ref.double() - y.double()).abs() / mag_y).max()) < 3e-7          # the other body: the same values
+    assert float(((dx_ref.double() - dx.double()).abs() / mag_dx).max()) < 3e-7
