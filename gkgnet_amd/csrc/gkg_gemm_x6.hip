@@ -556,10 +556,12 @@ static hipError_t x6_launch_ni(X6Args a, int nb, hipStream_t st) {
 // are added through LDS in wave order (deterministic), and the workgroup stores its tile (+ residual) and, EPI_BNSTATS, adds
 // the tile's centred column statistics to the fp64 sums like the kernel above.  2 560 x 320 -> 320: 400 workgroups of
 // 3 + 3 + 2 + 2 K-steps.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
-  constexpr int NI = 2, BN = 64, BM = 32, BK = 32, SA = 3;
-  extern __shared__ uint4 lds[];                       // [4 waves][SA][4 KB] A rings; then [4][32][64] fp32 partials (aliased)
+// MI — 32-row blocks per workgroup (and wave): 1 (default), or 2 (opt-in: 64-row tiles halve the plane traffic at one wave per
+// SIMD and a 2-stage ring; measured no better, see the launch site).
+template <int EPI, int MI>
+__global__ __launch_bounds__(256, MI == 1 ? 2 : 1) void gemm_x6_ks_kernel(X6Args g) {
+  constexpr int NI = 2, BN = 64, BM = 32 * MI, BK = 32, SA = MI == 1 ? 3 : 2, STAGE = 4096 * MI;
+  extern __shared__ uint4 lds[];                       // [4 waves][SA][STAGE] A rings; then [4][BM][64] fp32 partials (aliased)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int z = blockIdx.y;
   const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
@@ -574,14 +576,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
   const bool ktail = (K & (BK - 1)) != 0;
   const float* A = g.A + (size_t)z * g.a_bstride;
   const uint4* P = g.P + (size_t)z * g.p_bstride;
-  const unsigned lds0 = (unsigned)(size_t)lds + w * (SA * 4096);
-  const char* ring = (const char*)lds + w * (SA * 4096);
+  const unsigned lds0 = (unsigned)(size_t)lds + w * (SA * STAGE);
+  const char* ring = (const char*)lds + w * (SA * STAGE);
 
-  // A pieces (as gemm_x6_kernel): LDS slot L = 64 i + lane of the 32 x 128-B image holds chunk (L & 7) ^ ((row >> 1) & 7) of row L >> 3
-  unsigned aoff[4];
-  int achunk[4];
+  // A pieces (as gemm_x6_kernel): LDS slot L = 64 i + lane of the BM x 128-B image holds chunk (L & 7) ^ ((row >> 1) & 7) of row L >> 3
+  unsigned aoff[4 * MI];
+  int achunk[4 * MI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4 * MI; ++i) {
     const int L = 64 * i + lane, row = L >> 3, chunk = (L & 7) ^ ((row >> 1) & 7);
     const int gr = min(m0 + row, M - 1);
     aoff[i] = (unsigned)((size_t)gr * g.lda + chunk * 4) * 4u;
@@ -590,10 +592,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
   auto dma_a = [&](int k) {                                              // k: this wave's step index
     const int kt = kt0 + k;
     const char* base = (const char*)A + (size_t)kt * (BK * 4);
-    const unsigned dst = lds0 + (k % SA) * 4096;
+    const unsigned dst = lds0 + (k % SA) * STAGE;
     const bool last = ktail && kt == nk_total - 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * MI; ++i) {
       unsigned o = aoff[i];
       if (last && kt * BK + achunk[i] * 4 >= K) o -= achunk[i] * 16;    // past K: a valid address, masked after the read
       x6_dma16(base, o, dst + i * 1024);
@@ -608,42 +610,48 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[j][p] = base[p * plane + j * 32];
   };
-  x6_f32x16 acc[NI], accs[NI];
+  x6_f32x16 acc[MI][NI], accs[MI][NI];
 #pragma unroll
-  for (int j = 0; j < NI; ++j)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { acc[j][q] = 0.f; accs[j][q] = 0.f; }
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[mi][j][q] = 0.f; accs[mi][j][q] = 0.f; }
 
   uint4 b0f[NI][3], b1f[NI][3], bnx[NI][3];           // halves 0 / 1 of the current K-step, half 0 of the next one
   // issue order per wave: A0 A1 A2 B0.0 B0.1 | B(k+1).0 (wait A(k), B(k)) step k, B(k+1).1, A(k+3) | ...
   if (cnt > 0) dma_a(0);
   if (cnt > 1) dma_a(1);
-  if (cnt > 2) dma_a(2);
+  if (SA > 2 && cnt > 2) dma_a(2);
   if (cnt > 0) { load_b(b0f, 0, 0); load_b(b1f, 0, 1); }
   auto mma = [&](const char* ab, int s2, bool last, int kglob, const uint4 (&bq)[NI][3]) {
-    const float4 f0 = *(const float4*)(ab + r * 128 + (((4 * s2 + 2 * h) ^ sw) << 4));
-    const float4 f1 = *(const float4*)(ab + r * 128 + (((4 * s2 + 2 * h + 1) ^ sw) << 4));
-    float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-    if (last) {
-      const int kb = kglob * BK + 16 * s2 + 8 * h;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = kb + e < K ? f[e] : 0.f;
-    }
-    uint4 ah, am, al;
-    x6_split2(f[0], f[1], ah.x, am.x, al.x); x6_split2(f[2], f[3], ah.y, am.y, al.y);
-    x6_split2(f[4], f[5], ah.z, am.z, al.z); x6_split2(f[6], f[7], ah.w, am.w, al.w);
-    const x6_bf16x8 a0 = __builtin_bit_cast(x6_bf16x8, ah), a1 = __builtin_bit_cast(x6_bf16x8, am), a2 = __builtin_bit_cast(x6_bf16x8, al);
+    for (int mi = 0; mi < MI; ++mi) {
+      const char* rowp = ab + (32 * mi + r) * 128;
+      const float4 f0 = *(const float4*)(rowp + (((4 * s2 + 2 * h) ^ sw) << 4));
+      const float4 f1 = *(const float4*)(rowp + (((4 * s2 + 2 * h + 1) ^ sw) << 4));
+      float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+      if (last) {
+        const int kb = kglob * BK + 16 * s2 + 8 * h;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const x6_bf16x8 b0 = __builtin_bit_cast(x6_bf16x8, bq[j][0]), b1 = __builtin_bit_cast(x6_bf16x8, bq[j][1]),
-                      b2 = __builtin_bit_cast(x6_bf16x8, bq[j][2]);
-      // small terms first, the hi*hi product into its own accumulator (gemm_x6_kernel's order)
-      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, accs[j], 0, 0, 0);
-      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, accs[j], 0, 0, 0);
-      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, accs[j], 0, 0, 0);
-      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, accs[j], 0, 0, 0);
-      accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, accs[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) f[e] = kb + e < K ? f[e] : 0.f;
+      }
+      uint4 ah, am, al;
+      x6_split2(f[0], f[1], ah.x, am.x, al.x); x6_split2(f[2], f[3], ah.y, am.y, al.y);
+      x6_split2(f[4], f[5], ah.z, am.z, al.z); x6_split2(f[6], f[7], ah.w, am.w, al.w);
+      const x6_bf16x8 a0 = __builtin_bit_cast(x6_bf16x8, ah), a1 = __builtin_bit_cast(x6_bf16x8, am), a2 = __builtin_bit_cast(x6_bf16x8, al);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const x6_bf16x8 b0 = __builtin_bit_cast(x6_bf16x8, bq[j][0]), b1 = __builtin_bit_cast(x6_bf16x8, bq[j][1]),
+                        b2 = __builtin_bit_cast(x6_bf16x8, bq[j][2]);
+        // small terms first, the hi*hi product into its own accumulator (gemm_x6_kernel's order)
+        accs[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, accs[mi][j], 0, 0, 0);
+        accs[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, accs[mi][j], 0, 0, 0);
+        accs[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, accs[mi][j], 0, 0, 0);
+        accs[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, accs[mi][j], 0, 0, 0);
+        accs[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, accs[mi][j], 0, 0, 0);
+        acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[mi][j], 0, 0, 0);
+      }
     }
   };
   for (int k = 0; k < cnt; ++k) {
@@ -652,12 +660,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
     // A(k) and both halves of B(k) have landed once at most the operations issued AFTER B(k).1 are outstanding: A(k+2) (issued
     // right behind B(k).1 at the end of step k-1; k == 0: A1, A2 are OLDER than B0) and the 6 loads just issued.  (The
     // compiler's own waits cover the plain loads it can see; this asm wait is for the LDS-DMA pieces it cannot.)
-    const int after = (more ? 6 : 0) + ((k >= 1 && k + 2 < cnt) ? 4 : 0);
-    if (after == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    const int after = (more ? 6 : 0) + ((k >= 1 && k - 1 + SA < cnt) ? 4 * MI : 0);
+    if (after == 6 + 4 * MI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 + 4 * MI) : "memory");
     else if (after == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (after == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (after == 4 * MI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * MI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* ab = ring + (k % SA) * 4096;
+    const char* ab = ring + (k % SA) * STAGE;
     const bool last = ktail && kt0 + k == nk_total - 1;
     mma(ab, 0, last, kt0 + k, b0f);
     mma(ab, 1, last, kt0 + k, b1f);
@@ -677,19 +685,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                                       // every wave is done with its ring
-  float* red = reinterpret_cast<float*>(lds);                            // [4][32][64]
+  float* red = reinterpret_cast<float*>(lds);                            // [4][BM][64]
 #pragma unroll
-  for (int j = 0; j < NI; ++j)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-      red[(w * BM + row) * BN + j * 32 + r] = acc[j][q] + accs[j][q];
-    }
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 32 * mi + (q & 3) + 8 * (q >> 2) + 4 * h;
+        red[(w * BM + row) * BN + j * 32 + r] = acc[mi][j][q] + accs[mi][j][q];
+      }
   __syncthreads();
   float* C = g.C + (size_t)z * g.c_bstride;
-  float v[8];
+  float v[8 * MI];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
+  for (int u = 0; u < 8 * MI; ++u) {
     const int e = tid + 256 * u, row = e >> 6, col = e & 63;
     v[u] = ((red[e] + red[BM * BN + e]) + red[2 * BM * BN + e]) + red[3 * BM * BN + e];      // wave order: the same bits every run
     const int m = m0 + row, n = n0 + col;
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
   // (mean, M2) over the tile's valid rows, ONE fp64 atomic pair per column and tile:  S += n mean,  Q += M2 + n mean^2
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 8; ++u) red[tid + 256 * u] = v[u];
+  for (int u = 0; u < 8 * MI; ++u) red[tid + 256 * u] = v[u];
   __syncthreads();
   if (tid < BN && n0 + tid < N) {
     const int rows = max(0, min(BM, M - m0));
@@ -720,15 +730,26 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ks_kernel(X6Args g) {
   }
 }
 
-static unsigned gkg_x6_flags = 0;       // gkg_x6_set_flags: bit 0 = never take the K-split-in-workgroup form, bit 1 = wherever it applies (A/B, tests)
+static unsigned gkg_x6_flags = 0;       // gkg_x6_set_flags: bit 0 = never take the K-split-in-workgroup form, bit 1 = wherever it applies,
+                                        // bit 2 / bit 3 = always 32-row / 64-row tiles in it (A/B, tests)
 
-template <int EPI>
+template <int EPI, int MI>
 static hipError_t x6_launch_ks(X6Args a, int nb, hipStream_t st) {
-  a.mtiles = (a.M + 31) / 32;
+  a.mtiles = (a.M + 32 * MI - 1) / (32 * MI);
   a.ntiles = (a.N + 63) / 64;
-  const size_t sh = 4 * 3 * 4096;                    // 48 KB of A rings (the 32 KB of partials alias them)
+  const size_t sh = MI == 1 ? 4 * 3 * 4096 : 4 * 2 * 8192;      // 48 / 64 KB of A rings (the 32 / 64 KB of partials alias them)
+  if (MI == 2) {
+    static bool once[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !once[dev]) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_x6_ks_kernel<EPI, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) once[dev] = true;
+    }
+  }
   const int groups = (a.mtiles + 7) / 8;
-  hipLaunchKernelGGL((gemm_x6_ks_kernel<EPI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
+  hipLaunchKernelGGL((gemm_x6_ks_kernel<EPI, MI>), dim3(groups * 8 * a.ntiles, nb), dim3(256), sh, st, a);
   return hipGetLastError();
 }
 
@@ -756,8 +777,13 @@ static hipError_t x6_launch(X6Args a, int nb, hipStream_t st, void* sk_ws = null
   // gkg_x6_set_flags(2) forces it for every short matrix (tests).
   if constexpr (EPI != X6_BNBWD) {
     if (sk_ws && !(gkg_x6_flags & 1u) && a.M <= 4096 && (long long)((a.M + 31) / 32) * ((a.N + 63) / 64) * nb <= 65535 * 8 &&
-        ((gkg_x6_flags & 2u) || (nb == 1 && a.N <= 640)))
-      return x6_launch_ks<EPI>(a, nb, st);
+        ((gkg_x6_flags & 2u) || (nb == 1 && a.N <= 640))) {
+      // 64-row tiles (half the plane traffic, one wave per SIMD) measured no better on the long contractions they were built
+      // for (2 560 x 1280 -> 320: 26.8 vs 24.3 us, its transpose-side gradient 26.5 vs 25.4): what bounds those launches is the
+      // wave-serial K loop, not the B planes — opt-in (gkg_x6_set_flags bit 3)
+      const bool mi2 = (gkg_x6_flags & 8u) != 0;
+      return mi2 ? x6_launch_ks<EPI, 2>(a, nb, st) : x6_launch_ks<EPI, 1>(a, nb, st);
+    }
   }
   if (sk_ws && sk_bytes >= X6_SK_BYTES && base2 < 320 && base2 <= 1024 && nk_total >= 8 && EPI != X6_BNBWD) {
     int ks = (int)(X6_SK_MAX_WG / base2);

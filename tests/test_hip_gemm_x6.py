@@ -472,7 +472,8 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
     stats = torch.zeros(lib.gkg_linear_stats_doubles(), dtype=torch.float64, device="cuda")
     out = {}
     try:
-        for flags in (2, 2, 1):                      # the K-split body (forced for every short matrix) twice, gemm_x6_kernel once
+        # the K-split body forced for every short matrix: 32-row tiles twice (flags 2 | 4), 64-row tiles (2 | 8); gemm_x6_kernel (1)
+        for flags in (6, 6, 10, 1):
             lib.gkg_x6_set_flags(flags)
             y = torch.full((nb, R, cout), float("nan"), device="cuda")
             stats.zero_()
@@ -485,8 +486,9 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
             out.setdefault(flags, []).append((y, dx, stats[:nb * 2 * cout].clone()))
     finally:
         lib.gkg_x6_set_flags(0)
-    (y, dx, st), (y_b, dx_b, _), (y_ref, dx_ref, st_ref) = out[2][0], out[2][1], out[1][0]
+    (y, dx, st), (y_b, dx_b, _), (y_ref, dx_ref, st_ref) = out[6][0], out[6][1], out[1][0]
     assert torch.equal(y, y_b) and torch.equal(dx, dx_b)
+    y2, dx2, st2 = out[10][0]                                                          # 64-row tiles: fp32 accuracy, same sums
     ref_y = torch.bmm(x.double(), w.double().transpose(1, 2))
     ref_dx = torch.bmm(dy.double(), w.double()) + res.double()
     mag_y = torch.bmm(x.double().abs(), w.double().abs().transpose(1, 2)) + 1e-30
@@ -501,3 +503,6 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
     assert torch.allclose(sums[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
     assert float(((y_ref.double() - y.double()).abs() / mag_y).max()) < 3e-7          # the other body: the same values
     assert float(((dx_ref.double() - dx.double()).abs() / mag_dx).max()) < 3e-7
+    assert _rel(y2, ref_y, mag_y) < 2e-7 and _rel(dx2, ref_dx, mag_dx) < 2e-7
+    s2 = st2.view(nb, 2, cout)
+    assert torch.allclose(s2[:, 0], ref_y.sum(1), rtol=1e-6, atol=1e-3) and torch.allclose(s2[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
