@@ -618,8 +618,8 @@ __global__ __launch_bounds__(256, MI == 1 ? 2 : 1) void gemm_x6_ks_kernel(X6Args
 #pragma unroll
       for (int q = 0; q < 16; ++q) { acc[mi][j][q] = 0.f; accs[mi][j][q] = 0.f; }
 
-  uint4 b0f[NI][3], b1f[NI][3], bnx[NI][3];           // halves 0 / 1 of the current K-step, half 0 of the next one
-  // issue order per wave: A0 A1 A2 B0.0 B0.1 | B(k+1).0 (wait A(k), B(k)) step k, B(k+1).1, A(k+3) | ...
+  uint4 b0f[NI][3], b1f[NI][3], bn0[NI][3], bn1[NI][3];      // both halves of the current K-step and of the next one
+  // issue order per wave: A0 A1 A2 B0.0 B0.1 | B(k+1).0 B(k+1).1 (wait A(k), B(k)) step k, A(k+3) | ...
   if (cnt > 0) dma_a(0);
   if (cnt > 1) dma_a(1);
   if (SA > 2 && cnt > 2) dma_a(2);
@@ -656,13 +656,13 @@ __global__ __launch_bounds__(256, MI == 1 ? 2 : 1) void gemm_x6_ks_kernel(X6Args
   };
   for (int k = 0; k < cnt; ++k) {
     const bool more = k + 1 < cnt;
-    if (more) load_b(bnx, k + 1, 0);
-    // A(k) and both halves of B(k) have landed once at most the operations issued AFTER B(k).1 are outstanding: A(k+2) (issued
-    // right behind B(k).1 at the end of step k-1; k == 0: A1, A2 are OLDER than B0) and the 6 loads just issued.  (The
+    if (more) { load_b(bn0, k + 1, 0); load_b(bn1, k + 1, 1); }
+    // A(k) and both halves of B(k) have landed once at most the operations issued AFTER B(k).1 are outstanding: A(k - 1 + SA)
+    // (issued at the end of step k-1; k == 0: the prologue's A pieces are OLDER than B0) and the 12 loads just issued.  (The
     // compiler's own waits cover the plain loads it can see; this asm wait is for the LDS-DMA pieces it cannot.)
-    const int after = (more ? 6 : 0) + ((k >= 1 && k - 1 + SA < cnt) ? 4 * MI : 0);
-    if (after == 6 + 4 * MI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 + 4 * MI) : "memory");
-    else if (after == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    const int after = (more ? 12 : 0) + ((k >= 1 && k - 1 + SA < cnt) ? 4 * MI : 0);
+    if (after == 12 + 4 * MI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 4 * MI) : "memory");
+    else if (after == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (after == 4 * MI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * MI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const char* ab = ring + (k % SA) * STAGE;
@@ -671,16 +671,14 @@ __global__ __launch_bounds__(256, MI == 1 ? 2 : 1) void gemm_x6_ks_kernel(X6Args
     mma(ab, 1, last, kt0 + k, b1f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the ring slot's reads are in registers: it may be refilled
     if (more) {
-      // first the copy (its wait sees only B(k+1).0, a whole step old), then the new loads: behind them the compiler's count of
-      // outstanding loads would be short by the DMA pieces and its wait for the copy would stall on the loads just issued
+      // the copies first (their wait sees only this step's loads, a whole step old), then the DMA: behind it the compiler's count
+      // of outstanding loads would be short by the DMA pieces
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b0f[j][p] = bnx[j][p];
-      asm volatile("" ::: "memory");
-      load_b(b1f, k + 1, 1);
+        for (int p = 0; p < 3; ++p) { b0f[j][p] = bn0[j][p]; b1f[j][p] = bn1[j][p]; }
     }
-    asm volatile("" ::: "memory");                                        // (keeps the order: B(k+1).1, then A(k+3))
+    asm volatile("" ::: "memory");
     if (k + SA < cnt) dma_a(k + SA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
