@@ -1263,6 +1263,7 @@ class _KnnMaxRelativeTM(torch.autograd.Function):
         ctx.save_for_backward(arg)
         ctx.meta = (B, G, C, N, M, k, src is not None)
         ctx.mark_non_differentiable(edge)
+        ctx.set_materialize_grads(False)          # (no zero-filled int64 "gradient" of the graph output: 4.8 us per step)
         return U, edge
 
     @staticmethod
@@ -1270,6 +1271,8 @@ class _KnnMaxRelativeTM(torch.autograd.Function):
         lib = _lib.load()
         (arg,) = ctx.saved_tensors
         B, G, C, N, M, k, has_src = ctx.meta
+        if g is None:
+            return (None,) * 7
         g = g.contiguous()
         gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
