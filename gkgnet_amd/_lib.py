@@ -67,7 +67,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
-           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts", "gkg_x6_set_flags")
+           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts", "gkg_x6_set_flags", "gkg_x6_prep_weights_zero")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -187,6 +187,8 @@ def load():
     lib.gkg_x6_prep_desc_fill.argtypes = [V, I, V, V, V, I, I, I, C.c_longlong]
     lib.gkg_x6_prep_weights.restype = I
     lib.gkg_x6_prep_weights.argtypes = [V, I, C.c_longlong, V]
+    lib.gkg_x6_prep_weights_zero.restype = I
+    lib.gkg_x6_prep_weights_zero.argtypes = [V, I, C.c_longlong, V, Z, V, Z, V]
     lib.gkg_linear_bn_fwd_x6.restype = I
     lib.gkg_linear_bn_fwd_x6.argtypes = [V, I, Z, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V]
     lib.gkg_linear_dgrad_x6.restype = I

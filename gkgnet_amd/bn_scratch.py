@@ -79,6 +79,21 @@ class _BnBwdScratch:
         self.cur ^= 1
         return cur, other, zero
 
+    def fold_reset(self, cap):
+        """The first use of the pair inside hipGraph capture ``cap`` would clear both buffers with a launch of its own: when the
+        weight-plane refresh (the first launch of a captured step) runs first, it clears them in ITS launch — returns the storage
+        to clear, or None when this capture has already been seen."""
+        if not cap or cap == self.capture_id:
+            return None
+        self.captured = True
+        self.capture_id = cap
+        self.dirty = [0, 0]
+        self.poisoned = False
+        if self.pending is not None:
+            self.pending.ready = None
+            self.pending = None
+        return self.store
+
     def _reset(self):
         self.store.fill_(0.0)            # ONE elementwise launch (a captured memset node measured far slower than a kernel node)
         self.dirty = [0, 0]

@@ -68,7 +68,22 @@ struct X6PrepDesc {
   int unit_begin;
 };
 
-__global__ __launch_bounds__(256) void x6_prep_kernel(const X6PrepDesc* __restrict__ descs, int ndesc, int total_units) {
+// Zero jobs riding in the same launch (round 5): a training step begins by clearing its gradient arena and the BN scratch — two
+// more 5 us launches in front of the first projection.  Workgroups past the unit blocks clear up to two buffers (16-byte units).
+struct X6ZeroJobs {
+  uint4* p[2];
+  unsigned long long n16[2];        // 16-byte units
+  int unit_blocks;                  // workgroups [0, unit_blocks) split weights, the rest clear
+};
+
+__global__ __launch_bounds__(256) void x6_prep_kernel(const X6PrepDesc* __restrict__ descs, int ndesc, int total_units, X6ZeroJobs zj) {
+  if ((int)blockIdx.x >= zj.unit_blocks) {
+    const unsigned long long zb = blockIdx.x - zj.unit_blocks, stride = (unsigned long long)(gridDim.x - zj.unit_blocks) * 256;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      for (unsigned long long i = zb * 256 + threadIdx.x; i < zj.n16[j]; i += stride) zj.p[j][i] = make_uint4(0, 0, 0, 0);
+    return;
+  }
   __shared__ int begin[256];
   __shared__ int first;
   const int u0 = blockIdx.x * 256;
@@ -1350,13 +1365,35 @@ extern "C" long long gkg_x6_prep_desc_fill(void* host_descs, int index, const fl
 
 // One launch splits every described weight into its forward and dgrad planes.  `descs_dev`: the descriptor array copied to
 // the device (it holds device pointers only).
-extern "C" int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long total_units, void* stream) {
+static int x6_prep_impl(const void* descs_dev, int ndesc, long long total_units, void* z0, size_t z0_bytes, void* z1,
+                        size_t z1_bytes, void* stream) {
   if (!descs_dev) return gkg_fail(GKG_ERR_NULL, "gkg_x6_prep_weights: null descriptor array");
   if (ndesc <= 0 || ndesc > 256 || total_units <= 0 || total_units > 0x7fffffffLL) return gkg_fail(GKG_ERR_SHAPE, "gkg_x6_prep_weights: need 1 <= ndesc <= 256 and 0 < total_units < 2^31");
-  hipLaunchKernelGGL(x6_prep_kernel, dim3((unsigned)((total_units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const X6PrepDesc*)descs_dev, ndesc, (int)total_units);
+  if (((size_t)z0 & 15) || ((size_t)z1 & 15) || (z0_bytes & 15) || (z1_bytes & 15) || (!z0 && z0_bytes) || (!z1 && z1_bytes))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_x6_prep_weights_zero: buffers to clear must be 16-byte aligned multiples of 16 bytes");
+  X6ZeroJobs zj{};
+  zj.p[0] = (uint4*)z0; zj.n16[0] = z0_bytes / 16;
+  zj.p[1] = (uint4*)z1; zj.n16[1] = z1_bytes / 16;
+  zj.unit_blocks = (int)((total_units + 255) / 256);
+  const unsigned long long zmax = zj.n16[0] > zj.n16[1] ? zj.n16[0] : zj.n16[1];
+  unsigned zblocks = (unsigned)((zmax + 256 * 16 - 1) / (256 * 16));          // ~16 stores per thread
+  if (zblocks > 1024) zblocks = 1024;
+  hipLaunchKernelGGL(x6_prep_kernel, dim3((unsigned)zj.unit_blocks + zblocks), dim3(256), 0, (hipStream_t)stream,
+                     (const X6PrepDesc*)descs_dev, ndesc, (int)total_units, zj);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "x6_prep_kernel");
+}
+
+extern "C" int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long total_units, void* stream) {
+  return x6_prep_impl(descs_dev, ndesc, total_units, nullptr, 0, nullptr, 0, stream);
+}
+
+// gkg_x6_prep_weights that also CLEARS up to two buffers (zero0 / zero1, 16-byte aligned, byte counts multiples of 16; NULL / 0:
+// none) in the same launch: what a training step clears before its first projection anyway — the flat gradient buffer the
+// weight-gradient kernels accumulate into and the fp64 BN scratch.
+extern "C" int gkg_x6_prep_weights_zero(const void* descs_dev, int ndesc, long long total_units, void* zero0, size_t zero0_bytes,
+                                        void* zero1, size_t zero1_bytes, void* stream) {
+  return x6_prep_impl(descs_dev, ndesc, total_units, zero0, zero0_bytes, zero1, zero1_bytes, stream);
 }
 
 // gkg_linear_bn_fwd with the weights given as forward planes (gkg_x6_prep_weights).  x (nb, R, cin) with row pitch ldx and

@@ -193,7 +193,9 @@ def flush_wgrads():
 
 
 from . import parallel as _parallel      # noqa: E402
+from . import planes as _planes_mod      # noqa: E402
 _parallel._FLUSH.append(flush_wgrads)
+_parallel._ZERO_DEFER[:] = [_planes_mod.defer_zero, _planes_mod.flush_deferred_zero]
 
 
 def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs) -> bool:

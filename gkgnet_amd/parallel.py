@@ -35,6 +35,7 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+_ZERO_DEFER = []     # [defer(t) -> bool, flush()]: fused registers planes.defer_zero / planes.flush_deferred_zero
 _FLUSH = []          # callables that complete gradients still queued for a batched launch (fused.flush_wgrads registers itself)
 
 
@@ -136,7 +137,9 @@ class GradBucket:
             p._gkg_handed = False
             p._gkg_clean = prezero
         if prezero:
-            self.flat.zero_()
+            # inside a captured step the clear rides in the step's first launch (the weight-plane refresh: planes.defer_zero)
+            if not (_ZERO_DEFER and _ZERO_DEFER[0](self.flat)):
+                self.flat.zero_()
             self._zero = {id(p) for p in self.params}
         self._ready = {}
         self._complete = set()
@@ -256,6 +259,8 @@ def grad_view(p: torch.nn.Parameter, shape=None):
     adopts as ``p.grad`` — no separate gradient tensor, no re-pack.  A slot is handed out ONCE per backward
     (``GradBucket.release`` re-arms it)."""
     b = getattr(p, "_gkg_bucket", None)
+    if _ZERO_DEFER:
+        _ZERO_DEFER[1]()                           # a deferred clear nobody has picked up yet: before the first gradient lands
     if b is None or p.grad is not None or getattr(p, "_gkg_handed", False):
         # handed out already in this backward (a block or weight used twice in one graph): the second backward node gets
         # a fresh tensor and autograd ADDS it to the adopted view — two kernels writing the same slot would keep only

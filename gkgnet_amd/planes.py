@@ -56,6 +56,26 @@ class _WeightPlanes:
         self.unit_ends = []
         self.capture_id = 0
         self.captured = False
+        self.pending_zero = None     # a buffer (the flat gradient arena) to clear in the next refresh launch of this capture
+
+    def defer_zero(self, t) -> bool:
+        """Inside a hipGraph capture whose weight-plane refresh is still to come (it is the first launch of a captured step that
+        uses an x6 projection): take over the clearing of ``t`` — it rides in the refresh launch.  False: the caller clears it."""
+        if not (ZERO_FOLD and torch.cuda.is_current_stream_capturing() and self.entries and self.pending_zero is None
+                and t.is_contiguous() and t.data_ptr() % 16 == 0 and (t.numel() * t.element_size()) % 16 == 0):
+            return False
+        cap = _lib.load().gkg_stream_capture_id(_stream())
+        if not cap or cap == self.capture_id:
+            return False
+        self.pending_zero = (cap, t)
+        return True
+
+    def flush_zero(self):
+        """A deferred clear that no refresh has picked up (no x6 projection ran in this capture before a gradient was needed)."""
+        if self.pending_zero is not None:
+            _, t = self.pending_zero
+            self.pending_zero = None
+            t.zero_()
 
     def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None):
         if torch.cuda.is_current_stream_capturing():
@@ -104,8 +124,8 @@ class _WeightPlanes:
         _lib.check(lib.gkg_x6_prep_weights(self.solo.data_ptr() + e["slot"] * size, 1, e["solo_units"], _stream()),
                    "gkg_x6_prep_weights")
 
-    def refresh(self, lib):
-        """Re-split every registered weight (one launch)."""
+    def refresh(self, lib, zero=()):
+        """Re-split every registered weight (one launch); ``zero``: up to two tensors cleared by the same launch."""
         if self.descs is None:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.GkgError("x6 weight planes: descriptor table is stale inside a capture; run a warm-up step first")
@@ -114,8 +134,14 @@ class _WeightPlanes:
             return
         n = len(self.entries)
         size = lib.gkg_x6_prep_desc_bytes()
+        zero = [t for t in zero if t is not None]
         for i0 in range(0, n, 256):                                   # at most 256 descriptors per launch
             i1 = min(n, i0 + 256)
+            if zero and i0 == 0:
+                z = [(t.data_ptr(), t.numel() * t.element_size()) for t in zero[:2]] + [(None, 0)] * (2 - len(zero[:2]))
+                _lib.check(lib.gkg_x6_prep_weights_zero(self.descs.data_ptr(), i1, self.unit_ends[i1 - 1], z[0][0], z[0][1], z[1][0],
+                                                        z[1][1], _stream()), "gkg_x6_prep_weights_zero")
+                continue
             _lib.check(lib.gkg_x6_prep_weights(self.descs.data_ptr() + i0 * size, i1 - i0, self.unit_ends[i1 - 1], _stream()),
                        "gkg_x6_prep_weights")
         for e in self.entries.values():
@@ -133,7 +159,22 @@ class _WeightPlanes:
             self.captured = True
             if cap != self.capture_id:
                 self.capture_id = cap
-                self.refresh(lib)
+                # the first launch of a captured step: it also clears what the step clears before its first projection anyway
+                # — the gradient arena handed over by GradBucket.release(prezero=True) and the fp64 BN scratch pair
+                zero = []
+                if self.pending_zero is not None:
+                    pcap, t = self.pending_zero
+                    self.pending_zero = None
+                    if pcap == cap:
+                        zero.append(t)
+                    else:
+                        t.zero_()
+                if ZERO_FOLD:
+                    from .bn_scratch import _BnBwdScratch
+                    scr = _BnBwdScratch._inst.get((self.device.type, self.device.index))
+                    if scr is not None:
+                        zero.append(scr.fold_reset(cap))
+                self.refresh(lib, zero)
         elif e["version"] != param_version(weight):
             self.refresh(lib)                    # eager call, stale by the version / step counters (an eager optimiser step)
         elif self.captured:
@@ -144,6 +185,20 @@ class _WeightPlanes:
 
 
 _PLANES = {}
+# GKG_DISABLE=zero_fold: the gradient arena and the BN scratch cleared by launches of their own again (A/B)
+import os as _os      # noqa: E402
+ZERO_FOLD = "zero_fold" not in {t.strip() for t in _os.environ.get("GKG_DISABLE", "").split(",")}
+
+
+def defer_zero(t) -> bool:
+    """GradBucket.release(prezero=True): let the weight-plane refresh of the captured step clear ``t`` (see _WeightPlanes)."""
+    reg = _PLANES.get((t.device.type, t.device.index))
+    return reg is not None and reg.defer_zero(t)
+
+
+def flush_deferred_zero():
+    for reg in _PLANES.values():
+        reg.flush_zero()
 
 
 def _planes(lib, weight, nb, cout, cin, need_f=True, need_d=True):

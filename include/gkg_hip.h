@@ -376,6 +376,11 @@ int gkg_x6_prep_desc_bytes(void);
 long long gkg_x6_prep_desc_fill(void* host_descs, int index, const float* w, void* planes_fwd, void* planes_dgrad, int cin,
                                 int cout, int nb, long long unit_begin);
 int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long total_units, void* stream);
+/* The same launch also clearing up to two caller buffers (16-byte aligned, sizes multiples of 16; NULL / 0: none) — round 5: a
+ * training step clears its flat gradient buffer and the fp64 BN scratch in front of the first projection anyway; riding in the
+ * weight-split launch they cost no launch of their own. */
+int gkg_x6_prep_weights_zero(const void* descs_dev, int ndesc, long long total_units, void* zero0, size_t zero0_bytes,
+                             void* zero1, size_t zero1_bytes, void* stream);
 int gkg_linear_bn_fwd_x6(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R, int cin,
                          int cout, int nb, int train, const float* gamma, const float* beta, const float* bias,
                          float* running_mean, float* running_var, long long* num_batches_tracked, float* bn_a, float* bn_c,
