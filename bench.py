@@ -666,6 +666,24 @@ def main():
     prof = _lib.prof_read()
 
     from gkgnet_amd import fused
+    # Row g2 (round 5): by default the k-NN kernel also does the aggregation (fused epilogue), so `knn_tile`'s time below is the
+    # fused kernel's and there is no mr_fwd launch.  For continuity with earlier rounds the two-launch form is timed as well.
+    prof_two = None
+    if fused.KNN_MR:
+        fused.KNN_MR = False
+        try:
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            for _ in range(prof_steps):
+                eager_step()
+            torch.cuda.synchronize()
+            _lib.prof_enable(False)
+            prof_two = (_lib.prof_read(), _lib.prof_work("mr_fwd") / prof_steps)
+        finally:
+            fused.KNN_MR = True
     lib_desc = "vendor-library GEMMs (TunableOp-selected)" if not args.no_tune else "vendor-library GEMMs (default heuristic)"
     gemm_desc = {"x6": "fp32 projections: every forward, input-gradient and weight-gradient GEMM on the bf16 matrix cores with an "
                        "exact 3-way operand split, 6 cross products, fp32 accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 below an "
@@ -708,10 +726,27 @@ def main():
         if tile_n:
             per_step_ms = tile_ms / prof_steps
             ach = flops_knn / (per_step_ms * 1e-3) / 1e12
-            roof = dict(kernel="knn_tile_kernel", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+            fused_now = prof_two is not None and not prof.get("mr_fwd", (0, 0))[1]
+            roof = dict(kernel="knn_tile_kernel<..., MRF> (k-NN + max-relative aggregation in one kernel, row g2)" if fused_now
+                        else "knn_tile_kernel", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                         avg_launch_us=round(1e3 * tile_ms / tile_n, 2), launches_per_step=tile_n // prof_steps,
                         algorithmic_flops_per_step=flops_knn)
+            if fused_now:
+                # SURVEY §8(d) "Fused fwd (k-NN+MR)": the same contraction flop, more bytes — the kernel's time now includes the
+                # gather, so `frac` is NOT comparable with the k-NN-only kernel of rounds 1-4 (0.21-0.23); that kernel, timed
+                # in the two-launch form by this run:
+                t2_ms, t2_n = prof_two[0]["knn_tile"]
+                m2_ms, m2_n = prof_two[0]["mr_fwd"]
+                if t2_n:
+                    ach2 = flops_knn / (t2_ms / prof_steps * 1e-3) / 1e12
+                    roof["two_launch_form"] = dict(kernel="knn_tile_kernel (k-NN only) + mr_fwd_tm_kernel (GKG_DISABLE=knn_mr)",
+                                                   knn_achieved=round(ach2, 2), knn_frac=round(ach2 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                                   knn_us_per_step=round(1e3 * t2_ms / prof_steps, 2),
+                                                   mr_fwd_us_per_step=round(1e3 * m2_ms / prof_steps, 2),
+                                                   mr_fwd_frac_of_hbm=round(prof_two[1] / max(1e3 * m2_ms / prof_steps, 1e-9) / 1e3 / PEAK_HBM_GBPS, 4))
+                roof["note"] = ("frac counts the contraction's flop over the FUSED kernel's whole time (matrix phase + selection + "
+                                "neighbour gather); two_launch_form.knn_frac is the figure comparable with earlier rounds")
         kernels = {k: dict(us_per_step=round(1e3 * v[0] / prof_steps, 2), launches_per_step=v[1] // prof_steps)
                    for k, v in prof.items() if v[1]}
         # HBM-bound companions of the k-NN kernel (the gather + max-relative forward and its scatter backward): ALGORITHMIC
@@ -727,6 +762,18 @@ def main():
                 roof_hbm[name] = dict(kernel=kern, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                                       frac=round(gbs / PEAK_HBM_GBPS, 4), algorithmic_bytes_per_step=nbytes,
                                       us_per_step=kernels[name]["us_per_step"], launches_per_step=kernels[name]["launches_per_step"])
+        if roof is not None and "two_launch_form" in roof:
+            # the fused kernel against the HBM roofline with §8(d)'s "Fused fwd (k-NN+MR)" bytes per graph:
+            # x + (y) + relative_pos + index lists + the aggregated output
+            e4 = 4.0
+            by_g = e4 * B * C * N + 4.0 * N * M + 8.0 * BG * N * w["k"] + e4 * B * C * N + (e4 * B * C * M if M != N else 0.0)
+            by_l = e4 * B * C * L + e4 * B * C * N + 8.0 * BG * L * w["k"] + e4 * B * C * L
+            us = kernels["knn_tile"]["us_per_step"]
+            gbs = (by_g + by_l) / us / 1e3
+            roof_hbm["knn_mr_fused"] = dict(kernel="knn_tile_kernel<..., MRF>", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBPS,
+                                            unit="GB/s", frac=round(gbs / PEAK_HBM_GBPS, 4), algorithmic_bytes_per_step=by_g + by_l,
+                                            us_per_step=us, launches_per_step=kernels["knn_tile"]["launches_per_step"],
+                                            note="compute-bound kernel (SURVEY §8d: 3.7 us at 8 TB/s vs 13.7 us at the fp32 matrix peak for the Grapher graph)")
         if "gemm_x6" in kernels and kernels["gemm_x6"]["us_per_step"] > 0:
             # the projection GEMMs that run on the split-bf16 kernels: algorithmic fp32 flop (2 R cin cout, reported by the
             # library per launch) per second, against the fp32-MFMA peak they replace and against their own bound — six

@@ -1596,6 +1596,21 @@ static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float
   const int main_ntiles = !wide ? a.ntiles : (swap ? (cout + 127) / 128 : (cin + 127) / 128);
   const int tiles = main_mtiles * main_ntiles * nb, units = R / 128;
   int splits = 1, share = 0;
+  // the stand-alone rule (below): the slab count that minimises rounds x (units per slab + fixed cost) over an XCD's 32 CUs
+  int sp_alone = 1;
+  {
+    long long best = -1;
+    for (int sp = 1; sp <= units && sp <= 4096; ++sp) {
+      const long long per_xcd = (long long)tiles * ((sp + 7) / 8);
+      const long long rounds = (per_xcd + 31) / 32;
+      const long long cost = rounds * ((units + sp - 1) / sp + 6);
+      if (best < 0 || cost < best) { best = cost; sp_alone = sp; }
+    }
+  }
+  // a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 weight gradients: thousands of 128-row units) keeps
+  // its stand-alone slabs inside a batch too — ~20-unit slabs doubled its workgroup count (cfg4: 12.6 -> 13.3 ms of weight
+  // gradients per step)
+  if (batched && (long long)tiles * sp_alone >= 512) batched = 0;
   if (batched) {
     // ~`batched` (default 20) units of 128 rows per workgroup (its fixed cost — ring fill, LDS reduction, the tile's atomics — is worth about 6):
     // 1 / 2 / 4 slabs shared by 8 / 4 / 2 XCDs each, or a multiple of 8 slabs on one XCD each
@@ -1612,13 +1627,7 @@ static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float
     // over tiles x ceil(slabs / 8) workgroups: pick the slab count that minimises rounds x (units per slab + fixed cost), the
     // fixed cost (ring fill, LDS reduction, the tile's atomics) being worth about 6 units of streaming.  (Counting rounds over
     // the whole chip instead put 36 workgroups on two XCDs at 6 tiles x 42 slabs: 245 -> 393 us at 663 552 x 160 -> 80.)
-    long long best = -1;
-    for (int sp = 1; sp <= units && sp <= 4096; ++sp) {
-      const long long per_xcd = (long long)tiles * ((sp + 7) / 8);
-      const long long rounds = (per_xcd + 31) / 32;
-      const long long cost = rounds * ((units + sp - 1) / sp + 6);
-      if (best < 0 || cost < best) { best = cost; splits = sp; }
-    }
+    splits = sp_alone;
   }
   a.rows_per_split = units > 0 ? (units + splits - 1) / splits * 128 : 128;
   const int main_rows = aligned ? units * 128 : 0;

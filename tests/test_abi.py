@@ -60,3 +60,23 @@ def test_no_kernel_runs_out_of_scratch_memory():
     assert not bad, bad
     heavy = {n: k.get("vgpr_spill_count") for n, k in ks.items() if k.get("vgpr_spill_count", 0) > 8}
     assert not heavy, heavy
+
+
+def test_round5_host_side_queries_and_argument_checks():
+    """Pure host code of the round-5 entry points: which graph shapes take the fused k-NN + aggregation kernel (the launch plan
+    without a launch), the split-K workspace size, and the argument validation of the batched weight gradient."""
+    from gkgnet_amd import _build, _lib
+    lib = _lib.load()
+    f = _lib.KNN_NORMALIZE
+    assert lib.gkg_knn_mr_fused_supported(32, 4, 80, 324, 324, 9, 1, 0, 1, f) == 1          # cfg2 Grapher graph
+    assert lib.gkg_knn_mr_fused_supported(32, 4, 80, 80, 324, 9, 1, 1, 0, f) == 1           # cfg2 label graph
+    assert lib.gkg_knn_mr_fused_supported(2, 4, 80, 324, 324, 9, 1, 0, 1, f) == 0           # 48 workgroups: the keys are split
+    assert lib.gkg_knn_mr_fused_supported(32, 2, 40, 20736, 1296, 9, 1, 1, 1, f | _lib.KNN_RELPOS_UNIT) == 0   # prefilter shape
+    assert lib.gkg_knn_mr_fused_supported(32, 4, 80, 324, 324, 9, 1, 0, 1, f | _lib.KNN_BF16_CONTRACT) == 0    # bf16 contraction
+    assert lib.gkg_knn_mr_fused_supported(0, 4, 80, 324, 324, 9, 1, 0, 1, f) == 0
+    ws = lib.gkg_x6_splitk_workspace_bytes()
+    assert ws >= 4096 + 512 * 32768 and ws % 16 == 0
+    assert lib.gkg_linear_wgrad_x6_batch(None, 0, 0, None) != 0
+    assert lib.gkg_linear_wgrad_x6_batch(None, 3, 0, None) != 0 and b"no problems" in lib.gkg_last_error_string()
+    h = _build.csrc_sha16()
+    assert len(h) == 16 and int(h, 16) >= 0 and h == _build.csrc_sha16()
