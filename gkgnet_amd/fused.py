@@ -173,6 +173,7 @@ class _WgradQueue:
 
     def __init__(self):
         self.items, self.keep, self.task = [], [], -1
+        self.stream, self.device = None, None        # where the queued operands are produced: the batch is launched THERE
 
 
 _WQ = _WgradQueue()
@@ -186,10 +187,17 @@ def flush_wgrads():
         return
     items, q.items, q.task = q.items, [], -1
     try:
-        arr = (_lib.WgradProblem * len(items))(*items)
-        _lib.check(_lib.load().gkg_linear_wgrad_x6_batch(arr, len(items), WGRAD_UNITS, _stream()), "gkg_linear_wgrad_x6_batch")
+        _launch_wgrads(q, items)
     finally:
         q.keep = []                      # the launch is stream-ordered behind the operands' producers and ahead of their reuse
+
+
+def _launch_wgrads(q, items):
+    """One batched launch on the stream (and device) the operands were produced on — the engine callback that flushes the queue
+    runs in the thread that called backward(), whose current stream need not be the backward nodes'."""
+    arr = (_lib.WgradProblem * len(items))(*items)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().gkg_linear_wgrad_x6_batch(arr, len(items), WGRAD_UNITS, q.stream), "gkg_linear_wgrad_x6_batch")
 
 
 from . import parallel as _parallel      # noqa: E402
@@ -205,22 +213,27 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs) -> bool:
             and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
             and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
         return False
-    task = torch._C._current_graph_task_id()
+    task_id = getattr(torch._C, "_current_graph_task_id", None)
+    task = task_id() if task_id is not None else -1
     if task < 0:
-        return False                     # not inside a backward pass: nobody would flush
+        return False                     # not inside a backward pass (or a torch without the query): nobody would flush
     q = _WQ
+    st = _stream()
     if q.task != task:
         q.items, q.keep = [], []         # leftovers of a backward pass that raised before its callback
         q.task = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    elif q.items and (q.stream != st or q.device != dY.device):
+        items, q.items = q.items, []     # another stream / device: what is queued goes out where it was produced
+        _launch_wgrads(q, items)
+    q.stream, q.device = st, dY.device
     if not getattr(out, "_gkg_zero", False):
         out.zero_()
     q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb))
     q.keep.append((dY, x))
     if len(q.items) >= q.MAX:
         items, q.items = q.items, []
-        arr = (_lib.WgradProblem * len(items))(*items)
-        _lib.check(_lib.load().gkg_linear_wgrad_x6_batch(arr, len(items), WGRAD_UNITS, _stream()), "gkg_linear_wgrad_x6_batch")
+        _launch_wgrads(q, items)
         q.keep = []
     return True
 

@@ -126,3 +126,37 @@ def test_without_a_bucket_nothing_is_queued(monkeypatch):
     g(x).sum().backward()
     assert not fused._WQ.items and not fused._WQ.keep
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in g.parameters() if p.requires_grad and p.dim() > 1)
+
+
+def test_backward_on_a_side_stream_launches_the_batch_there(monkeypatch):
+    """Forward and backward under a non-default stream, the engine callback fires in the calling thread: the batch must go to
+    the stream its operands were produced on (gradients complete and correct after synchronising THAT stream only)."""
+    from gkgnet_amd import fused, parallel
+    from gkgnet_amd.grapher import Grapher
+    monkeypatch.setattr(fused, "WGRAD_BATCH", True)
+    torch.manual_seed(5)
+    g = Grapher(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=256, relative_pos=True, use_multi_group=True,
+                num_group=2).cuda().train()
+    x = torch.randn(8, 64, 16, 16, device="cuda").requires_grad_(True)
+    cot = torch.randn(8, 64, 16, 16, device="cuda")
+    params = list(g.parameters())
+    # reference gradients: per-layer launches on the default stream
+    monkeypatch.setattr(fused, "WGRAD_BATCH", False)
+    g(x).backward(cot)
+    torch.cuda.synchronize()
+    want = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+    g.zero_grad(set_to_none=True)
+    x.grad = None
+    monkeypatch.setattr(fused, "WGRAD_BATCH", True)
+    bucket = parallel.GradBucket(params)
+    bucket.release(prezero=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = g(x)
+        out.backward(cot)
+    s.synchronize()                                     # only the side stream
+    got = {n: p.grad for n, p in g.named_parameters() if p.grad is not None}
+    for n, v in want.items():
+        assert float((got[n] - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-5, n
+    torch.cuda.synchronize()
