@@ -706,6 +706,7 @@ def main():
         # NOT measured by this run — it is the value of the newest committed rocprofv3 --pmc collection for this workload
         # (tools/pmc_refresh.sh -> profiles/rNN_pmc.json), labelled with its file and the commit it was taken at.
         traffic, traffic_source = None, None
+        issue_slots = None
         if args.workload == "cfg2" and B == 32:
             import glob
             for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
@@ -715,6 +716,10 @@ def main():
                     traffic = pj["knn_tile_per_step_traffic_bytes"] / pj.get("knn_tile_launches_per_step", 2)   # per launch
                     from gkgnet_amd._build import csrc_sha16
                     same = pj.get("csrc_sha16") == csrc_sha16()
+                    if "knn_tile_issue_slot_frac" in pj:
+                        issue_slots = dict(issue_slot_frac=pj["knn_tile_issue_slot_frac"], mfma_slot_frac=pj.get("knn_tile_mfma_slot_frac"),
+                                           formula="(4 * SQ_INSTS_VALU + SQ_VALU_MFMA_BUSY_CYCLES) / (32 * SQ_BUSY_CYCLES): vector + matrix "
+                                                   "issue cycles per SIMD over the launch's busy cycles (same counter collection as `traffic`)")
                     traffic_source = (f"{os.path.relpath(pmc_path, ROOT)} @ {pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                       f"passes, not this run); collected on " +
                                       ("the kernel sources this run uses (csrc hash matches)" if same else
@@ -732,6 +737,8 @@ def main():
                         unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                         avg_launch_us=round(1e3 * tile_ms / tile_n, 2), launches_per_step=tile_n // prof_steps,
                         algorithmic_flops_per_step=flops_knn)
+            if issue_slots:
+                roof["issue_slots"] = issue_slots
             if fused_now:
                 # SURVEY §8(d) "Fused fwd (k-NN+MR)": the same contraction flop, more bytes — the kernel's time now includes the
                 # gather, so `frac` is NOT comparable with the k-NN-only kernel of rounds 1-4 (0.21-0.23); that kernel, timed

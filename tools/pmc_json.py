@@ -54,10 +54,22 @@ def main():
         for k, v in acc.items():
             if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 v["hbm_bytes_per_launch"] = round(v["FETCH_SIZE"] * 1024 / f + v["WRITE_SIZE"] * 1024)
+    # Issue-slot fraction: vector + matrix issue cycles per SIMD over the kernel's busy time.
+    #   SQ_INSTS_VALU counts wave-instructions (4 cycles each on a SIMD16... wave64), SQ_VALU_MFMA_BUSY_CYCLES counts cycles (64 per
+    #   v_mfma_f32_32x32x2_f32); both are summed over the chip's 1 024 SIMDs.  SQ_BUSY_CYCLES is summed over the 32 shader engines.
+    for k, v in acc.items():
+        if all(c in v for c in ("SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")) and v["SQ_BUSY_CYCLES"] > 0:
+            v["issue_slot_frac"] = round((4.0 * v["SQ_INSTS_VALU"] + v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (32.0 * v["SQ_BUSY_CYCLES"]) , 4)
+            v["mfma_slot_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * v["SQ_BUSY_CYCLES"]), 4)
     tiles = {k: v for k, v in acc.items() if k.startswith("knn_tile_kernel") and "hbm_bytes_per_launch" in v}
     if tiles:
         res["knn_tile_per_step_traffic_bytes"] = sum(v["hbm_bytes_per_launch"] for v in tiles.values())
         res["knn_tile_launches_per_step"] = len(tiles)
+        fr = [(v.get("issue_slot_frac"), v.get("mfma_slot_frac"), v.get("SQ_BUSY_CYCLES", 0)) for v in tiles.values() if v.get("issue_slot_frac")]
+        if fr:
+            wsum = sum(b for _, _, b in fr)
+            res["knn_tile_issue_slot_frac"] = round(sum(f * b for f, _, b in fr) / wsum, 4)
+            res["knn_tile_mfma_slot_frac"] = round(sum(m * b for _, m, b in fr) / wsum, 4)
     print(json.dumps(res, indent=1))
 
 
