@@ -4,8 +4,8 @@
     within rounding — through BOTH C-ABI layouts (channel-major gkg_knn_fwd / gkg_mr_*, token-major *_tm used by the
     fused block).  Shapes: SURVEY.md §8 per-layer table (reference gkgnet.py:180-183,234: reduce_ratios [4,2,1,1],
     dilation min(idx//4+1, 49//k)) and its pvig_m counterpart (blocks [2,2,16,2], channels [96,192,384,768]).
-(b) Full batch of the config (B = 32 / 16): size-independent properties checked against a dense fp64 evaluation on
-    the GPU in problem chunks — in-range distinct neighbours, ascending distances, top-(k*d) optimality, dilation
+(b) Full batch of the config (B = 32 / 16): three of the launch's problems bit-exact against the C oracle, and
+    size-independent properties of ALL of them checked against a dense fp64 evaluation on the GPU in problem chunks — in-range distinct neighbours, ascending distances, top-(k*d) optimality, dilation
     picks ranks 0,d,2d.., aggregation equal to the dense gather/max bit for bit, gradient mass conservation.
 """
 import numpy as np
@@ -145,6 +145,13 @@ def test_full_batch_properties(name, B):
     srt = nn_idx.sort(dim=-1).values
     assert bool((srt[..., 1:] != srt[..., :-1]).all()), "duplicate neighbours"
     assert torch.equal(edge[1], torch.arange(N, device="cuda").view(1, N, 1).expand(BG, N, k))
+    # bit-exact against the C oracle on a SAMPLE of the launch's problems (first, a middle one, last): the full-batch launch is
+    # where the interleaved XCD map, the single-batch prefilter form and the single-wave forms engage
+    from oracle import c_oracle as O
+    rp_np = None if rp is None else rp[0].cpu().numpy()
+    for bg in sorted({0, BG // 2 + 1, BG - 1}):
+        want_idx, _ = O.knn(x[bg:bg + 1].cpu().numpy(), None if y is None else y[bg:bg + 1].cpu().numpy(), rp_np, k, d)
+        assert np.array_equal(nn_idx[bg:bg + 1].cpu().numpy(), want_idx), (name, bg)
     kd = k * d
     chunk = max(1, int(2e9 // (8 * N * Mk)))
     src = x if y is None else y

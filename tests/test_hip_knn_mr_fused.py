@@ -172,3 +172,50 @@ def test_blocks_take_the_fused_kernel_and_nothing_changes(monkeypatch):
     assert torch.equal(a[2], b[2])                   # GrapherLabel's returned edge_index: identical
     for u, v in zip(a, b):
         assert torch.equal(u, v)                     # same arithmetic in the same order: identical bits
+
+
+def test_fuzz_fused_kernel_random_shapes():
+    """Random eligible shapes (ragged tiles, odd channel quads, every list size up to 36, self and bipartite graphs, with and
+    without a bias, exact duplicates): the fused kernel against the C oracle and the two-launch form, ~10 s."""
+    import time
+    from gkgnet_amd import _lib
+    from oracle import c_oracle as O
+    lib = _lib.load()
+    rng = np.random.RandomState(123)
+    t0, done = time.time(), 0
+    while time.time() - t0 < 10.0:
+        G = int(rng.choice([1, 2, 4]))
+        c = int(rng.choice([4, 8, 12, 16, 20, 40, 80])) * (4 // G if G < 4 else 1)
+        if (G * c) % 16:
+            continue
+        N = int(rng.randint(20, 400))
+        self_graph = rng.rand() < 0.5
+        M = N if self_graph else int(rng.randint(40, 600))
+        d = int(rng.randint(1, 4))
+        k = int(rng.choice([3, 5, 9, 12, 18]))
+        if k * d > min(M, 36):
+            continue
+        use_rp = rng.rand() < 0.5
+        qt = (N + 63) // 64
+        B = max(1, (300 + qt * G - 1) // (qt * G))                # enough workgroups that the plan does not split the keys
+        flags = _lib.KNN_NORMALIZE
+        if not lib.gkg_knn_mr_fused_supported(B, G, c, N, M, k, d, 0 if self_graph else 1, 1 if use_rp else 0, flags):
+            continue
+        x = rng.standard_normal((B * G, c, N)).astype(np.float32)
+        y = None if self_graph else rng.standard_normal((B * G, c, M)).astype(np.float32)
+        if rng.rand() < 0.3:                                       # exact duplicates: ties decide membership and the maximum
+            t = x if y is None else y
+            T = t.shape[2] // 3
+            if T:
+                t[:, :, T:2 * T] = t[:, :, :T]
+        rp = (np.round(-rng.random_sample((N, M)) * 8) / 8).astype(np.float32) if use_rp else None
+        want_idx, _ = O.knn(x, y, rp, k, d)
+        want_m, _ = O.mr_fwd(x, y, want_idx)
+        x_tm, y_tm = _tm(x, B, G), None if y is None else _tm(y, B, G)
+        U, arg, nn16, U2, arg2, idx2 = _fused(x_tm, y_tm, rp, B, G, c, N, M, k, d)
+        tag = (B, G, c, N, M, k, d, use_rp)
+        assert np.array_equal(nn16.astype(np.int64), want_idx), tag
+        assert np.array_equal(U, _expect_U(x_tm, _tm(want_m, B, G))), tag
+        assert np.array_equal(U, U2) and np.array_equal(arg, arg2), tag
+        done += 1
+    assert done >= 5, done
