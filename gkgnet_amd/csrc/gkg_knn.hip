@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
 // ================================================================================================ host side
 using namespace gkg;
 
-#ifdef KNN_TIMELINE
-static void* gkg_knn_tl_buf = nullptr;      // measurement builds only (tools/ubench/knn_timeline.py)
+#if defined(KNN_TIMELINE) || defined(KNN_ABLATE)
+static void* gkg_knn_tl_buf = nullptr;      // measurement builds only (tools/ubench/knn_timeline.py, knn_ablate.py)
 extern "C" void gkg_debug_set_knn_timeline(void* buf) { gkg_knn_tl_buf = buf; }
 #endif
 
@@ -504,7 +504,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
   a.mr_x = a.mr_src = nullptr; a.mr_out = nullptr; a.mr_arg = nullptr; a.nn16 = nullptr; a.mr_G = 1; a.mr_c = c;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
-#ifdef KNN_TIMELINE
+#if defined(KNN_TIMELINE) || defined(KNN_ABLATE)
   if (p.S == 1 && gkg_knn_tl_buf) a.part_v = (float*)gkg_knn_tl_buf;
 #endif
   a.rp_major = 0; a.rp_group = 1;

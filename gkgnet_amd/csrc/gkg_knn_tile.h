@@ -205,7 +205,17 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   top.init();
   // buffered selection state: the buffer lives behind the staged queries, [BUF][256] x {distance, index}
   float2* cbuf = reinterpret_cast<float2*>(smem + qfloats) + tid;
-  int bcnt = 0;
+  // the lane's append cursor IS its entry count (cursor - cbuf = count * TH): an admitted candidate costs the store, one add on
+  // the cursor and the move of its index; the count is only formed inside a flush
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2u_t lds_v2u_t;   // a 32-bit LDS pointer: the cursor is ONE register, ds_write takes it as is
+  // (kept as opaque integers: when the compiler can relate the cursor to the buffer's base it carries an OFFSET instead and
+  // re-adds the base at every store)
+  unsigned cw0 = (unsigned)(size_t)(lds_v2u_t*)cbuf;
+  asm volatile("" : "+v"(cw0));
+  unsigned cw_lim = cw0 + (BUF > 8 ? BUF - 8 : 0) * TH * 8;
+  asm volatile("" : "+v"(cw_lim));
+  unsigned cw = cw0;
   float thr = INFINITY;
   // Shared admission bound (SHARE: the buffered form; in the guarded direct form the two extra selects per candidate cost
   // more than the saved inserts — C = 640 / k*d = 27 at 18 x 18: 119 -> 157 us — so it keeps its own bound).  The 4 waves of the workgroup keep separate lists
@@ -239,6 +249,22 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // same k*d smallest (distance, index) keys.
   constexpr bool NET = BUF >= 12 && KD >= 16;
   auto flush = [&]() {
+    unsigned cw_now = cw;
+    asm volatile("" : "+v"(cw_now));
+    int bcnt = (int)((cw_now - cw0) / (TH * 8));
+#if defined(KNN_ABLATE) && KNN_ABLATE == 3
+    unsigned long long* gkg_knn_ablate_counters = reinterpret_cast<unsigned long long*>(a.part_v);
+    if (lane == 0) {                               // tools/ubench/knn_ablate.py: flushes, batches through the network
+      atomicAdd(&gkg_knn_ablate_counters[0], 1ull);
+      if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) atomicAdd(&gkg_knn_ablate_counters[1], 1ull);
+    }
+    atomicAdd(&gkg_knn_ablate_counters[2], (unsigned long long)bcnt);
+    {
+      int mx = bcnt;
+      for (int m_ = 1; m_ < 64; m_ <<= 1) mx = max(mx, __shfl_xor(mx, m_, 64));
+      if (lane == 0) atomicAdd(&gkg_knn_ablate_counters[3], (unsigned long long)mx);
+    }
+#endif
     if constexpr (NET) {
       if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) {
         double b[16];
@@ -262,13 +288,19 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
       const double k = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
       top.template insert_key<false>(k);
     }
-    bcnt = 0;
+    cw = cw0;
     thr = key_dist(top.key[KD - 1]);               // +inf while the list is not full
     if (SHARE) {
       refresh_shared();
       thr = fminf(thr, next_up(sh));               // strict '<' against own KD-th entry, '<=' against the shared bound
     }
+#if defined(KNN_ABLATE) && KNN_ABLATE == 1
+    thr = -INFINITY;                               // tools/ubench/knn_ablate.py: every candidate tested, none admitted after the first flush
+#endif
   };
+#if defined(KNN_ABLATE) && KNN_ABLATE == 2
+  float abl_sink = INFINITY;
+#endif
 
   const int ktiles = (M + KT - 1) / KT;
   const int t_end = min(t_begin + a.tiles_per_split, ktiles);
@@ -330,7 +362,8 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
     }
     // ---- contraction: acc0 = keys x (-2 queries[0..31]), acc1 = keys x (-2 queries[32..63]).
     //      Key operand double-buffered in registers (KU k-pairs per batch).
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc0, acc1;
+    if (BF) acc0 = acc1 = f32x16{0};
     if (BF && HAS_RP) {
       // bf16 form: the accumulators START from relative_pos (fetched one tile ahead, see fetch_side): the bias rides through
       // the contraction instead of costing an add per candidate
@@ -376,22 +409,59 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
       const float* ykn = yp + (size_t)kk * M + mk_next;
       const float* xsp = smem + kk * QT + l31;
       float ac[KU];
-      if (two_blocks) {
-        for (int s = 0; s < CP; s += KU) {
-          const bool last = s + KU >= CP;                       // uniform: prefetch the NEXT tile's first batch
-          const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
+      // One batch = KU k-pairs.  The first MFMA of a tile takes a zero literal as its accumulator (no 32 v_mov per tile), and the
+      // query operands are read from LDS two k-pairs ahead of the MFMAs that use them (sched_group_barrier: the compiler
+      // otherwise reuses ONE register pair — ds_read2, s_waitcnt lgkmcnt(0), two MFMAs, ds_read2 ... — and every k-pair
+      // waits out an LDS round trip).
+      const f32x16 zero16 = {0};
+      // (the peeled first batch and the second operand pair in flight cost ~4 registers: not in the instantiations that sit at
+      // their register cap — those keep the zero-filled accumulators and the compiler's own order)
+      constexpr bool PIPE = !(HAS_RP && KU == 8 && ((KD <= 12 && !MRF) || KD == 27));
+      auto batch2 = [&](int s, auto first_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const bool last = s + KU >= CP;                       // uniform: prefetch the NEXT tile's first batch
+        const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
 #pragma unroll
-          for (int u = 0; u < KU; ++u) ac[u] = an[u];
+        for (int u = 0; u < KU; ++u) ac[u] = an[u];
 #pragma unroll
-          for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
-          __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
+        for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
+        __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads ahead of this batch's MFMAs
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const float b0 = xsp[(2 * (s + u)) * QT];
+          const float b1 = xsp[(2 * (s + u)) * QT + 32];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b0, (FIRST && u == 0) ? zero16 : acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, (FIRST && u == 0) ? zero16 : acc1, 0, 0, 0);
+        }
+        if constexpr (PIPE) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS reads of k-pairs 0, 1
 #pragma unroll
           for (int u = 0; u < KU; ++u) {
-            const float b0 = xsp[(2 * (s + u)) * QT];
-            const float b1 = xsp[(2 * (s + u)) * QT + 32];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b1, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the k-pair's two MFMAs
+            if (u + 2 < KU) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
+        }
+      };
+      auto batch1 = [&](int s, auto first_c) __attribute__((always_inline)) {   // <= 32 queries: one query block
+        constexpr bool FIRST = decltype(first_c)::value;
+        const bool last = s + KU >= CP;
+        const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) ac[u] = an[u];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], xsp[(2 * (s + u)) * QT], (FIRST && u == 0) ? zero16 : acc0, 0, 0, 0);
+      };
+      if (two_blocks) {
+        if constexpr (PIPE) {
+          batch2(0, std::true_type{});
+          for (int s = KU; s < CP; s += KU) batch2(s, std::false_type{});
+        } else {
+          acc0 = acc1 = zero16;
+          for (int s = 0; s < CP; s += KU) batch2(s, std::false_type{});
         }
         if (FOLD) {
           const float atail = kk ? sy32 : 1.0f;                // k-pair (1, |y|^2) x (|x|^2, 1)
@@ -399,19 +469,17 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(atail, qtail1, acc1, 0, 0, 0);
         }
       } else {                                    // tail query tile with <= 32 queries: one query block only
-        for (int s = 0; s < CP; s += KU) {
-          const bool last = s + KU >= CP;
-          const float* pb = last ? ykn : ykp + (size_t)(2 * (s + KU)) * M;
-#pragma unroll
-          for (int u = 0; u < KU; ++u) ac[u] = an[u];
-#pragma unroll
-          for (int u = 0; u < KU; ++u) an[u] = pb[(size_t)(2 * u) * M];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < KU; ++u)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], xsp[(2 * (s + u)) * QT], acc0, 0, 0, 0);
+        if constexpr (PIPE) {
+          batch1(0, std::true_type{});
+          for (int s = KU; s < CP; s += KU) batch1(s, std::false_type{});
+        } else {
+          acc0 = zero16;
+          for (int s = 0; s < CP; s += KU) batch1(s, std::false_type{});
         }
         if (FOLD) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kk ? sy32 : 1.0f, qtail0, acc0, 0, 0, 0);
+        // lanes 32-63 hold no query here: acc1's registers are left as they are (an empty asm "defines" them — a zero fill or a
+        // copy of acc0 is sunk into the join block and then runs on every tile of the common path too)
+        asm volatile("" : "=v"(acc1));
       }
     }
     KNN_TL(3 + 2 * (iv / NWV));
@@ -451,17 +519,26 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
             if (HAS_RP) dist = dist + rp[row];
           }
           if (BUF > 0) {
+#if defined(KNN_ABLATE) && KNN_ABLATE == 2
+            abl_sink = fminf(abl_sink, dist);       // tools/ubench/knn_ablate.py: the contraction + distance adds alone
+#else
             if (HAS_RP ? dist <= thr : dist < thr) { // NaN fails; '<=' where the tiles are not visited in index order
-              cbuf[bcnt * TH] = make_float2(dist, __int_as_float(m0 + row));
-              ++bcnt;
+              *(lds_v2u_t*)(size_t)cw = v2u_t{__float_as_uint(dist), (unsigned)(m0 + row)};
+              // in place, behind the store (left to the compiler the add lands in a temporary in front of it, plus a copy back)
+              asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(cw) : "i"(TH * 8) : "memory");
             }
+#endif
           } else {
             top.template insert<GUARD>(dist, m0 + row);
           }
         }
       }
       // room for the next 8 candidates?  (the stream's last group flushes unconditionally)
-      if (BUF > 0 && ((g == 3 && iv + NWV >= TV) || __builtin_amdgcn_ballot_w64(bcnt > BUF - 8) != 0ull)) flush();
+#if defined(KNN_ABLATE) && KNN_ABLATE == 2
+      if (BUF > 0 && g == 3 && iv + NWV >= TV) { top.template insert<false>(abl_sink, 0); }
+#else
+      if (BUF > 0 && ((g == 3 && iv + NWV >= TV) || __builtin_amdgcn_ballot_w64(cw > cw_lim) != 0ull)) flush();
+#endif
     }
     KNN_TL(4 + 2 * (iv / NWV));
   }
