@@ -37,6 +37,7 @@ class _BnBwdScratch:
         self.captured = False
         self.poisoned = False
         self.last_stream = None
+        self.last_raw = None
         self.pending = None             # a _BnLink whose consumer has accumulated into a buffer while the clear of the other one
                                         # waits for the producer's apply pass (fused._dgrad_x6_with_link)
 
@@ -59,10 +60,13 @@ class _BnBwdScratch:
                 self.capture_id = cap
                 self._reset()
         else:
-            here = torch.cuda.current_stream(self.store.device)
-            if self.last_stream is not None and self.last_stream != here:
-                here.wait_stream(self.last_stream)
-            self.last_stream = here
+            raw = _stream()
+            if self.last_raw != raw:                    # (Stream objects only when the caller's stream actually changed)
+                here = torch.cuda.current_stream(self.store.device)
+                if self.last_stream is not None and self.last_stream != here:
+                    here.wait_stream(self.last_stream)
+                self.last_stream = here
+                self.last_raw = raw
             if self.captured or self.poisoned:
                 self._reset()
         if self.pending is not None:

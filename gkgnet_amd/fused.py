@@ -613,8 +613,7 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
         else:
             rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
         _lib.check(rc, "gkg_linear_bn_fwd (statistics only)")
-        a = torch.empty(nb * cout, dtype=_F32, device=dev)
-        c, mean, invstd = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        a, c, mean, invstd = torch.empty((4, nb * cout), dtype=_F32, device=dev).unbind(0)     # one allocation
         track = bn.training and bn.track_running_stats
         _touch_stats(bn, track)
         if out_tm is not None:           # channel-major AND token-major result, residual token-major (gkg_bn_apply_train_dual)

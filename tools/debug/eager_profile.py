@@ -33,12 +33,24 @@ for _ in range(50):
     step()
 torch.cuda.synchronize()
 print("eager ms/step", (time.perf_counter() - t0) / 50 * 1e3)
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(50):
-    step()
-torch.cuda.synchronize()
-pr.disable()
+if len(sys.argv) > 1 and sys.argv[1] == "time":
+    sys.exit(0)
+# backward on the calling thread, so that the profile sees the custom Functions' backward methods too
+with torch.autograd.set_multithreading_enabled(False):
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(100):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(35)
-print(s.getvalue()[:6000])
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("tottime").print_stats(45)
+print(s.getvalue()[:9000])
+s = io.StringIO()
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("cumtime").print_stats("gkgnet_amd", 40)
+print(s.getvalue()[:9000])
