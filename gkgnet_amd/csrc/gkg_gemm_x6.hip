@@ -48,6 +48,10 @@ __device__ __forceinline__ unsigned x6_cvt2(float a, float b) {
 
 // two floats -> packed (hi, mid, lo) bf16 pairs; the residuals are exact fp32 differences
 __device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef X6_ABLATE_NOSPLIT
+  h = x6_cvt2(x0, x1); m = x6_cvt2(x1, x0); l = h ^ 0x00010001u;
+  return;
+#endif
   h = x6_cvt2(x0, x1);
   const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
   m = x6_cvt2(r0, r1);
@@ -292,6 +296,9 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(X6Args g) {
   auto op = [&](int i) {
     const int p = i & 3, o = i >> 2;
     float& x0 = f[2 * p]; float& x1 = f[2 * p + 1];
+#ifdef X6_ABLATE_NOSPLIT          // tools/ubench/x6_nosplit.py: what the kernels cost without the operand split (3 of 11 steps kept)
+    if (o != 0 && o != 5 && o != 10) return;
+#endif
     if (o == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(sh_[p]) : "v"(x0), "v"(x1));
     if (o == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0_[p]) : "v"(sh_[p]));
     if (o == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1_[p]) : "v"(sh_[p]));
@@ -855,6 +862,9 @@ __device__ __forceinline__ void x6w_op(float (&raw)[4][8], X6WFrag& fn, unsigned
   constexpr int blk = I / 44, u = I % 44, p = u & 3, o = u >> 2;
   float& x0 = raw[blk][2 * p]; float& x1 = raw[blk][2 * p + 1];
   unsigned w;
+#ifdef X6_ABLATE_NOSPLIT
+  if constexpr (o != 0 && o != 5 && o != 10) return;
+#endif
   if constexpr (o == 0) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(x0), "v"(x1)); fn[blk][0][p] = w; }
   if constexpr (o == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0[p]) : "v"(fn[blk][0][p]));
   if constexpr (o == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1[p]) : "v"(fn[blk][0][p]));
