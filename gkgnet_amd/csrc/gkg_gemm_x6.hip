@@ -1334,8 +1334,19 @@ __global__ __launch_bounds__(256) void wgrad_x6_batch_kernel(X6WgradBatch b) {
   const int local = bid - b.begin[i], gx = b.gridx[i];
   const int z = local / gx, lin = local - z * gx;
   const X6WgradArgs g = b.p[i];
+#ifdef X6_TIMELINE      // tools/ubench/wgrad_batch_timeline.py: every workgroup's start / end / placement / problem
+  if (x6_tl_buf && threadIdx.x == 0 && bid < 4096) {
+    long long* t = x6_tl_buf + 4096 * 8 + bid * 4;
+    t[0] = (long long)__builtin_readcyclecounter();
+    t[2] = ((long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) << 8) | (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf);
+    t[3] = i * 2 + (b.wide[i] ? 1 : 0);
+  }
+#endif
   if (b.wide[i]) wgrad_x6_wide_body(g, lin, z);
   else wgrad_x6_dma_body(g, lin, z);
+#ifdef X6_TIMELINE
+  if (x6_tl_buf && threadIdx.x == 0 && bid < 4096) x6_tl_buf[4096 * 8 + bid * 4 + 1] = (long long)__builtin_readcyclecounter();
+#endif
 }
 
 inline bool x6_bad_dim(int v) { return v <= 0 || (v & 3) != 0; }
