@@ -39,7 +39,12 @@ ODD = [(777, 36, 40, 1), (1280, 64, 64, 1), (128, 32, 64, 1), (3000, 1, 3, 1), (
        (5120, 80, 80, 1), (19, 16, 8, 1), (2048 + 128 * 9, 200, 72, 1), (129, 64, 8, 2)]
 
 
-@pytest.mark.parametrize("shapes", [CFG2, ODD, CFG2 + ODD + CFG2[:3]], ids=["cfg2", "odd", "two_launches"])
+# GKGNet-576's stage widths (80 / 160 / 400, grouped 40): widths that pad to the 64 x 128 and 64 x 64 tile forms in one launch
+STAGES = [(6400, 80, 80, 1), (6400, 160, 80, 1), (6400, 80, 320, 1), (6400, 320, 80, 1), (5120, 40, 40, 4), (3200, 160, 160, 1),
+          (3200, 160, 640, 1), (1296, 400, 400, 1), (1296, 1600, 400, 1), (2560, 320, 320, 1)]
+
+
+@pytest.mark.parametrize("shapes", [CFG2, ODD, CFG2 + ODD + CFG2[:3], STAGES], ids=["cfg2", "odd", "two_launches", "stage_widths"])
 def test_batch_matches_fp64(shapes):
     from gkgnet_amd import _lib
     lib = _lib.load()

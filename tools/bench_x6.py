@@ -11,16 +11,16 @@ lib = _lib.load()
 SHAPES = [(10368, 320, 320, 1), (10368, 160, 160, 4), (10368, 640, 320, 1), (10368, 320, 640, 1), (2560, 320, 320, 1),
           (2560, 160, 160, 4), (2560, 640, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1), (41472, 400, 400, 1),
           (41472, 800, 400, 1)]
-if len(sys.argv) > 1 and sys.argv[1] == "cfg4":        # GKGNet-576 (pvig_s) stage shapes at B = 32
+if len(sys.argv) > 1 and sys.argv[1] in ("cfg4", "wgradcfg4"):        # GKGNet-576 (pvig_s) stage shapes at B = 32
     SHAPES = [(663552, 80, 80, 1), (663552, 160, 80, 1), (663552, 80, 320, 1), (663552, 320, 80, 1), (165888, 160, 160, 1),
               (165888, 320, 160, 1), (165888, 160, 640, 1), (165888, 640, 160, 1), (41472, 400, 400, 1), (41472, 800, 400, 1),
               (41472, 400, 1600, 1), (41472, 1600, 400, 1), (10368, 640, 640, 1), (10368, 1280, 640, 1)]
 if len(sys.argv) > 1 and sys.argv[1] == "coltiles":    # one vs two column tiles at the stage-1 row count
     SHAPES = [(663552, 80, 64, 1), (663552, 80, 80, 1), (663552, 80, 128, 1), (663552, 160, 64, 1), (663552, 160, 80, 1),
               (663552, 160, 128, 1), (663552, 320, 64, 1), (663552, 320, 80, 1), (663552, 64, 320, 1), (663552, 80, 320, 1)]
-WGRAD_ONLY = len(sys.argv) > 1 and sys.argv[1] == "wgrad"
+WGRAD_ONLY = len(sys.argv) > 1 and sys.argv[1] in ("wgrad", "wgradcfg4")      # wgradcfg4: the weight gradients at GKGNet-576's stage shapes
 X6_ONLY = bool(os.environ.get("X6_ONLY"))               # forward / dgrad of the own kernels only (A/B of two library builds)
-if WGRAD_ONLY:                                         # every weight gradient of the cfg2 step (Grapher rows 10 368, label rows 2 560)
+if WGRAD_ONLY and sys.argv[1] == "wgrad":               # every weight gradient of the cfg2 step (Grapher rows 10 368, label rows 2 560)
     SHAPES = [(10368, 320, 320, 1), (10368, 160, 160, 4), (10368, 640, 320, 1), (10368, 320, 1280, 1), (10368, 1280, 320, 1),
               (2560, 320, 320, 1), (2560, 160, 160, 4), (2560, 640, 320, 1), (2560, 320, 1280, 1), (2560, 1280, 320, 1)]
 flush = torch.empty(128 << 20, dtype=torch.float32, device="cuda")

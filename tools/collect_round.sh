@@ -4,6 +4,10 @@
 TAG=${1:-rXX}
 R=$PWD
 mkdir -p $R/gpurun_out
+# 0. hardware counters first (separate passes): the default bench line quotes profiles/<tag>_pmc.json and checks that it was
+#    taken on the kernel sources it runs (csrc hash) — so the box's copy of profiles/ gets this collection's file before step 1
+bash tools/pmc_refresh.sh ${TAG} > /dev/null 2>&1
+[ -s gpurun_out/${TAG}_pmc.json ] && cp gpurun_out/${TAG}_pmc.json profiles/${TAG}_pmc.json
 # 1. the default bench line (with CPU baseline), and every other workload through the same entry point
 python bench.py > gpurun_out/${TAG}_final_bench_cfg2.json 2> gpurun_out/${TAG}_final_bench_cfg2.err
 for w in cfg2ref stage3 stage1; do
@@ -27,8 +31,7 @@ for cfg in cfg3 cfg5 cfg4; do
   python $R/tools/prof_detail.py /tmp/p_$cfg $win 60 > $R/gpurun_out/${TAG}_final_${cfg}_per_kernel.txt
 done
 cd $R
-# 4. hardware counters (separate passes)
-bash tools/pmc_refresh.sh ${TAG} > /dev/null 2>&1
+# 4. SQ counters of the k-NN kernels (separate passes)
 bash tools/pmc_knn_run.sh > gpurun_out/${TAG}_knn_tile_sq_counters.txt 2>&1
 # 5. per-shape tables
 python tools/bench_x6.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_x6_gemm_shapes.txt
