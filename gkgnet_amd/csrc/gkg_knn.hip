@@ -477,6 +477,17 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // fp32 contract forms: single-wave workgroups for the narrowest groups (see the launch below)
   const int nqt_ = (N + QT - 1) / QT;
   const bool solo32 = buffered && !pf && p.S == 1 && (size_t)nqt_ * BG >= 2048 && lds_q <= 4 * 1024;
+  // Round 5: the buffered fp32 forms also exist with 6 k-pairs per operand batch — channels padded to a multiple of 12 where
+  // that is no more than the multiple of 8 (c = 9..12, 17..24, 33..36, 57..60: pvig_m's groups of 12 and 24).  The workspace was sized
+  // for the wider padding; cpad is only the row count / stride of the prepared copies.
+  {
+    const int c12 = (c + 11) / 12 * 12;
+    if (buffered && !pf && !bf && !mr && !probe_only && p.KD <= 36 && (c12 % 16) != 0 && (c12 < p.cpad || (c12 == p.cpad && (p.cpad % 16) != 0))) {
+      p.cpad = c12;
+      lds_q = (size_t)p.cpad * QT * sizeof(float);
+      lds = lds_q > lds_m ? lds_q : lds_m;
+    }
+  }
   if (mr || probe_only) {
     const bool ok = !bf && dtype == GKG_F32 && G_tm > 0 && knn_mr_plan_ok(p, c, N, M, k, pf, solo32);
     if (probe_only) return ok ? 0 : GKG_ERR_UNSUPPORTED;

@@ -20,13 +20,17 @@ template <int KD, bool HAS_RP>
 static hipError_t launch_tile_f32(const KnnArgs& a, dim3 grid, size_t lds, int mode, hipStream_t st) {
   GkgProfScope prof(GKG_PROF_KNN_TILE, st);
   const bool deep = (a.cpad % 16) == 0;      // 8 k-pairs per register batch when the channel count allows
+  // 6 per batch for padded widths of 12, 24, 36, 60 ... (the plan pads to a multiple of 12 only for the buffered forms below)
+  const bool six = !deep && (a.cpad % 12) == 0;
   // the catch-all 64-entry list has no buffered form: its list (128 registers) + the 16-entry batch + the merge network's
   // temporaries spilled 100-400 VGPRs to scratch in every such instantiation; the guarded direct insert fits
   if constexpr (KD <= 36) {
     // mode 5: buffered selection with ONE wave per workgroup (the wave streams all keys of its 64 queries: one list per query
     // instead of four quarter-stream lists, no merge) — launches with enough query tiles to fill the chip that way
     if constexpr (!kMRF) {
+      if (mode == 5 && six) return launch_tile_v<KD, HAS_RP, 6, false, KNN_BUF, false, 1>(a, grid, lds, st);
       if (mode == 5) return deep ? launch_tile_v<KD, HAS_RP, 8, false, KNN_BUF, false, 1>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF, false, 1>(a, grid, lds, st);
+      if (mode == 2 && six) return launch_tile_v<KD, HAS_RP, 6, false, KNN_BUF, false, NW, false>(a, grid, lds, st);
     }
     if (mode == 2) return deep ? launch_tile_v<KD, HAS_RP, 8, false, KNN_BUF, false, NW, kMRF>(a, grid, lds, st) : launch_tile_v<KD, HAS_RP, 4, false, KNN_BUF, false, NW, kMRF>(a, grid, lds, st);
   }

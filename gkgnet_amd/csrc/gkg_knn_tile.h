@@ -123,9 +123,10 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
   // The last k-pair of every contraction adds |x|^2 and |y|^2 on the matrix pipe: keys feed (1, |y|^2), queries
   // (|x|^2, 1), so acc = fma(|y|^2, 1, fma(1, |x|^2, acc)) — bit for bit ((|x|^2 + (-2 x.y)) + |y|^2), the contract's
   // order — and each candidate saves two vector adds and a v_readlane (the vector pipe is the contended one).
-  // Used by the deep-batch instantiations (KU == 8: channel counts that are multiples of 16); measured a few per cent
-  // slower on the KU == 4 ones (c = 200 at 36x36), which keep the three vector adds.
-  constexpr bool FOLD = KU == 8 && !BF;
+  // Used by the deep-batch instantiations (KU == 8: channel counts that are multiples of 16; KU == 6, round 5: multiples of 12 —
+  // pvig_m's 12 / 24 channels per group run 6 + 1 / 12 + 1 k-pairs instead of 8 + 1 / 12 with three vector adds per candidate);
+  // measured a few per cent slower on the KU == 4 ones (c = 200 at 36x36), which keep the three vector adds.
+  constexpr bool FOLD = (KU == 8 || KU == 6) && !BF;
   const float qtail0 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + l31, N - 1)];
   const float qtail1 = (!FOLD || kk) ? 1.0f : a.sqx[(size_t)bg * N + min(n0 + 32 + l31, N - 1)];
   const float sqx = FOLD ? 0.0f : a.sqx[(size_t)bg * N + nc];
