@@ -45,7 +45,7 @@ def step():
     bucket.pack()
 
 
-tl = torch.zeros(4096 * 8 + 4096 * 4, dtype=torch.int64, device="cuda")
+tl = torch.zeros(4096 * 8 + 4096 * 4 + 4096, dtype=torch.int64, device="cuda")
 for _ in range(5):
     step()
 torch.cuda.synchronize()
@@ -53,8 +53,12 @@ lib.gkg_debug_set_x6_timeline(tl.data_ptr())
 tl.zero_()
 step()
 torch.cuda.synchronize()
-g = tl[4096 * 8:].cpu().numpy().reshape(4096, 4)
-g = g[g[:, 0] > 0]
+full = tl.cpu().numpy()
+g = full[4096 * 8:4096 * 12].reshape(4096, 4)
+loopdone = full[4096 * 12:]
+keep = g[:, 0] > 0
+loopdone = loopdone[keep]
+g = g[keep]
 hw, xcc = g[:, 2] >> 8, g[:, 2] & 0xf
 cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 0x7
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
@@ -86,3 +90,8 @@ for p_ in np.unique(prob):
     m = (prob == p_) & real
     if m.any():
         print(f"   problem {int(p_):2d} ({'64x128' if (g[m, 3][0] & 1) else '64x64 '} body): {int(m.sum()):3d} workgroups, life min/median/max {life[m].min()}/{int(np.median(life[m]))}/{life[m].max()} ticks")
+ep = (g[:, 1] - loopdone)[real & (loopdone > 0)]
+lf = life[real & (loopdone > 0)]
+if len(ep):
+    print(f"epilogue (all waves' K loops done -> end: LDS reduction of the four partial tiles + 8 192 atomics): median {int(np.median(ep))} ticks = "
+          f"{np.median(ep / lf):.2f} of a workgroup's life (min {ep.min()}, max {ep.max()})")
