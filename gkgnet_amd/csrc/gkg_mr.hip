@@ -662,6 +662,261 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_i64_kernel(const float*
   }
 }
 
+// ---- streaming form of the exact scatter (round 5) ----------------------------------------------------------------------
+// At the HBM-bound shapes (pooled 1 296-key images under 5 184 / 20 736 queries, the 36 x 36 self graphs) BOTH kernels above take
+// the same time whatever their accumulator type (tools/bench_mr_bwd.py: 420-426 us at stage 1 for fp32 and 64-bit atomics, chunk
+// widths 4 / 8): they are bound by their sweep — one (index, gradient) row per thread and iteration, nothing in flight behind
+// it — and the fixed-point form pays that sweep twice to learn its scale first.  This form
+//   * keeps U rows per thread in flight (all index / gradient loads of an iteration issued before the first use) in workgroups
+//     of up to 1 024 threads: one workgroup per CU (83 KB of accumulators at 1 296 rows x 8 channels) still has >= 100 KB of
+//     loads outstanding;
+//   * sweeps ONCE: the fixed-point scale comes from a strided SAMPLE of the chunk's rows (one load round trip) plus HEAD binary
+//     orders of headroom instead of the exact maximum.  A gradient beyond the headroom (or inf / NaN) raises a flag; the
+//     workgroup then discards its image and re-runs the exact two-sweep form — same result contract, rare path.  The sample,
+//     the flag and therefore the path taken depend on the data only: bit-identical from run to run, like the two-sweep form
+//     (the scale sits HEAD orders above the sampled maximum: values more than 2^-(SHMAX - HEAD) below THAT lose low bits —
+//     17 binary orders at N = 20 736).
+// ACC == 1 (measurement): fp64 LDS atomics (ds_add_f64) instead of fixed point — no scale at all, not order-independent.
+template <int NT, bool SELF, int MODE, int AK>
+__device__ __forceinline__ void mr_i64_two_sweep_body(long long* acc64, unsigned* ctl, const float* __restrict__ gin,
+                                                      const int64_t* __restrict__ nn_idx, const uint8_t* __restrict__ argmax,
+                                                      float* __restrict__ gx, float* __restrict__ gsrc, int b, int G, int c, int N,
+                                                      int M, int k, int CW, int ch0, size_t T, int shmax, bool write_gx) {
+  const int C = G * c;
+  const int cw4 = CW >> 2;
+  const int tid = threadIdx.x;
+  const int qd = tid % cw4, tl = tid / cw4, TL = NT / cw4;
+  const int ch = ch0 + 4 * qd;
+  unsigned mx = 0;
+  if (tl < TL) {
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      float4 direct, gm;
+      load_grad<MODE>(gin, T, t, C, ch, MODE, direct, gm);
+      if (!SELF && write_gx)
+        *reinterpret_cast<float4*>(gx + t * C + ch) = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+      mx = max(max(mx, __float_as_uint(gm.x) & 0x7fffffffu), max(__float_as_uint(gm.y) & 0x7fffffffu,
+               max(__float_as_uint(gm.z) & 0x7fffffffu, __float_as_uint(gm.w) & 0x7fffffffu)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if ((tid & 63) == 0) atomicMax(ctl, mx);
+  __syncthreads();
+  mx = ctl[0];
+  const int emax = (int)(mx >> 23);
+  if (emax == 255) {                              // inf / NaN somewhere in this chunk: the fp32-atomic form propagates them
+    __syncthreads();
+    float* acc = reinterpret_cast<float*>(acc64);   // fp32 atomics on the same LDS (mr_scatter_f32_body for NT threads)
+    if (tl < TL) {
+      for (int m = tl; m < M; m += TL) {
+        float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (SELF) {
+          float4 direct, gm;
+          load_grad<MODE>(gin, T, (size_t)b * N + m, C, ch, MODE, direct, gm);
+          seed = make_float4(direct.x - gm.x, direct.y - gm.y, direct.z - gm.z, direct.w - gm.w);
+        }
+        *reinterpret_cast<float4*>(acc + (size_t)m * CW + 4 * qd) = seed;
+      }
+    }
+    __syncthreads();
+    if (tl < TL) {
+      const int g = ch / c;
+      for (int n = tl; n < N; n += TL) {
+        const size_t t = (size_t)b * N + n;
+        const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+        int j[4];
+        mr_targets<AK>(argmax, AK, t * C + ch, ip, k, M, j);
+        float4 direct, gm;
+        load_grad<MODE>(gin, T, t, C, ch, MODE, direct, gm);
+        atomicAdd(acc + (size_t)j[0] * CW + 4 * qd + 0, gm.x);
+        atomicAdd(acc + (size_t)j[1] * CW + 4 * qd + 1, gm.y);
+        atomicAdd(acc + (size_t)j[2] * CW + 4 * qd + 2, gm.z);
+        atomicAdd(acc + (size_t)j[3] * CW + 4 * qd + 3, gm.w);
+      }
+    }
+    __syncthreads();
+    if (tl < TL) {
+      float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch0;
+      for (int m = tl; m < M; m += TL)
+        *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = *reinterpret_cast<const float4*>(acc + (size_t)m * CW + 4 * qd);
+    }
+    return;
+  }
+  if (tl < TL && mx != 0) {
+    const int g = ch / c;
+    const int em = max(emax, 1);
+    for (int n = tl; n < N; n += TL) {
+      const size_t t = (size_t)b * N + n;
+      const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+      int j[4];
+      mr_targets<AK>(argmax, AK, t * C + ch, ip, k, M, j);
+      float4 direct, gm;
+      load_grad<MODE>(gin, T, t, C, ch, MODE, direct, gm);
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[0] * CW + 4 * qd + 0), (unsigned long long)mr_to_fixed(gm.x, em, shmax));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[1] * CW + 4 * qd + 1), (unsigned long long)mr_to_fixed(gm.y, em, shmax));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[2] * CW + 4 * qd + 2), (unsigned long long)mr_to_fixed(gm.z, em, shmax));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[3] * CW + 4 * qd + 3), (unsigned long long)mr_to_fixed(gm.w, em, shmax));
+    }
+  }
+  __syncthreads();
+  if (tl < TL) {
+    const int em = max(emax, 1);
+    float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch0;
+    for (int m = tl; m < M; m += TL) {
+      const long long* a = acc64 + (size_t)m * CW + 4 * qd;
+      float4 o = make_float4(mr_from_fixed(a[0], em, shmax), mr_from_fixed(a[1], em, shmax), mr_from_fixed(a[2], em, shmax),
+                             mr_from_fixed(a[3], em, shmax));
+      if (SELF) {
+        float4 direct, gm;
+        load_grad<MODE>(gin, T, (size_t)b * N + m, C, ch, MODE, direct, gm);
+        o = make_float4(o.x + (direct.x - gm.x), o.y + (direct.y - gm.y), o.z + (direct.z - gm.z), o.w + (direct.w - gm.w));
+      }
+      *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = o;
+    }
+  }
+}
+
+constexpr int MR_STREAM_HEAD = 6;       // binary orders of headroom above the sampled maximum
+
+template <int NT, bool SELF, int MODE, int AK, int ACC, int U>     // U: rows in flight per thread
+__global__ __launch_bounds__(NT) void mr_bwd_tm_stream_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
+                                                               const uint8_t* __restrict__ argmax, float* __restrict__ gx,
+                                                               float* __restrict__ gsrc, int B, int G, int c, int N, int M,
+                                                               int k, int CW, int shmax) {
+  extern __shared__ long long acc64[];            // [M][CW] (fixed point, or the bits of doubles) + control words
+  const int C = G * c;
+  const int nchunk = C / CW;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, seq = lin >> 3;        // XCD-aware map, as mr_bwd_tm_scatter_kernel
+  const int b = (seq / nchunk) * 8 + xcd;
+  if (b >= B) return;
+  const int ch0 = (seq - (seq / nchunk) * nchunk) * CW;
+  const int cw4 = CW >> 2;
+  const int tid = threadIdx.x;
+  const int qd = tid % cw4, tl = tid / cw4, TL = NT / cw4;
+  const size_t T = (size_t)B * N;
+  const int ch = ch0 + 4 * qd;
+  const int g = ch / c;
+  unsigned* ctl = reinterpret_cast<unsigned*>(acc64 + (size_t)M * CW);
+  float4 direct[U], gm[U];
+  int j[U][4];
+  auto load_rows = [&](int n0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = min(n0 + u * TL, N - 1);
+      const size_t t = (size_t)b * N + n;
+      const int64_t* ip = AK == 1 ? nullptr : nn_idx + (((size_t)b * G + g) * N + n) * k;
+      mr_targets<AK>(argmax, AK, t * C + ch, ip, k, M, j[u]);
+      load_grad<MODE>(gin, T, t, C, ch, MODE, direct[u], gm[u]);
+    }
+  };
+  auto absmax4 = [](const float4& v) -> unsigned {
+    return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+  };
+  // ---- prologue: the first U rows of every thread AND (longer sweeps) a strided sample of the chunk's rows are requested in one
+  //      go; the LDS image is cleared in their shadow.  The fixed-point scale comes from what arrived: the exact maximum when the
+  //      first iteration is the whole sweep (N <= TL * U: the 18 x 18 stages — no headroom needed, the flag cannot rise), the
+  //      sample's maximum plus HEAD binary orders otherwise.
+  const bool whole = N <= TL * U;                 // uniform
+  unsigned mx = 0;
+  float4 sd[2], sg[2];
+  if (ACC == 0 && !whole) {
+    const int stride = max(N / (TL * 2), 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      load_grad<MODE>(gin, T, (size_t)b * N + min((tl + u * TL) * stride, N - 1), C, ch, MODE, sd[u], sg[u]);
+  }
+  load_rows(tl);
+  for (int i = tid; i < M * CW; i += NT) acc64[i] = 0;
+  if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+  __syncthreads();
+  int em = 0;
+  unsigned lim = 0xffffffffu;
+  if (ACC == 0) {
+    if (!whole) mx = max(absmax4(sg[0]), absmax4(sg[1]));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (tl + u * TL < N) mx = max(mx, absmax4(gm[u]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((tid & 63) == 0) atomicMax(ctl, mx);
+    __syncthreads();
+    mx = ctl[0];
+    // an all-zero (or denormal) sample still gets a scale — whatever lies above it raises the flag
+    em = min(max((int)(mx >> 23), 1) + (whole ? 0 : MR_STREAM_HEAD), 254);
+    lim = (unsigned)(em + 1) << 23;               // |bits| >= lim: beyond the scale (inf / NaN always are)
+  }
+  bool over = false;
+  auto process_rows = [&](int n0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = n0 + u * TL;
+      if (n < N) {
+        const size_t t = (size_t)b * N + n;
+        if (!SELF)
+          *reinterpret_cast<float4*>(gx + t * C + ch) =
+              make_float4(direct[u].x - gm[u].x, direct[u].y - gm[u].y, direct[u].z - gm[u].z, direct[u].w - gm[u].w);
+        if (ACC == 0) {
+          over |= absmax4(gm[u]) >= lim;
+          atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[u][0] * CW + 4 * qd + 0), (unsigned long long)mr_to_fixed(gm[u].x, em, shmax));
+          atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[u][1] * CW + 4 * qd + 1), (unsigned long long)mr_to_fixed(gm[u].y, em, shmax));
+          atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[u][2] * CW + 4 * qd + 2), (unsigned long long)mr_to_fixed(gm[u].z, em, shmax));
+          atomicAdd(reinterpret_cast<unsigned long long*>(acc64 + (size_t)j[u][3] * CW + 4 * qd + 3), (unsigned long long)mr_to_fixed(gm[u].w, em, shmax));
+        } else {
+          double* ad = reinterpret_cast<double*>(acc64);
+          unsafeAtomicAdd(ad + (size_t)j[u][0] * CW + 4 * qd + 0, (double)gm[u].x);
+          unsafeAtomicAdd(ad + (size_t)j[u][1] * CW + 4 * qd + 1, (double)gm[u].y);
+          unsafeAtomicAdd(ad + (size_t)j[u][2] * CW + 4 * qd + 2, (double)gm[u].z);
+          unsafeAtomicAdd(ad + (size_t)j[u][3] * CW + 4 * qd + 3, (double)gm[u].w);
+        }
+      }
+    }
+  };
+  // ---- the sweep: U rows per thread in flight
+  process_rows(tl);
+  for (int n0 = tl + TL * U; n0 < N; n0 += TL * U) {
+    load_rows(n0);
+    process_rows(n0);
+  }
+  if (ACC == 0) {
+    if (over) ctl[1] = 1;
+    __syncthreads();
+    if (ctl[1]) {                                   // beyond the scale somewhere (inf / NaN included): the exact two-sweep form on a clean image
+      __syncthreads();
+      for (int i = tid; i < M * CW; i += NT) acc64[i] = 0;
+      if (tid == 0) ctl[0] = 0;
+      __syncthreads();
+      mr_i64_two_sweep_body<NT, SELF, MODE, AK>(acc64, ctl, gin, nn_idx, argmax, gx, gsrc, b, G, c, N, M, k, CW, ch0, T, shmax, false);
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
+  // ---- store: one conversion per element (+ the token's own seed for the self graph)
+  if (tl < TL) {
+    float* db = (SELF ? gx : gsrc) + (size_t)b * M * C + ch0;
+    for (int m = tl; m < M; m += TL) {
+      const long long* a = acc64 + (size_t)m * CW + 4 * qd;
+      float4 o;
+      if (ACC == 0) {
+        o = make_float4(mr_from_fixed(a[0], em, shmax), mr_from_fixed(a[1], em, shmax), mr_from_fixed(a[2], em, shmax),
+                        mr_from_fixed(a[3], em, shmax));
+      } else {
+        const double* ad = reinterpret_cast<const double*>(a);
+        o = make_float4((float)ad[0], (float)ad[1], (float)ad[2], (float)ad[3]);
+      }
+      if (SELF) {
+        float4 direct1, gm1;
+        load_grad<MODE>(gin, T, (size_t)b * N + m, C, ch, MODE, direct1, gm1);
+        o = make_float4(o.x + (direct1.x - gm1.x), o.y + (direct1.y - gm1.y), o.z + (direct1.z - gm1.z), o.w + (direct1.w - gm1.w));
+      }
+      *reinterpret_cast<float4*>(db + (size_t)m * C + 4 * qd) = o;
+    }
+  }
+}
+
 // Deterministic scatter (GKG_MR_DETERMINISTIC): the LDS-atomic kernel above adds the fan-in of a key in whatever order
 // its lanes arrive, so gsrc differs in the last bit from run to run (like the reference's CUDA index_put_(accumulate)).
 // Here a workgroup owns ONE channel quad of one image; each of its TL threads sweeps its own residue class of queries
@@ -971,6 +1226,26 @@ static void launch_tm_i64(bool self, int mode, int ak, dim3 grid, size_t lds, hi
 #undef GKG_TM64_CASE
 }
 
+template <int NT, bool SELF, int MODE, int AK, int ACC, int U>
+static void launch_tm_stream_one(dim3 grid, size_t lds, hipStream_t st, const float* gin, const int64_t* nn_idx, const uint8_t* argmax,
+                                 float* gx, float* gsrc, int B, int G, int c, int N, int M, int k, int CW, int shmax) {
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_stream_kernel<NT, SELF, MODE, AK, ACC, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mr_bwd_tm_stream_kernel<NT, SELF, MODE, AK, ACC, U>), grid, dim3(NT), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, shmax);
+}
+template <int NT, int ACC, int U>
+static void launch_tm_stream_nt(bool self, int mode, int ak, dim3 grid, size_t lds, hipStream_t st, const float* gin, const int64_t* nn_idx,
+                                const uint8_t* argmax, float* gx, float* gsrc, int B, int G, int c, int N, int M, int k, int CW, int shmax) {
+#define GKG_TMS_CASE(S, MO, A) launch_tm_stream_one<NT, S, MO, A, ACC, U>(grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, shmax)
+  if (self) {
+    if (mode == 0) { if (ak) GKG_TMS_CASE(true, 0, 1); else GKG_TMS_CASE(true, 0, 0); }
+    else { if (ak) GKG_TMS_CASE(true, 1, 1); else GKG_TMS_CASE(true, 1, 0); }
+  } else {
+    if (mode == 0) { if (ak) GKG_TMS_CASE(false, 0, 1); else GKG_TMS_CASE(false, 0, 0); }
+    else { if (ak) GKG_TMS_CASE(false, 1, 1); else GKG_TMS_CASE(false, 1, 0); }
+  }
+#undef GKG_TMS_CASE
+}
+
 extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint8_t* argmax, float* gx, float* gsrc,
                              int B, int G, int c, int N, int M, int k, int mode, int arg_kind, unsigned flags, void* stream) {
   if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_bwd_tm: arg_kind is 0 or 1");
@@ -998,7 +1273,39 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
   // 20 736 queries: 209 vs 164, 492 vs 425).  Rule: destination images of up to 512 rows; with GKG_MR_DETERMINISTIC wherever it
   // fits (the private-accumulator form it replaces there is 1.6x the fp32 time).  Chunk width 8 (measured best or tied at
   // every shape: the kernel lives on workgroups per CU), 4 when 8 does not fit.
-  if (!(flags & GKG_MR_FP32_ATOMICS) && N < (1 << 24) && (M <= 512 || (flags & GKG_MR_DETERMINISTIC))) {
+  // Streaming fixed-point form (mr_bwd_tm_stream_kernel, round 5): the default from 160 query rows per image wherever an (image,
+  // channel chunk) of 64-bit accumulators fits the LDS budget — one sweep, 4 / 8 rows per thread in flight, 512 threads.  Order-
+  // independent like the two-sweep form, so it serves GKG_MR_DETERMINISTIC too.  Measured against what it replaces
+  // (tools/bench_mr_bwd.py, us, profiles/r05_bench_mr_bwd_stream.txt): cfg2 21.8 -> 16.6, C = 640 at 18 x 18 38.7 -> 25.1,
+  // 36 x 36 self graph 117.6 -> 89.9, pooled 1 296-key images under 5 184 / 20 736 queries 165 -> 133 / 424 -> 359; the label
+  // graphs (80 queries) keep the two-sweep kernel (8.6 vs 9.2-9.9).  Chunk width: the widest of 16 / 8 / 4 channels that fits.
+  // Measurement: flags bits 16..17 = 1 force this form (bits 8..15 chunk width, 20..21 = 2: 256 threads, bit 22: 8 rows in
+  // flight), 2 = its fp64-atomic variant (ds_add_f64: 45-98 cycles per wave instruction against 170-183 for ds_add_f32 —
+  // tools/ubench/lds_atomic_rate.hip), 3 = the two-sweep kernel wherever it fits.
+  const int sv = (int)((flags >> 16) & 3);
+  if (N < (1 << 24) && (sv == 1 || sv == 2 || (sv == 0 && !(flags & GKG_MR_FP32_ATOMICS) && N >= 160))) {
+    int CW = (int)((flags >> 8) & 0xff);
+    auto sfits = [&](int cw) { return (size_t)M * cw * 8 + 16 <= (size_t)MR_LDS_BUDGET && C % cw == 0 && c % cw == 0; };
+    if (!CW || !sv) CW = sfits(16) ? 16 : (sfits(8) ? 8 : 4);
+    if ((sv && (size_t)M * CW * 8 + 16 <= 150 * 1024 && C % CW == 0 && c % CW == 0) || sfits(CW)) {
+      const bool nt256 = sv && ((flags >> 20) & 3) == 2;
+      const bool u8 = sv ? ((flags >> 22) & 1) != 0 : M > 512;       // long sweeps: 8 rows in flight
+      const size_t lds = (size_t)M * CW * 8 + 16;
+      int bitsN = 0;
+      while ((1 << bitsN) <= N) ++bitsN;
+      const dim3 grid((C / CW) * ((B + 7) / 8) * 8);
+      const bool self = gsrc == nullptr;
+      if (sv == 2) launch_tm_stream_nt<512, 1, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      else if (nt256 && u8) launch_tm_stream_nt<256, 0, 8>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      else if (nt256) launch_tm_stream_nt<256, 0, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      else if (u8) launch_tm_stream_nt<512, 0, 8>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      else launch_tm_stream_nt<512, 0, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      hipError_t es = hipGetLastError();
+      return es == hipSuccess ? 0 : gkg_fail_hip(es, "mr_bwd_tm_stream_kernel");
+    }
+    if (sv) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_bwd_tm: forced streaming form does not fit");
+  }
+  if (!(flags & GKG_MR_FP32_ATOMICS) && N < (1 << 24) && (M <= 512 || sv == 3 || (flags & GKG_MR_DETERMINISTIC))) {
     int CW = 8;
     const int forced = (int)((flags >> 8) & 0xff);          // measurement only: bits 8..15 force the chunk width
     auto fits = [&](int cw, size_t budget) { return (size_t)M * cw * 8 + 16 <= budget && C % cw == 0 && c % cw == 0; };

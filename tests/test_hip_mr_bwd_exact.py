@@ -123,3 +123,101 @@ def test_non_finite_gradients_reach_their_destination(bad):
     assert bool(torch.isfinite(gx[mask]).all())                  # ... and nowhere else
     ref, _ = _run(x, None, idx, G, 0, torch.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0))
     assert torch.allclose(gx[0], ref[0], atol=1e-5, rtol=1e-5)
+
+
+# ---- the one-sweep streaming form (round 5: mr_bwd_tm_stream_kernel, the default from 160 query rows per image) -------------
+def _raw(g, idx, arg, B, G, C, N, M, k, flags, self_graph=False):
+    from gkgnet_amd import _lib
+    from gkgnet_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    gx = torch.full((B, N, C), float("nan"), device="cuda")
+    gsrc = None if self_graph else torch.full((B, M, C), float("nan"), device="cuda")
+    _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 0, 1, flags, _stream()),
+               "gkg_mr_bwd_tm")
+    return gx, gsrc
+
+
+TWO_SWEEP = 3 << 16          # measurement flags (csrc/gkg_mr.hip gkg_mr_bwd_tm): the two-sweep kernel wherever it fits
+STREAM = 1 << 16             # the streaming form, whatever the rule says
+
+
+@pytest.mark.parametrize("N,M,nt256,u8", [(3000, 600, 0, 0), (3000, 600, 1, 1), (5184, 1296, 0, 1), (700, 324, 0, 0)])
+def test_streaming_form_sampled_scale_wide_dynamic_range(N, M, nt256, u8):
+    """Sweeps longer than one iteration take their fixed-point scale from a strided sample + 6 binary orders of headroom: every
+    total must be within one fp32 rounding of the fp64 sum plus the truncation of addends below the scale — relative to the
+    chunk's LARGEST magnitude at most 2^(6 - 23 - SHMAX) per addend — and bit-identical from run to run."""
+    gen = torch.Generator(device="cuda").manual_seed(N + M)
+    B, G, C, k = 2, 2, 32, 9
+    idx = torch.randint(0, M, (B * G, N, k), device="cuda", generator=gen)
+    arg = torch.randint(0, M, (B, N, C), device="cuda", generator=gen).to(torch.int16)
+    mag = 10.0 ** (torch.rand(B, N, C, device="cuda", generator=gen) * 1.5 - 3)                 # inside the headroom
+    g = mag * torch.sign(torch.randn(B, N, C, device="cuda", generator=gen))
+    flags = STREAM | (8 << 8) | ((2 if nt256 else 1) << 20) | (u8 << 22)
+    gx, gsrc = _raw(g, idx, arg, B, G, C, N, M, k, flags)
+    want = torch.zeros(B, M, C, dtype=torch.float64, device="cuda")
+    want.scatter_add_(1, arg.long() & 0xffff, g.double())
+    assert torch.equal(gx, -g)
+    bits_n = N.bit_length()
+    shmax = 38 - bits_n
+    big = float(g.abs().max())
+    err = (gsrc.double() - want).abs()
+    bound = want.abs() * 2.0 ** -23 + 2 * big * 2.0 ** (6 - 23 - shmax) * N
+    assert bool((err <= bound).all()), float((err / bound).max())
+    gx2, gsrc2 = _raw(g, idx, arg, B, G, C, N, M, k, flags)
+    assert torch.equal(gsrc, gsrc2) and torch.equal(gx, gx2)
+    # and what the library picks by itself for this shape is this form (same bits as one of its instantiations' arithmetic:
+    # the scale depends on the rows a thread holds, so compare against the fp64 sum only)
+    _, auto = _raw(g, idx, arg, B, G, C, N, M, k, 0)
+    assert bool(((auto.double() - want).abs() <= bound).all())
+
+
+def test_streaming_form_falls_back_to_the_two_sweep_result_beyond_its_headroom():
+    """A gradient far above everything the sample saw (here 2^30 times) raises the workgroup's flag: its image is discarded and
+    the exact two-sweep form runs — bit for bit the two-sweep kernel's result; chunks that stay inside their headroom keep the
+    one-sweep result."""
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    B, G, C, N, M, k = 2, 2, 32, 3000, 600, 9
+    idx = torch.randint(0, M, (B * G, N, k), device="cuda", generator=gen)
+    arg = torch.randint(0, M, (B, N, C), device="cuda", generator=gen).to(torch.int16)
+    g = torch.randn(B, N, C, device="cuda", generator=gen) * 1e-3
+    g[1, 2999, 3] = 4.0e6                     # row 2999: not in the first iteration's prefix, not on the sample's stride
+    want = torch.zeros(B, M, C, dtype=torch.float64, device="cuda")
+    want.scatter_add_(1, arg.long() & 0xffff, g.double())
+    two_x, two_s = _raw(g, idx, arg, B, G, C, N, M, k, TWO_SWEEP | (8 << 8))
+    for flags in (STREAM | (8 << 8) | (1 << 20), STREAM | (8 << 8) | (2 << 20) | (1 << 22), 0):
+        gx, gsrc = _raw(g, idx, arg, B, G, C, N, M, k, flags)
+        assert torch.equal(gx, two_x)
+        if flags:                                                            # same 8-channel chunks as the two-sweep launch:
+            assert torch.equal(gsrc[1, :, 0:8], two_s[1, :, 0:8])            # the chunk that overflowed carries the two-sweep bits
+        assert torch.allclose(gsrc.double(), want, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_streaming_form_propagates_non_finite_gradients(bad):
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    B, G, C, N, k = 2, 2, 64, 400, 9
+    x = torch.randn(B, N, C, device="cuda", generator=gen)
+    idx = torch.randint(0, N, (B * G, N, k), device="cuda", generator=gen)
+    g = torch.randn(B, N, C, device="cuda", generator=gen)
+    g[1, 317, 5] = bad
+    gx, _ = _run(x, None, idx, G, 0, g)
+    assert not bool(torch.isfinite(gx[1, :, 5]).all())
+    mask = torch.ones_like(gx, dtype=torch.bool)
+    mask[1, :, 5] = False
+    assert bool(torch.isfinite(gx[mask]).all())
+    ref, _ = _run(x, None, idx, G, 0, torch.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0))
+    assert torch.allclose(gx[0], ref[0], atol=1e-5, rtol=1e-5)
+
+
+def test_streaming_form_single_iteration_equals_the_two_sweep_kernel_bit_for_bit():
+    """When a thread's first rows are the whole sweep (the 18 x 18 stages) the scale is the exact maximum, i.e. the two-sweep
+    kernel's: same fixed-point sums, same bits — self graph (seeded store) and bipartite."""
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    B, G, C, k = 3, 4, 320, 9
+    for N, M, self_graph in ((324, 324, True), (324, 200, False)):
+        idx = torch.randint(0, M, (B * G, N, k), device="cuda", generator=gen)
+        arg = torch.randint(0, M, (B, N, C), device="cuda", generator=gen).to(torch.int16)
+        g = torch.randn(B, N, C, device="cuda", generator=gen) * 10.0 ** (torch.rand(B, N, C, device="cuda", generator=gen) * 6 - 3)
+        a = _raw(g, idx, arg, B, G, C, N, M, k, 0, self_graph)                          # the rule: 16-channel chunks here
+        b = _raw(g, idx, arg, B, G, C, N, M, k, TWO_SWEEP | (16 << 8), self_graph)     # (the scale is per chunk: same chunks)
+        assert torch.equal(a[0], b[0]) and (self_graph or torch.equal(a[1], b[1]))

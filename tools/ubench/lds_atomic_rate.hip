@@ -1,4 +1,4 @@
-// LDS atomic throughput on gfx950: ds_add_f32 vs ds_add_u32 vs ds_add_u64 (no-return forms), addresses spread over an image
+// LDS atomic throughput on gfx950: ds_add_f32 vs ds_add_u32 vs ds_add_u64 vs ds_add_f64 (no-return forms), addresses spread over an image
 // like the aggregation backward's (M rows x CW floats).  hipcc --offload-arch=gfx950 -O3 -o lds_atomic_rate lds_atomic_rate.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k(const int* __restrict__ idx, float* out
     if (KIND == 1) atomicAdd(u + a, (unsigned)(v * 1024.f));
     if (KIND == 2) atomicAdd(q + (a >> 1), (unsigned long long)(v * 1024.f));
     if (KIND == 3) f[a] += v;                       // plain read-modify-write (racy: rate reference only)
+    if (KIND == 4) unsafeAtomicAdd(reinterpret_cast<double*>(lds) + (a >> 1), (double)v);   // ds_add_f64
   }
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = f[blockIdx.x % words];
@@ -40,8 +41,8 @@ int main() {
     int* d; float* o;
     hipMalloc(&d, n_idx * sizeof(int)); hipMalloc(&o, blocks * sizeof(float));
     hipMemcpy(d, h, n_idx * sizeof(int), hipMemcpyHostToDevice);
-    const char* names[4] = {"ds_add_f32", "ds_add_u32", "ds_add_u64", "plain rmw (racy)"};
-    for (int kind = 0; kind < 4; ++kind) {
+    const char* names[5] = {"ds_add_f32", "ds_add_u32", "ds_add_u64", "plain rmw (racy)", "ds_add_f64"};
+    for (int kind = 0; kind < 5; ++kind) {
       hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(a);
@@ -49,6 +50,7 @@ int main() {
         if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), words * 4, 0, d, o, rounds, n_idx, words);
         if (kind == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), words * 4, 0, d, o, rounds, n_idx, words);
         if (kind == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), words * 4, 0, d, o, rounds, n_idx, words);
+        if (kind == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), words * 4, 0, d, o, rounds, n_idx, words);
         hipEventRecord(b); hipEventSynchronize(b);
       }
       float ms; hipEventElapsedTime(&ms, a, b);
