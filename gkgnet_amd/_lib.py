@@ -10,7 +10,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GKG_HIP_LIB") or os.path.join(PKG, "libgkg_hip.so")   # GKG_HIP_LIB: same-box A/B of two builds (tools)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 KNN_BF16_CONTRACT = 2
@@ -67,7 +67,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
-           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts", "gkg_x6_set_flags", "gkg_x6_prep_weights_zero")
+           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts", "gkg_x6_set_flags", "gkg_x6_prep_weights_zero",
+           "gkg_knn_fwd_tm16", "gkg_mr_fwd_tm16", "gkg_mr_linear_bf16_nn16")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None
@@ -115,6 +116,10 @@ def load():
     lib.gkg_knn_mr_fwd_tm.argtypes = [V] * 8 + [I] * 7 + [C.c_uint, V, Z, V]
     lib.gkg_mr_fwd_tm.restype = I
     lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 9 + [V]
+    lib.gkg_mr_fwd_tm16.restype = I
+    lib.gkg_mr_fwd_tm16.argtypes = [V] * 5 + [I] * 9 + [V]
+    lib.gkg_knn_fwd_tm16.restype = I
+    lib.gkg_knn_fwd_tm16.argtypes = [V] * 4 + [I] * 8 + [C.c_uint, V, Z, V]
     lib.gkg_mr_bwd_tm.restype = I
     lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V]
     lib.gkg_nchw_to_tm.restype = I
@@ -207,6 +212,8 @@ def load():
     lib.gkg_mr_linear_planes_bytes.argtypes = [I]
     lib.gkg_mr_linear_bf16.restype = I
     lib.gkg_mr_linear_bf16.argtypes = [V] * 7 + [I] * 8 + [V]
+    lib.gkg_mr_linear_bf16_nn16.restype = I
+    lib.gkg_mr_linear_bf16_nn16.argtypes = [V] * 7 + [I] * 8 + [V]
     lib.gkg_mr_linear_x6_supported.restype = I
     lib.gkg_mr_linear_x6_supported.argtypes = [I, I, I]
     lib.gkg_mr_linear_x6.restype = I

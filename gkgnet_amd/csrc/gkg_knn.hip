@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
 // so ranks 0,d,2d,.. < kd are written straight to their output slot — no serial merge.
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i,
                                                         int64_t* __restrict__ nn_idx, int64_t* __restrict__ center,
+                                                        uint16_t* __restrict__ nn16,
                                                         int S, int BG, int N, int M, int k, int dilation, int kd) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;        // (s, q, p) flattened as s*nq*kd + q*kd + p
   const size_t nq = (size_t)BG * N;
@@ -263,7 +264,9 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   if (rank < kd && rank % dilation == 0) {
     const int outj = rank / dilation;
     if (outj < k) {
-      nn_idx[q * k + outj] = id < M ? id : 0;       // masked tail keys can only rank here on non-finite inputs
+      const int bc = id < M ? id : 0;               // masked tail keys can only rank here on non-finite inputs
+      if (nn16) nn16[q * k + outj] = (uint16_t)bc;
+      else nn_idx[q * k + outj] = bc;
     }
   }
 }
@@ -416,8 +419,9 @@ static bool knn_mr_plan_ok(const KnnPlan& p, int c, int N, int M, int k, bool pf
 static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                         int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                         void* workspace, size_t workspace_bytes, void* stream, int G_tm, const KnnMrFuse* mr = nullptr,
-                        bool probe_only = false) {
-  if (!probe_only && (!x || (!nn_idx && !mr) || !workspace)) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
+                        bool probe_only = false, uint16_t* nn16_only = nullptr) {
+  // nn16_only (gkg_knn_fwd_tm16): the neighbour lists as u16 rows INSTEAD of the int64 plane (M <= 65 536)
+  if (!probe_only && (!x || (!nn_idx && !mr && !nn16_only) || !workspace)) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
   if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32, GKG_BF16 or GKG_F16");
   KnnPlan p;
   int rc = make_plan(BG, c, N, M, k, dilation, y != nullptr, &p);
@@ -513,7 +517,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.nqt = (N + QT - 1) / QT;
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
   a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
-  a.mr_x = a.mr_src = nullptr; a.mr_out = nullptr; a.mr_arg = nullptr; a.nn16 = nullptr; a.mr_G = 1; a.mr_c = c;
+  a.mr_x = a.mr_src = nullptr; a.mr_out = nullptr; a.mr_arg = nullptr; a.nn16 = nn16_only; a.mr_G = 1; a.mr_c = c;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
 #if defined(KNN_TIMELINE) || defined(KNN_ABLATE)
   if (p.S == 1 && gkg_knn_tl_buf) a.part_v = (float*)gkg_knn_tl_buf;
@@ -586,9 +590,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     const size_t ne = (size_t)BG * N * p.kd * p.S;
     GkgProfScope prof(GKG_PROF_KNN_MERGE, st);
     // ranks that no finite candidate claims (non-finite inputs only) must still hold a valid index
-    (void)hipMemsetAsync(nn_idx, 0, sizeof(int64_t) * (size_t)BG * N * k, st);
+    if (nn16_only) (void)hipMemsetAsync(nn16_only, 0, sizeof(uint16_t) * (size_t)BG * N * k, st);
+    else (void)hipMemsetAsync(nn_idx, 0, sizeof(int64_t) * (size_t)BG * N * k, st);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.part_v, a.part_i,
-                       nn_idx, center, p.S, BG, N, M, k, dilation, p.kd);
+                       nn_idx, center, nn16_only, p.S, BG, N, M, k, dilation, p.kd);
     e = hipGetLastError();
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_merge_kernel");
   }
@@ -608,6 +613,19 @@ extern "C" int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos,
   if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm: bad B / G");
   return knn_fwd_impl(x, y, relpos, nn_idx, center, B * G, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
                       stream, G);
+}
+
+// The same graph as gkg_knn_fwd_tm with COMPACT neighbour lists: nn16 (B * G, N, k) u16 rows instead of the (2, B G, N, k) int64
+// edge_index — for callers that consume the graph on the device and never hand it out (Grapher.forward discards it, reference
+// torch_vertex.py:330).  At GKGNet-576's stage 1 the int64 pair is 191 MB written per launch, the compact lists 24 MB (pvig_m
+// stage 1, k = 18: 1.36 GB / 170 MB).  Needs M <= 65 536.  Same bits as the int64 lists (tests/test_hip_knn_compact.py).
+extern "C" int gkg_knn_fwd_tm16(const void* x, const void* y, const float* relpos, uint16_t* nn16, int B, int G, int c, int N, int M,
+                                int k, int dilation, int dtype, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm16: bad B / G");
+  if (!nn16) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd_tm16: nn16 must be non-null");
+  if (M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd_tm16: M <= 65536 (u16 rows)");
+  return knn_fwd_impl(x, y, relpos, nullptr, nullptr, B * G, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
+                      stream, G, nullptr, false, nn16);
 }
 
 // Row g2: k-NN + max-relative aggregation in one kernel (knn_tile_kernel<..., MRF = true>) for token-major fp32 callers.

@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
     for (int j = 0; j < KD; ++j) {
       if (j < a.kd && j % a.dilation == 0 && outj < a.k) {
         const int bi = key_index(fin.key[j]);
-        a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;
+        const int bc = (unsigned)bi < (unsigned)M ? bi : 0;
+        if (a.nn16) a.nn16[obase + outj] = (uint16_t)bc;
+        else a.nn_idx[obase + outj] = bc;
         if (a.center) a.center[obase + outj] = lane_n;
         ++outj;
       }

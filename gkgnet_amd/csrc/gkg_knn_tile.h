@@ -546,6 +546,8 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
 
   const int kd = a.kd;
   const bool partial = a.splits > 1;
+  char* const out_base = (!MRF && a.nn16) ? reinterpret_cast<char*>(a.nn16) : reinterpret_cast<char*>(a.nn_idx);   // uniform
+  const int out_sh = (!MRF && a.nn16) ? 1 : 3;
   const size_t obase = ((size_t)bg * N + nc) * a.k;
   const size_t pbase = (((size_t)split * a.BG + bg) * N + nc) * (size_t)kd;
   if constexpr (NWV == 1) {
@@ -561,7 +563,11 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
             a.part_v[pbase + j] = bv;
             a.part_i[pbase + j] = bi;
           } else if (j == next_rank) {
-            a.nn_idx[obase + outj] = (unsigned)bi < (unsigned)M ? bi : 0;   // non-finite distances only: stay in range
+            const int bc = (unsigned)bi < (unsigned)M ? bi : 0;             // non-finite distances only: stay in range
+            // compact lists (gkg_knn_fwd_tm16: callers inside the block) or the int64 plane: ONE address, two store widths
+            char* const op = out_base + ((obase + outj) << out_sh);
+            if (out_sh == 1) *reinterpret_cast<uint16_t*>(op) = (uint16_t)bc;
+            else *reinterpret_cast<int64_t*>(op) = bc;
             if (a.center) a.center[obase + outj] = n;
             ++outj;
             next_rank += a.dilation;
@@ -631,7 +637,9 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
                   if (a.nn16) a.nn16[obase + q] = (uint16_t)bc;
                   if (a.nn_idx) a.nn_idx[obase + q] = bc;
                 } else {
-                  a.nn_idx[obase + q] = bc;
+                  char* const op = out_base + ((obase + q) << out_sh);
+                  if (out_sh == 1) *reinterpret_cast<uint16_t*>(op) = (uint16_t)bc;
+                  else *reinterpret_cast<int64_t*>(op) = bc;
                 }
                 if (a.center) a.center[obase + q] = n;
               }

@@ -243,11 +243,13 @@ __global__ __launch_bounds__(256) void negate_kernel(const float* __restrict__ g
 // AK — what `argmax` holds for the backward: 0 = the winning SLOT j (u8, the C-ABI's documented form), 1 = the winning
 // neighbour's ROW INDEX itself (u16; needs M <= 65536).  With the row stored the backward scatters straight from it: no
 // index-row lookup, i.e. one dependent global round trip less per query and no 72-byte index rows to fetch.
-template <int KS, int QP, typename OutT = float, int AK = 0>   // KS: compile-time k (all k index loads and row gathers issued up front);
+__device__ __forceinline__ int clamp_idx(uint16_t v, int M) { return min((int)v, M - 1); }     // compact lists (gkg_mr_fwd_tm16)
+
+template <int KS, int QP, typename OutT = float, int AK = 0, typename IdxT = int64_t>   // KS: compile-time k (all k index loads and row gathers issued up front);
                             // QP: channel quads per thread (share one index row; QP*4 channels stay inside a group)
                             // OutT: element type of `out` (float, or uint16_t = bf16 for the grouped GEMM's operand)
 __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
-                                                        const int64_t* __restrict__ nn_idx, OutT* __restrict__ out,
+                                                        const IdxT* __restrict__ nn_idx, OutT* __restrict__ out,
                                                         uint8_t* __restrict__ argmax, int B, int G, int c, int N, int M,
                                                         int k_rt, int mode) {
   const int k = KS > 0 ? KS : k_rt;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
   const int ch = 4 * QP * (jt - n * CT);
   const size_t t = (size_t)b * N + n;
   const int g = ch / c;
-  const int64_t* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
+  const IdxT* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
   const float* sb = src + (size_t)b * M * C + ch;
   float4 xi[QP], best[QP];
   int ai[QP][4];                                                  // winner per channel: neighbour slot j (AK == 0) / row index (AK == 1)
@@ -1144,8 +1146,9 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
 }
 
 // ------------------------------------------------------------------------------------------ token-major entry points
-extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out, uint8_t* argmax,
-                             int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
+template <typename IdxT>
+static int mr_fwd_tm_impl(const float* x, const float* src, const IdxT* nn_idx, void* out, uint8_t* argmax,
+                          int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
   if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: arg_kind is 0 (u8 slot) or 1 (u16 row index)");
   if (arg_kind == 1 && M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: arg_kind 1 needs M <= 65536");
   if (!x || !nn_idx || !out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_fwd_tm: x, nn_idx and out must be non-null");
@@ -1157,7 +1160,7 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
   // algorithmic bytes (SURVEY §8d "MR gather-max fwd"): x + (keys) + int64 indices + m (+ 1 byte of argmax per element)
   const double e_out = out_dtype == GKG_BF16 ? 2.0 : 4.0;
-  const double work = 4.0 * B * (double)G * c * N + (has_src ? 4.0 * B * (double)G * c * M : 0.0) + 8.0 * B * (double)G * N * k
+  const double work = 4.0 * B * (double)G * c * N + (has_src ? 4.0 * B * (double)G * c * M : 0.0) + (double)sizeof(IdxT) * B * (double)G * N * k
                       + e_out * B * (double)G * c * N + (argmax ? 1.0 * B * (double)G * c * N : 0.0);
   GkgProfScope prof(GKG_PROF_MR_FWD, (hipStream_t)stream, work);
   // one channel quad per thread: two quads per thread (shared index row) measured 20 % slower at cfg2 — the kernel
@@ -1168,15 +1171,28 @@ extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
-    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
   } else {
     float* o = (float*)out;
-    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
-    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 1>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 0>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
+}
+
+extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out, uint8_t* argmax,
+                             int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
+  return mr_fwd_tm_impl<int64_t>(x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode, out_dtype, arg_kind, stream);
+}
+
+// gkg_mr_fwd_tm over the compact neighbour lists of gkg_knn_fwd_tm16 (u16 rows, M <= 65 536): same outputs, same bits; the
+// index stream is a quarter of the int64 one (SURVEY §8d "MR gather-max fwd": 8 B G N k -> 2 B G N k bytes).
+extern "C" int gkg_mr_fwd_tm16(const float* x, const float* src, const uint16_t* nn16, void* out, uint8_t* argmax,
+                               int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
+  if (M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm16: M <= 65536 (u16 rows)");
+  return mr_fwd_tm_impl<uint16_t>(x, src, nn16, out, argmax, B, G, c, N, M, k, mode, out_dtype, arg_kind, stream);
 }
 
 // The LDS-image backward kernels are instantiated per (self graph, mode, arg kind): 8 forms each, picked here.

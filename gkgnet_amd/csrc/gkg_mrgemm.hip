@@ -47,6 +47,7 @@ struct MrGemmArgs {
   const float* x;          // (B, N, C) token-major fp32
   const float* src;        // (B, M, C) or null (self graph: src = x, M = N)
   const int64_t* nn_idx;   // (B*G, N, k)
+  const uint16_t* nn16;    // (B*G, N, k) compact lists (gkg_knn_fwd_tm16) instead of nn_idx, or null
   const uint4* wp;         // [4][ci_pad/8][co_pad] fragments of 8 consecutive input channels (bf16)
   const float* a;          // (4*co) BN scale
   const float* cs;         // (4*co) BN shift (conv bias folded)
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(64 * MG_NW, WPE) void mr_linear_bf16_kernel(MrGemmA
       int v = 0;
       if (t < g.T) {
         const int b = (int)(t / N), n = (int)(t - (long long)b * N);
-        v = (MG_ABL & 8) ? min(n, M - 1) : mg_clamp(g.nn_idx[(((size_t)b * g.G + glo + gi) * N + n) * k + jj], M);
+        const size_t ie = (((size_t)b * g.G + glo + gi) * N + n) * k + jj;
+        v = (MG_ABL & 8) ? min(n, M - 1) : (g.nn16 ? min((int)g.nn16[ie], M - 1) : mg_clamp(g.nn_idx[ie], M));
       }
       ids[e] = v;
     }
@@ -330,10 +332,10 @@ extern "C" size_t gkg_mr_linear_planes_bytes(int C) {
 // out (T, ldo) bf16 [:, 0 : 2C] = act(a * (Conv1x1_{groups=4}([x, max_k(src[idx] - x)] interleaved)) + c), token-major.
 //   x (B, N, C) fp32, src (B, M, C) fp32 or NULL (self graph, M == N), nn_idx (B*G, N, k) int64, C = G * c,
 //   wplanes: gkg_mr_linear_planes_bytes(C) bytes (layout above), a / cshift (2C) fp32, act 0 none / 1 GELU (erf).
-extern "C" int gkg_mr_linear_bf16(const float* x, const float* src, const int64_t* nn_idx, const void* wplanes, const float* a,
-                                  const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k, int act,
-                                  void* stream) {
-  if (!x || !nn_idx || !wplanes || !a || !cshift || !out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_linear_bf16: null pointer");
+static int mr_linear_bf16_impl(const float* x, const float* src, const int64_t* nn_idx, const uint16_t* nn16, const void* wplanes,
+                               const float* a, const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k,
+                               int act, void* stream) {
+  if (!x || (!nn_idx && !nn16) || !wplanes || !a || !cshift || !out) return gkg_fail(GKG_ERR_NULL, "gkg_mr_linear_bf16: null pointer");
   if (B <= 0 || G <= 0 || c <= 0 || N <= 0 || M <= 0 || k <= 0 || k > 64 || act < 0 || act > 1)
     return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_linear_bf16: bad sizes (need > 0, k <= 64, act in 0..1)");
   const long long C = (long long)G * c;
@@ -341,7 +343,7 @@ extern "C" int gkg_mr_linear_bf16(const float* x, const float* src, const int64_
   if (!src && M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_linear_bf16: self graph needs M == N");
   if (ldo < 2 * C || (ldo & 7)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_linear_bf16: need ldo >= 2C and ldo % 8 == 0");
   MrGemmArgs g;
-  g.x = x; g.src = src; g.nn_idx = nn_idx; g.wp = (const uint4*)wplanes; g.a = a; g.cs = cshift;
+  g.x = x; g.src = src; g.nn_idx = nn_idx; g.nn16 = nn16; g.wp = (const uint4*)wplanes; g.a = a; g.cs = cshift;
   g.out = (uint16_t*)out; g.ldo = ldo;
   g.B = B; g.G = G; g.c = c; g.N = N; g.M = M; g.k = k; g.C = (int)C; g.Cq = (int)C / 4; g.ci = (int)C / 2; g.co = (int)C / 2;
   g.ci_pad = (g.ci + 15) & ~15; g.co_pad = (g.co + 31) & ~31; g.act = act;
@@ -361,4 +363,18 @@ extern "C" int gkg_mr_linear_bf16(const float* x, const float* src, const int64_
   else if (all_groups) e = k == 9 ? mg_launch<9, 4>(g, st) : (k == 18 ? mg_launch<18, 4>(g, st) : mg_launch<0, 4>(g, st));
   else e = k == 9 ? mg_launch<9, 1>(g, st) : (k == 18 ? mg_launch<18, 1>(g, st) : mg_launch<0, 1>(g, st));
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_linear_bf16_kernel");
+}
+
+extern "C" int gkg_mr_linear_bf16(const float* x, const float* src, const int64_t* nn_idx, const void* wplanes, const float* a,
+                                  const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k, int act,
+                                  void* stream) {
+  return mr_linear_bf16_impl(x, src, nn_idx, nullptr, wplanes, a, cshift, out, ldo, B, G, c, N, M, k, act, stream);
+}
+
+// gkg_mr_linear_bf16 over the compact neighbour lists of gkg_knn_fwd_tm16 (u16 rows, M <= 65 536): same result.
+extern "C" int gkg_mr_linear_bf16_nn16(const float* x, const float* src, const uint16_t* nn16, const void* wplanes, const float* a,
+                                       const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k, int act,
+                                       void* stream) {
+  if (M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_linear_bf16_nn16: M <= 65536 (u16 rows)");
+  return mr_linear_bf16_impl(x, src, nullptr, nn16, wplanes, a, cshift, out, ldo, B, G, c, N, M, k, act, stream);
 }

@@ -1206,6 +1206,36 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
 
 _KNN_GRAPH_TM = knn_graph_tm             # the library's own function (tests patch ``fused.knn_graph_tm`` to record / force graphs)
 
+# Compact graph inside the block (round 5): a Grapher discards its graph (reference torch_vertex.py:330), so between the k-NN
+# and the aggregation launches the neighbour lists travel as u16 rows (B*G, N, k) — no int64 plane, no centre plane (GKGNet-576
+# stage 1: 24 MB written per launch instead of 191 MB; pvig_m stage 1: 170 MB instead of 1.36 GB).  Same neighbours, same bits.
+# Taken when nobody asked for the edge_index, M <= 65536 and ``fused.knn_graph_tm`` is the library's own function (tests that
+# record or force graphs patch it and get the int64 form).  GKG_DISABLE=knn_compact: off.
+KNN_COMPACT = "knn_compact" not in _DISABLED
+
+
+@torch.no_grad()
+def knn_graph_tm16(x, y, relative_pos, k, dilation, G):
+    """x (B,N,C), y (B,M,C)|None token-major -> neighbour lists (B*G, N, k) int16 (the bits of u16 rows)."""
+    lib = _lib.load()
+    B, N, C = x.shape
+    c = C // G
+    M = N if y is None else y.shape[1]
+    flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags()
+    if KNN_BF16 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        flags |= _lib.KNN_BF16_CONTRACT
+    rp = None
+    if relative_pos is not None:
+        rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
+        if tuple(rp.shape) != (N, M):
+            raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+        flags |= _lib.relpos_flags(relative_pos)
+    nn16 = torch.empty((B * G, N, k), dtype=torch.int16, device=x.device)
+    ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
+    _lib.check(lib.gkg_knn_fwd_tm16(_ptr(x), _ptr(y), _ptr(rp), _ptr(nn16), B, G, c, N, M, k, dilation, _lib.F32, flags,
+                                    _ptr(ws), ws.numel(), _stream()), "gkg_knn_fwd_tm16")
+    return nn16
+
 
 class _MaxRelativeTM(torch.autograd.Function):
     @staticmethod
@@ -1220,8 +1250,13 @@ class _MaxRelativeTM(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:2])
         ak = 1 if M <= 65536 else 0              # the winning neighbour's row index (u16) instead of its slot (u8)
         arg = torch.empty((B, N, C), dtype=torch.int16 if ak else torch.uint8, device=x.device) if need else None
-        _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
-                                     code, ak, _stream()), "gkg_mr_fwd_tm")
+        if nn_idx.dtype == torch.int16:          # compact lists (knn_graph_tm16; M <= 65536, so ak == 1: the backward needs no index)
+            _lib.check(lib.gkg_mr_fwd_tm16(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
+                                           code, ak, _stream()), "gkg_mr_fwd_tm16")
+            nn_idx = None
+        else:
+            _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
+                                         code, ak, _stream()), "gkg_mr_fwd_tm")
         ctx.save_for_backward(nn_idx, arg)
         ctx.meta = (B, G, C, N, M, k, mode, src is not None, ak)
         return out
@@ -1455,8 +1490,9 @@ def mr_grouped_linear_eval(x, src, nn_idx, G, conv, bn, act=1):
     src = None if src is None else src.contiguous()
     a, c = _bn_eval_ac(lib, bn, conv.bias, 2 * C)
     out = torch.empty((B * N, 2 * C), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.gkg_mr_linear_bf16(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(_mr_planes_of(conv)), _ptr(a), _ptr(c), _ptr(out),
-                                      2 * C, B, G, C // G, N, M, nn_idx.shape[2], act, _stream()), "gkg_mr_linear_bf16")
+    fn = lib.gkg_mr_linear_bf16_nn16 if nn_idx.dtype == torch.int16 else lib.gkg_mr_linear_bf16      # compact lists: knn_graph_tm16
+    _lib.check(fn(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(_mr_planes_of(conv)), _ptr(a), _ptr(c), _ptr(out),
+                  2 * C, B, G, C // G, N, M, nn_idx.shape[2], act, _stream()), "gkg_mr_linear_bf16")
     return out
 
 
@@ -1550,6 +1586,10 @@ def _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge):
         U, edge = _KnnMaxRelativeTM.apply(x1b, yb, relative_pos, gc.k, gc.d, groups, want_edge)
         a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, False, None)
         return a2, (edge if want_edge else None)
+    M = N if yb is None else yb.shape[1]
+    if KNN_COMPACT and not want_edge and M <= 65536 and knn_graph_tm is _KNN_GRAPH_TM and not MR_X6:
+        nn16 = knn_graph_tm16(x1b, yb, relative_pos, gc.k, gc.d, groups)        # u16 lists: no int64 edge_index, no centre plane
+        return _aggregate_project(x1b, yb, nn16, groups, nn_, C, lp), None
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
     return _aggregate_project(x1b, yb, edge[0], groups, nn_, C, lp), edge      # row g1: aggregation = the projection's operand producer
 

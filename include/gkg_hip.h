@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 7
+#define GKG_ABI_VERSION 8
 
 /* dtype codes */
 #define GKG_F32 0
@@ -162,12 +162,26 @@ int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t
  *                    largest magnitude, the fan-in is summed with 64-bit integer LDS atomics and rounded ONCE to fp32:
  *                    independent of the arrival order (bit-identical from run to run) and at least as accurate as an
  *                    fp32 sum; non-finite gradients fall back to fp32 atomics per chunk (inf / NaN propagate).
+ *                    From 160 query rows per image the same accumulation runs in ONE sweep (round 5): the scale comes from
+ *                    a strided sample of the chunk's rows plus 6 binary orders of headroom (the exact maximum when a thread's
+ *                    first rows are the whole sweep); a gradient beyond the headroom makes that workgroup redo its chunk with
+ *                    the exact two-sweep form.  Still order-independent and bit-identical from run to run.
  *                    flags & GKG_MR_FP32_ATOMICS: the round-1 fp32 LDS-atomic kernels (fan-in summed in arrival order);
  *                    flags & GKG_MR_DETERMINISTIC (shapes beyond the LDS budget): private accumulators, fixed order.
  */
 int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Compact graph (round 5): gkg_knn_fwd_tm's neighbour lists as u16 rows, nn16 (B*G, N, k), INSTEAD of the int64 planes — for
+ * callers that consume the graph on the device and do not hand it out (Grapher.forward discards it, reference
+ * torch_vertex.py:330): no int64 index plane, no centre plane (GKGNet-576 stage 1: 24 MB written per launch instead of 191 MB).
+ * Same contract, same neighbours in the same order as gkg_knn_fwd_tm; M <= 65536.  gkg_mr_fwd_tm16 / gkg_mr_linear_bf16_nn16
+ * are gkg_mr_fwd_tm / gkg_mr_linear_bf16 reading these lists (same outputs, same bits). */
+int gkg_knn_fwd_tm16(const void* x, const void* y, const float* relpos, uint16_t* nn16, int B, int G, int c, int N, int M, int k,
+                     int dilation, int dtype, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+int gkg_mr_fwd_tm16(const float* x, const float* src, const uint16_t* nn16, void* out /* out_dtype elements */, uint8_t* argmax,
+                    int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream);
 
 /* Row g2 (round 5): the k-NN graph AND the max-relative aggregation over it in ONE kernel, for token-major fp32 callers — the
  * reference chain DenseDilatedKnnGraph.forward (torch_edge.py:164-176) -> MRConv2d.forward's two batched_index_select + max
@@ -213,6 +227,9 @@ size_t gkg_mr_linear_planes_bytes(int C);
 int gkg_mr_linear_bf16(const float* x, const float* src, const int64_t* nn_idx, const void* wplanes, const float* a,
                        const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k, int act,
                        void* stream);
+int gkg_mr_linear_bf16_nn16(const float* x, const float* src, const uint16_t* nn16, const void* wplanes, const float* a,
+                            const float* cshift, void* out, int ldo, int B, int G, int c, int N, int M, int k, int act,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bandwidth kernels between the dense 1x1 projections (Conv2d 1x1 + SyncBN [+ GELU], reference
