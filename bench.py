@@ -759,8 +759,10 @@ def main():
         # HBM-bound companions of the k-NN kernel (the gather + max-relative forward and its scatter backward): ALGORITHMIC
         # bytes per SURVEY §8d, reported by the library per launch (gkg_prof_work), / measured time, vs 8 TB/s
         roof_hbm = {}
-        mr_bwd_kernel = ("mr_bwd_tm_det_* (GKG_DETERMINISTIC)" if fused.DETERMINISTIC else
-                         "mr_bwd_tm_scatter_i64_kernel" if fused.MR_I64 else "mr_bwd_tm_scatter_kernel")
+        # (round 5: from 160 query rows per image the exact scatter is the one-sweep streaming form; label graphs keep the
+        # two-sweep kernel; both are order-independent, so GKG_DETERMINISTIC runs them too)
+        mr_bwd_kernel = ("mr_bwd_tm_stream_kernel (>= 160 query rows) / mr_bwd_tm_scatter_i64_kernel" if fused.MR_I64
+                         else "mr_bwd_tm_scatter_kernel")
         for name, kern in (("mr_fwd", "mr_fwd_tm_kernel"), ("mr_bwd", mr_bwd_kernel)):
             if name in kernels and kernels[name]["us_per_step"] > 0:
                 nbytes = _lib.prof_work(name) / prof_steps
