@@ -49,7 +49,11 @@ struct PrepStrides { int G; size_t sb, sg, sc, sn; };
 // tb_lo != null (prefilter mode, see knn_pf_kernel): besides the fp32 channel-major copy th (the exact re-rank reads it) the
 // two leading bf16 terms of every normalised value, hi = bf16(v) and lo = bf16(v - hi), are written as token-major
 // (bg, n, cp16) planes (tb = hi, tb_lo = lo) for the matrix-core prefilter.
-struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; uint16_t* tb_lo; };
+// Prefilter planes, round 5: channels c and c + 1 of the HI plane carry the two leading bf16 terms of the token's |th|^2 (LO plane:
+// zeros) — the kernel stages a query's copy of those two channels as (1, 1), so the matrix cores add |y|^2 to every distance and
+// the selection loses a v_readlane + s_nop + v_add per candidate; the planes have `rows` = Tn rounded up to 32 rows, the pad rows
+// hold MASKED_SQ there (keys past M mask themselves).  cp16 >= c + 2 in that mode.
+struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; uint16_t* tb_lo; int rows; };
 
 template <typename T, bool NORM, int PT>
 __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
@@ -63,7 +67,22 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   const PrepStrides ps = S.ps;
   const int n = ((int)blockIdx.x - (second ? nbx1 : 0)) * PT + threadIdx.x;
   const int bg = blockIdx.y;
-  if (n >= Tn) return;
+  if (n >= Tn) {
+    if (S.tb_lo && n < S.rows) {                    // prefilter planes: pad rows up to a multiple of 32 mask themselves
+      uint4* ohi = reinterpret_cast<uint4*>(S.tb) + (size_t)bg * (S.cp16 >> 3) * S.rows + n;
+      uint4* olo = reinterpret_cast<uint4*>(S.tb_lo) + (size_t)bg * (S.cp16 >> 3) * S.rows + n;
+      for (int c0 = 0; c0 < S.cp16; c0 += 8) {
+        uint32_t wv[4] = {0u, 0u, 0u, 0u};
+        if (c >= c0 && c < c0 + 8) {
+          const uint32_t mk = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)MASKED_SQ);
+          wv[(c - c0) >> 1] = ((c - c0) & 1) ? (mk << 16) : mk;
+        }
+        ohi[(size_t)(c0 >> 3) * S.rows] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        olo[(size_t)(c0 >> 3) * S.rows] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    return;
+  }
   // element (bg = b*G + g, ch, n) of the input lives at  b*sb + g*sg + ch*sc + n*sn
   const T* tp = t + (size_t)(bg / ps.G) * ps.sb + (size_t)(bg % ps.G) * ps.sg + (size_t)n * ps.sn;
   float* cp = col + threadIdx.x;
@@ -107,25 +126,45 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   // ---- (3) normalise, store, |th|^2
   float q2 = 0.0f;
   if (S.tb_lo) {                                    // prefilter mode: bf16 hi / lo planes (token-major) + th / sq below
-    // octet-major planes (bg, cp16 / 8, Tn, 8): consecutive tokens are consecutive 16-byte fragments
-    uint4* ohi = reinterpret_cast<uint4*>(S.tb) + (size_t)bg * (S.cp16 >> 3) * Tn + n;
-    uint4* olo = reinterpret_cast<uint4*>(S.tb_lo) + (size_t)bg * (S.cp16 >> 3) * Tn + n;
+    // the fp32 copy and |th|^2 first (the exact re-rank reads them): the two leading bf16 terms of |th|^2 ride in channels c, c + 1
+    float q2p = 0.0f;
+    {
+      float* op = th + (size_t)bg * cpad * Tn + n;
+#pragma unroll 8
+      for (int ch = 0; ch < c; ++ch) {
+        float v = cp[ch * PT];
+        if (NORM) { v = v / den; cp[ch * PT] = v; }      // the planes below split the normalised value: one division per element
+        op[(size_t)ch * Tn] = v;
+        q2p = __builtin_fmaf(v, v, q2p);
+      }
+      for (int chp = c; chp < cpad; ++chp) op[(size_t)chp * Tn] = 0.0f;
+      sq[(size_t)bg * Tn + n] = q2p;
+    }
+    const float q2h = __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)q2p)) << 16);
+    const float q2l = q2p - q2h;
+    // octet-major planes (bg, cp16 / 8, rows, 8): consecutive tokens are consecutive 16-byte fragments
+    const int R = S.rows;
+    uint4* ohi = reinterpret_cast<uint4*>(S.tb) + (size_t)bg * (S.cp16 >> 3) * R + n;
+    uint4* olo = reinterpret_cast<uint4*>(S.tb_lo) + (size_t)bg * (S.cp16 >> 3) * R + n;
     for (int c0 = 0; c0 < S.cp16; c0 += 8) {
       uint32_t wh[4], wl[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float v0 = c0 + 2 * u < c ? cp[(c0 + 2 * u) * PT] : 0.0f;
-        float v1 = c0 + 2 * u + 1 < c ? cp[(c0 + 2 * u + 1) * PT] : 0.0f;
-        if (NORM) { v0 = v0 / den; v1 = v1 / den; }
-        const float h0 = __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v0)) << 16);
-        const float h1 = __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v1)) << 16);
+        const int e0 = c0 + 2 * u, e1 = e0 + 1;
+        float v0 = e0 < c ? cp[e0 * PT] : 0.0f;
+        float v1 = e1 < c ? cp[e1 * PT] : 0.0f;
+        float l0 = v0 - __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v0)) << 16);
+        float l1 = v1 - __uint_as_float(((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v1)) << 16);
+        if (e0 == c) { v0 = q2h; l0 = 0.0f; } else if (e0 == c + 1) { v0 = q2l; l0 = 0.0f; }
+        if (e1 == c) { v1 = q2h; l1 = 0.0f; } else if (e1 == c + 1) { v1 = q2l; l1 = 0.0f; }
         wh[u] = pack_bf16x2(v0, v1);
-        wl[u] = pack_bf16x2(v0 - h0, v1 - h1);
+        wl[u] = pack_bf16x2(l0, l1);
       }
-      ohi[(size_t)(c0 >> 3) * Tn] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-      olo[(size_t)(c0 >> 3) * Tn] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+      ohi[(size_t)(c0 >> 3) * R] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+      olo[(size_t)(c0 >> 3) * R] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
     }
-  } else
+    return;
+  }
   if (S.tb) {                                       // bf16 token-major copy: 16-byte stores of 8 channels
     uint4* ob = reinterpret_cast<uint4*>(S.tb) + (size_t)bg * (S.cp16 >> 3) * Tn + n;      // octet-major (bg, cp16/8, Tn, 8)
     for (int c0 = 0; c0 < S.cp16; c0 += 8) {
@@ -342,9 +381,10 @@ static int make_plan(int BG, int c, int N, int M, int k, int dilation, bool has_
   } else {
     p->off_pv = p->off_pi = 0;
     // prefilter mode (un-split problems): bf16 hi + lo planes (BG, T, cp16) of the queries and keys
-    const size_t cp16 = (size_t)((c + 15) & ~15);
-    p->off_xp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * N * cp16);
-    if (has_y) { p->off_yp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * M * cp16); }
+    const size_t cp16 = (size_t)((c + 2 + 15) & ~15);               // + the two |th|^2 channels (see PrepSet)
+    const size_t Nr = (size_t)((N + 31) & ~31), Mr = (size_t)((M + 31) & ~31);
+    p->off_xp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * Nr * cp16);
+    if (has_y) { p->off_yp = o; o = al(o + 2 * sizeof(uint16_t) * (size_t)BG * Mr * cp16); }
     else p->off_yp = p->off_xp;
     p->off_flags = o; o = al(o + sizeof(int) * (size_t)((N + QT - 1) / QT) * ((BG + 7) / 8) * 8);   // one per workgroup
   }
@@ -362,8 +402,8 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
 
 template <typename T, int PT>
 static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
-  const int nbx1 = (s1.Tn + PT - 1) / PT;
-  const int nbx2 = s2 ? (s2->Tn + PT - 1) / PT : 0;
+  const int nbx1 = ((s1.tb_lo ? s1.rows : s1.Tn) + PT - 1) / PT;
+  const int nbx2 = s2 ? ((s2->tb_lo ? s2->rows : s2->Tn) + PT - 1) / PT : 0;
   dim3 grid(nbx1 + nbx2, BG);
   const size_t lds = (size_t)c * PT * sizeof(float);
   const PrepSet second = s2 ? *s2 : s1;
@@ -448,8 +488,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // otherwise the flag is ignored
   const bool bf = (flags & GKG_KNN_BF16_CONTRACT) != 0 && p.cpad >= 16;
   const int cp16 = (c + 15) & ~15;
+  const int cp16p = (c + 2 + 15) & ~15;            // prefilter planes: + the two |th|^2 channels (see PrepSet)
+  const int Nr = (N + 31) & ~31, Mr = (M + 31) & ~31;
   // prefilter mode: the bit-exact contract path for normalised, un-split problems with lists up to 36 entries (LDS)
-  const size_t pf_stage = (size_t)2 * QT * (cp16 + 8) * 2;
+  const size_t pf_stage = (size_t)2 * QT * (cp16p + 8) * 2;
   // Where it pays (MI355X, tools/bench_ops.py, prefilter vs fp32 tile kernel, us per launch incl. the extra preparation
   // work): long key streams, where the contraction dominates — pvig_s@576 stage 3 (c = 200, 1296 x 1296) k*d = 18:
   // 437 + 92 vs 594 + 57, k*d = 27: 525 + 91 vs 827 + 56; stage 2 (c = 80, 5184 x 1296, k*d = 9): 675 + 82 vs 882 + 58;
@@ -499,10 +541,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   }
   uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
   uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
-  const PrepSet sx{x, xh, sqx, N, strides(N), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), cp16,
-                   pf ? xpl + (size_t)BG * N * cp16 : nullptr};
-  const PrepSet sy{y, yh, sqy, M, strides(M), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), cp16,
-                   pf ? ypl + (size_t)BG * M * cp16 : nullptr};
+  const PrepSet sx{x, xh, sqx, N, strides(N), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), pf ? cp16p : cp16,
+                   pf ? xpl + (size_t)BG * Nr * cp16p : nullptr, Nr};
+  const PrepSet sy{y, yh, sqy, M, strides(M), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), pf ? cp16p : cp16,
+                   pf ? ypl + (size_t)BG * Mr * cp16p : nullptr, Mr};
   if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
@@ -536,7 +578,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // (counters, pvig_s stage 1: 7.5 GB of L2 misses per launch at B*G = 64 — the launch ran at the speed of that stream).
   // Interleave the XCD's problems in groups whose key sets stay in the L2 (<= 2 MB): the bias is fetched once per group.
   if (relpos && a.rp_major == 0 && p.S == 1 && BG >= 16 && (size_t)N * M * 4 >= ((size_t)8 << 20)) {
-    const size_t key_bytes = (size_t)M * (pf ? (size_t)cp16 * 4 : (size_t)p.cpad * 4);
+    const size_t key_bytes = (size_t)M * (pf ? (size_t)cp16p * 4 : (size_t)p.cpad * 4);
     const int bpx = (BG + 7) / 8;
     int g = (int)(((size_t)2 << 20) / (key_bytes ? key_bytes : 1));
     g = g > bpx ? bpx : g;
@@ -544,11 +586,13 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     if (g >= 2) { a.rp_major = 2; a.rp_group = g; }
   }
   if (pf) {
-    a.xb = xpl; a.xb_lo = xpl + (size_t)BG * N * cp16;
-    a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * M * cp16 : a.xb_lo;
-    // eps = split terms dropped (3 * 2^-18 * 2 = 2.3e-5) + fp32 accumulation of the 3c products, the bias and |y|^2 on partial
-    // sums <= |bias| + 2 <= 3.125 (9.4c * 2^-24) + the contract's own chain (2c * 2^-24): 11.4 c u = 6.8e-7 c; margin = 2 eps
-    a.margin = 2.0f * (3.0e-5f + 7.0e-7f * (float)p.cpad);
+    a.xb = xpl; a.xb_lo = xpl + (size_t)BG * Nr * cp16p;
+    a.yb = y ? ypl : xpl; a.yb_lo = y ? ypl + (size_t)BG * Mr * cp16p : a.xb_lo;
+    a.cp16 = cp16p; a.pf_c = c; a.pf_nrows = Nr; a.pf_mrows = y ? Mr : Nr;
+    // eps = split terms dropped (3 * 2^-18 * 2 = 2.3e-5) + |y|^2 entering as its two leading bf16 terms (2^-17 |y|^2 <= 7.7e-6)
+    // + fp32 accumulation of the 3c + 2 products and the bias on partial sums <= |bias| + 2 + |y|^2 <= 4.125 (12.4c * 2^-24) +
+    // the contract's own chain (2c * 2^-24): 14.4 c u = 8.6e-7 c; margin = 2 eps
+    a.margin = 2.0f * (4.0e-5f + 9.0e-7f * (float)cp16p);
     a.wg_flags = (int*)(ws + p.off_flags);
     e = hipMemsetAsync(a.wg_flags, 0, sizeof(int) * (size_t)grid.x, st);
     if (e != hipSuccess) return gkg_fail_hip(e, "knn_pf_kernel (flags)");

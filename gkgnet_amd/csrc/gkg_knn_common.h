@@ -134,6 +134,7 @@ struct KnnArgs {
   const uint16_t* xb_lo;  // lo planes
   const uint16_t* yb_lo;
   float margin;           // 2 * eps: eps bounds |prefilter distance - contract distance| (see knn_pf_kernel)
+  int pf_c, pf_nrows, pf_mrows;   // prefilter planes: channel count (|th|^2 rides in channels pf_c, pf_c + 1), padded row counts
   int* wg_flags;          // [gridDim.x] or null.  knn_pf_kernel: sets [blockIdx.x] = 1 (and writes no output) for a query
                           // tile it cannot settle; knn_tile_kernel: when non-null, only flagged workgroups run (clean-up pass)
   // fused aggregation (knn_tile_kernel<..., MRF = true>): token-major fp32 centre / source rows, outputs (see the kernel)

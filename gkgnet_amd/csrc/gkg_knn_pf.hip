@@ -4,6 +4,12 @@
 #include "gkg_knn_common.h"
 #include "gkg_topk_merge.h"
 
+// -DPF_ABL=<bits> (tools/ubench/pf_ablate.py only; results wrong, timing valid): 1 no candidate appends (tested, never stored),
+// 2 no MFMAs, 4 no relative_pos loads, 8 no selection at all (the accumulators are summed into a sink), 16 no key-operand loads
+#ifndef PF_ABL
+#define PF_ABL 0
+#endif
+
 namespace gkg {
 
 // ------------------------------------------------------------------------------------------ prefilter + exact re-rank
@@ -87,17 +93,20 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
     return nleft >= nright ? c0 - (i - nboth) : c0 + (i - nboth);
   };
   const int t_first = tile_at(min(w, ktiles - 1));
-  const uint4* yhp = reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * M;       // octet-major planes
-  const uint4* ylp = reinterpret_cast<const uint4*>(a.yb_lo) + (size_t)bg * (cp16 >> 3) * M;
+  // octet-major planes with MR = M rounded up to 32 rows (round 5): the pad rows carry MASKED_SQ in the |y|^2 channel, so the
+  // keys past M of the last tile mask themselves and no row index is clamped
+  const int MR = a.pf_mrows, NR = a.pf_nrows;
+  const uint4* yhp = reinterpret_cast<const uint4*>(a.yb) + (size_t)bg * (cp16 >> 3) * MR;
+  const uint4* ylp = reinterpret_cast<const uint4*>(a.yb_lo) + (size_t)bg * (cp16 >> 3) * MR;
   uint4 bh_[KB], bl_[KB];
   {
-    const int mk0 = min(t_first * KT + l31, M - 1);
-    const uint4* h0 = yhp + (size_t)kk * M + mk0;
-    const uint4* l0 = ylp + (size_t)kk * M + mk0;
+    const int mk0 = t_first * KT + l31;
+    const uint4* h0 = yhp + (size_t)kk * MR + mk0;
+    const uint4* l0 = ylp + (size_t)kk * MR + mk0;
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-      bh_[u] = u < S16 ? h0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
-      bl_[u] = u < S16 ? l0[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
+      bh_[u] = u < S16 ? h0[(size_t)(2 * u) * MR] : make_uint4(0, 0, 0, 0);
+      bl_[u] = u < S16 ? l0[(size_t)(2 * u) * MR] : make_uint4(0, 0, 0, 0);
     }
   }
   // ---- stage the query tile: hi and lo planes scaled by -2 (exact), rows of cp16 + 8 bf16
@@ -105,8 +114,9 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   char* xq_hi = reinterpret_cast<char*>(smem);
   char* xq_lo = xq_hi + QT * qpitch;
   {
-    const uint4* xhp = reinterpret_cast<const uint4*>(a.xb) + (size_t)bg * (cp16 >> 3) * N;
-    const uint4* xlp = reinterpret_cast<const uint4*>(a.xb_lo) + (size_t)bg * (cp16 >> 3) * N;
+    const uint4* xhp = reinterpret_cast<const uint4*>(a.xb) + (size_t)bg * (cp16 >> 3) * NR;
+    const uint4* xlp = reinterpret_cast<const uint4*>(a.xb_lo) + (size_t)bg * (cp16 >> 3) * NR;
+    const int qc = a.pf_c;                          // channels qc, qc + 1: the keys' |y|^2 terms; a QUERY stages (1, 1) there (hi), (0, 0) (lo)
     const int chunks = cp16 >> 3;
     auto m2h = [](unsigned hv) -> unsigned {
       const unsigned e = hv & 0x7f80u;
@@ -121,11 +131,26 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       const int r = i - pl * QT * chunks;
       const int ck = r >> 6, q = r & 63;           // consecutive threads: consecutive queries of one octet (coalesced)
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (n0 + q < N) v = (pl ? xlp : xhp)[(size_t)ck * N + n0 + q];
+      if (n0 + q < N) v = (pl ? xlp : xhp)[(size_t)ck * NR + n0 + q];
       v.x = m2(v.x); v.y = m2(v.y); v.z = m2(v.z); v.w = m2(v.w);
+      {
+        unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r8 = qc + e - 8 * ck;           // position of channel qc + e inside this octet
+          if (r8 >= 0 && r8 < 8) {
+            const unsigned one = pl ? 0u : 0x3f80u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if ((r8 >> 1) == u) wv[u] = (r8 & 1) ? ((wv[u] & 0x0000ffffu) | (one << 16)) : ((wv[u] & 0xffff0000u) | one);
+          }
+        }
+        v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      }
       *reinterpret_cast<uint4*>((pl ? xq_lo : xq_hi) + q * qpitch + 16 * ck) = v;
     }
   }
+  if (PBUF > 0) reinterpret_cast<float*>(xq_lo + QT * qpitch + (size_t)PBUF * 256 * 8)[tid] = INFINITY;   // shared admission bounds (see flush)
   __syncthreads();
   KNN_TL(2);
 
@@ -134,9 +159,33 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   TopList<KDW> top;
   top.init();
   float2* cbuf = reinterpret_cast<float2*>(xq_lo + QT * qpitch) + tid;      // [PBUF][256] behind the staged queries
-  int bcnt = 0;
+  // the lane's append cursor IS its entry count (knn_tile_kernel's form): an admitted candidate costs the store + one add
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2u_t lds_v2u_t;
+  unsigned cw0 = (unsigned)(size_t)(lds_v2u_t*)cbuf;
+  asm volatile("" : "+v"(cw0));
+  unsigned cw_lim = cw0 + (PBUF > 8 ? PBUF - 8 : 0) * 256 * 8;
+  asm volatile("" : "+v"(cw_lim));
+  unsigned cw = cw0;
   float thr = INFINITY;
+  constexpr bool PSHARE = PBUF > 0;
+  constexpr int QSH = (KD + NW - 1) / NW;
+  float* ths = reinterpret_cast<float*>(xq_lo + QT * qpitch + (size_t)PBUF * 256 * 8);      // [NW][64] behind the candidate buffer (set to +inf before the staging barrier)
+  const float margin_s = a.margin;
   auto flush = [&]() {
+    unsigned cw_now = cw;
+    asm volatile("" : "+v"(cw_now));
+    int bcnt = (int)((cw_now - cw0) / (256 * 8));
+#if PF_ABL & 64
+    {                                               // tools/ubench/pf_ablate.py counters: flushes, entries, insert rounds (max over lanes)
+      unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.part_v);
+      if (lane == 0) atomicAdd(&ctr[0], 1ull);
+      atomicAdd(&ctr[1], (unsigned long long)bcnt);
+      int mx = bcnt;
+      for (int m_ = 1; m_ < 64; m_ <<= 1) mx = max(mx, __shfl_xor(mx, m_, 64));
+      if (lane == 0) atomicAdd(&ctr[2], (unsigned long long)mx);
+    }
+#endif
     if constexpr (PBUF >= 12 && KDW >= 16) {
       if (__builtin_amdgcn_ballot_w64(bcnt > 3) != 0ull) {
         double b[16];
@@ -160,8 +209,26 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       const double k = i < bcnt ? pack_key(e.x, __float_as_int(e.y)) : (double)INFINITY;
       top.template insert_key<false>(k);
     }
-    bcnt = 0;
+    cw = cw0;
     thr = key_dist(top.key[KDW - 1]);
+    if constexpr (PSHARE) {
+      // shared admission bound (round 5; knn_tile_kernel's SHARE carried over): the Q = ceil(KD / 4) best entries of the four
+      // waves' lists are >= KD distinct keys, so the query's final KD-th prefilter distance tau is <= sh = the largest of the
+      // waves' Q-th entries.  A candidate beyond sh + margin is no survivor (S = {d <= tau + margin}) and cannot be one of the
+      // KD best: it never needs to enter a list.  Published / read without synchronisation: a stale value is an older, larger
+      // one — still a bound.  What it buys: the appends and the flushes behind them are a third of this launch at pvig_s
+      // stage 1 (tools/ubench/pf_ablate.py: 1 915 -> 1 330 us without them); a wave's own KDW-th entry over its quarter of the
+      // keys admits ~4 x 50 candidates per query, the shared bound ~70.
+      const float mine = key_dist(top.key[QSH - 1]);              // +inf while the list holds fewer than Q entries
+      ths[w * 64 + lane] = mine;
+      float m = mine;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) m = fmaxf(m, ths[ww * 64 + lane]);
+      if (m < INFINITY) {
+        const float b = m + margin_s;
+        thr = fminf(thr, __int_as_float(__float_as_int(b) + (b >= 0.0f ? 1 : -1)));       // rounded away: never tighter than sh + margin
+      }
+    }
   };
   // relative_pos rows of the two query blocks this lane's accumulator columns belong to
   const int nq0 = min(n0 + l31, N - 1), nq1 = min(n0 + 32 + l31, N - 1);
@@ -171,7 +238,12 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   // stage 3).  With 12-entry lists they cost the third wave per SIMD and the kernel loses (stage 1 2230 -> 2450 us).
   constexpr bool AHEAD = KDW > 16 || SB;
   float4 rq0[4], rq1[4];
-  float sy_n = MASKED_SQ;
+#if PF_ABL & 4
+  for (int g_ = 0; g_ < 4; ++g_) { rq0[g_] = make_float4(0.f, 0.f, 0.f, 0.f); rq1[g_] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#endif
+#if PF_ABL & (1 | 8)
+  float abl_sink = INFINITY;
+#endif
   const size_t rp_row0 = (size_t)min(n0, N - 1) * M;
   const size_t rp_left = ((size_t)N * M - rp_row0) * sizeof(float);
   const __amdgpu_buffer_rsrc_t rp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -180,8 +252,7 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
   const unsigned rp_o1 = (unsigned)(((size_t)(32 + l31) * M + 4 * kk) * sizeof(float));
   auto fetch_side = [&](int tt) __attribute__((always_inline)) {
     const int mm0 = tt * KT;
-    sy_n = (mm0 + l31 < M) ? sqy[min(mm0 + l31, M - 1)] : MASKED_SQ;
-    if (HAS_RP) {
+    if (HAS_RP && !(PF_ABL & 4)) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         rq0[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp_rsrc, (int)(rp_o0 + 32 * g), mm0 * 4, 0));
@@ -194,10 +265,9 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
     const int t = tile_at(iv);
     const int t_next = iv + NW < ktiles ? tile_at(iv + NW) : t;
     const int m0 = t * KT;
-    const int mk = min(m0 + l31, M - 1);
-    const int mk_next = min(t_next * KT + l31, M - 1);
+    const int mk = m0 + l31;
+    const int mk_next = t_next * KT + l31;
     if (!AHEAD) fetch_side(t);
-    const float sy32 = sy_n;
     // accumulators start from relative_pos: lane (l31, kk), register 4 g + j <-> key row m0 + 8 g + 4 kk + j
     f32x16 acc0, acc1;
     if (HAS_RP) {
@@ -211,10 +281,10 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     }
     {
-      const uint4* ykh = yhp + (size_t)kk * M + mk;
-      const uint4* ykl = ylp + (size_t)kk * M + mk;
-      const uint4* ynh = yhp + (size_t)kk * M + mk_next;
-      const uint4* ynl = ylp + (size_t)kk * M + mk_next;
+      const uint4* ykh = yhp + (size_t)kk * MR + mk;
+      const uint4* ykl = ylp + (size_t)kk * MR + mk;
+      const uint4* ynh = yhp + (size_t)kk * MR + mk_next;
+      const uint4* ynl = ylp + (size_t)kk * MR + mk_next;
       const char* xh0 = xq_hi + l31 * qpitch + 16 * kk;
       const char* xl0 = xq_lo + l31 * qpitch + 16 * kk;
       const char* xh1 = xh0 + 32 * qpitch;
@@ -227,6 +297,10 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
             const bf16x8_t kl = __builtin_bit_cast(bf16x8_t, bl_[u]);
             const bf16x8_t qh0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh0 + 32 * u));
             const bf16x8_t ql0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl0 + 32 * u));
+#if PF_ABL & 2
+            acc0[u] += __uint_as_float(bh_[u].x ^ bl_[u].y) + __builtin_bit_cast(float, (unsigned)(qh0[0] != ql0[1]));
+            acc1[u] += __uint_as_float(bh_[u].z ^ bl_[u].w);
+#else
             if (two_blocks) {
               const bf16x8_t qh1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xh1 + 32 * u));
               const bf16x8_t ql1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xl1 + 32 * u));
@@ -241,14 +315,17 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
               acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql0, acc0, 0, 0, 0);
               acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh0, acc0, 0, 0, 0);
             }
+#endif
           }
         }
         __builtin_amdgcn_sched_barrier(0);                        // the next tile's batch: behind the MFMAs that read this one
+#if !(PF_ABL & 16)
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
-          bh_[u] = u < S16 ? ynh[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
-          bl_[u] = u < S16 ? ynl[(size_t)(2 * u) * M] : make_uint4(0, 0, 0, 0);
+          bh_[u] = u < S16 ? ynh[(size_t)(2 * u) * MR] : make_uint4(0, 0, 0, 0);
+          bl_[u] = u < S16 ? ynl[(size_t)(2 * u) * MR] : make_uint4(0, 0, 0, 0);
         }
+#endif
       } else
       for (int s0 = 0; s0 < S16; s0 += KB) {
         const bool last = s0 + KB >= S16;                         // uniform: prefetch the NEXT tile's first batch
@@ -258,8 +335,8 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
           const int sn = last ? u : s0 + KB + u;
-          bh_[u] = sn < S16 ? (last ? ynh : ykh)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
-          bl_[u] = sn < S16 ? (last ? ynl : ykl)[(size_t)(2 * sn) * M] : make_uint4(0, 0, 0, 0);
+          bh_[u] = sn < S16 ? (last ? ynh : ykh)[(size_t)(2 * sn) * MR] : make_uint4(0, 0, 0, 0);
+          bl_[u] = sn < S16 ? (last ? ynl : ykl)[(size_t)(2 * sn) * MR] : make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -291,6 +368,10 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
     if (AHEAD && iv + NW < ktiles) fetch_side(t_next); // in flight during the selection below
     // ---- lane l <- all 32 keys of query n0 + l (permlane swap as in knn_tile_kernel); approximate distance (without the
     //      query's own |x|^2, a per-query constant) = acc + |y|^2, keys past M masked by MASKED_SQ
+#if PF_ABL & 8
+    for (int r_ = 0; r_ < 16; ++r_) abl_sink = fminf(abl_sink, acc0[r_] + acc1[r_]);
+    if (iv + NW >= ktiles) top.template insert<false>(abl_sink, 0);
+#else
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float lo[4], hi[4];
@@ -306,20 +387,27 @@ __global__ __launch_bounds__(256, KDW <= 16 ? 3 : 2) void knn_pf_kernel(KnnArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int row = 8 * g + 4 * hh + j;
-          const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sy32), row));
-          const float d = (hh ? hi[j] : lo[j]) + sy;
+          const float d = hh ? hi[j] : lo[j];     // |y|^2 is already inside (channels pf_c, pf_c + 1 of the contraction)
           if constexpr (PBUF > 0) {
+#if PF_ABL & 1
+            abl_sink = fminf(abl_sink, d <= thr ? d : abl_sink);
+#else
             if (d <= thr) {                       // '<=': the tiles are not visited in index order (NaN fails)
-              cbuf[bcnt * 256] = make_float2(d, __int_as_float(m0 + row));
-              ++bcnt;
+              *(lds_v2u_t*)(size_t)cw = v2u_t{__float_as_uint(d), (unsigned)(m0 + row)};
+              asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(cw) : "i"(256 * 8) : "memory");
             }
+#endif
           } else {
             top.template insert<KDW >= 18>(d, m0 + row);
           }
         }
       }
-      if (PBUF > 0 && ((g == 3 && iv + NW >= ktiles) || __builtin_amdgcn_ballot_w64(bcnt > PBUF - 8) != 0ull)) flush();
+      if (PBUF > 0 && ((g == 3 && iv + NW >= ktiles) || __builtin_amdgcn_ballot_w64(cw > cw_lim) != 0ull)) flush();
     }
+#if PF_ABL & 1
+    if (iv + NW >= ktiles) top.template insert<false>(abl_sink, 0);
+#endif
+#endif
     if (iv / NW < 10) KNN_TL(4 + 2 * (iv / NW));
   }
 
@@ -494,7 +582,7 @@ static hipError_t launch_pf(const KnnArgs& a, dim3 grid, hipStream_t st) {
   // workgroups per CU the register budget allows (3 for lists <= 16, 2 above)
   const size_t per_wg = (size_t)160 * 1024 / (KDW <= 16 ? 3 : 2);
   const int pbuf = stage + 16 * 2048 <= per_wg ? 16 : (stage + 12 * 2048 <= per_wg ? 12 : 0);
-  const size_t need = stage + (size_t)pbuf * 2048;
+  const size_t need = stage + (size_t)pbuf * 2048 + (pbuf ? NW * 64 * sizeof(float) : 0);      // + the shared admission bounds
   const size_t lds = need > lists ? need : lists;
   if (pbuf == 16) return launch_pf_v<KD, KDW, HAS_RP, 16>(a, grid, lds, st);
   if (pbuf == 12) return launch_pf_v<KD, KDW, HAS_RP, 12>(a, grid, lds, st);

@@ -9,7 +9,7 @@ import torch
 import numpy as np
 
 CS = os.path.join(ROOT, "gkgnet_amd", "csrc")
-SRCS = ["gkg_api.hip", "gkg_knn.hip", "gkg_knn_f32.hip", "gkg_knn_f32_norp.hip", "gkg_knn_bf.hip", "gkg_knn_bf_norp.hip",
+SRCS = ["gkg_api.hip", "gkg_knn.hip", "gkg_knn_f32.hip", "gkg_knn_f32_norp.hip", "gkg_knn_f32_mr.hip", "gkg_knn_f32_mr_norp.hip", "gkg_knn_bf.hip", "gkg_knn_bf_norp.hip",
         "gkg_knn_pf.hip", "gkg_knn_pf_norp.hip"]
 
 
