@@ -785,7 +785,7 @@ template <int NT, bool SELF, int MODE, int AK, int ACC, int U>     // U: rows in
 __global__ __launch_bounds__(NT) void mr_bwd_tm_stream_kernel(const float* __restrict__ gin, const int64_t* __restrict__ nn_idx,
                                                                const uint8_t* __restrict__ argmax, float* __restrict__ gx,
                                                                float* __restrict__ gsrc, int B, int G, int c, int N, int M,
-                                                               int k, int CW, int shmax) {
+                                                               int k, int CW, int shmax, int arg_planes) {
   extern __shared__ long long acc64[];            // [M][CW] (fixed point, or the bits of doubles) + control words
   const int C = G * c;
   const int nchunk = C / CW;
@@ -801,6 +801,9 @@ __global__ __launch_bounds__(NT) void mr_bwd_tm_stream_kernel(const float* __res
   const int ch = ch0 + 4 * qd;
   const int g = ch / c;
   unsigned* ctl = reinterpret_cast<unsigned*>(acc64 + (size_t)M * CW);
+  // arg_planes (measurement, AK == 1): the winning rows as 8-channel planes (B, C / 8, N, 8) instead of (B, N, C) rows — a chunk's
+  // 16 bytes per query row are then contiguous over the rows
+  const size_t pl_base = (((size_t)b * (C >> 3) + (ch >> 3)) * N) * 8 + (ch & 7);
   float4 direct[U], gm[U];
   int j[U][4];
   auto load_rows = [&](int n0) __attribute__((always_inline)) {
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(NT) void mr_bwd_tm_stream_kernel(const float* __res
       const int n = min(n0 + u * TL, N - 1);
       const size_t t = (size_t)b * N + n;
       const int64_t* ip = AK == 1 ? nullptr : nn_idx + (((size_t)b * G + g) * N + n) * k;
-      mr_targets<AK>(argmax, AK, t * C + ch, ip, k, M, j[u]);
+      mr_targets<AK>(argmax, AK, arg_planes ? pl_base + (size_t)n * 8 : t * C + ch, ip, k, M, j[u]);
       load_grad<MODE>(gin, T, t, C, ch, MODE, direct[u], gm[u]);
     }
   };
@@ -1246,7 +1249,7 @@ template <int NT, bool SELF, int MODE, int AK, int ACC, int U>
 static void launch_tm_stream_one(dim3 grid, size_t lds, hipStream_t st, const float* gin, const int64_t* nn_idx, const uint8_t* argmax,
                                  float* gx, float* gsrc, int B, int G, int c, int N, int M, int k, int CW, int shmax) {
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mr_bwd_tm_stream_kernel<NT, SELF, MODE, AK, ACC, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mr_bwd_tm_stream_kernel<NT, SELF, MODE, AK, ACC, U>), grid, dim3(NT), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, shmax);
+  hipLaunchKernelGGL((mr_bwd_tm_stream_kernel<NT, SELF, MODE, AK, ACC, U>), grid, dim3(NT), lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, shmax & 0xffff, shmax >> 16);
 }
 template <int NT, int ACC, int U>
 static void launch_tm_stream_nt(bool self, int mode, int ak, dim3 grid, size_t lds, hipStream_t st, const float* gin, const int64_t* nn_idx,
@@ -1311,11 +1314,12 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
       while ((1 << bitsN) <= N) ++bitsN;
       const dim3 grid((C / CW) * ((B + 7) / 8) * 8);
       const bool self = gsrc == nullptr;
-      if (sv == 2) launch_tm_stream_nt<512, 1, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
-      else if (nt256 && u8) launch_tm_stream_nt<256, 0, 8>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
-      else if (nt256) launch_tm_stream_nt<256, 0, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
-      else if (u8) launch_tm_stream_nt<512, 0, 8>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
-      else launch_tm_stream_nt<512, 0, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, 38 - bitsN);
+      const int planes_bit = (sv && ((flags >> 23) & 1) && arg_kind == 1) ? (1 << 16) : 0;      // measurement: 8-channel planes of winning rows
+      if (sv == 2) launch_tm_stream_nt<512, 1, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, (38 - bitsN) | planes_bit);
+      else if (nt256 && u8) launch_tm_stream_nt<256, 0, 8>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, (38 - bitsN) | planes_bit);
+      else if (nt256) launch_tm_stream_nt<256, 0, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, (38 - bitsN) | planes_bit);
+      else if (u8) launch_tm_stream_nt<512, 0, 8>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, (38 - bitsN) | planes_bit);
+      else launch_tm_stream_nt<512, 0, 4>(self, mode, arg_kind, grid, lds, st, gin, nn_idx, argmax, gx, gsrc, B, G, c, N, M, k, CW, (38 - bitsN) | planes_bit);
       hipError_t es = hipGetLastError();
       return es == hipSuccess ? 0 : gkg_fail_hip(es, "mr_bwd_tm_stream_kernel");
     }

@@ -25,6 +25,8 @@ def main():
     g = torch.randn(4, B * N, C // 2, device="cuda")
     gx = torch.empty(B, N, C, device="cuda")
     gs = None if M is None else torch.empty(B, Mk, C, device="cuda")
+    if (flags >> 23) & 1:                      # measurement: the winning rows as 8-channel planes (B, C / 8, N, 8)
+        arg = arg.view(B, N, C // 8, 8).permute(0, 2, 1, 3).contiguous()
     def call():
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(idx), _ptr(arg), _ptr(gx), _ptr(gs), B, G, C // G, N, Mk, k, 1, 1, flags, _stream()), "gkg_mr_bwd_tm")
     for _ in range(3):
