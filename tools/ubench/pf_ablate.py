@@ -35,22 +35,23 @@ def build(abl):
 def main():
     variants = [int(a, 0) for a in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 1 | 2, 2 | 4 | 16]
     torch.manual_seed(0)
-    shapes = (("pvig_s stage 1", 64, 40, 20736, 1296), ("pvig_s stage 2", 64, 80, 5184, 1296))
+    shapes = (("pvig_s stage 1", 64, 40, 20736, 1296, 1), ("pvig_s stage 2", 64, 80, 5184, 1296, 1),
+              ("pvig_s stage 3 (self graph, d = 2)", 64, 200, 1296, 1296, 2))
     data = {}
-    for name, BG, c, N, M in shapes:
-        data[name] = (torch.randn(BG, c, N, device="cuda"), torch.randn(BG, c, M, device="cuda"), -torch.rand(N, M, device="cuda"),
-                      torch.empty(BG, N, 9, dtype=torch.int64, device="cuda"))
+    for name, BG, c, N, M, dil in shapes:
+        data[name] = (torch.randn(BG, c, N, device="cuda"), None if dil > 1 else torch.randn(BG, c, M, device="cuda"),
+                      -torch.rand(N, M, device="cuda"), torch.empty(BG, N, 9, dtype=torch.int64, device="cuda"))
     for abl in variants:
         lib = build(abl)
-        for name, BG, c, N, M in shapes:
+        for name, BG, c, N, M, dil in shapes:
             x, y, r, idx = data[name]
             flags = 1 | 64                                  # GKG_KNN_NORMALIZE | GKG_KNN_RELPOS_UNIT
-            nb = lib.gkg_knn_workspace_bytes(BG, c, N, M, 9, 1, 0, flags)
+            nb = lib.gkg_knn_workspace_bytes(BG, c, N, M, 9, dil, 0, flags)
             ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
             ctr = torch.zeros(64, dtype=torch.int64, device="cuda")
             lib.gkg_debug_set_knn_timeline(ctr.data_ptr())
             def call():
-                assert lib.gkg_knn_fwd(x.data_ptr(), y.data_ptr(), r.data_ptr(), idx.data_ptr(), None, BG, c, N, M, 9, 1, 0, flags,
+                assert lib.gkg_knn_fwd(x.data_ptr(), None if y is None else y.data_ptr(), r.data_ptr(), idx.data_ptr(), None, BG, c, N, M, 9, dil, 0, flags,
                                        ws.data_ptr(), nb, None) == 0
             for _ in range(2):
                 call()
