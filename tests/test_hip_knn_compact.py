@@ -106,3 +106,29 @@ def test_block_takes_the_compact_path_and_matches_the_int64_path(C, G, HW, r, tr
     assert torch.equal(res[0][0], res[1][0])                     # same graph, same aggregation: the same forward bits
     for a, b in zip(res[0][1:], res[1][1:]):                    # gradients: the step's atomic sums (weight gradients, BN backward)
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12      # vary in the last bits from run to run
+
+
+def test_fuzz_compact_lists_random_shapes():
+    """Random (B, G, c, N, M, k, dilation, bias, graph kind): the u16 lists equal the int64 plane for every launch plan the sizes
+    select (key splits with the merge kernel, single-wave workgroups, buffered / direct selection, prefilter)."""
+    import numpy as np
+    from gkgnet_amd import fused
+    rng = np.random.RandomState(5)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for trial in range(40):
+        G = int(rng.choice([1, 2, 4, 8]))
+        c = 4 * int(rng.randint(1, 26))
+        B = int(rng.randint(1, 5))
+        N = int(rng.choice([rng.randint(1, 100), rng.randint(100, 600), rng.randint(600, 2500)]))
+        self_graph = bool(rng.rand() < 0.5)
+        M = N if self_graph else int(rng.choice([rng.randint(20, 300), rng.randint(300, 3000)]))
+        d = int(rng.randint(1, 4))
+        k = int(rng.randint(1, 19))
+        if k * d > min(M, 64):
+            d, k = 1, min(k, M, 64)
+        x = torch.randn(B, N, G * c, device="cuda", generator=gen)
+        y = None if self_graph else torch.randn(B, M, G * c, device="cuda", generator=gen)
+        rp = -torch.rand(1, N, M, device="cuda", generator=gen) if rng.rand() < 0.5 else None
+        edge = fused.knn_graph_tm(x, y, rp, k, d, G)
+        nn16 = fused.knn_graph_tm16(x, y, rp, k, d, G)
+        assert torch.equal(nn16.to(torch.int64) & 0xFFFF, edge[0]), (trial, B, G, c, N, M, k, d)

@@ -221,3 +221,63 @@ def test_streaming_form_single_iteration_equals_the_two_sweep_kernel_bit_for_bit
         a = _raw(g, idx, arg, B, G, C, N, M, k, 0, self_graph)                          # the rule: 16-channel chunks here
         b = _raw(g, idx, arg, B, G, C, N, M, k, TWO_SWEEP | (16 << 8), self_graph)     # (the scale is per chunk: same chunks)
         assert torch.equal(a[0], b[0]) and (self_graph or torch.equal(a[1], b[1]))
+
+
+def test_fuzz_token_major_scatter_random_shapes():
+    """Random (B, G, C, N, M, k, layout, graph kind) through gkg_mr_bwd_tm's own rule (streaming form from 160 query rows, two-sweep
+    / fp32-atomic forms below) and through the forced streaming form at every chunk width that fits: against an fp64 scatter of
+    the same gradients, and bit-identical between two runs wherever the form is order-independent."""
+    from gkgnet_amd import _lib
+    from gkgnet_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    rng = np.random.RandomState(77)
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    done = 0
+    for trial in range(60):
+        G = int(rng.choice([1, 2, 4]))
+        c = 4 * int(rng.randint(1, 21))
+        C = G * c
+        mode = int(rng.randint(0, 2))
+        if mode == 1 and C % 16:
+            continue
+        B = int(rng.randint(1, 6))
+        N = int(rng.choice([rng.randint(1, 160), rng.randint(160, 700), rng.randint(700, 4000)]))
+        self_graph = bool(rng.rand() < 0.4)
+        M = N if self_graph else int(rng.choice([rng.randint(1, 200), rng.randint(200, 1500)]))
+        k = int(rng.randint(1, 10))
+        idx = torch.randint(0, M, (B * G, N, k), device="cuda", generator=gen)
+        arg = torch.randint(0, M, (B, N, C), device="cuda", generator=gen).to(torch.int16)
+        scale = 10.0 ** float(rng.uniform(-4, 3))
+        if mode == 1:
+            g = torch.randn(4, B * N, C // 2, device="cuda", generator=gen) * scale
+            gi = g.view(4, B, N, C // 4, 2).permute(1, 2, 0, 3, 4).reshape(B, N, C, 2)
+            direct, gm = gi[..., 0].contiguous(), gi[..., 1].contiguous()
+        else:
+            g = torch.randn(B, N, C, device="cuda", generator=gen) * scale
+            direct, gm = torch.zeros_like(g), g
+        want = torch.zeros(B, M, C, dtype=torch.float64, device="cuda")
+        want.scatter_add_(1, arg.long() & 0xffff, gm.double())
+        want_x = direct.double() - gm.double()
+        if self_graph:
+            want_x = want_x + want
+        forced = [STREAM | (cw << 8) | (nt << 20) | (u8 << 22) for cw in (4, 8, 16) for nt, u8 in ((1, 0), (2, 1))
+                  if C % cw == 0 and c % cw == 0 and M * cw * 8 + 16 <= 96 * 1024]
+        for flags in [0] + forced[:: max(1, len(forced) // 3)]:
+            outs = []
+            for rep in range(2):
+                gx = torch.full((B, N, C), float("nan"), device="cuda")
+                gs = None if self_graph else torch.full((B, M, C), float("nan"), device="cuda")
+                _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(idx), _ptr(arg), _ptr(gx), _ptr(gs), B, G, c, N, M, k, mode, 1, flags,
+                                             _stream()), "gkg_mr_bwd_tm")
+                outs.append((gx, gs))
+            gx, gs = outs[0]
+            big = float(gm.abs().max())
+            tol = 1e-5 * big * max(1.0, N / 64) + 1e-30
+            assert float((gx.double() - want_x).abs().max()) <= tol + 1e-6 * float(want_x.abs().max()), (trial, flags)
+            if gs is not None:
+                assert float((gs.double() - want).abs().max()) <= tol + 1e-6 * float(want.abs().max()), (trial, flags)
+            deterministic = flags != 0 or N >= 160 or M <= 512          # the rule's fp32-atomic form: few query rows over > 512 keys
+            if deterministic:
+                assert torch.equal(outs[0][0], outs[1][0]) and (gs is None or torch.equal(outs[0][1], outs[1][1])), (trial, flags)
+            done += 1
+    assert done >= 60
