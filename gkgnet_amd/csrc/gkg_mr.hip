@@ -669,11 +669,13 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_i64_kernel(const float*
 // the same time whatever their accumulator type (tools/bench_mr_bwd.py: 420-426 us at stage 1 for fp32 and 64-bit atomics, chunk
 // widths 4 / 8): they are bound by their sweep — one (index, gradient) row per thread and iteration, nothing in flight behind
 // it — and the fixed-point form pays that sweep twice to learn its scale first.  This form
-//   * keeps U rows per thread in flight (all index / gradient loads of an iteration issued before the first use) in workgroups
-//     of up to 1 024 threads: one workgroup per CU (83 KB of accumulators at 1 296 rows x 8 channels) still has >= 100 KB of
-//     loads outstanding;
-//   * sweeps ONCE: the fixed-point scale comes from a strided SAMPLE of the chunk's rows (one load round trip) plus HEAD binary
-//     orders of headroom instead of the exact maximum.  A gradient beyond the headroom (or inf / NaN) raises a flag; the
+//   * keeps U = 4 / 8 rows per thread in flight (all winning-row / gradient loads of an iteration issued before the first use) in
+//     512-thread workgroups: one workgroup per CU (83 KB of accumulators at 1 296 rows x 8 channels) still has >= 80 KB of loads
+//     outstanding (1 024-thread workgroups measured the same);
+//   * sweeps ONCE: the fixed-point scale is the exact maximum when a thread's first U rows are the whole sweep (the 18 x 18
+//     stages: the two-sweep kernel's bits), otherwise the maximum of a strided SAMPLE of the chunk's rows (requested together
+//     with the first iteration's rows: one round trip) plus HEAD binary orders of headroom.  A gradient beyond the headroom (or
+//     inf / NaN) raises a flag; the
 //     workgroup then discards its image and re-runs the exact two-sweep form — same result contract, rare path.  The sample,
 //     the flag and therefore the path taken depend on the data only: bit-identical from run to run, like the two-sweep form
 //     (the scale sits HEAD orders above the sampled maximum: values more than 2^-(SHMAX - HEAD) below THAT lose low bits —
