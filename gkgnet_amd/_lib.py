@@ -10,7 +10,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GKG_HIP_LIB") or os.path.join(PKG, "libgkg_hip.so")   # GKG_HIP_LIB: same-box A/B of two builds (tools)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, BF16, F16 = 0, 1, 2
 KNN_NORMALIZE = 1
 KNN_BF16_CONTRACT = 2
@@ -63,7 +63,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_linear_bn_fwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
-           "gkg_mr_linear_x6", "gkg_mr_linear_x6_supported", "gkg_mr_regather_tm", "gkg_linear_dgrad_x6_bnbwd",
+           "gkg_avgpool_tm", "gkg_linear_dgrad_x6_bnbwd",
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
@@ -77,7 +77,8 @@ _lib = None
 class WgradProblem(C.Structure):
     """include/gkg_hip.h GkgWgradProblem"""
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("g_bstride", C.c_size_t), ("x_bstride", C.c_size_t),
-                ("ldg", C.c_int), ("ldx", C.c_int), ("R", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("nb", C.c_int)]
+                ("ldg", C.c_int), ("ldx", C.c_int), ("R", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("nb", C.c_int),
+                ("kperm", C.c_int)]
 
 
 class GkgError(RuntimeError):
@@ -109,17 +110,19 @@ def load():
     lib.gkg_mr_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
     V, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
     lib.gkg_knn_fwd_tm.restype = I
-    lib.gkg_knn_fwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V, Z, V]
+    lib.gkg_knn_fwd_tm.argtypes = [V, I, I] + [V] * 4 + [I] * 8 + [C.c_uint, V, Z, V]
     lib.gkg_knn_mr_fused_supported.restype = I
     lib.gkg_knn_mr_fused_supported.argtypes = [I] * 9 + [C.c_uint]
     lib.gkg_knn_mr_fwd_tm.restype = I
-    lib.gkg_knn_mr_fwd_tm.argtypes = [V] * 8 + [I] * 7 + [C.c_uint, V, Z, V]
+    lib.gkg_knn_mr_fwd_tm.argtypes = [V, I, I] + [V] * 7 + [I] * 7 + [C.c_uint, V, Z, V]
     lib.gkg_mr_fwd_tm.restype = I
-    lib.gkg_mr_fwd_tm.argtypes = [V] * 5 + [I] * 9 + [V]
+    lib.gkg_mr_fwd_tm.argtypes = [V, I, I] + [V] * 4 + [I] * 9 + [V]
     lib.gkg_mr_fwd_tm16.restype = I
-    lib.gkg_mr_fwd_tm16.argtypes = [V] * 5 + [I] * 9 + [V]
+    lib.gkg_mr_fwd_tm16.argtypes = [V, I, I] + [V] * 4 + [I] * 9 + [V]
+    lib.gkg_avgpool_tm.restype = I
+    lib.gkg_avgpool_tm.argtypes = [V, I, I, V, I, I, I, I, I, V]
     lib.gkg_knn_fwd_tm16.restype = I
-    lib.gkg_knn_fwd_tm16.argtypes = [V] * 4 + [I] * 8 + [C.c_uint, V, Z, V]
+    lib.gkg_knn_fwd_tm16.argtypes = [V, I, I] + [V] * 3 + [I] * 8 + [C.c_uint, V, Z, V]
     lib.gkg_mr_bwd_tm.restype = I
     lib.gkg_mr_bwd_tm.argtypes = [V] * 5 + [I] * 8 + [C.c_uint, V]
     lib.gkg_nchw_to_tm.restype = I
@@ -139,11 +142,11 @@ def load():
     lib.gkg_bn_eval_affine.restype = I
     lib.gkg_bn_eval_affine.argtypes = [V] * 7 + [I, F, V]
     lib.gkg_affine_act.restype = I
-    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, I, V, I, V]
+    lib.gkg_affine_act.argtypes = [V] * 5 + [I, I, I, I, Z, I, I, I, V, I, V]
     lib.gkg_bn_bwd.restype = I
     lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_apply_train.restype = I
-    lib.gkg_bn_apply_train.argtypes = [V] * 14 + [I, I, I, I, Z, I, I, V, I, F, F, V, Z, V]
+    lib.gkg_bn_apply_train.argtypes = [V] * 14 + [I, I, I, I, Z, I, I, I, V, I, F, F, V, Z, V]
     lib.gkg_x6_set_flags.restype = None
     lib.gkg_x6_set_flags.argtypes = [C.c_uint]
     lib.gkg_bn_set_flags.restype = None
@@ -189,7 +192,7 @@ def load():
     lib.gkg_x6_prep_desc_bytes.restype = I
     lib.gkg_x6_prep_desc_bytes.argtypes = []
     lib.gkg_x6_prep_desc_fill.restype = C.c_longlong
-    lib.gkg_x6_prep_desc_fill.argtypes = [V, I, V, V, V, I, I, I, C.c_longlong]
+    lib.gkg_x6_prep_desc_fill.argtypes = [V, I, V, V, V, I, I, I, C.c_longlong, I]
     lib.gkg_x6_prep_weights.restype = I
     lib.gkg_x6_prep_weights.argtypes = [V, I, C.c_longlong, V]
     lib.gkg_x6_prep_weights_zero.restype = I
@@ -199,13 +202,13 @@ def load():
     lib.gkg_linear_dgrad_x6.restype = I
     lib.gkg_linear_dgrad_x6.argtypes = [V, I, Z, V, V, I, I, I, I, V]
     lib.gkg_linear_wgrad_x6.restype = I
-    lib.gkg_linear_wgrad_x6.argtypes = [V, I, Z, V, I, Z, V, I, I, I, I, V]
+    lib.gkg_linear_wgrad_x6.argtypes = [V, I, Z, V, I, Z, V, I, I, I, I, I, V]
     lib.gkg_x6_splitk_workspace_bytes.restype = Z
     lib.gkg_x6_splitk_workspace_bytes.argtypes = []
     lib.gkg_linear_bn_fwd_x6_sk.restype = I
     lib.gkg_linear_bn_fwd_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V, Z, V]
     lib.gkg_linear_dgrad_x6_sk.restype = I
-    lib.gkg_linear_dgrad_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, V, V, Z, V]
+    lib.gkg_linear_dgrad_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, V, V, Z, I, Z, V]
     lib.gkg_linear_wgrad_x6_batch.restype = I
     lib.gkg_linear_wgrad_x6_batch.argtypes = [C.POINTER(WgradProblem), I, I, V]
     lib.gkg_mr_linear_planes_bytes.restype = Z
@@ -214,12 +217,6 @@ def load():
     lib.gkg_mr_linear_bf16.argtypes = [V] * 7 + [I] * 8 + [V]
     lib.gkg_mr_linear_bf16_nn16.restype = I
     lib.gkg_mr_linear_bf16_nn16.argtypes = [V] * 7 + [I] * 8 + [V]
-    lib.gkg_mr_linear_x6_supported.restype = I
-    lib.gkg_mr_linear_x6_supported.argtypes = [I, I, I]
-    lib.gkg_mr_linear_x6.restype = I
-    lib.gkg_mr_linear_x6.argtypes = [V] * 8 + [I] * 6 + [V]
-    lib.gkg_mr_regather_tm.restype = I
-    lib.gkg_mr_regather_tm.argtypes = [V] * 4 + [I] * 4 + [V]
     lib.gkg_stem_conv3x3s2_supported.restype = I
     lib.gkg_stem_conv3x3s2_supported.argtypes = [I, I]
     lib.gkg_stem_conv3x3s2_fwd.restype = I

@@ -28,6 +28,17 @@ __device__ __forceinline__ void stf4(uint16_t* p, const float4& v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
 }
 
+// "XM layout" (include/gkg_hip.h): the grouped projection's [x | m] operand buffer, (T, 2C) fp32 with C = 4h.  Row t is
+//   [x_0 | m_0 | x_1 | m_1 | x_2 | m_2 | x_3 | m_3],  x_q = x[t][q h .. (q+1) h),  m_q = m[t][q h .. (q+1) h):
+// conv group q of BasicConv (reference torch_nn.py:61, groups = 4) reads the 2h contiguous floats at column 2 q h.  Channel ch
+// of x sits at column xm_col(ch, h), of m at xm_col(ch, h) + h.  A token-major tensor is passed as (pointer, row pitch, chunk):
+// chunk == 0 is the plain (T, C) matrix, chunk == h the x half of an XM buffer (pitch 2C).  4 consecutive channels never
+// straddle a chunk (h % 4 == 0).
+// (ch / chunk as a multiply-high: exact for ch < 2^32 / chunk, chunk >= 2; the reciprocal is loop-invariant)
+__device__ __forceinline__ int xm_col(int ch, int chunk) {
+  return chunk > 0 ? ch + (int)__umulhi((unsigned)ch, 0xffffffffu / (unsigned)chunk + 1u) * chunk : ch;
+}
+
 // GELU, erf form (the reference's nn.GELU(), torch_nn.py:24) and its derivative.  erf comes from Abramowitz & Stegun 7.1.26,
 // |error| <= 1.5e-7 — at the level of fp32 rounding for O(1) activations and four orders below this path's 1e-3 contract —
 // in ~15 vector instructions instead of erff's ~40 (the compile-time ablation of the fused inference kernel showed erff as

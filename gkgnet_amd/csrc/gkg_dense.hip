@@ -135,6 +135,31 @@ __global__ __launch_bounds__(256) void tm_affine_to_nchw_kernel(const float* __r
   }
 }
 
+// Pooled key set of a Grapher with r > 1 (reference torch_vertex.py:194-196: F.avg_pool2d(x, r, r) of the (B, C, H, W) map) on a
+// token-major map x (B, H, W, C) given as a view (row pitch ldx, chunk: gkg_common.h "XM layout") -> out (B, H/r, W/r, C) plain.
+// Floor mode like the reference's pooling: rows / columns past the last full window are ignored.  Window sum in (h, w) order,
+// one division by r^2.  One thread = one pooled token x 4 channels.
+__global__ __launch_bounds__(256) void avgpool_tm_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C,
+                                                         int r, int ldx, int xchunk, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int C4 = C >> 2, Hr = H / r, Wr = W / r;
+  const int cg = (int)(i % C4);
+  size_t t = i / C4;
+  const int wo = (int)(t % Wr); t /= Wr;
+  const int ho = (int)(t % Hr);
+  const size_t b = t / Hr;
+  const float* p = x + ((b * H + (size_t)ho * r) * W + (size_t)wo * r) * ldx + xm_col(4 * cg, xchunk);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int dh = 0; dh < r; ++dh)
+    for (int dw = 0; dw < r; ++dw) {
+      const float4 v = *reinterpret_cast<const float4*>(p + ((size_t)dh * W + dw) * ldx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  const float d = (float)(r * r);
+  *reinterpret_cast<float4*>(out + 4 * i) = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+}
+
 // ------------------------------------------------------------------------------------------ column statistics
 // part[q][chunk][0][c] = sum_r y[q][r][c], part[q][chunk][1][c] = sum_r y^2 over the chunk's row range.
 // 2-D decomposition: a workgroup owns one 64-channel column tile (16 float4 groups) x one row chunk, its 256
@@ -410,7 +435,8 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          const float* __restrict__ cs, const float* __restrict__ res,
                                                          OutT* __restrict__ out, size_t total4, int C, int ldo,
                                                          size_t o_bstride, const float* __restrict__ row_scale,
-                                                         int rows_per_scale, uint16_t* __restrict__ out2, BnDerive d) {
+                                                         int rows_per_scale, uint16_t* __restrict__ out2, BnDerive d,
+                                                         int ochunk = 0) {
   extern __shared__ float ac_tab[];                 // derive mode: [2][C] scale / shift of this group
   const int C4 = C >> 2;
   const int q = blockIdx.y;
@@ -450,8 +476,11 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       const float4 rv = *reinterpret_cast<const float4*>(res + 4 * i);
       o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
-    stf4(out + r * (size_t)ldo + 4 * cg, o);
-    if (out2) stf4(out2 + r * (size_t)ldo + 4 * cg, o);       // second, bf16 copy of the same values (gkg_affine_act_dual)
+    // ochunk > 0: column ch lands at ch + (ch / ochunk) * ochunk — the x half of the grouped projection's [x | m] operand
+    // buffer (gkg_hip.h "XM layout"): the Grapher's fc1 writes its result where BasicConv reads it
+    const int oc = ochunk > 0 ? 4 * cg + (4 * cg / ochunk) * ochunk : 4 * cg;
+    stf4(out + r * (size_t)ldo + oc, o);
+    if (out2) stf4(out2 + r * (size_t)ldo + oc, o);           // second, bf16 copy of the same values (gkg_affine_act_dual)
   }
 }
 
@@ -687,10 +716,26 @@ extern "C" int gkg_bn_eval_affine(const float* gamma, const float* beta, const f
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_eval_affine_kernel");
 }
 
+extern "C" int gkg_avgpool_tm(const float* x, int ldx, int xchunk, float* out, int B, int H, int W, int C, int r, void* stream) {
+  if (!x || !out) return gkg_fail(GKG_ERR_NULL, "gkg_avgpool_tm: null pointer");
+  if (ldx == 0) ldx = C;
+  if (B <= 0 || H <= 0 || W <= 0 || bad_c(C) || r <= 0 || H / r <= 0 || W / r <= 0 || ldx < C || (ldx & 3) || xchunk < 0 || (xchunk & 3) ||
+      (xchunk > 0 && (C % xchunk || ldx < 2 * C)) || ((size_t)x & 15) || ((size_t)out & 15))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_avgpool_tm: bad sizes (C % 4 == 0, r <= H, W; 16-byte aligned rows)");
+  const size_t total4 = (size_t)B * (H / r) * (W / r) * (C >> 2);
+  if ((total4 + 255) / 256 > 0x7fffffffull) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_avgpool_tm: too large for one launch");
+  hipLaunchKernelGGL(avgpool_tm_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, H, W, C, r, ldx,
+                     xchunk, total4);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gkg_fail_hip(e, "avgpool_tm_kernel");
+}
+
 extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
-                              int nb, int ldo, size_t out_bstride, int act, int out_dtype, const float* row_scale,
+                              int nb, int ldo, size_t out_bstride, int ochunk, int act, int out_dtype, const float* row_scale,
                               int rows_per_scale, void* stream) {
   if (row_scale && rows_per_scale <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: rows_per_scale must be positive");
+  if (ochunk < 0 || (ochunk & 3) || (ochunk > 0 && (C % ochunk || ldo < 2 * C)))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: ochunk must be a multiple of 4 dividing C, with ldo >= 2 C");
   if (!y || !a || !c || !out) return gkg_fail(GKG_ERR_NULL, "gkg_affine_act: null pointer");
   if (R <= 0 || bad_c(C) || nb <= 0 || nb > 64 || ldo < C || (ldo & 3) || (out_bstride & 3) || (act != 0 && act != 1))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_affine_act: bad sizes");
@@ -701,12 +746,12 @@ extern "C" int gkg_affine_act(const float* y, const float* a, const float* c, co
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
-    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{}, ochunk);
+    else hipLaunchKernelGGL((affine_act_kernel<0, uint16_t>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{}, ochunk);
   } else {
     float* o = (float*)out;
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
-    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{});
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{}, ochunk);
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), 0, st, y, a, c, res, o, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, BnDerive{}, ochunk);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "affine_act_kernel");
@@ -1025,7 +1070,7 @@ static int bn_bwd_atomic_impl(const float* dout, const float* y, const float* a,
 extern "C" int gkg_bn_apply_train(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
                                   float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
                                   float* mean, float* invstd, const float* res, float* out, int R, int C, int nb, int ldo,
-                                  size_t out_bstride, int act, int nchw_B, const float* row_scale, int rows_per_scale,
+                                  size_t out_bstride, int ochunk, int act, int nchw_B, const float* row_scale, int rows_per_scale,
                                   float momentum, float eps, double* zero_buf, size_t zero_doubles, void* stream) {
   if (!y || !sums || !gamma || !beta || !a || !c || !mean || !invstd || !out)
     return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_train: null pointer");
@@ -1044,12 +1089,14 @@ extern "C" int gkg_bn_apply_train(const float* y, const double* sums, const floa
   } else {
     if (row_scale && rows_per_scale <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: rows_per_scale must be positive");
     if (ldo < C || (ldo & 3) || (out_bstride & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: bad output pitch");
+    if (ochunk < 0 || (ochunk & 3) || (ochunk > 0 && (C % ochunk || ldo < 2 * C)))
+      return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_train: ochunk must be a multiple of 4 dividing C, with ldo >= 2 C");
     const size_t total4 = (size_t)R * (C >> 2);
     const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
     const dim3 grid(blocks, nb);
     const size_t lds = (size_t)2 * C * sizeof(float);
-    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), lds, st, y, (const float*)nullptr, (const float*)nullptr, res, out, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, d);
-    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), lds, st, y, (const float*)nullptr, (const float*)nullptr, res, out, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, d);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, float>), grid, dim3(256), lds, st, y, (const float*)nullptr, (const float*)nullptr, res, out, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, d, ochunk);
+    else hipLaunchKernelGGL((affine_act_kernel<0, float>), grid, dim3(256), lds, st, y, (const float*)nullptr, (const float*)nullptr, res, out, total4, C, ldo, out_bstride, row_scale, rows_per_scale, (uint16_t*)nullptr, d, ochunk);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "bn_apply_train");

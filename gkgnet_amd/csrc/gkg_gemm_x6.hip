@@ -64,13 +64,19 @@ __device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& h, unsig
 //   forward planes  pf: [nb][3][KCf][NPf][8]   B[n][k] = w[n][k]      NPf = roundup(N, 128), KCf = roundup(K, 32) / 8
 //   dgrad planes    pd: [nb][3][KCd][NPd][8]   B[n][k] = w[k][n]      NPd = roundup(K, 128), KCd = roundup(N, 32) / 8
 // A work unit is one (k/8, n) pair = 8 floats in, 3 x 16 B out; unit_begin is the running unit count over descriptors.
+// kperm (the grouped projection behind the max-relative aggregation, reference torch_vertex.py:57-61 + torch_nn.py:61): the
+// activation operand arrives as [x chunk | m chunk] (gkg_common.h "XM layout") instead of the reference's interleave
+// [x_0, m_0, x_1, m_1, ...], so the planes hold the weight's INPUT columns in that order: plane position p < K/2 is column 2p
+// (an x channel), p >= K/2 column 2 (p - K/2) + 1 (its m).  The weight tensor itself keeps the reference's layout.
 struct X6PrepDesc {
   const float* w;
   uint4* pf;
   uint4* pd;
   int nb, N, K;
   int unit_begin;
+  int kperm;
 };
+__device__ __host__ __forceinline__ int x6_kperm_src(int p, int K) { const int h = K >> 1; return p < h ? 2 * p : 2 * (p - h) + 1; }
 
 // Zero jobs riding in the same launch (round 5): a training step begins by clearing its gradient arena and the BN scratch — two
 // more 5 us launches in front of the first projection.  Workgroups past the unit blocks clear up to two buffers (16-byte units).
@@ -115,7 +121,13 @@ __global__ __launch_bounds__(256) void x6_prep_kernel(const X6PrepDesc* __restri
   const int n = v % NP, kc = (v / NP) % KC, z = v / (NP * KC);
   const float* w = g.w + (size_t)z * g.N * g.K;
   float f[8];
-  if (!dgrad && n < Nn && kc * 8 + 8 <= Kk && (g.K & 3) == 0) {          // forward orientation: 8 consecutive floats of row n
+  if (g.kperm) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kc * 8 + j;
+      f[j] = (n < Nn && k < Kk) ? (dgrad ? w[(size_t)k * g.K + x6_kperm_src(n, g.K)] : w[(size_t)n * g.K + x6_kperm_src(k, g.K)]) : 0.f;
+    }
+  } else if (!dgrad && n < Nn && kc * 8 + 8 <= Kk && (g.K & 3) == 0) {          // forward orientation: 8 consecutive floats of row n
     const float4 v0 = *reinterpret_cast<const float4*>(w + (size_t)n * g.K + kc * 8);
     const float4 v1 = *reinterpret_cast<const float4*>(w + (size_t)n * g.K + kc * 8 + 4);
     f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
@@ -849,6 +861,8 @@ struct X6WgradArgs {
   int swap;                                          // wide kernel: A / B roles exchanged, C written transposed
   int share, rot;                                    // workgroup -> (slab, tile) map of batched launches (x6w_map); 0, 0 otherwise
   int ubase, urem;                                   // LDS-DMA kernels: slab s = ubase + (s < urem) units of 128 rows (K = 128 * units)
+  int kperm;                                         // X arrives as [x chunk | m chunk] (X6PrepDesc::kperm): operand column j of X is
+                                                     // dW column x6_kperm_src(j, cin) — applied where the tile is added to dW
 };
 
 typedef unsigned x6_u32x4 __attribute__((ext_vector_type(4)));
@@ -986,7 +1000,7 @@ __global__ __launch_bounds__(256) void wgrad_x6_kernel(X6WgradArgs g) {
     const int e = tid + 256 * u, row = e >> 6, col = e & 63;
     const float v = (red[e] + red[4096 + e]) + (red[8192 + e] + red[12288 + e]);
     if (m0 + row < g.M && n0 + col < g.N)
-      __hip_atomic_fetch_add(C + (size_t)(m0 + row) * g.ldc + n0 + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(C + (size_t)(m0 + row) * g.ldc + (g.kperm ? x6_kperm_src(n0 + col, g.N) : n0 + col), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1128,7 +1142,7 @@ __device__ __forceinline__ void wgrad_x6_dma_body(const X6WgradArgs& g, const in
     const int e = tid + 256 * u, row = e >> 6, col = e & 63;
     const float v = (red[e] + red[4096 + e]) + (red[8192 + e] + red[12288 + e]);
     if (m0 + row < g.M && n0 + col < g.N)
-      __hip_atomic_fetch_add(C + (size_t)(m0 + row) * g.ldc + n0 + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(C + (size_t)(m0 + row) * g.ldc + (g.kperm ? x6_kperm_src(n0 + col, g.N) : n0 + col), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1303,7 +1317,10 @@ __device__ __forceinline__ void wgrad_x6_wide_body(const X6WgradArgs& g, const i
     const int o = row * RP + col;
     const float v = (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]);
     if (m0 + row < g.M && n0 + col < g.N) {
-      float* dst = g.swap ? C + (size_t)(n0 + col) * g.ldc + m0 + row : C + (size_t)(m0 + row) * g.ldc + n0 + col;
+      // (roles exchanged: the kernel's M side is cin)
+      const int wr = g.swap ? n0 + col : m0 + row, wc0 = g.swap ? m0 + row : n0 + col;
+      const int wc = g.kperm ? x6_kperm_src(wc0, g.swap ? g.M : g.N) : wc0;
+      float* dst = C + (size_t)wr * g.ldc + wc;
       __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1374,11 +1391,12 @@ extern "C" int gkg_x6_prep_desc_bytes(void) { return (int)sizeof(X6PrepDesc); }
 // be null: that orientation is not produced) and returns the unit count after
 // it (pass it as unit_begin of the next entry; the last return value is total_units of gkg_x6_prep_weights).
 extern "C" long long gkg_x6_prep_desc_fill(void* host_descs, int index, const float* w, void* planes_fwd, void* planes_dgrad,
-                                           int cin, int cout, int nb, long long unit_begin) {
+                                           int cin, int cout, int nb, long long unit_begin, int kperm) {
   if (!host_descs || !w || (!planes_fwd && !planes_dgrad) || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || index < 0) return -1;
+  if (kperm && (cin & 1)) return -1;
   X6PrepDesc* d = reinterpret_cast<X6PrepDesc*>(host_descs) + index;
   d->w = w; d->pf = (uint4*)planes_fwd; d->pd = (uint4*)planes_dgrad;
-  d->nb = nb; d->N = cout; d->K = cin; d->unit_begin = (int)unit_begin;
+  d->nb = nb; d->N = cout; d->K = cin; d->unit_begin = (int)unit_begin; d->kperm = kperm ? 1 : 0;
   const long long units = (long long)((planes_fwd ? x6_plane_units(cout, cin, nb) : 0) + (planes_dgrad ? x6_plane_units(cin, cout, nb) : 0)) / 3;
   if (unit_begin + units > 0x7fffffffLL) return -1;
   return unit_begin + units;
@@ -1488,8 +1506,11 @@ extern "C" int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride
 
 // dx (nb, R, cin) = dy (nb, R, cout; row pitch ldg, batch stride g_bstride) * w, the weights given as dgrad planes.
 static int x6_dgrad_impl(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
-                         int cin, int cout, int nb, const float* residual, void* sk_ws, size_t sk_bytes, void* stream) {
+                         int cin, int cout, int nb, const float* residual, void* sk_ws, size_t sk_bytes, void* stream,
+                         int ldx = 0, size_t x_bstride = 0) {
   if (!dy || !planes_dgrad || !dx) return gkg_fail(GKG_ERR_NULL, "gkg_linear_dgrad_x6: null pointer");
+  if (ldx == 0) { ldx = cin; x_bstride = (size_t)R * cin; }
+  if (ldx < cin || (ldx & 3) || (x_bstride & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6: bad dx pitch / batch stride");
   if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || nb > 64 || ldg < cout || (ldg & 3) || (g_bstride & 3) ||
       ((size_t)dy & 15))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6: need R > 0, cin % 4 == 0, cout % 4 == 0, 1 <= nb <= 64, 16-byte aligned rows");
@@ -1498,7 +1519,7 @@ static int x6_dgrad_impl(const float* dy, int ldg, size_t g_bstride, const void*
   a.A = dy; a.a_bstride = g_bstride; a.lda = ldg;
   a.NP = (cin + X6_NPAD - 1) / X6_NPAD * X6_NPAD; a.KC = (cout + 31) / 32 * 4;
   a.P = (const uint4*)planes_dgrad; a.p_bstride = (size_t)3 * a.KC * a.NP;
-  a.C = dx; a.c_bstride = (size_t)R * cin; a.ldc = cin;
+  a.C = dx; a.c_bstride = x_bstride; a.ldc = ldx;
   a.M = R; a.N = cin; a.K = cout;
   a.add = residual;
   hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream, sk_ws, sk_bytes);
@@ -1514,10 +1535,10 @@ extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, c
 // skip connection (reference torch_vertex.py:331,354,402 `+ _tmp`), added in the epilogue instead of by a stand-alone kernel.
 extern "C" int gkg_linear_dgrad_x6_sk(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
                                       int cin, int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes,
-                                      void* stream) {
+                                      int ldx, size_t x_bstride, void* stream) {
   if (splitk_ws && (splitk_bytes < X6_SK_BYTES || ((size_t)splitk_ws & 15)))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6_sk: need a 16-byte aligned workspace of gkg_x6_splitk_workspace_bytes() bytes (or NULL: no split)");
-  return x6_dgrad_impl(dy, ldg, g_bstride, planes_dgrad, dx, R, cin, cout, nb, residual, splitk_ws, splitk_bytes, stream);
+  return x6_dgrad_impl(dy, ldg, g_bstride, planes_dgrad, dx, R, cin, cout, nb, residual, splitk_ws, splitk_bytes, stream, ldx, x_bstride);
 }
 
 // The same input gradient with the BACKWARD statistics of the producer's BN in the epilogue (X6_BNBWD): dx is the upstream
@@ -1580,8 +1601,9 @@ static int x6_wgrad_set_attr(bool wide) {
 // problems (gkg_linear_wgrad_x6_batch) — slabs of ~`batched` units whatever the tile count, few-slab problems spread over the
 // XCDs by tiles.
 static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride, float* dw, int R,
-                         int cin, int cout, int nb, int batched, X6WgradPlan& pl) {
+                         int cin, int cout, int nb, int batched, X6WgradPlan& pl, int kperm = 0) {
   if (!dy || !x || !dw) return gkg_fail(GKG_ERR_NULL, "gkg_linear_wgrad_x6: null pointer");
+  if (kperm && (cin & 1)) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6: kperm needs an even cin");
   if (R <= 0 || cin <= 0 || cout <= 0 || nb <= 0 || nb > 64 || ldg < cout || ldx < cin)
     return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_wgrad_x6: need R, cin, cout > 0, 1 <= nb <= 64, pitches >= widths");
   if ((size_t)ldg * 4 * 16 > 0x7fffffffull || (size_t)ldx * 4 * 16 > 0x7fffffffull) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_linear_wgrad_x6: row pitch too large");
@@ -1590,6 +1612,7 @@ static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float
   a.B = x; a.b_bstride = x_bstride; a.ldb = ldx;
   a.C = dw; a.c_bstride = (size_t)cout * cin; a.ldc = cin;
   a.M = cout; a.N = cin; a.K = R;
+  a.kperm = kperm ? 1 : 0;
   a.mtiles = (cout + 63) / 64; a.ntiles = (cin + 63) / 64;
   // whole 128-row units go through an LDS-DMA kernel when the rows are 16-byte aligned; the ragged rest (and everything,
   // when they are not) through the register-load kernel
@@ -1693,9 +1716,9 @@ static int x6_wgrad_plan(const float* dy, int ldg, size_t g_bstride, const float
 }  // namespace gkg
 
 extern "C" int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride,
-                                   float* dw, int R, int cin, int cout, int nb, void* stream) {
+                                   float* dw, int R, int cin, int cout, int nb, int kperm, void* stream) {
   X6WgradPlan pl;
-  int rc = x6_wgrad_plan(dy, ldg, g_bstride, x, ldx, x_bstride, dw, R, cin, cout, nb, 0, pl);
+  int rc = x6_wgrad_plan(dy, ldg, g_bstride, x, ldx, x_bstride, dw, R, cin, cout, nb, 0, pl, kperm);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
@@ -1744,7 +1767,7 @@ extern "C" int gkg_linear_wgrad_x6_batch(const GkgWgradProblem* p, int n, int un
   for (int oi = 0; oi < n; ++oi) {
     const GkgWgradProblem& q = p[order[oi]];
     X6WgradPlan pl;
-    int rc = x6_wgrad_plan(q.dy, q.ldg, q.g_bstride, q.x, q.ldx, q.x_bstride, q.dw, q.R, q.cin, q.cout, q.nb, units_per_slab, pl);
+    int rc = x6_wgrad_plan(q.dy, q.ldg, q.g_bstride, q.x, q.ldx, q.x_bstride, q.dw, q.R, q.cin, q.cout, q.nb, units_per_slab, pl, q.kperm);
     if (rc) return rc;
     if (pl.main.K > 0) {
       const int i = b.n;

@@ -31,7 +31,8 @@
 namespace gkg {
 
 // ------------------------------------------------------------------------------------------ prep
-struct PrepStrides { int G; size_t sb, sg, sc, sn; };
+struct PrepStrides { int G; size_t sb, sg, sc, sn; int chunk; };      // chunk > 0 (token-major fp32 only): the x half of an XM
+                                                                        // buffer (gkg_common.h) — channel ch at column xm_col(ch, chunk)
 
 // One thread per token.  The two ordered fma chains over the channels are inherently serial per token and the
 // problem has few tokens per CU (cfg2: 160), so the kernel is latency-bound.  Structure: (1) pull the token's
@@ -88,12 +89,13 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
   float* cp = col + threadIdx.x;
   // ---- (1) gather the column
   if (sizeof(T) == 4 && ps.sc == 1 && (c & 3) == 0 && ((ps.sn | ps.sg | ps.sb) & 3) == 0) {
-    const float4* tp4 = reinterpret_cast<const float4*>(tp);
+    const int goff = (bg % ps.G) * (int)ps.sg;      // the group's first channel; quad q sits xm_col(goff + 4 q) - goff floats into tp
+    const float* tpf = reinterpret_cast<const float*>(tp) - goff;
     int q = 0;
     for (; q + 8 <= (c >> 2); q += 8) {
       float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = tp4[q + u];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(tpf + xm_col(goff + 4 * (q + u), ps.chunk));
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         cp[(4 * (q + u) + 0) * PT] = v[u].x; cp[(4 * (q + u) + 1) * PT] = v[u].y;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
       }
     }
     for (; q < (c >> 2); ++q) {
-      const float4 v = tp4[q];
+      const float4 v = *reinterpret_cast<const float4*>(tpf + xm_col(goff + 4 * q, ps.chunk));
       cp[(4 * q + 0) * PT] = v.x; cp[(4 * q + 1) * PT] = v.y; cp[(4 * q + 2) * PT] = v.z; cp[(4 * q + 3) * PT] = v.w;
     }
   } else {
@@ -216,13 +218,15 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
   const int nt = min(TK, Tn - n0);
   const float* tp = static_cast<const float*>(S.t) + (size_t)(bg / ps.G) * ps.sb + (size_t)(bg % ps.G) * ps.sg + (size_t)n0 * ps.sn;
   const int c4 = c >> 2;
+  const int goff = (bg % ps.G) * (int)ps.sg;      // the group's first channel (token-major: sg == c)
   // ---- (1) gather: lane (tid & 15) walks the float4s of the rows tid >> 4, + 16, ...
   for (int q = tid & 15; q < c4; q += 16) {
     float4 v[TK / 16];
+    const int xo = xm_col(goff + 4 * q, ps.chunk) - goff;
 #pragma unroll
     for (int u = 0; u < TK / 16; ++u) {
       const int tok = (tid >> 4) + 16 * u;
-      v[u] = tok < nt ? *reinterpret_cast<const float4*>(tp + (size_t)tok * ps.sn + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u] = tok < nt ? *reinterpret_cast<const float4*>(tp + (size_t)tok * ps.sn + xo) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < TK / 16; ++u) {
@@ -444,7 +448,7 @@ static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int 
 
 // Fused aggregation request of gkg_knn_mr_fwd_tm (token-major fp32 callers): outputs of knn_tile_kernel<..., MRF = true>.
 struct KnnMrFuse {
-  float* out;             // (4, B * N, C / 2)
+  float* out;             // XM (B * N, 2 C): m into the m chunks; x into the x chunks unless x already lives there
   uint16_t* arg;          // (B, N, C)
   uint16_t* nn16;         // (B * G, N, k) or null
 };
@@ -459,7 +463,17 @@ static bool knn_mr_plan_ok(const KnnPlan& p, int c, int N, int M, int k, bool pf
 static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                         int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                         void* workspace, size_t workspace_bytes, void* stream, int G_tm, const KnnMrFuse* mr = nullptr,
-                        bool probe_only = false, uint16_t* nn16_only = nullptr) {
+                        bool probe_only = false, uint16_t* nn16_only = nullptr, int ldx = 0, int xchunk = 0) {
+  // ldx / xchunk (token-major fp32 callers, G_tm > 0): x as a view — row pitch ldx floats (0: G_tm * c), chunk xchunk
+  // (gkg_common.h "XM layout": xchunk = C / 4 with ldx = 2 C is the x half of the grouped projection's operand buffer)
+  if (G_tm > 0) {
+    const int C = G_tm * c;
+    if (ldx == 0) ldx = C;
+    if (ldx < C || xchunk < 0 || (xchunk > 0 && (dtype != GKG_F32 || (xchunk & 3) || (c & 3) || (ldx & 3) || C % xchunk || ldx < 2 * C)))
+      return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm: bad x view (ldx >= C; a chunk needs fp32, c % 4 == 0, chunk % 4 == 0, chunk | C, ldx >= 2 C)");
+  } else if (ldx != 0 || xchunk != 0) {
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd: x views are a token-major feature");
+  }
   // nn16_only (gkg_knn_fwd_tm16): the neighbour lists as u16 rows INSTEAD of the int64 plane (M <= 65 536)
   if (!probe_only && (!x || (!nn_idx && !mr && !nn16_only) || !workspace)) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
   if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32, GKG_BF16 or GKG_F16");
@@ -477,10 +491,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   const bool norm = (flags & GKG_KNN_NORMALIZE) != 0;
   hipError_t e;
   // input addressing: channel-major (BG,c,T)  or  token-major (B,T,C=G*c) when G_tm > 0
-  auto strides = [&](int Tn) {
+  auto strides = [&](int Tn, int ld, int chunk) {
     PrepStrides ps;
-    if (G_tm > 0) { ps.G = G_tm; ps.sb = (size_t)Tn * G_tm * c; ps.sg = c; ps.sc = 1; ps.sn = (size_t)G_tm * c; }
-    else { ps.G = 1; ps.sb = (size_t)c * Tn; ps.sg = 0; ps.sc = Tn; ps.sn = 1; }
+    if (G_tm > 0) { ps.G = G_tm; ps.sb = (size_t)Tn * ld; ps.sg = c; ps.sc = 1; ps.sn = (size_t)ld; ps.chunk = chunk; }
+    else { ps.G = 1; ps.sb = (size_t)c * Tn; ps.sg = 0; ps.sc = Tn; ps.sn = 1; ps.chunk = 0; }
     return ps;
   };
   // bf16 contraction: the normalised copies are bf16 octet-major planes (they fit the fp32 copies' workspace slots); needs
@@ -541,9 +555,9 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   }
   uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
   uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
-  const PrepSet sx{x, xh, sqx, N, strides(N), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), pf ? cp16p : cp16,
+  const PrepSet sx{x, xh, sqx, N, strides(N, ldx, xchunk), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), pf ? cp16p : cp16,
                    pf ? xpl + (size_t)BG * Nr * cp16p : nullptr, Nr};
-  const PrepSet sy{y, yh, sqy, M, strides(M), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), pf ? cp16p : cp16,
+  const PrepSet sy{y, yh, sqy, M, strides(M, G_tm * c, 0), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), pf ? cp16p : cp16,
                    pf ? ypl + (size_t)BG * Mr * cp16p : nullptr, Mr};
   if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
@@ -560,6 +574,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   a.xb = (const uint16_t*)xh; a.yb = (const uint16_t*)yh; a.cp16 = cp16;
   a.xb_lo = a.yb_lo = nullptr; a.margin = 0.f; a.wg_flags = nullptr;
   a.mr_x = a.mr_src = nullptr; a.mr_out = nullptr; a.mr_arg = nullptr; a.nn16 = nn16_only; a.mr_G = 1; a.mr_c = c;
+  a.mr_ldx = a.mr_lds = c; a.mr_xchunk = a.mr_schunk = 0; a.mr_write_x = 1;
   dim3 grid((unsigned)(a.nqt * ((BG + 7) / 8) * 8), 1, p.S);
 #if defined(KNN_TIMELINE) || defined(KNN_ABLATE)
   if (p.S == 1 && gkg_knn_tl_buf) a.part_v = (float*)gkg_knn_tl_buf;
@@ -624,6 +639,10 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     if (mr) {
       a.mr_x = (const float*)x; a.mr_src = (const float*)(y ? y : x);
       a.mr_out = mr->out; a.mr_arg = mr->arg; a.nn16 = mr->nn16; a.mr_G = G_tm; a.mr_c = c;
+      a.mr_ldx = ldx; a.mr_xchunk = xchunk;
+      a.mr_lds = y ? G_tm * c : ldx; a.mr_schunk = y ? 0 : xchunk;
+      // x already lives in the operand buffer when the caller passes that buffer's x half as the view of x
+      a.mr_write_x = !((const void*)x == (const void*)mr->out && ldx == 2 * G_tm * c && xchunk == (G_tm * c) / 4);
       e = launch_knn_tile_f32_mr(a, grid, lds, p.KD, buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0), st);
     } else {
       e = launch_knn_tile_f32(a, grid, lds, p.KD, solo32 ? 5 : (buffered ? 2 : ((short_stream && p.KD == 9) ? 1 : 0)), st);
@@ -651,31 +670,32 @@ extern "C" int gkg_knn_fwd(const void* x, const void* y, const float* relpos, in
                       stream, 0);
 }
 
-extern "C" int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+extern "C" int gkg_knn_fwd_tm(const void* x, int ldx, int xchunk, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                               int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm: bad B / G");
   return knn_fwd_impl(x, y, relpos, nn_idx, center, B * G, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
-                      stream, G);
+                      stream, G, nullptr, false, nullptr, ldx, xchunk);
 }
 
 // The same graph as gkg_knn_fwd_tm with COMPACT neighbour lists: nn16 (B * G, N, k) u16 rows instead of the (2, B G, N, k) int64
 // edge_index — for callers that consume the graph on the device and never hand it out (Grapher.forward discards it, reference
 // torch_vertex.py:330).  At GKGNet-576's stage 1 the int64 pair is 191 MB written per launch, the compact lists 24 MB (pvig_m
 // stage 1, k = 18: 1.36 GB / 170 MB).  Needs M <= 65 536.  Same bits as the int64 lists (tests/test_hip_knn_compact.py).
-extern "C" int gkg_knn_fwd_tm16(const void* x, const void* y, const float* relpos, uint16_t* nn16, int B, int G, int c, int N, int M,
+extern "C" int gkg_knn_fwd_tm16(const void* x, int ldx, int xchunk, const void* y, const float* relpos, uint16_t* nn16, int B, int G, int c, int N, int M,
                                 int k, int dilation, int dtype, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
   if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd_tm16: bad B / G");
   if (!nn16) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd_tm16: nn16 must be non-null");
   if (M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd_tm16: M <= 65536 (u16 rows)");
   return knn_fwd_impl(x, y, relpos, nullptr, nullptr, B * G, c, N, M, k, dilation, dtype, flags, workspace, workspace_bytes,
-                      stream, G, nullptr, false, nn16);
+                      stream, G, nullptr, false, nn16, ldx, xchunk);
 }
 
 // Row g2: k-NN + max-relative aggregation in one kernel (knn_tile_kernel<..., MRF = true>) for token-major fp32 callers.
 // x (B, N, C = G c), y (B, M, C) or NULL (self graph), relative_pos (N, M) or NULL -> the graph of gkg_knn_fwd_tm (same
-// contract, same bits) is built and consumed on the spot: u_out (4, B N, C / 2) = the grouped projection's interleaved
-// operand of gkg_mr_fwd_tm mode 1, arg_out (B, N, C) u16 = the winning neighbour rows of gkg_mr_fwd_tm arg_kind 1,
+// contract, same bits) is built and consumed on the spot: xm_out (B N, 2 C) = the grouped projection's operand buffer of
+// gkg_mr_fwd_tm mode 1 (m into the m chunks; the x chunks are written unless x IS that buffer's x half: x == xm_out,
+// ldx == 2 C, xchunk == C / 4), arg_out (B, N, C) u16 = the winning neighbour rows of gkg_mr_fwd_tm arg_kind 1,
 // nn16_out (B G, N, k) u16 = the neighbour lists (optional); nn_idx_out / center_out (B G, N, k) int64 = gkg_knn_fwd_tm's outputs
 // for callers that return the graph (GrapherLabel), optional — otherwise no int64 index tensor and no centre plane exist.
 extern "C" int gkg_knn_mr_fused_supported(int B, int G, int c, int N, int M, int k, int dilation, int has_y, int has_relpos,
@@ -686,16 +706,19 @@ extern "C" int gkg_knn_mr_fused_supported(int B, int G, int c, int N, int M, int
                       dilation, GKG_F32, flags, nullptr, 0, nullptr, G, nullptr, true) == 0 ? 1 : 0;
 }
 
-extern "C" int gkg_knn_mr_fwd_tm(const float* x, const float* y, const float* relpos, float* u_out, uint16_t* arg_out,
-                                 uint16_t* nn16_out, int64_t* nn_idx_out, int64_t* center_out, int B, int G, int c, int N, int M,
-                                 int k, int dilation, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int gkg_knn_mr_fwd_tm(const float* x, int ldx, int xchunk, const float* y, const float* relpos, float* xm_out,
+                                 uint16_t* arg_out, uint16_t* nn16_out, int64_t* nn_idx_out, int64_t* center_out, int B, int G, int c,
+                                 int N, int M, int k, int dilation, unsigned flags, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   if (B <= 0 || G <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: bad B / G");
-  if (!u_out || !arg_out) return gkg_fail(GKG_ERR_NULL, "gkg_knn_mr_fwd_tm: null output");
+  if (!xm_out || !arg_out) return gkg_fail(GKG_ERR_NULL, "gkg_knn_mr_fwd_tm: null output");
   if ((G * c) & 15) return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: C = G * c must be a multiple of 16");
-  if (((size_t)x & 15) || ((size_t)y & 15) || ((size_t)u_out & 15) || ((size_t)arg_out & 7))
+  if (((size_t)x & 15) || ((size_t)y & 15) || ((size_t)xm_out & 15) || ((size_t)arg_out & 7) || (ldx & 3))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: 16-byte aligned rows");
-  const KnnMrFuse mr{u_out, arg_out, nn16_out};
+  if ((const void*)x == (const void*)xm_out && !(ldx == 2 * G * c && xchunk == (G * c) / 4))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_mr_fwd_tm: x aliases xm_out but is not its x half (ldx = 2 C, xchunk = C / 4)");
+  const KnnMrFuse mr{xm_out, arg_out, nn16_out};
   if (center_out && !nn_idx_out) return gkg_fail(GKG_ERR_NULL, "gkg_knn_mr_fwd_tm: center_out without nn_idx_out");
   return knn_fwd_impl(x, y, relpos, nn_idx_out, center_out, B * G, c, N, M, k, dilation, GKG_F32, flags, workspace, workspace_bytes,
-                      stream, G, &mr);
+                      stream, G, &mr, false, nullptr, ldx, xchunk);
 }

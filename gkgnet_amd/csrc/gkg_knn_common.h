@@ -138,12 +138,13 @@ struct KnnArgs {
   int* wg_flags;          // [gridDim.x] or null.  knn_pf_kernel: sets [blockIdx.x] = 1 (and writes no output) for a query
                           // tile it cannot settle; knn_tile_kernel: when non-null, only flagged workgroups run (clean-up pass)
   // fused aggregation (knn_tile_kernel<..., MRF = true>): token-major fp32 centre / source rows, outputs (see the kernel)
-  const float* mr_x;      // (B, N, G * mr_c)
-  const float* mr_src;    // (B, M, G * mr_c)
-  float* mr_out;          // (4, B * N, G * mr_c / 2) interleaved [x, m]: the grouped projection's operand
+  const float* mr_x;      // (B, N, G * mr_c) as a view: row pitch mr_ldx, chunk mr_xchunk (gkg_common.h "XM layout")
+  const float* mr_src;    // (B, M, G * mr_c) likewise (mr_lds, mr_schunk)
+  float* mr_out;          // XM (B * N, 2 G mr_c): the grouped projection's [x | m] operand buffer; m is written, x when mr_write_x
   uint16_t* mr_arg;       // (B, N, G * mr_c) winning neighbour rows
   uint16_t* nn16;         // (BG, N, k) compact neighbour lists, or null
   int mr_G, mr_c;
+  int mr_ldx, mr_xchunk, mr_lds, mr_schunk, mr_write_x;
 };
 
 // the aggregation's maximum rule (gkg_mr.hip `takes`): the first maximum wins, a NaN is the maximum and sticks

@@ -655,15 +655,17 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
     const int b = bg / G, g = bg - b * G;
     const int f4n = c >> 2;                                    // float4 columns of a query's group segment
     const int nq = min(QT, N - n0);
-    const size_t T = (size_t)(a.BG / G) * N;
-    const float* xrow0 = a.mr_x + ((size_t)b * N + n0) * C + (size_t)g * c;
-    const float* sb = a.mr_src + (size_t)b * M * C + (size_t)g * c;
-    const int Cq = C >> 2;                                     // original channels per conv group (reference torch_nn.py:61)
+    // x / src are token-major views (pointer, pitch, chunk: gkg_common.h "XM layout"); a group's c channels may span chunks,
+    // a float4 never does
+    const int ldx = a.mr_ldx, lds_ = a.mr_lds;
+    const float* xrow0 = a.mr_x + ((size_t)b * N + n0) * ldx;
+    const float* sb = a.mr_src + (size_t)b * M * lds_;
+    const int Cq = C >> 2;                                     // channels per conv group (reference torch_nn.py:61) = XM chunk width
     // Two (query, 4-channel) tasks per thread at a time: all 2 (k + 1) row-segment loads are issued before the first maximum
     // chain (the gather is latency-bound: one task at a time measured +20 us on the cfg2 launch against 14.7 us for the
     // stand-alone aggregation kernel it replaces).
     const int ntask = nq * f4n;
-    auto run = [&](auto careful, auto ks, int f4, const float4& xi, const int* id, const float4* v, float4& best, int (&ai)[4]) {
+    auto run = [&](auto careful, auto ks, const float4& xi, const int* id, const float4* v, float4& best, int (&ai)[4]) {
       constexpr int KS = decltype(ks)::value;
       float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
       constexpr int KS = decltype(ks)::value;
       constexpr int TU = KS <= 9 ? 2 : 1;                      // tasks in flight per thread
       for (int task0 = tid; task0 < ntask; task0 += TU * TH) {
-        int q[TU], f4[TU], id[TU][KS];
+        int q[TU], chq[TU], id[TU][KS];
         float4 xi[TU], v[TU][KS];
         bool on[TU];
 #pragma unroll
@@ -704,32 +706,34 @@ __global__ __launch_bounds__(64 * NWV, (BF && HAS_RP) ? (KD <= 18 ? 3 : 2) : (KD
           const int task = task0 + u * TH;
           on[u] = task < ntask;
           const int tk = on[u] ? task : task0;
-          q[u] = tk / f4n; f4[u] = tk - q[u] * f4n;
+          q[u] = tk / f4n;
+          chq[u] = g * c + 4 * (tk - q[u] * f4n);
 #pragma unroll
           for (int j = 0; j < KS; ++j) id[u][j] = nbr[(j < k ? j : 0) * 64 + q[u]];
-          xi[u] = *reinterpret_cast<const float4*>(xrow0 + (size_t)q[u] * C + 4 * f4[u]);
+          xi[u] = *reinterpret_cast<const float4*>(xrow0 + (size_t)q[u] * ldx + xm_col(chq[u], a.mr_xchunk));
         }
 #pragma unroll
-        for (int u = 0; u < TU; ++u)
+        for (int u = 0; u < TU; ++u) {
+          const float* sp = sb + xm_col(chq[u], a.mr_schunk);
 #pragma unroll
-          for (int j = 0; j < KS; ++j) v[u][j] = *reinterpret_cast<const float4*>(sb + (size_t)id[u][j] * C + 4 * f4[u]);
+          for (int j = 0; j < KS; ++j) v[u][j] = *reinterpret_cast<const float4*>(sp + (size_t)id[u][j] * lds_);
+        }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
           float4 best;
           int ai[4];
           // mr_fwd_tm_kernel's chain: a plain '>' (first maximum wins) while chk accumulates d * 0 — NaN as soon as a difference
           // is NaN or infinite; such a lane (non-finite inputs only) redoes the chain with `takes` (a NaN is the maximum and sticks)
-          const float chk = run(std::false_type{}, ks, f4[u], xi[u], id[u], v[u], best, ai);
-          if (chk != chk) (void)run(std::true_type{}, ks, f4[u], xi[u], id[u], v[u], best, ai);
+          const float chk = run(std::false_type{}, ks, xi[u], id[u], v[u], best, ai);
+          if (chk != chk) (void)run(std::true_type{}, ks, xi[u], id[u], v[u], best, ai);
           if (on[u]) {
             const size_t t = (size_t)b * N + n0 + q[u];
-            const int chq = g * c + 4 * f4[u];
-            *reinterpret_cast<uint2*>(a.mr_arg + t * C + chq) =
+            *reinterpret_cast<uint2*>(a.mr_arg + t * C + chq[u]) =
                 make_uint2((uint32_t)ai[0] | ((uint32_t)ai[1] << 16), (uint32_t)ai[2] | ((uint32_t)ai[3] << 16));
-            const int qc = chq / Cq, il = chq - qc * Cq;       // 4 channels never straddle a conv group (C % 16 == 0)
-            float* o = a.mr_out + ((size_t)qc * T + t) * (size_t)(2 * Cq) + 2 * il;
-            *reinterpret_cast<float4*>(o) = make_float4(xi[u].x, best.x, xi[u].y, best.y);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(xi[u].z, best.z, xi[u].w, best.w);
+            // the grouped projection's operand buffer XM (T, 2C): m into the m chunk; the x chunk only when x does not live there
+            float* o = a.mr_out + t * (size_t)(2 * C) + xm_col(chq[u], Cq);
+            if (a.mr_write_x) *reinterpret_cast<float4*>(o) = xi[u];
+            *reinterpret_cast<float4*>(o + Cq) = best;
           }
         }
       }

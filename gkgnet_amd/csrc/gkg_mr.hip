@@ -238,8 +238,12 @@ __global__ __launch_bounds__(256) void negate_kernel(const float* __restrict__ g
 // segment of c floats, so the aggregation is a coalesced row gather — no LDS staging.  One thread = one token x
 // 4 consecutive channels (one group): k float4 gathers + centre float4, all issued before the max chain.
 //   mode 0: m (B,N,C) token-major.
-//   mode 1: the grouped 1x1 projection's input directly, U[q][t][2i] = x[t][q*C/4+i], U[q][t][2i+1] = m[...]
-//           (reference interleave torch_vertex.py:57-61 + Conv2d(groups=4) channel split torch_nn.py:61).
+//   mode 1: the grouped 1x1 projection's operand buffer XM (T, 2C) (gkg_common.h "XM layout"): the reference's interleave
+//           [x_0, m_0, x_1, m_1, ...] (torch_vertex.py:57-61) + Conv2d(groups=4) channel split (torch_nn.py:61) with the
+//           columns of each conv group reordered to [x chunk | m chunk] — a permutation of the weight's input columns that the
+//           weight-plane build folds in, so nothing is interleaved at run time.  m goes to the m chunks; the x chunks are
+//           written only when `write_x` (x does not live in the buffer already: the producer of x writes it there itself).
+// x / src are token-major VIEWS (pointer, row pitch, chunk): chunk 0 = plain rows, chunk h = the x half of an XM buffer.
 // AK — what `argmax` holds for the backward: 0 = the winning SLOT j (u8, the C-ABI's documented form), 1 = the winning
 // neighbour's ROW INDEX itself (u16; needs M <= 65536).  With the row stored the backward scatters straight from it: no
 // index-row lookup, i.e. one dependent global round trip less per query and no 72-byte index rows to fetch.
@@ -251,7 +255,8 @@ template <int KS, int QP, typename OutT = float, int AK = 0, typename IdxT = int
 __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict__ x, const float* __restrict__ src,
                                                         const IdxT* __restrict__ nn_idx, OutT* __restrict__ out,
                                                         uint8_t* __restrict__ argmax, int B, int G, int c, int N, int M,
-                                                        int k_rt, int mode) {
+                                                        int k_rt, int mode, int ldx, int xchunk, int lds_, int schunk,
+                                                        int write_x) {
   const int k = KS > 0 ? KS : k_rt;
   const int C = G * c, CT = C / (4 * QP);                         // thread-columns per token
   const size_t T = (size_t)B * N;
@@ -271,12 +276,13 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
   const size_t t = (size_t)b * N + n;
   const int g = ch / c;
   const IdxT* ip = nn_idx + (((size_t)b * G + g) * N + n) * k;
-  const float* sb = src + (size_t)b * M * C + ch;
+  const float* sb = src + (size_t)b * M * lds_ + xm_col(ch, schunk);
+  const float* xb = x + t * (size_t)ldx + xm_col(ch, xchunk);
   float4 xi[QP], best[QP];
   int ai[QP][4];                                                  // winner per channel: neighbour slot j (AK == 0) / row index (AK == 1)
   MR_STAMP(0);
 #pragma unroll
-  for (int q = 0; q < QP; ++q) xi[q] = *reinterpret_cast<const float4*>(x + t * C + ch + 4 * q);
+  for (int q = 0; q < QP; ++q) xi[q] = *reinterpret_cast<const float4*>(xb + 4 * q);
   // `takes` (first maximum wins, a NaN is the maximum and sticks) costs 3 compares + 2 scalar mask operations + exec-masked
   // moves per (channel, neighbour): 420 vector + 330 scalar instructions per thread (SQ counters, profiles/r04_pmc_mr_stage1.txt).
   // Fast chain: a plain '>' (identical to `takes` whenever no difference is NaN) while chk accumulates d * 0 — NaN as soon as
@@ -322,9 +328,9 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
       float4 v[KS > 0 ? KS : 1];
 #pragma unroll
 #if MR_ABL & 1
-      for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)(id[j] & 3) * C + 4 * q);
+      for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)(id[j] & 3) * lds_ + 4 * q);
 #else
-      for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * C + 4 * q);
+      for (int j = 0; j < KS; ++j) v[j] = *reinterpret_cast<const float4*>(sb + (size_t)id[j] * lds_ + 4 * q);
 #endif
 #ifdef MR_TL
       if (v[0].x == 1.25e-33f || id[8] == -7) MR_STAMP(7);      // (forces the index loads to have arrived)
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
   } else {
     for (int j = 0; j < k; ++j) {
       const int rid = clamp_idx(ip[j], M);
-      const size_t row = (size_t)rid * C;
+      const size_t row = (size_t)rid * lds_;
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(sb + row + 4 * q);
@@ -365,11 +371,10 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
     if (mode == 0) {
       stf4(out + t * C + chq, best[q]);
     } else {
-      const int Cq = C >> 2;                      // original channels per conv group
-      const int qc = chq / Cq, il = chq - qc * Cq;   // 4 channels never straddle a conv group (C % 16 == 0)
-      OutT* o = out + ((size_t)qc * T + t) * (size_t)(2 * Cq) + 2 * il;
-      stf4(o, make_float4(xi[q].x, best[q].x, xi[q].y, best[q].y));
-      stf4(o + 4, make_float4(xi[q].z, best[q].z, xi[q].w, best[q].w));
+      const int Cq = C >> 2;                      // channels per conv group = chunk width of the XM buffer (C % 16 == 0)
+      OutT* o = out + t * (size_t)(2 * C) + xm_col(chq, Cq);
+      if (write_x) stf4(o, xi[q]);
+      stf4(o + Cq, best[q]);
     }
   }
 #ifdef MR_TL
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void mr_fwd_tm_kernel(const float* __restrict_
 #endif
 }
 
-// Backward, pass 1: gx[t][ch] = direct[t][ch] - gm[t][ch]   (mode 1: direct/gm are the even/odd columns of dU)
+// Backward, pass 1: gx[t][ch] = direct[t][ch] - gm[t][ch]   (mode 1: direct / gm are the x / m chunks of dXM)
 __global__ __launch_bounds__(256) void mr_bwd_tm_init_kernel(const float* __restrict__ gin, float* __restrict__ gx,
                                                              int C, size_t T, int mode) {
   const int C4 = C >> 2;
@@ -393,10 +398,9 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_init_kernel(const float* __rest
     o = make_float4(-g.x, -g.y, -g.z, -g.w);
   } else {
     const int Cq = C >> 2;
-    const int q = ch / Cq, il = ch - q * Cq;
-    const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
-    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
-    o = make_float4(u0.x - u0.y, u0.z - u0.w, u1.x - u1.y, u1.z - u1.w);
+    const float* p = gin + t * (size_t)(2 * C) + xm_col(ch, Cq);
+    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + Cq);
+    o = make_float4(u0.x - u1.x, u0.y - u1.y, u0.z - u1.z, u0.w - u1.w);
   }
   *reinterpret_cast<float4*>(gx + t * C + ch) = o;
 }
@@ -416,13 +420,11 @@ __device__ __forceinline__ void load_grad(const float* __restrict__ gin, size_t 
   if (mode == 0) {
     gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
     direct = make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
+  } else {                                     // XM layout (T, 2C): the x chunk carries the direct gradient, the m chunk gm
     const int Cq = C >> 2;
-    const int q = ch / Cq, il = ch - q * Cq;
-    const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
-    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
-    direct = make_float4(u0.x, u0.z, u1.x, u1.z);
-    gm = make_float4(u0.y, u0.w, u1.y, u1.w);
+    const float* p = gin + t * (size_t)(2 * C) + xm_col(ch, Cq);
+    direct = *reinterpret_cast<const float4*>(p);
+    gm = *reinterpret_cast<const float4*>(p + Cq);
   }
 }
 
@@ -1038,10 +1040,7 @@ __global__ __launch_bounds__(256) void mr_bwd_tm_scatter_atomic_kernel(const flo
     gm = *reinterpret_cast<const float4*>(gin + t * C + ch);
   } else {
     const int Cq = C >> 2;
-    const int q = ch / Cq, il = ch - q * Cq;
-    const float* p = gin + ((size_t)q * T + t) * (size_t)(2 * Cq) + 2 * il;
-    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
-    gm = make_float4(u0.y, u0.w, u1.y, u1.w);
+    gm = *reinterpret_cast<const float4*>(gin + t * (size_t)(2 * C) + xm_col(ch, Cq) + Cq);
   }
   float* db = dst + (size_t)b * M * C + ch;
   atomicAdd(db + (size_t)j[0] * C + 0, gm.x);
@@ -1152,7 +1151,7 @@ extern "C" int gkg_mr_bwd(const void* g, const int64_t* nn_idx, const uint8_t* a
 
 // ------------------------------------------------------------------------------------------ token-major entry points
 template <typename IdxT>
-static int mr_fwd_tm_impl(const float* x, const float* src, const IdxT* nn_idx, void* out, uint8_t* argmax,
+static int mr_fwd_tm_impl(const float* x, int ldx, int xchunk, const float* src, const IdxT* nn_idx, void* out, uint8_t* argmax,
                           int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
   if (arg_kind != 0 && arg_kind != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: arg_kind is 0 (u8 slot) or 1 (u16 row index)");
   if (arg_kind == 1 && M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: arg_kind 1 needs M <= 65536");
@@ -1161,8 +1160,16 @@ static int mr_fwd_tm_impl(const float* x, const float* src, const IdxT* nn_idx, 
   if (mode != 0 && mode != 1) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode is 0 or 1");
   if (mode == 1 && ((G * c) & 15)) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: mode 1 needs C % 16 == 0");
   if (out_dtype != GKG_F32 && out_dtype != GKG_BF16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm: out_dtype is GKG_F32 or GKG_BF16");
+  const int C = G * c;
+  if (ldx == 0) ldx = C;
+  if (ldx < C || (ldx & 3) || xchunk < 0 || (xchunk & 3) || (xchunk > 0 && (C % xchunk || ldx < 2 * C)))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: bad x view (ldx >= C, ldx % 4 == 0; a chunk is a multiple of 4 dividing C, with ldx >= 2 C)");
   const bool has_src = src != nullptr;
-  if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; }
+  int lds_ = C, schunk = 0;
+  if (!src) { if (M != N) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: self graph needs M == N"); src = x; lds_ = ldx; schunk = xchunk; }
+  // mode 1: x already lives in the operand buffer when the caller passes that buffer's x half as the view of x
+  const int write_x = !(mode == 1 && (const void*)x == (const void*)out && ldx == 2 * C && xchunk == (C >> 2) && out_dtype == GKG_F32);
+  if (mode == 1 && (const void*)x == (const void*)out && write_x) return gkg_fail(GKG_ERR_SHAPE, "gkg_mr_fwd_tm: x aliases out but is not its x half (ldx = 2 C, xchunk = C / 4, fp32)");
   // algorithmic bytes (SURVEY §8d "MR gather-max fwd"): x + (keys) + int64 indices + m (+ 1 byte of argmax per element)
   const double e_out = out_dtype == GKG_BF16 ? 2.0 : 4.0;
   const double work = 4.0 * B * (double)G * c * N + (has_src ? 4.0 * B * (double)G * c * M : 0.0) + (double)sizeof(IdxT) * B * (double)G * N * k
@@ -1176,28 +1183,28 @@ static int mr_fwd_tm_impl(const float* x, const float* src, const IdxT* nn_idx, 
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == GKG_BF16) {
     uint16_t* o = (uint16_t*)out;
-    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
-    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, uint16_t, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); }
+    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, uint16_t, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); }
   } else {
     float* o = (float*)out;
-    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
-    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode); }
+    if (k == 9) { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); else hipLaunchKernelGGL((mr_fwd_tm_kernel<9, 1, float, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); }
+    else { if (arg_kind == 1) hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 1, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); else hipLaunchKernelGGL((mr_fwd_tm_kernel<0, 1, float, 0, IdxT>), grid, dim3(256), 0, st, x, src, nn_idx, o, argmax, B, G, c, N, M, k, mode, ldx, xchunk, lds_, schunk, write_x); }
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "mr_fwd_tm_kernel");
 }
 
-extern "C" int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out, uint8_t* argmax,
+extern "C" int gkg_mr_fwd_tm(const float* x, int ldx, int xchunk, const float* src, const int64_t* nn_idx, void* out, uint8_t* argmax,
                              int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
-  return mr_fwd_tm_impl<int64_t>(x, src, nn_idx, out, argmax, B, G, c, N, M, k, mode, out_dtype, arg_kind, stream);
+  return mr_fwd_tm_impl<int64_t>(x, ldx, xchunk, src, nn_idx, out, argmax, B, G, c, N, M, k, mode, out_dtype, arg_kind, stream);
 }
 
 // gkg_mr_fwd_tm over the compact neighbour lists of gkg_knn_fwd_tm16 (u16 rows, M <= 65 536): same outputs, same bits; the
 // index stream is a quarter of the int64 one (SURVEY §8d "MR gather-max fwd": 8 B G N k -> 2 B G N k bytes).
-extern "C" int gkg_mr_fwd_tm16(const float* x, const float* src, const uint16_t* nn16, void* out, uint8_t* argmax,
+extern "C" int gkg_mr_fwd_tm16(const float* x, int ldx, int xchunk, const float* src, const uint16_t* nn16, void* out, uint8_t* argmax,
                                int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream) {
   if (M > 65536) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_mr_fwd_tm16: M <= 65536 (u16 rows)");
-  return mr_fwd_tm_impl<uint16_t>(x, src, nn16, out, argmax, B, G, c, N, M, k, mode, out_dtype, arg_kind, stream);
+  return mr_fwd_tm_impl<uint16_t>(x, ldx, xchunk, src, nn16, out, argmax, B, G, c, N, M, k, mode, out_dtype, arg_kind, stream);
 }
 
 // The LDS-image backward kernels are instantiated per (self graph, mode, arg kind): 8 forms each, picked here.

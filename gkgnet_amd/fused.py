@@ -8,8 +8,10 @@ torch_vertex.py:278-403), restructured for MI355X:
 * everything between two GEMMs is a hand-written bandwidth kernel from ``libgkg_hip.so``
   (``csrc/gkg_dense.hip``): train-mode BN statistics (deterministic two-stage), BN-apply (+GELU) (+residual),
   the BN/GELU backward pair, layout changes fused into the first/last kernel of the block;
-* the max-relative kernel writes the grouped projection's interleaved input directly (no ``stack``/``cat``),
-  its backward consumes the grouped projection's input gradient directly.
+* the reference's interleave ``[x_0, m_0, x_1, m_1, ...]`` (torch_vertex.py:57-61) is never built: the grouped projection reads
+  ONE operand buffer XM (T, 2C) whose conv-group columns are ordered [x chunk | m chunk] (include/gkg_hip.h "XM layout"); fc1's
+  BN-apply writes x straight into its x chunks, the aggregation fills the m chunks, the permutation lives in the weight planes,
+  and the backward's input-gradient GEMM writes dXM in the same layout for the scatter to read.
 
 Autograd sees four custom Functions (layout, linear+BN+act, grouped linear+BN+act, max-relative) with
 hand-written backward passes.  Used automatically by ``Grapher`` / ``GrapherLabel`` when supported
@@ -206,7 +208,7 @@ _parallel._FLUSH.append(flush_wgrads)
 _parallel._ZERO_DEFER[:] = [_planes_mod.defer_zero, _planes_mod.flush_deferred_zero]
 
 
-def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs) -> bool:
+def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) -> bool:
     """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
     if not (WGRAD_BATCH and not DETERMINISTIC and X6_WGRAD and GEMM_MATH in ("x6", "x6all") and OWN_GEMM != "none"
             and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
@@ -229,7 +231,7 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs) -> bool:
     q.stream, q.device = st, dY.device
     if not getattr(out, "_gkg_zero", False):
         out.zero_()
-    q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb))
+    q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm))
     q.keep.append((dY, x))
     if len(q.items) >= q.MAX:
         items, q.items = q.items, []
@@ -255,7 +257,7 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
         elif not getattr(out, "_gkg_zero", False):          # a bucket slot cleared by GradBucket.release(prezero=True) is clean
             out.zero_()
         _lib.check(_lib.load().gkg_linear_wgrad_x6(_ptr(dY), dY.stride(0), 0, _ptr(x), x.stride(0), 0, _ptr(out), R, cin, cout,
-                                                   1, _stream()), "gkg_linear_wgrad_x6")
+                                                   1, 0, _stream()), "gkg_linear_wgrad_x6")
         return out
     if R >= 4096:                # short contractions (the label branch): the partial-sum kernel costs more than it saves
         for S in (8, 6, 4, 3, 2):
@@ -265,16 +267,35 @@ def _wgrad(dY: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
     return torch.mm(dY.t(), x) if out is None else torch.mm(dY.t(), x, out=out)
 
 
-def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None) -> torch.Tensor:
+def _kperm_weight(Wg: torch.Tensor) -> torch.Tensor:
+    """(nb, co, ci) weight with its input columns as [even | odd]: the order an XM operand buffer presents them in (the x
+    chunk, then the m chunk) — for the GEMM paths that read the weight tensor itself rather than its x6 planes."""
+    nb, co, ci = Wg.shape
+    return Wg.view(nb, co, ci // 2, 2).permute(0, 1, 3, 2).reshape(nb, co, ci)
+
+
+def _kperm_grad_back(dWp: torch.Tensor, out=None) -> torch.Tensor:
+    """Inverse of _kperm_weight on a gradient: columns [x chunk | m chunk] -> the reference's interleave."""
+    nb, co, ci = dWp.shape
+    dW = dWp.view(nb, co, 2, ci // 2).permute(0, 1, 3, 2).reshape(nb, co, ci)
+    if out is None:
+        return dW
+    out.copy_(dW)
+    return out
+
+
+def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None, kperm=0) -> torch.Tensor:
     """Grouped projection: dW[q] (co, ci) = dY[q]^T @ U[q] for the nb groups; long contractions are split like
-    ``_wgrad`` (nb*S batched GEMMs + one partial sum)."""
+    ``_wgrad`` (nb*S batched GEMMs + one partial sum).  ``U`` (nb, R, ci) may be a strided view (the XM operand buffer:
+    strides (ci, 2C, 1)); ``kperm``: its columns are [x chunk | m chunk] and dW is returned in the reference's interleaved
+    column order (the x6 kernels permute where they add their tiles to dW)."""
     nb, R, co = dY.shape
     ci = U.shape[2]
     S = 4
     if out is not None and (out.dtype != dY.dtype or not out.is_contiguous()):
         out = None
     if (dY.stride(2) == 1 and U.stride(2) == 1
-            and _wgrad_defer(dY, U, out, R, ci, co, nb, dY.stride(1), dY.stride(0), U.stride(1), U.stride(0))):
+            and _wgrad_defer(dY, U, out, R, ci, co, nb, dY.stride(1), dY.stride(0), U.stride(1), U.stride(0), kperm)):
         return out
     if (_x6_wgrad_ok(dY, U, nb) and dY.stride(2) == 1 and U.stride(2) == 1
             and all(t.stride(d) % 4 == 0 for t in (dY, U) for d in (0, 1))):
@@ -283,9 +304,11 @@ def _wgrad_grouped(dY: torch.Tensor, U: torch.Tensor, out=None) -> torch.Tensor:
         elif not getattr(out, "_gkg_zero", False):
             out.zero_()
         _lib.check(_lib.load().gkg_linear_wgrad_x6(_ptr(dY), dY.stride(1), dY.stride(0), _ptr(U), U.stride(1), U.stride(0), _ptr(out),
-                                                   R, ci, co, nb, _stream()), "gkg_linear_wgrad_x6 (grouped)")
+                                                   R, ci, co, nb, kperm, _stream()), "gkg_linear_wgrad_x6 (grouped)")
         return out
-    if R >= 4096 and R % S == 0:
+    if kperm:
+        return _kperm_grad_back(_wgrad_grouped(dY, U.contiguous() if R >= 4096 else U, None, 0), out)
+    if R >= 4096 and R % S == 0 and U.is_contiguous():
         part = torch.bmm(dY.reshape(nb * S, R // S, co).transpose(1, 2), U.reshape(nb * S, R // S, ci))
         return part.view(nb, S, co, ci).sum(1) if out is None else torch.sum(part.view(nb, S, co, ci), 1, out=out)
     return torch.bmm(dY.transpose(1, 2), U) if out is None else torch.bmm(dY.transpose(1, 2), U, out=out)
@@ -326,11 +349,12 @@ def _sk_ws(device) -> torch.Tensor:
     return t
 
 
-def _dgrad_x6(lib, dY, ldg, g_bs, pd, dx, R, cin, cout, nb, residual=None):
-    """dx = dY W (+ residual: the skip connection's gradient, added in the epilogue) on the x6 kernel."""
+def _dgrad_x6(lib, dY, ldg, g_bs, pd, dx, R, cin, cout, nb, residual=None, ldx=0, x_bs=0):
+    """dx = dY W (+ residual: the skip connection's gradient, added in the epilogue) on the x6 kernel.  ``ldx`` / ``x_bs``: row
+    pitch / batch stride of dx (0: contiguous (nb, R, cin)) — the grouped projection writes dXM (R, 2C) with (2C, C/2)."""
     ws = _sk_ws(dY.device) if SPLIT_K else None
     _lib.check(lib.gkg_linear_dgrad_x6_sk(_ptr(dY), ldg, g_bs, _ptr(pd), _ptr(dx), R, cin, cout, nb, _ptr(residual), _ptr(ws),
-                                          ws.numel() if SPLIT_K else 0, _stream()), "gkg_linear_dgrad_x6")
+                                          ws.numel() if SPLIT_K else 0, ldx, x_bs, _stream()), "gkg_linear_dgrad_x6")
 
 
 def _own_gemm(x, weight, bn) -> bool:
@@ -366,15 +390,15 @@ def _grad_outs(gparams, wshape, nch, dev):
     return w, g, b
 
 
-def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, planes=None):
+def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, planes=None, xld=None, xbs=None):
     """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue); ``planes``: the
-    weight's forward bf16 planes -> gkg_linear_bn_fwd_x6."""
+    weight's forward bf16 planes -> gkg_linear_bn_fwd_x6 (``xld`` / ``xbs``: row pitch / batch stride of x there)."""
     dev = x.device
     if planes is not None:
         def fwd(xp, wp, yp, R_, cin_, cout_, nb_, *rest):
             ws = _sk_ws(dev) if SPLIT_K else None
-            return lib.gkg_linear_bn_fwd_x6_sk(xp, cin_, R_ * cin_, _ptr(planes), yp, R_, cin_, cout_, nb_, *rest[:-1], _ptr(ws),
-                                               ws.numel() if SPLIT_K else 0, rest[-1])
+            return lib.gkg_linear_bn_fwd_x6_sk(xp, cin_ if xld is None else xld, R_ * cin_ if xbs is None else xbs, _ptr(planes), yp,
+                                               R_, cin_, cout_, nb_, *rest[:-1], _ptr(ws), ws.numel() if SPLIT_K else 0, rest[-1])
     else:
         fwd = lib.gkg_linear_bn_fwd
     Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
@@ -594,7 +618,7 @@ from .bn_scratch import _BnBwdScratch, _BnFwdScratch      # noqa: E402  (fp64 co
 
 
 def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale,
-                           launch=None, out_tm=None):
+                           launch=None, out_tm=None, xld=None, xbs=None, ochunk=0):
     """Projection (statistics in its epilogue) -> BN-apply straight from the fp64 sums: two launches, no finalize kernel.
     Returns (Y, a, c, mean, invstd).  ``launch(Y, sums) -> rc``: a caller-supplied producer of Y and its column sums (the
     fused aggregation + projection kernel) instead of the plain projection of ``x``."""
@@ -608,7 +632,8 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
             rc = launch(Y, cur)
         elif planes is not None:
             ws = _sk_ws(dev) if SPLIT_K else None
-            rc = lib.gkg_linear_bn_fwd_x6_sk(_ptr(x), cin, R * cin, _ptr(planes), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
+            rc = lib.gkg_linear_bn_fwd_x6_sk(_ptr(x), cin if xld is None else xld, R * cin if xbs is None else xbs, _ptr(planes),
+                                             _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
                                              _ptr(cur), _ptr(ws), ws.numel() if SPLIT_K else 0, _stream())
         else:
             rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
@@ -627,7 +652,7 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
             _lib.check(lib.gkg_bn_apply_train(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
                                               _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
                                               _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean), _ptr(invstd),
-                                              _ptr(res), _ptr(out), R, cout, nb, ldo, obs, act, nchw_B, _ptr(scale), rows_per_scale,
+                                              _ptr(res), _ptr(out), R, cout, nb, ldo, obs, ochunk, act, nchw_B, _ptr(scale), rows_per_scale,
                                               float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
                        "gkg_bn_apply_train")
     except Exception:
@@ -771,13 +796,16 @@ class _LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None, scale=None,
-                rows_per_scale=0, want16=False, alias=False, dual=False):
+                rows_per_scale=0, want16=False, alias=False, dual=False, xm=None):
         """``alias``: also return ``x`` itself as a second output (a view).  A caller that uses the layer's input again
         as the residual of a later layer takes the alias for that: both gradient contributions then arrive at THIS node
         and the input-gradient GEMM adds the residual one in its epilogue (``addmm``), instead of autograd summing two
         tensors with a stand-alone add kernel.
         ``dual`` (with ``nchw``, fp32, no DropPath scale): ``residual`` is given TOKEN-MAJOR (R, cout) and the result is
-        returned in both layouts, ``(out (B, C, H, W), out_tm (R, cout))`` — see DUAL_LAYOUT below."""
+        returned in both layouts, ``(out (B, C, H, W), out_tm (R, cout))`` — see DUAL_LAYOUT below.
+        ``xm`` = (B, N) (fp32 token-major output, no residual): the result is written into the x half of a fresh XM operand
+        buffer (R, 2 cout) and returned as its (B, N, 4, cout / 4) view (see _xm_xview) — a Grapher's fc1, whose output the
+        aggregation and the grouped projection read in place."""
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
@@ -788,7 +816,13 @@ class _LinearBNAct(torch.autograd.Function):
         pf, pd = _planes(lib, weight, 1, cout, cin, x6f, x6d) if x6f or x6d else (None, None)
         pf, pd = (pf if x6f else None), (pd if x6d else None)
         res = None if residual is None else residual.contiguous()
-        if nchw is None:
+        ochunk, ldo = 0, cout
+        if xm is not None:
+            assert nchw is None and not out_lowp and not want16 and residual is None and not dual and cout % 16 == 0
+            dt, code = _F32, _lib.F32
+            out = torch.empty((R, 2 * cout), dtype=_F32, device=x.device)       # XM: x chunks now, m chunks by the aggregation
+            ochunk, ldo = cout // 4, 2 * cout
+        elif nchw is None:
             dt, code = _tm_dtype(out_lowp)
             out = torch.empty((R, cout), dtype=dt, device=x.device)
         else:
@@ -805,8 +839,8 @@ class _LinearBNAct(torch.autograd.Function):
         fused_apply = own and _derive_ok(bn, 1, cout, code, want16)
         if fused_apply:                               # projection (statistics epilogue) -> apply from the sums: 2 launches
             Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, pf, res, out,
-                                                           cout, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale,
-                                                           out_tm=out_tm)
+                                                           ldo, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale,
+                                                           out_tm=out_tm, ochunk=ochunk)
         elif own:                                     # projection kernel with the BN statistics in its epilogue
             Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
         else:
@@ -821,7 +855,7 @@ class _LinearBNAct(torch.autograd.Function):
                                                _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act_dual")
             out._gkg_bf16_tm = out16
         elif nchw is None:
-            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, cout, 0, act,
+            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), R, cout, 1, ldo, 0, ochunk, act,
                                           code, _ptr(scale), rows_per_scale, _stream()), "gkg_affine_act")
         elif dual:
             _lib.check(lib.gkg_tm_affine_to_nchw_dual(_ptr(Y), _ptr(a), _ptr(c), _ptr(res), _ptr(out), _ptr(out_tm), nchw[0], cout,
@@ -837,7 +871,9 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.sync = sync
         ctx.pd = pd
         ctx.prev = prev if (prev is not None and pd is not None and prev.nb * prev.co == cin and prev.R == R) else None
-        ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, 1, cout, R, bn, sync, scale) if nchw is None else None
+        ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, 1, cout, R, bn, sync, scale) if (nchw is None and xm is None) else None
+        if xm is not None:
+            out = _xm_xview(out, xm[0], xm[1], cout)
         if alias:
             ctx.set_materialize_grads(False)
             return out, x.view_as(x)
@@ -855,9 +891,9 @@ class _LinearBNAct(torch.autograd.Function):
         if ctx.dual:
             dtm, dalias = dalias, None
             if dout is None and dtm is None:
-                return (None,) * 16
+                return (None,) * 17
         elif dout is None:                                 # only the alias was used downstream
-            return (dalias,) + (None,) * 15
+            return (dalias,) + (None,) * 16
         R, cin = x.shape
         cout = weight.shape[0]
         dres = dout if has_res else None
@@ -889,7 +925,7 @@ class _LinearBNAct(torch.autograd.Function):
         elif ctx.scale[0] is not None:
             g = (dout.view(-1, ctx.scale[1], cout) * ctx.scale[0].view(-1, 1, 1)).view(R, cout)
         else:
-            g = dout.contiguous()
+            g = dout.contiguous()                # (an xm output's gradient arrives (B, N, 4, cout / 4): the same memory as (R, cout))
         if mean is None:
             raise _lib.GkgError("backward through eval-mode BN is only supported on the composable path")
         # a conv bias in front of train-mode BN has exactly zero gradient (BN removes the mean): not materialised
@@ -919,48 +955,51 @@ class _LinearBNAct(torch.autograd.Function):
         elif dalias is not None:
             dx = dalias
         dW = _wgrad(dY, x, dWv).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
-    """The reference's BasicConv: Conv2d(1x1, groups=4) + BN + act on the interleaved [x, m] channels.
-    U (4, R, ci) group-major -> out (R, 4*co) token-major (column q*co + j)."""
+    """The reference's BasicConv: Conv2d(1x1, groups=4) + BN + act on the interleaved [x, m] channels (torch_nn.py:57-69 behind
+    torch_vertex.py:57-61), reading the XM operand buffer (R, 4 ci) instead of an interleaved tensor: group q's ci inputs are
+    the contiguous columns [q ci, (q+1) ci) = [x chunk | m chunk]; the weight's input columns are taken in that order (x6 planes
+    built with kperm, or _kperm_weight for the library paths).  -> out (R, 4 co) token-major (column q co + j)."""
 
     @staticmethod
-    def forward(ctx, U, weight, bias, gamma, beta, bn, act, out_lowp=False, w16=None):
+    def forward(ctx, XM, weight, bias, gamma, beta, bn, act, out_lowp=False, w16=None):
         lib = _lib.load()
-        nb, R, ci = U.shape
+        nb = 4
+        R, ci = XM.shape[0], XM.shape[1] // nb
+        XM = XM.contiguous()
+        U = XM.view(R, nb, ci).permute(1, 0, 2)                     # (nb, R, ci): strides (ci, 4 ci, 1)
         cout = weight.shape[0]
         co = cout // nb
         Wg = weight.view(nb, co, ci)
         x6f, x6d = _x6(U, weight, bn, nb, "fwd") and act == 1, _x6(U, weight, bn, nb, "dgrad")
-        own = x6f or (_own_gemm(U, weight, bn) and act == 1)
-        pf, pd = _planes(lib, weight, nb, co, ci, x6f, x6d) if x6f or x6d else (None, None)
+        own = x6f                                                   # (the fp32-MFMA forward kernel takes no operand pitch)
+        pf, pd = _planes(lib, weight, nb, co, ci, x6f, x6d, kperm=1) if x6f or x6d else (None, None)
         pf, pd = (pf if x6f else None), (pd if x6d else None)
         dt, code = _tm_dtype(out_lowp)
-        out = torch.empty((R, cout), dtype=dt, device=U.device)
+        out = torch.empty((R, cout), dtype=dt, device=XM.device)
         sync = None
         fused_apply = own and _derive_ok(bn, nb, co, code, False)
         if fused_apply:
-            U = U.contiguous()
-            Y, a, c, mean, invstd = _train_apply_from_sums(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, pf, None, out,
-                                                           cout, co, act, 0, None, 0)
+            Y, a, c, mean, invstd = _train_apply_from_sums(lib, XM, None, bias, bn, R, ci, co, nb, pf, None, out,
+                                                           cout, co, act, 0, None, 0, xld=nb * ci, xbs=ci)
         elif own:
-            U = U.contiguous()
-            Y, a, c, mean, invstd = _linear_fwd_own(lib, U, Wg.contiguous(), bias, bn, R, ci, co, nb, planes=pf)
+            Y, a, c, mean, invstd = _linear_fwd_own(lib, XM, None, bias, bn, R, ci, co, nb, planes=pf, xld=nb * ci, xbs=ci)
         else:
-            if U.dtype == torch.bfloat16:
+            if XM.dtype == torch.bfloat16:
                 Wb = weight.to(torch.bfloat16) if w16 is None else w16
-                Y = torch.bmm(U, Wb.view(nb, co, ci).transpose(1, 2), out_dtype=_F32)
+                Y = torch.bmm(U, _kperm_weight(Wb.view(nb, co, ci)).transpose(1, 2), out_dtype=_F32)
             else:
-                Y = torch.bmm(U, Wg.transpose(1, 2))                       # (nb, R, co)
+                Y = torch.bmm(U, _kperm_weight(Wg).transpose(1, 2))        # (nb, R, co)
                 if Y.dtype != _F32:
                     Y = Y.float()
             a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, bias, R, co, nb)
         if not fused_apply:
-            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, act,
+            _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, co, nb, cout, co, 0, act,
                                           code, None, 0, _stream()), "gkg_affine_act")
-        ctx.save_for_backward(U, weight, Y, a, c, mean, invstd)
+        ctx.save_for_backward(XM, weight, Y, a, c, mean, invstd)
         ctx.meta = (act, bias is not None)
         ctx.gparams = (weight, gamma, beta)
         ctx.sync = sync
@@ -971,9 +1010,10 @@ class _GroupedLinearBNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        U, weight, Y, a, c, mean, invstd = ctx.saved_tensors
+        XM, weight, Y, a, c, mean, invstd = ctx.saved_tensors
         act, has_bias = ctx.meta
-        nb, R, ci = U.shape
+        nb = 4
+        R, ci = XM.shape[0], XM.shape[1] // nb
         cout = weight.shape[0]
         co = cout // nb
         g = dout.contiguous()
@@ -984,14 +1024,14 @@ class _GroupedLinearBNAct(torch.autograd.Function):
         _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, co, nb, cout, co, act, ctx.sync, ctx.link)
         Wg = weight.view(nb, co, ci)
         if not ctx.needs_input_grad[0]:
-            dU = None
-        elif ctx.pd is not None:
-            dU = torch.empty((nb, R, ci), dtype=_F32, device=dY.device)
-            _dgrad_x6(lib, dY, co, R * co, ctx.pd, dU, R, ci, co, nb)
+            dXM = None
+        elif ctx.pd is not None:                                    # dXM (R, 4 ci) written in place: [direct chunk | dm chunk] per group
+            dXM = torch.empty((R, nb * ci), dtype=_F32, device=dY.device)
+            _dgrad_x6(lib, dY, co, R * co, ctx.pd, dXM, R, ci, co, nb, ldx=nb * ci, x_bs=ci)
         else:
-            dU = torch.bmm(dY, Wg)
-        dW = _wgrad_grouped(dY, U, dWv).view_as(weight)
-        return dU, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
+            dXM = torch.bmm(dY, _kperm_weight(Wg)).permute(1, 0, 2).reshape(R, nb * ci)
+        dW = _wgrad_grouped(dY, XM.view(R, nb, ci).permute(1, 0, 2), dWv, kperm=1).view_as(weight)
+        return dXM, dW, None, dgamma, dbeta, None, None, None, None      # dbias == 0 exactly (see _LinearBNAct)
 
 
 # ----------------------------------------------------------------------------------------------- BN (+ act) behind a library conv
@@ -1011,7 +1051,7 @@ class _BNActTM(torch.autograd.Function):
         R, C = Y.shape
         a, c, mean, invstd, sync = _bn_forward_params(lib, Y, bn, None, R, C, 1)
         out = torch.empty_like(Y)
-        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, C, 1, C, 0, act, _lib.F32, None, 0, _stream()),
+        _lib.check(lib.gkg_affine_act(_ptr(Y), _ptr(a), _ptr(c), None, _ptr(out), R, C, 1, C, 0, 0, act, _lib.F32, None, 0, _stream()),
                    "gkg_affine_act")
         ctx.save_for_backward(Y, a, c, mean, invstd)
         ctx.act, ctx.sync, ctx.gparams = act, sync, (gamma, beta)
@@ -1115,7 +1155,7 @@ def conv_bn_act_eval(conv, bn, act_mod, x, want32=True, want16=False):
                    "gkg_affine_act_dual")
     else:
         out = o32 if want32 else o16
-        _lib.check(lib.gkg_affine_act(_ptr(y), _ptr(a), _ptr(c), None, _ptr(out), R, cout, 1, cout, 0, act,
+        _lib.check(lib.gkg_affine_act(_ptr(y), _ptr(a), _ptr(c), None, _ptr(out), R, cout, 1, cout, 0, 0, act,
                                       _lib.F32 if want32 else _lib.BF16, None, 0, _stream()), "gkg_affine_act")
     if want32:
         res = o32.permute(0, 3, 1, 2)
@@ -1180,11 +1220,59 @@ def stem_conv_bn_act_eval(conv, bn, act_mod, x, out_bf16: bool):
 
 
 # ----------------------------------------------------------------------------------------------- graph ops
+# Token-major tensors reach the graph kernels as VIEWS (pointer, row pitch, chunk) — include/gkg_hip.h "XM layout".  A Grapher's
+# fc1 writes its output x into the x half of the grouped projection's operand buffer XM (T, 2C); that half travels through
+# autograd as a (B, N, 4, C/4) tensor with strides (N 2C, 2C, C/2, 1) over the buffer's storage (an alias without a view
+# relation: the aggregation fills the m half of the same storage behind autograd's back, which must not bump x's version).
+def _alias(t, size, stride, offset=0):
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset() + offset, size, stride)
+
+
+def _xm_xview(XM, B, N, C):
+    """The x half of an XM buffer (B N, 2C) as a (B, N, 4, C/4) tensor."""
+    return _alias(XM, (B, N, 4, C // 4), (N * 2 * C, 2 * C, C // 2, 1))
+
+
+def _is_xm_half(x) -> bool:
+    if x.dim() != 4 or x.shape[2] != 4 or x.dtype != _F32:
+        return False
+    B, N, _, h = x.shape
+    return x.stride() == (N * 8 * h, 8 * h, 2 * h, 1) and x.data_ptr() % 16 == 0
+
+
+def _xm_of(x):
+    """The whole XM buffer (B N, 2C) whose x half ``x`` is."""
+    B, N, _, h = x.shape
+    return _alias(x, (B * N, 8 * h), (8 * h, 1))
+
+
+def _tm_view(x):
+    """(B, N, C, ldx, xchunk) of a token-major tensor: a contiguous (B, N, C) / (B N, C) matrix or the x half of an XM buffer."""
+    if _is_xm_half(x):
+        B, N, _, h = x.shape
+        return B, N, 4 * h, 8 * h, h
+    B, N, C = x.shape
+    return B, N, C, C, 0
+
+
+def _as_tokens(x):
+    """What a kernel takes as the x pointer: the tensor itself when it is an XM half (read through its view), else contiguous."""
+    return x if _is_xm_half(x) else x.contiguous()
+
+
+def _rp_arg(relative_pos, N, M):
+    rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
+    if tuple(rp.shape) != (N, M):
+        raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+    return rp
+
+
 @torch.no_grad()
 def knn_graph_tm(x, y, relative_pos, k, dilation, G):
-    """x (B,N,C), y (B,M,C)|None token-major -> edge_index (2, B*G, N, k) int64."""
+    """x (B,N,C) [or the x half of an XM buffer], y (B,M,C)|None token-major -> edge_index (2, B*G, N, k) int64."""
     lib = _lib.load()
-    B, N, C = x.shape
+    B, N, C, ldx, xchunk = _tm_view(x)
+    x = _as_tokens(x)
     c = C // G
     M = N if y is None else y.shape[1]
     flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags()
@@ -1192,13 +1280,11 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
         flags |= _lib.KNN_BF16_CONTRACT          # the reference's own x.y^T runs in bf16 here (and rounds the result to bf16)
     rp = None
     if relative_pos is not None:
-        rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
-        if tuple(rp.shape) != (N, M):
-            raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+        rp = _rp_arg(relative_pos, N, M)
         flags |= _lib.relpos_flags(relative_pos)
     edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device=x.device)
     ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
-    rc = lib.gkg_knn_fwd_tm(_ptr(x), _ptr(y), _ptr(rp), edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k,
+    rc = lib.gkg_knn_fwd_tm(_ptr(x), ldx, xchunk, _ptr(y), _ptr(rp), edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k,
                             dilation, _lib.F32, flags, _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "gkg_knn_fwd_tm")
     return edge
@@ -1216,9 +1302,10 @@ KNN_COMPACT = "knn_compact" not in _DISABLED
 
 @torch.no_grad()
 def knn_graph_tm16(x, y, relative_pos, k, dilation, G):
-    """x (B,N,C), y (B,M,C)|None token-major -> neighbour lists (B*G, N, k) int16 (the bits of u16 rows)."""
+    """x (B,N,C) [or the x half of an XM buffer], y (B,M,C)|None token-major -> neighbour lists (B*G, N, k) int16 (the bits of u16 rows)."""
     lib = _lib.load()
-    B, N, C = x.shape
+    B, N, C, ldx, xchunk = _tm_view(x)
+    x = _as_tokens(x)
     c = C // G
     M = N if y is None else y.shape[1]
     flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags()
@@ -1226,57 +1313,64 @@ def knn_graph_tm16(x, y, relative_pos, k, dilation, G):
         flags |= _lib.KNN_BF16_CONTRACT
     rp = None
     if relative_pos is not None:
-        rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
-        if tuple(rp.shape) != (N, M):
-            raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+        rp = _rp_arg(relative_pos, N, M)
         flags |= _lib.relpos_flags(relative_pos)
     nn16 = torch.empty((B * G, N, k), dtype=torch.int16, device=x.device)
     ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
-    _lib.check(lib.gkg_knn_fwd_tm16(_ptr(x), _ptr(y), _ptr(rp), _ptr(nn16), B, G, c, N, M, k, dilation, _lib.F32, flags,
+    _lib.check(lib.gkg_knn_fwd_tm16(_ptr(x), ldx, xchunk, _ptr(y), _ptr(rp), _ptr(nn16), B, G, c, N, M, k, dilation, _lib.F32, flags,
                                     _ptr(ws), ws.numel(), _stream()), "gkg_knn_fwd_tm16")
     return nn16
 
 
+def _xm_out(x, B, N, C, dt):
+    """The operand buffer a mode-1 aggregation writes: the buffer ``x`` already lives in (only m is written then), else a fresh one."""
+    if _is_xm_half(x) and dt == _F32:
+        return _xm_of(x)
+    return torch.empty((B * N, 2 * C), dtype=dt, device=x.device)
+
+
 class _MaxRelativeTM(torch.autograd.Function):
+    """mode 0: m (B, N, C); mode 1: the grouped projection's operand buffer XM (B N, 2C) (x may be its x half already)."""
+
     @staticmethod
     def forward(ctx, x, src, nn_idx, G, mode, out_lowp=False):
         lib = _lib.load()
-        B, N, C = x.shape
+        B, N, C, ldx, xchunk = _tm_view(x)
+        x = _as_tokens(x)
         M = N if src is None else src.shape[1]
         k = nn_idx.shape[2]
-        T = B * N
         dt, code = _tm_dtype(out_lowp)
-        out = torch.empty((4, T, C // 2) if mode == 1 else (B, N, C), dtype=dt, device=x.device)
+        out = _xm_out(x, B, N, C, dt) if mode == 1 else torch.empty((B, N, C), dtype=dt, device=x.device)
         need = any(ctx.needs_input_grad[:2])
         ak = 1 if M <= 65536 else 0              # the winning neighbour's row index (u16) instead of its slot (u8)
         arg = torch.empty((B, N, C), dtype=torch.int16 if ak else torch.uint8, device=x.device) if need else None
         if nn_idx.dtype == torch.int16:          # compact lists (knn_graph_tm16; M <= 65536, so ak == 1: the backward needs no index)
-            _lib.check(lib.gkg_mr_fwd_tm16(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
-                                           code, ak, _stream()), "gkg_mr_fwd_tm16")
+            _lib.check(lib.gkg_mr_fwd_tm16(_ptr(x), ldx, xchunk, _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k,
+                                           mode, code, ak, _stream()), "gkg_mr_fwd_tm16")
             nn_idx = None
         else:
-            _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k, mode,
-                                         code, ak, _stream()), "gkg_mr_fwd_tm")
+            _lib.check(lib.gkg_mr_fwd_tm(_ptr(x), ldx, xchunk, _ptr(src), _ptr(nn_idx), _ptr(out), _ptr(arg), B, G, C // G, N, M, k,
+                                         mode, code, ak, _stream()), "gkg_mr_fwd_tm")
         ctx.save_for_backward(nn_idx, arg)
-        ctx.meta = (B, G, C, N, M, k, mode, src is not None, ak)
+        ctx.meta = (B, G, C, N, M, k, mode, src is not None, ak, tuple(x.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         nn_idx, arg = ctx.saved_tensors
-        B, G, C, N, M, k, mode, has_src, ak = ctx.meta
+        B, G, C, N, M, k, mode, has_src, ak, xshape = ctx.meta
         g = g.contiguous()
         gx = torch.empty((B, N, C), dtype=_F32, device=g.device)
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, mode, ak,
                                      _mr_bwd_flags(), _stream()), "gkg_mr_bwd_tm")
-        return gx, gsrc, None, None, None, None
+        return gx.view(xshape), gsrc, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------- row g2: k-NN + aggregation
 # ONE kernel builds the graph and consumes it (csrc/gkg_knn_tile.h, MRF): the workgroup that has merged the lists of its 64
-# queries gathers their neighbour rows and writes the grouped projection's interleaved operand and the winning rows; no
+# queries gathers their neighbour rows and writes m into the grouped projection's operand buffer, plus the winning rows; no
 # (2, B*G, N, k) int64 edge_index, no centre plane, no mr_fwd launch (reference torch_edge.py:164-176 -> torch_vertex.py:49-61).
 # Taken for fp32 training / inference blocks whose graph runs on the fp32 tile kernel with merged per-wave lists
 # (gkg_knn_mr_fused_supported: the 18 x 18 stages and the label graphs over them; key-split and prefilter shapes keep the two
@@ -1286,40 +1380,39 @@ KNN_MR = "knn_mr" not in _DISABLED
 
 
 class _KnnMaxRelativeTM(torch.autograd.Function):
-    """(U (4, B*N, C/2), edge_index (2, B*G, N, k) | empty) = aggregation over the k-NN graph of x (B, N, C) [keys / values src (B, M, C)]."""
+    """(XM (B N, 2C), edge_index (2, B*G, N, k) | empty) = aggregation over the k-NN graph of x (B, N, C) [keys / values src (B, M, C)]."""
 
     @staticmethod
     def forward(ctx, x, src, relative_pos, k, d, G, want_nn):
         lib = _lib.load()
-        B, N, C = x.shape
+        B, N, C, ldx, xchunk = _tm_view(x)
+        x = _as_tokens(x)
         M = N if src is None else src.shape[1]
         c = C // G
         flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags()
         rp = None
         if relative_pos is not None:
-            rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
-            if tuple(rp.shape) != (N, M):
-                raise _lib.GkgError(f"relative_pos must be (1,{N},{M}), got {tuple(relative_pos.shape)}")
+            rp = _rp_arg(relative_pos, N, M)
             flags |= _lib.relpos_flags(relative_pos)
-        U = torch.empty((4, B * N, C // 2), dtype=_F32, device=x.device)
+        XM = _xm_out(x, B, N, C, _F32)
         arg = torch.empty((B, N, C), dtype=torch.int16, device=x.device)
         # the (2, B*G, N, k) int64 edge_index only for callers that return the graph (GrapherLabel / tests): written by the kernel
         edge = torch.empty((2, B * G, N, k) if want_nn else (0,), dtype=torch.int64, device=x.device)
         ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), x.device)
-        _lib.check(lib.gkg_knn_mr_fwd_tm(_ptr(x), _ptr(src), _ptr(rp), _ptr(U), _ptr(arg), None,
+        _lib.check(lib.gkg_knn_mr_fwd_tm(_ptr(x), ldx, xchunk, _ptr(src), _ptr(rp), _ptr(XM), _ptr(arg), None,
                                          edge[0].data_ptr() if want_nn else None, edge[1].data_ptr() if want_nn else None, B, G, c,
                                          N, M, k, d, flags, _ptr(ws), ws.numel(), _stream()), "gkg_knn_mr_fwd_tm")
         ctx.save_for_backward(arg)
-        ctx.meta = (B, G, C, N, M, k, src is not None)
+        ctx.meta = (B, G, C, N, M, k, src is not None, tuple(x.shape))
         ctx.mark_non_differentiable(edge)
         ctx.set_materialize_grads(False)          # (no zero-filled int64 "gradient" of the graph output: 4.8 us per step)
-        return U, edge
+        return XM, edge
 
     @staticmethod
     def backward(ctx, g, _gnn=None):
         lib = _lib.load()
         (arg,) = ctx.saved_tensors
-        B, G, C, N, M, k, has_src = ctx.meta
+        B, G, C, N, M, k, has_src, xshape = ctx.meta
         if g is None:
             return (None,) * 7
         g = g.contiguous()
@@ -1327,17 +1420,17 @@ class _KnnMaxRelativeTM(torch.autograd.Function):
         gsrc = torch.empty((B, M, C), dtype=_F32, device=g.device) if has_src else None
         _lib.check(lib.gkg_mr_bwd_tm(_ptr(g), None, _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 1, 1, _mr_bwd_flags(),
                                      _stream()), "gkg_mr_bwd_tm")
-        return gx, gsrc, None, None, None, None, None
+        return gx.view(xshape), gsrc, None, None, None, None, None
 
 
 def _knn_mr_ok(x, src, relative_pos, k, d, G, nn_, lp) -> bool:
     """The fused k-NN + aggregation kernel applies (see KNN_MR)."""
-    if not (KNN_MR and not lp and knn_graph_tm is _KNN_GRAPH_TM and x.dtype == _F32 and x.is_contiguous()
-            and (src is None or (src.dtype == _F32 and src.is_contiguous())) and not MR_X6):
+    if not (KNN_MR and not lp and knn_graph_tm is _KNN_GRAPH_TM and x.dtype == _F32 and (x.is_contiguous() or _is_xm_half(x))
+            and (src is None or (src.dtype == _F32 and src.is_contiguous()))):
         return False
     if KNN_BF16 and torch.is_autocast_enabled():
         return False
-    B, N, C = x.shape
+    B, N, C, _, _ = _tm_view(x)
     M = N if src is None else src.shape[1]
     if C % 16 or M > 65536 or len(nn_) != 3:
         return False
@@ -1346,106 +1439,13 @@ def _knn_mr_ok(x, src, relative_pos, k, d, G, nn_, lp) -> bool:
                                                        0 if relative_pos is None else 1, flags))
 
 
-# ----------------------------------------------------------------------------------------------- row g1 (training / fp32)
-# fp32 train step: gather + max-relative + interleave as the A-operand producer of the grouped projection on the split-bf16
-# matrix-core arithmetic (csrc/gkg_mrgemm_x6.hip), BN column sums in its epilogue, BN-apply (+ GELU) derived from the sums:
-# TWO launches for MRConv2d.forward (torch_vertex.py:47-62 + torch_nn.py:57-69) instead of gkg_mr_fwd_tm -> grouped GEMM ->
-# statistics passes -> apply.  Built, bit-checked against the oracle (tests/test_hip_mrgemm_x6.py) and MEASURED in round 4:
-# inside the step it is 1-4 % SLOWER than the separate launches at every shape tried (ms/step fused vs separate, TunableOp
-# leg / library-default leg: cfg2 0.942 / 0.981 vs 0.931 / 0.971, cfg2ref 2.225 / 2.331 vs 2.181 / 2.262, stage3 3.215 vs
-# 3.114, stage1 8.00 vs 7.70) — its matrix phase runs at 128 registers per wave with the weight fragments two steps ahead
-# (18 of its 46 us at cfg2) where gemm_x6_kernel streams both operands through LDS-DMA rings, and that costs more than the
-# 26.5 MB [x, m] round trip it removes (EXPERIMENTS.md has the phase ablation and the persistent producer / consumer variant
-# that was tried on top).  So it is OPT-IN: GKG_ENABLE=mr_x6.
-#   GKG_DISABLE=mr_save_u (with mr_x6): the interleaved [x, m] operand is NOT written by the forward; the backward rebuilds it
-#   for the weight gradient from x, src and the saved winning rows (gkg_mr_regather_tm: one dword gather per channel) — 425 MB
-#   per block less held between forward and backward at GKGNet-576's stage 1, one more launch in the backward.
-MR_X6 = "mr_x6" in _ENABLED
-MR_SAVE_U = "mr_save_u" not in _DISABLED
-
-
-def _mr_x6_ok(x, src, nn_, C, G, k) -> bool:
-    conv, bn = nn_[0], nn_[1]
-    M = x.shape[1] if src is None else src.shape[1]
-    return (MR_X6 and GEMM_MATH in ("x6", "x6all") and OWN_GEMM != "none" and x.dtype == _F32 and conv.weight.dtype == _F32
-            and not torch.is_autocast_enabled() and torch.is_grad_enabled() and _sync_group(bn) is None
-            and conv.groups == 4 and C % 16 == 0 and (C // G) % 4 == 0 and M <= 65536
-            and conv.weight.shape[0] == 2 * C and conv.weight.shape[1] == C // 2
-            and _lib.load().gkg_mr_linear_x6_supported(G, C // G, k)
-            and _derive_ok(bn, 4, C // 2, _lib.F32, False) and 4 * 2 * (C // 2) <= _lib.load().gkg_linear_stats_doubles())
-
-
-class _MRGroupedLinearBNAct(torch.autograd.Function):
-    """out (T, 2C) = act(BN_train(BasicConv([x, max_k(src[idx] - x)]))) — _MaxRelativeTM + _GroupedLinearBNAct as one autograd
-    node around the fused kernel.  x (B, N, C), src (B, M, C) | None, nn_idx (B*G, N, k)."""
-
-    @staticmethod
-    def forward(ctx, x, src, nn_idx, G, weight, bias, gamma, beta, bn, act):
-        lib = _lib.load()
-        B, N, C = x.shape
-        M = N if src is None else src.shape[1]
-        T, ci, co = B * N, C // 2, C // 2
-        x = x.contiguous()
-        src = None if src is None else src.contiguous()
-        x6d = _x6_rule(T, ci, co, 4, "dgrad")
-        pf, pd = _planes(lib, weight, 4, co, ci, True, x6d)
-        arg = torch.empty((B, N, C), dtype=torch.int16, device=x.device)
-        U = torch.empty((4, T, ci), dtype=_F32, device=x.device) if MR_SAVE_U else None
-        out = torch.empty((T, 2 * C), dtype=_F32, device=x.device)
-        k = nn_idx.shape[2]
-
-        def launch(Y, sums):
-            return lib.gkg_mr_linear_x6(_ptr(x), _ptr(src), _ptr(nn_idx), _ptr(pf), _ptr(Y), _ptr(arg), _ptr(U), _ptr(sums),
-                                        B, G, C // G, N, M, k, _stream())
-        Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, None, bias, bn, T, ci, co, 4, None, None, out, 2 * C, co, act, 0,
-                                                       None, 0, launch=launch)
-        ctx.save_for_backward(x, src, nn_idx, arg, U, weight, Y, a, c, mean, invstd)
-        ctx.meta = (B, G, C, N, M, k, act)
-        ctx.gparams = (weight, gamma, beta)
-        ctx.pd = pd if x6d else None
-        ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, 4, co, T, bn, None, None)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        lib = _lib.load()
-        x, src, nn_idx, arg, U, weight, Y, a, c, mean, invstd = ctx.saved_tensors
-        B, G, C, N, M, k, act = ctx.meta
-        T, ci, co = B * N, C // 2, C // 2
-        g = dout.contiguous()
-        dY = torch.empty_like(Y)
-        dWv, dgamma, dbeta = _grad_outs(ctx.gparams, (4, co, ci), 2 * C, Y.device)
-        _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, T, co, 4, 2 * C, co, act, None, ctx.link)
-        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        gx = gsrc = None
-        if need_in:
-            if ctx.pd is not None:
-                dU = torch.empty((4, T, ci), dtype=_F32, device=dY.device)
-                _dgrad_x6(lib, dY, co, T * co, ctx.pd, dU, T, ci, co, 4)
-            else:
-                dU = torch.bmm(dY, weight.view(4, co, ci))
-        if U is None:                                   # the weight gradient's operand, rebuilt from the saved winning rows
-            U = torch.empty((4, T, ci), dtype=_F32, device=dY.device)
-            _lib.check(lib.gkg_mr_regather_tm(_ptr(x), _ptr(src), _ptr(arg), _ptr(U), B, N, M, C, _stream()), "gkg_mr_regather_tm")
-        dW = _wgrad_grouped(dY, U, dWv).view_as(weight)
-        if need_in:
-            gx = torch.empty((B, N, C), dtype=_F32, device=dY.device)
-            gsrc = torch.empty((B, M, C), dtype=_F32, device=dY.device) if src is not None else None
-            _lib.check(lib.gkg_mr_bwd_tm(_ptr(dU), _ptr(nn_idx), _ptr(arg), _ptr(gx), _ptr(gsrc), B, G, C // G, N, M, k, 1, 1,
-                                         _mr_bwd_flags(), _stream()), "gkg_mr_bwd_tm")
-        return gx, gsrc, None, None, dW, None, dgamma, dbeta, None, None      # dbias == 0 exactly (see _LinearBNAct)
-
-
 def _aggregate_project(x1b, yb, nn_idx, groups, nn_, C, lp):
-    """MRConv2d.forward on token-major tensors -> (T, 2C): the fused launches where they apply, else aggregation kernel +
+    """MRConv2d.forward on token-major tensors -> (T, 2C): the fused launch where it applies, else aggregation kernel +
     grouped projection."""
     if _mr_gemm_ok(nn_, C, lp):                                     # row g1, bf16 inference: one launch
         return mr_grouped_linear_eval(x1b, yb, nn_idx, groups, nn_[0], nn_[1])
-    if _mr_x6_ok(x1b, yb, nn_, C, groups, nn_idx.shape[2]):                          # row g1, fp32 training: fused kernel + BN-apply from its sums
-        return _MRGroupedLinearBNAct.apply(x1b, yb, nn_idx, groups, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias,
-                                           nn_[1], 1)
-    U = _MaxRelativeTM.apply(x1b, yb, nn_idx, groups, 1, lp)        # (4, T, C/2) interleaved [x, m]
-    return _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
+    XM = _MaxRelativeTM.apply(x1b, yb, nn_idx, groups, 1, lp)       # (T, 2C) operand buffer [x | m]
+    return _GroupedLinearBNAct.apply(XM, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, lp,
                                      _w16_of(nn_[0]) if lp else None)   # (T, 2C)
 
 
@@ -1531,18 +1531,18 @@ def fused_supported(mod, x, groups: int) -> bool:
 
 
 def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False, alias=False,
-         dual=False):
+         dual=False, xm=None):
     """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
     output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402).
     ``alias``: returns ``(out, x')`` with ``x'`` the input again, to be used as a later layer's residual (see
     _LinearBNAct.forward)."""
     if alias:
         if not (torch.is_grad_enabled() and x.requires_grad):
-            return _lin(x, seq, act, residual, nchw, out_lowp, scale, rows_per_scale, want16), x
+            return _lin(x, seq, act, residual, nchw, out_lowp, scale, rows_per_scale, want16, xm=xm), x
         conv, bn = seq[0], seq[1]
         w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
         return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
-                                  rows_per_scale, want16, True)
+                                  rows_per_scale, want16, True, False, xm)
     conv, bn = seq[0], seq[1]
     if (FOLD_EPILOGUE and out_lowp and x.dtype == torch.bfloat16 and residual is None and nchw is None and scale is None
             and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and conv.weight.dim() == 4
@@ -1559,7 +1559,7 @@ def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, ro
         return torch.addmm(_folded_shift32(conv, bn), x, wf.t(), out_dtype=_F32)
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
     return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
-                              rows_per_scale, want16, False, dual)
+                              rows_per_scale, want16, False, dual, xm)
 
 
 # ---- a block output in both layouts (round 5) ---------------------------------------------------------------------------
@@ -1579,19 +1579,26 @@ def _drop_scale(drop_path, batch, device):
 
 
 def _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge):
-    """DyGraphConv2d.forward on token-major tensors (torch_vertex.py:191-205): -> (BasicConv output (T, 2C), edge_index | None)."""
+    """DyGraphConv2d.forward on token-major tensors (torch_vertex.py:191-205): -> (BasicConv output (T, 2C), edge_index | None).
+    ``x1b``: (B, N, C) or the x half of an XM operand buffer (see _xm_xview)."""
     nn_ = gc.gconv.nn
     N = x1b.shape[1]
     if _knn_mr_ok(x1b, yb, relative_pos, gc.k, gc.d, groups, nn_, lp):      # row g2: graph + aggregation in one kernel
-        U, edge = _KnnMaxRelativeTM.apply(x1b, yb, relative_pos, gc.k, gc.d, groups, want_edge)
-        a2 = _GroupedLinearBNAct.apply(U, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, False, None)
+        XM, edge = _KnnMaxRelativeTM.apply(x1b, yb, relative_pos, gc.k, gc.d, groups, want_edge)
+        a2 = _GroupedLinearBNAct.apply(XM, nn_[0].weight, nn_[0].bias, nn_[1].weight, nn_[1].bias, nn_[1], 1, False, None)
         return a2, (edge if want_edge else None)
     M = N if yb is None else yb.shape[1]
-    if KNN_COMPACT and not want_edge and M <= 65536 and knn_graph_tm is _KNN_GRAPH_TM and not MR_X6:
+    if KNN_COMPACT and not want_edge and M <= 65536 and knn_graph_tm is _KNN_GRAPH_TM:
         nn16 = knn_graph_tm16(x1b, yb, relative_pos, gc.k, gc.d, groups)        # u16 lists: no int64 edge_index, no centre plane
         return _aggregate_project(x1b, yb, nn16, groups, nn_, C, lp), None
     edge = knn_graph_tm(x1b, yb, relative_pos, gc.k, gc.d, groups)
     return _aggregate_project(x1b, yb, edge[0], groups, nn_, C, lp), edge      # row g1: aggregation = the projection's operand producer
+
+
+# fc1's output written straight into the grouped projection's operand buffer (see _LinearBNAct.forward ``xm``): fp32 blocks
+# outside the bf16-inference form (whose fused kernel never materialises the operand).  GKG_DISABLE=xm_direct: fc1 writes a plain
+# (T, C) matrix and the aggregation copies x into the buffer next to m (A/B, tests).
+XM_DIRECT = "xm_direct" not in _DISABLED
 
 
 def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
@@ -1605,14 +1612,15 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
     scale = _drop_scale(mod.drop_path, B, x.device)
     dual = (DUAL_LAYOUT and not cl and not lp and scale is None and torch.is_grad_enabled() and xt.dtype == _F32
             and getattr(mod, "_gkg_want_tm", False))
+    xm = (B, N) if (XM_DIRECT and not lp and xt.dtype == _F32 and not torch.is_autocast_enabled() and C % 16 == 0) else None
     if dual:
-        x1, xt_r = _lin(xt, mod.fc1, alias=True)                    # xt_r: xt again, the (token-major) residual of fc2
+        x1, xt_r = _lin(xt, mod.fc1, alias=True, xm=xm)             # xt_r: xt again, the (token-major) residual of fc2
     else:
-        x1 = _lin(xt, mod.fc1)                                      # fc1 + BN
-    x1b = x1.view(B, N, C)
+        x1 = _lin(xt, mod.fc1, xm=xm)                               # fc1 + BN
+    x1b = x1 if xm is not None else x1.view(B, N, C)
     yb = None
     if gc.r > 1:                                                    # pooled keys (torch_vertex.py:194-196)
-        yb = _AvgPoolTM.apply(x1.view(B, H, W, C), gc.r).reshape(B, -1, C)
+        yb = _AvgPoolTM.apply(x1b, H, W, gc.r)
     a2, edge = _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge)
     if cl:                                                          # fc2 + BN (+ DropPath) + residual, token-major = channels-last
         out = _lin(a2, mod.fc2, residual=x, scale=scale, rows_per_scale=N, want16=lp)
@@ -1643,9 +1651,10 @@ def grapher_label_forward(mod, e, features, groups: int):
             prod()._gkg_want_tm = True                                       # ... which it emits from its next call on
         ft = to_token_major(features.float().contiguous()).view(B, -1, C)
     e2 = e.float().reshape(B * L, C).contiguous()
-    x1, e2r = _lin(e2, mod.fc1, alias=True)                          # e2r: e2 again, for the residual of fc2 (one gradient node)
-    x1b = x1.view(B, L, C)
     lp = lowp_inference()
+    xm = (B, L) if (XM_DIRECT and not lp and not torch.is_autocast_enabled() and C % 16 == 0) else None
+    x1, e2r = _lin(e2, mod.fc1, alias=True, xm=xm)                   # e2r: e2 again, for the residual of fc2 (one gradient node)
+    x1b = x1 if xm is not None else x1.view(B, L, C)
     a2, edge = _graph_and_project(x1b, ft.contiguous(), None, gc, groups, C, lp, True)      # GrapherLabel returns its graph
     h2 = _lin(a2, mod.fc2, residual=e2r, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
     f1, h2r = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp, alias=True)

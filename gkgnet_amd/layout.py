@@ -90,27 +90,31 @@ class _BlockEntry(torch.autograd.Function):
 
 
 class _AvgPoolTM(torch.autograd.Function):
-    """avg_pool2d(r, r) of a token-major feature map x (B, H, W, C) -> (B, H/r, W/r, C) (the pooled key set of the reference,
-    torch_vertex.py:194-196).  Forward: the library's channels-last pooling on a view.  Backward: every pooled gradient goes
-    to its r x r window divided by r^2 — one broadcast copy; the library's NHWC backward ran at 0.87 TB/s (243 us per
-    GKGNet-576 stage-1 block, B = 32)."""
+    """avg_pool2d(r, r) of a token-major feature map (the pooled key set of the reference, torch_vertex.py:194-196):
+    x (B, H W, C) — or the x half of an XM operand buffer, (B, H W, 4, C/4) strided (fused._xm_xview) — -> (B, (H/r)(W/r), C).
+    Forward: gkg_avgpool_tm (reads the view in place).  Backward: every pooled gradient goes to its r x r window divided by
+    r^2 — one broadcast copy; the library's NHWC backward ran at 0.87 TB/s (243 us per GKGNet-576 stage-1 block, B = 32)."""
 
     @staticmethod
-    def forward(ctx, x, r):
-        ctx.r = r
-        ctx.hw = (x.shape[1], x.shape[2])
-        y = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), r, r)
-        return y.permute(0, 2, 3, 1).contiguous()
+    def forward(ctx, x, H, W, r):
+        from .fused import _tm_view, _as_tokens
+        B, N, C, ldx, xchunk = _tm_view(x)
+        x = _as_tokens(x)
+        ctx.r, ctx.hw, ctx.xshape = r, (H, W), tuple(x.shape)
+        y = torch.empty((B, (H // r) * (W // r), C), dtype=_F32, device=x.device)
+        _lib.check(_lib.load().gkg_avgpool_tm(_ptr(x), ldx, xchunk, _ptr(y), B, H, W, C, r, _stream()), "gkg_avgpool_tm")
+        return y
 
     @staticmethod
     def backward(ctx, g):
         r = ctx.r
-        B, Hr, Wr, C = g.shape
         H, W = ctx.hw
+        Hr, Wr = H // r, W // r
+        B, C = g.shape[0], g.shape[2]
+        g = g.reshape(B, Hr, Wr, C)
         gs = (g * (1.0 / (r * r))).view(B, Hr, 1, Wr, 1, C).expand(B, Hr, r, Wr, r, C)
         if Hr * r == H and Wr * r == W:
-            return gs.reshape(B, H, W, C), None
+            return gs.reshape(ctx.xshape), None, None, None
         out = g.new_zeros((B, H, W, C))                 # floor mode: rows / columns past the last full window get no gradient
         out[:, :Hr * r, :Wr * r] = gs.reshape(B, Hr * r, Wr * r, C)
-        return out, None
-
+        return out.view(ctx.xshape), None, None, None

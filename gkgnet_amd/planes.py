@@ -77,13 +77,13 @@ class _WeightPlanes:
             self.pending_zero = None
             t.zero_()
 
-    def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None):
+    def _register(self, lib, weight, nb, cout, cin, need_f, need_d, old=None, kperm=0):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.GkgError("x6 projection: a weight was first seen inside a hipGraph capture; run one eager "
                                 "warm-up step before capturing")
         same = (old is not None and old["ref"]() is weight and old["ptr"] == weight.data_ptr()
-                and (old["nb"], old["cout"], old["cin"]) == (nb, cout, cin))
-        e = dict(ref=weakref.ref(weight), nb=nb, cout=cout, cin=cin, ptr=weight.data_ptr(), version=-1,
+                and (old["nb"], old["cout"], old["cin"], old["kperm"]) == (nb, cout, cin, kperm))
+        e = dict(ref=weakref.ref(weight), nb=nb, cout=cout, cin=cin, kperm=kperm, ptr=weight.data_ptr(), version=-1,
                  pf=old["pf"] if same else None, pd=old["pd"] if same else None)
         if need_f and e["pf"] is None:
             e["pf"] = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device=self.device)
@@ -104,7 +104,7 @@ class _WeightPlanes:
             if i % 256 == 0:
                 units = 0                                             # unit numbering restarts with every launch's table
             units = lib.gkg_x6_prep_desc_fill(host, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"], e["nb"],
-                                              units)
+                                              units, e["kperm"])
             if units < 0:
                 raise _lib.GkgError("gkg_x6_prep_desc_fill rejected a weight")
             self.unit_ends.append(units)
@@ -113,7 +113,7 @@ class _WeightPlanes:
         for i, e in enumerate(live.values()):
             e["slot"] = i
             e["solo_units"] = lib.gkg_x6_prep_desc_fill(solo, i, e["ptr"], _ptr(e["pf"]), _ptr(e["pd"]), e["cin"], e["cout"],
-                                                        e["nb"], 0)
+                                                        e["nb"], 0, e["kperm"])
         self.solo = torch.frombuffer(bytearray(solo.raw), dtype=torch.uint8).to(self.device)
 
     def refresh_one(self, lib, e):
@@ -148,12 +148,13 @@ class _WeightPlanes:
             w = e["ref"]()
             e["version"] = -1 if w is None else param_version(w)
 
-    def get(self, lib, weight, nb, cout, cin, need_f=True, need_d=True):
+    def get(self, lib, weight, nb, cout, cin, need_f=True, need_d=True, kperm=0):
+        """``kperm``: the grouped projection behind the aggregation — input columns as [x chunk | m chunk] (gkg_hip.h "XM layout")."""
         e = self.entries.get(id(weight))
         if (e is None or e["ref"]() is not weight or e["ptr"] != weight.data_ptr()
-                or (e["nb"], e["cout"], e["cin"]) != (nb, cout, cin) or (need_f and e["pf"] is None)
+                or (e["nb"], e["cout"], e["cin"], e["kperm"]) != (nb, cout, cin, kperm) or (need_f and e["pf"] is None)
                 or (need_d and e["pd"] is None)):
-            e = self._register(lib, weight, nb, cout, cin, need_f, need_d, e)
+            e = self._register(lib, weight, nb, cout, cin, need_f, need_d, e, kperm)
         cap = lib.gkg_stream_capture_id(_stream()) if torch.cuda.is_current_stream_capturing() else 0
         if cap:
             self.captured = True
@@ -201,12 +202,12 @@ def flush_deferred_zero():
         reg.flush_zero()
 
 
-def _planes(lib, weight, nb, cout, cin, need_f=True, need_d=True):
+def _planes(lib, weight, nb, cout, cin, need_f=True, need_d=True, kperm=0):
     key = (weight.device.type, weight.device.index)
     reg = _PLANES.get(key)
     if reg is None:
         reg = _PLANES[key] = _WeightPlanes(weight.device)
-    return reg.get(lib, weight, nb, cout, cin, need_f, need_d)
+    return reg.get(lib, weight, nb, cout, cin, need_f, need_d, kperm)
 
 
 def refresh_weight_planes(device=None):

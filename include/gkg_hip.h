@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GKG_ABI_VERSION 8
+#define GKG_ABI_VERSION 9
 
 /* dtype codes */
 #define GKG_F32 0
@@ -150,12 +150,11 @@ int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t
  * Same arithmetic contracts as above; only the addressing differs.
  *   gkg_knn_fwd_tm : x (B,N,C), y (B,M,C) or NULL; nn_idx/center (B*G, N, k)
  *   gkg_mr_fwd_tm  : mode 0 -> out = m (B,N,C);
- *                    mode 1 -> out = U (4, B*N, C/2): the grouped projection's input, U[q][t][2i] = x[t][q*C/4+i],
- *                              U[q][t][2i+1] = m[t][q*C/4+i]  (reference interleave torch_vertex.py:57-61 followed by
- *                              Conv2d(groups=4)'s channel split torch_nn.py:61); needs C % 16 == 0
+ *                    mode 1 -> out = XM (B*N, 2C): the grouped projection's operand buffer (see "XM layout" below);
+ *                              needs C % 16 == 0
  *                    argmax (B,N,C) u8
- *   gkg_mr_bwd_tm  : mode 0: gin = g (B,N,C); mode 1: gin = dU (4,B*N,C/2) (even columns = gradient reaching x
- *                    directly, odd columns = gradient of m).  gx (B,N,C) and gsrc (B,M,C)|NULL fully overwritten.
+ *   gkg_mr_bwd_tm  : mode 0: gin = g (B,N,C); mode 1: gin = dXM (B*N, 2C) in the XM layout (x chunks = gradient reaching x
+ *                    directly, m chunks = gradient of m).  gx (B,N,C) and gsrc (B,M,C)|NULL fully overwritten.
  *                    Default for destination images of up to 512 rows (where it measured faster; with
  *                    GKG_MR_DETERMINISTIC wherever 8 channels of 64-bit accumulators per row fit the LDS): EXACT fixed-point
  *                    accumulation — every gradient becomes sign * (24-bit mantissa << shift) relative to the chunk's
@@ -168,27 +167,48 @@ int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t
  *                    the exact two-sweep form.  Still order-independent and bit-identical from run to run.
  *                    flags & GKG_MR_FP32_ATOMICS: the round-1 fp32 LDS-atomic kernels (fan-in summed in arrival order);
  *                    flags & GKG_MR_DETERMINISTIC (shapes beyond the LDS budget): private accumulators, fixed order.
+ *
+ * XM layout (round 6) — the reference's MRConv2d interleaves [x_0, m_0, x_1, m_1, ...] (torch_vertex.py:57-61) and feeds
+ * Conv2d(2C, 2C, 1, groups=4) (torch_nn.py:61): conv group q reads interleaved channels [q C/2, (q+1) C/2) = the x and m values
+ * of original channels [q h, (q+1) h), h = C/4.  Nothing is interleaved here.  The grouped projection's operand is ONE buffer
+ *     XM (T, 2C) fp32,   row t = [x_0 | m_0 | x_1 | m_1 | x_2 | m_2 | x_3 | m_3],   x_q = x[t][q h .. (q+1) h), m_q likewise,
+ * i.e. group q's 2h inputs are contiguous with the x half first; the weight's input columns are reordered to match when its
+ * bf16 planes are built (gkg_x6_prep_desc_fill kperm) and the weight gradient is permuted back where it is added to dW
+ * (GkgWgradProblem.kperm) — the weight tensor keeps the reference's layout.  The PRODUCER of x (the Grapher's fc1 BN-apply:
+ * gkg_bn_apply_train / gkg_affine_act with ochunk = h and ldo = 2C) writes x straight into the x chunks, the aggregation
+ * (gkg_knn_mr_fwd_tm / gkg_mr_fwd_tm mode 1) fills the m chunks and, in the backward, the grouped input-gradient GEMM writes
+ * dXM in the same layout (gkg_linear_dgrad_x6_sk ldx = 2C, x_bstride = 2h) for gkg_mr_bwd_tm mode 1: x is never copied.
+ * Token-major fp32 inputs are therefore passed as VIEWS (pointer, row pitch ld, chunk): channel ch of token t sits at
+ * p[t * ld + ch + (ch / chunk) * chunk] for chunk > 0 (chunk % 4 == 0, chunk | C, ld >= 2C: the x half of an XM buffer is
+ * (XM, 2C, h)), at p[t * ld + ch] for chunk == 0; ld == 0 means ld = C.  A self graph gathers its neighbours through the same view.
+ * When x passed to a mode-1 aggregation IS the output buffer's x half (x == out, ldx == 2C, xchunk == h) only m is written;
+ * otherwise both halves are (a caller whose x lives elsewhere).
  */
-int gkg_knn_fwd_tm(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
+int gkg_knn_fwd_tm(const void* x, int ldx, int xchunk, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* Pooled key set of a Grapher with r > 1 (reference torch_vertex.py:194-196, F.avg_pool2d(x, r, r)) from a token-major map
+ * x (B, H, W, C) given as a view -> out (B, H/r, W/r, C) plain fp32 (floor mode; window sum in (h, w) order, one division). */
+int gkg_avgpool_tm(const float* x, int ldx, int xchunk, float* out, int B, int H, int W, int C, int r, void* stream);
 
 /* Compact graph (round 5): gkg_knn_fwd_tm's neighbour lists as u16 rows, nn16 (B*G, N, k), INSTEAD of the int64 planes — for
  * callers that consume the graph on the device and do not hand it out (Grapher.forward discards it, reference
  * torch_vertex.py:330): no int64 index plane, no centre plane (GKGNet-576 stage 1: 24 MB written per launch instead of 191 MB).
  * Same contract, same neighbours in the same order as gkg_knn_fwd_tm; M <= 65536.  gkg_mr_fwd_tm16 / gkg_mr_linear_bf16_nn16
  * are gkg_mr_fwd_tm / gkg_mr_linear_bf16 reading these lists (same outputs, same bits). */
-int gkg_knn_fwd_tm16(const void* x, const void* y, const float* relpos, uint16_t* nn16, int B, int G, int c, int N, int M, int k,
-                     int dilation, int dtype, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
-int gkg_mr_fwd_tm16(const float* x, const float* src, const uint16_t* nn16, void* out /* out_dtype elements */, uint8_t* argmax,
-                    int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream);
+int gkg_knn_fwd_tm16(const void* x, int ldx, int xchunk, const void* y, const float* relpos, uint16_t* nn16, int B, int G, int c,
+                     int N, int M, int k, int dilation, int dtype, unsigned flags, void* workspace, size_t workspace_bytes,
+                     void* stream);
+int gkg_mr_fwd_tm16(const float* x, int ldx, int xchunk, const float* src, const uint16_t* nn16, void* out /* out_dtype elements */,
+                    uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind, void* stream);
 
 /* Row g2 (round 5): the k-NN graph AND the max-relative aggregation over it in ONE kernel, for token-major fp32 callers — the
  * reference chain DenseDilatedKnnGraph.forward (torch_edge.py:164-176) -> MRConv2d.forward's two batched_index_select + max
  * (torch_vertex.py:49-61) without the (2, B*G, N, k) int64 edge_index in between.  x (B, N, C = G*c), y (B, M, C) or NULL (self
  * graph), relative_pos (N, M) or NULL; flags as gkg_knn_fwd (GKG_KNN_NORMALIZE ...).  The graph is the one gkg_knn_fwd_tm
  * builds (same contract, same bits); it is consumed by the workgroup that built it:
- *   u_out   (4, B*N, C/2) fp32  the grouped projection's interleaved operand, exactly gkg_mr_fwd_tm(mode 1)'s output
+ *   xm_out  (B*N, 2C) fp32      the grouped projection's operand buffer (XM layout), exactly gkg_mr_fwd_tm(mode 1)'s output:
+ *                                m into the m chunks, x into the x chunks unless x is that buffer's x half already
  *   arg_out (B, N, C)     u16   the winning neighbour ROW per channel, exactly gkg_mr_fwd_tm(arg_kind 1)'s argmax (the
  *                                backward gkg_mr_bwd_tm(arg_kind 1) scatters from it and needs no index tensor)
  *   nn16_out (B*G, N, k)  u16   the neighbour lists, or NULL (M <= 65536)
@@ -198,12 +218,12 @@ int gkg_mr_fwd_tm16(const float* x, const float* src, const uint16_t* nn16, void
  * key splits, no prefilter, lists of <= 36 entries, k <= 18, c % 4 == 0, C % 16 == 0); otherwise call gkg_knn_fwd_tm and
  * gkg_mr_fwd_tm.  Workspace: gkg_knn_workspace_bytes. */
 int gkg_knn_mr_fused_supported(int B, int G, int c, int N, int M, int k, int dilation, int has_y, int has_relpos, unsigned flags);
-int gkg_knn_mr_fwd_tm(const float* x, const float* y, const float* relative_pos, float* u_out, uint16_t* arg_out,
-                      uint16_t* nn16_out, int64_t* nn_idx_out, int64_t* center_out, int B, int G, int c, int N, int M, int k,
-                      int dilation, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+int gkg_knn_mr_fwd_tm(const float* x, int ldx, int xchunk, const float* y, const float* relative_pos, float* xm_out,
+                      uint16_t* arg_out, uint16_t* nn16_out, int64_t* nn_idx_out, int64_t* center_out, int B, int G, int c, int N,
+                      int M, int k, int dilation, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 /* arg_kind: what `argmax` holds — 0: (B,N,C) u8, the winning slot j (as gkg_mr_fwd); 1: (B,N,C) u16, the winning
  * neighbour's row index itself (M <= 65536), which lets the backward scatter without looking the index row up again. */
-int gkg_mr_fwd_tm(const float* x, const float* src, const int64_t* nn_idx, void* out /* out_dtype elements */,
+int gkg_mr_fwd_tm(const float* x, int ldx, int xchunk, const float* src, const int64_t* nn_idx, void* out /* out_dtype elements */,
                   uint8_t* argmax, int B, int G, int c, int N, int M, int k, int mode, int out_dtype, int arg_kind,
                   void* stream);
 #define GKG_MR_DETERMINISTIC 1u /* fixed summation order in the scatter: bit-identical results from run to run */
@@ -266,10 +286,11 @@ int gkg_bn_eval_affine(const float* gamma, const float* beta, const float* bias,
                        const float* running_var, float* a, float* c, int C, float eps, void* stream);
 /* out = act(a*y + c) * row_scale[r / rows_per_scale] (+ res); act 0 = identity, 1 = GELU(erf); row_scale optional (NULL).
  * out[q] has row pitch ldo and batch stride out_bstride (both in elements of out_dtype: GKG_F32, or GKG_BF16 =
- * round-to-nearest-even of the fp32 result) */
+ * round-to-nearest-even of the fp32 result).  ochunk > 0: column ch is written at ch + (ch / ochunk) * ochunk — the x half of
+ * an XM buffer (ldo >= 2C; see "XM layout") */
 int gkg_affine_act(const float* y, const float* a, const float* c, const float* res, void* out, int R, int C,
-                   int nb, int ldo, size_t out_bstride, int act, int out_dtype, const float* row_scale, int rows_per_scale,
-                   void* stream);
+                   int nb, int ldo, size_t out_bstride, int ochunk, int act, int out_dtype, const float* row_scale,
+                   int rows_per_scale, void* stream);
 /* gkg_affine_act for one batch of contiguous rows writing the result twice: fp32 (the residual stream) and its bf16
  * rounding (the next projection's operand in bf16 inference) — no stand-alone cast pass between blocks. */
 int gkg_affine_act_dual(const float* y, const float* a, const float* c, const float* res, float* out_f32, void* out_bf16,
@@ -296,8 +317,8 @@ int gkg_bn_bwd(const float* dout, const float* y, const float* a, const float* c
 int gkg_bn_apply_train(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
                        float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
                        float* mean, float* invstd, const float* res, float* out, int R, int C, int nb, int ldo,
-                       size_t out_bstride, int act, int nchw_B, const float* row_scale, int rows_per_scale, float momentum,
-                       float eps, double* zero_buf, size_t zero_doubles, void* stream);
+                       size_t out_bstride, int ochunk /* as gkg_affine_act */, int act, int nchw_B, const float* row_scale,
+                       int rows_per_scale, float momentum, float eps, double* zero_buf, size_t zero_doubles, void* stream);
 /* gkg_bn_apply_train's channel-major form as gkg_tm_affine_to_nchw_dual: residual token-major, result in both layouts. */
 int gkg_bn_apply_train_dual(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c,
@@ -390,8 +411,10 @@ int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R, int cin, 
  * Rows must be 16-byte aligned (base pointer % 16 == 0, pitches % 4 == 0); each batch of x / dy below 4 GiB. */
 size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad);
 int gkg_x6_prep_desc_bytes(void);
+/* kperm != 0 (the grouped projection behind the aggregation, "XM layout"): the planes hold w's input columns as [even columns |
+ * odd columns] per group — plane position p < cin/2 is column 2p (an x channel), p >= cin/2 column 2 (p - cin/2) + 1 (its m). */
 long long gkg_x6_prep_desc_fill(void* host_descs, int index, const float* w, void* planes_fwd, void* planes_dgrad, int cin,
-                                int cout, int nb, long long unit_begin);
+                                int cout, int nb, long long unit_begin, int kperm);
 int gkg_x6_prep_weights(const void* descs_dev, int ndesc, long long total_units, void* stream);
 /* The same launch also clearing up to two caller buffers (16-byte aligned, sizes multiples of 16; NULL / 0: none) — round 5: a
  * training step clears its flat gradient buffer and the fp64 BN scratch in front of the first projection anyway; riding in the
@@ -423,13 +446,18 @@ int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride, const voi
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* bn_a, float* bn_c,
                             float* bn_mean, float* bn_invstd, float momentum, float eps, double* stats, void* splitk_ws,
                             size_t splitk_bytes, void* stream);
+/* ldx / x_bstride: row pitch and batch stride of dx in floats (ldx == 0: contiguous (nb, R, cin)); `residual` has dx's layout.
+ * The grouped projection behind the aggregation writes dXM (R, 2C) directly: nb = 4, cin = C/2, ldx = 2C, x_bstride = C/2. */
 int gkg_linear_dgrad_x6_sk(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R, int cin,
-                           int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes, void* stream);
+                           int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes, int ldx,
+                           size_t x_bstride, void* stream);
 /* dw (nb, cout, cin) += dy^T x over the R rows (both operands split in registers; no LDS staging, each wave streams its own
  * rows).  dw must be ZERO on entry: slabs of rows are added with fp32 atomics (run-dependent summation order, like a
  * split-K GEMM).  x (nb, R, cin) with row pitch ldx / batch stride x_bstride (floats).  Any cin, cout >= 1. */
+/* kperm != 0: x arrives with its columns as [x chunk | m chunk] per group (an XM buffer read with ldx = 2C, x_bstride = C/2):
+ * operand column j is added to dw column 2j (j < cin/2) or 2 (j - cin/2) + 1 — dw keeps the reference's interleaved layout. */
 int gkg_linear_wgrad_x6(const float* dy, int ldg, size_t g_bstride, const float* x, int ldx, size_t x_bstride, float* dw,
-                        int R, int cin, int cout, int nb, void* stream);
+                        int R, int cin, int cout, int nb, int kperm, void* stream);
 /* The weight gradients of SEVERAL layers in one launch (round 5).  Nothing downstream of a backward pass reads a dW, so the
  * host side may queue the weight gradients of every projection (reference torch_vertex.py:290-306, :334-360, torch_nn.py:57-69
  * backward) while the input gradients run and issue them together when the backward ends: at this path's sizes each of them
@@ -443,6 +471,7 @@ typedef struct GkgWgradProblem {
   float* dw;
   size_t g_bstride, x_bstride;
   int ldg, ldx, R, cin, cout, nb;
+  int kperm;
 } GkgWgradProblem;
 int gkg_linear_wgrad_x6_batch(const GkgWgradProblem* problems, int n, int units_per_slab, void* stream);
 
@@ -464,26 +493,6 @@ int gkg_bn_bwd_apply_from_sums(const float* dout, const float* y, const float* a
                                const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                                size_t dout_bstride, int act, const double* sums, double* zero_buf, size_t zero_doubles,
                                void* stream);
-
-/*
- * SURVEY §8 row g1, training / fp32 form (csrc/gkg_mrgemm_x6.hip): MRConv2d.forward's gather + max-relative + interleave
- * (torch_vertex.py:47-62) as the A-operand producer of BasicConv's grouped 1x1 convolution (torch_nn.py:57-61, bias folded
- * into the BN behind it) at the accuracy of gkg_linear_bn_fwd_x6, with the train-mode BN column sums in the epilogue: ONE
- * launch instead of gkg_mr_fwd_tm -> grouped GEMM -> statistics passes.
- *   y (4, T, C/2) fp32, T = B N: conv group q's pre-BN output (column j = output channel q C/2 + j);
- *   x (B, N, C) fp32 token-major, src (B, M, C) or NULL (self graph, M == N), nn_idx (B*G, N, k) int64, C = G c,
- *   C % 16 == 0, c % 4 == 0 and gkg_mr_linear_x6_supported(G, c, k) (the 64-token tile must fit the CU's LDS: C <= 640 .. 768);
- *   planes_fwd: FORWARD x6 planes of the weight as (nb = 4, cout = C/2, cin = C/2) (gkg_x6_planes_bytes(C/2, C/2, 4, 0));
- *   arg (T, C) u16 or NULL: winning neighbour ROW per channel (gkg_mr_bwd_tm's arg_kind 1; M <= 65536);
- *   u (4, T, C/2) fp32 or NULL: the interleaved [x, m] operand (the weight gradient's input) — NULL: never written, rebuilt in
- *   the backward by gkg_mr_regather_tm from x, src and arg (bit-identical);
- *   stats [4][2][C/2] fp64 or NULL: sum y and sum y^2 per output channel are ADDED with atomics (gkg_bn_apply_train's input).
- * m and arg are bit-identical to gkg_mr_fwd_tm (first maximum wins, NaN propagates).
- */
-int gkg_mr_linear_x6_supported(int G, int c, int k);
-int gkg_mr_linear_x6(const float* x, const float* src, const int64_t* nn_idx, const void* planes_fwd, float* y, void* arg,
-                     float* u, double* stats, int B, int G, int c, int N, int M, int k, void* stream);
-int gkg_mr_regather_tm(const float* x, const float* src, const void* arg, float* u, int B, int N, int M, int C, void* stream);
 
 /*
  * The backbone's first stem convolution (reference gkgnet.py:79-81: Conv2d(3 -> C1/2, 3x3, stride 2, padding 1) on the image),

@@ -79,29 +79,33 @@ def test_linear_bn_act_matches_torch(R, cin, cout, act, with_res, gemm_mode):
 
 
 def test_grouped_linear_matches_grouped_conv(gemm_mode):
-    """_GroupedLinearBNAct on the interleaved group-major input == Conv2d(groups=4)+BN+GELU on (B,2C,N,1)."""
+    """_GroupedLinearBNAct on the XM operand buffer == Conv2d(groups=4)+BN+GELU on the reference's interleaved (B,2C,N,1) input
+    (torch_vertex.py:57-61 + torch_nn.py:57-69): output, input gradient (in the XM layout) and the weight gradient in the
+    reference's column order."""
     from gkgnet_amd import fused
+    from util import xm_interleaved
     torch.manual_seed(1)
-    R, C = 900, 64                       # 2C = 128 channels, 4 groups of 32
-    U = torch.randn(4, R, C // 2, device="cuda", requires_grad=True)
-    conv = torch.nn.Conv2d(2 * C, 2 * C, 1, groups=4).cuda()
-    bn, ref_bn = _bn(2 * C), _bn(2 * C)
-    ref_bn.load_state_dict(bn.state_dict())
-    out = fused._GroupedLinearBNAct.apply(U, conv.weight, conv.bias, bn.weight, bn.bias, bn, 1)
-    g = torch.randn_like(out)
-    out.backward(g)
-    U2 = U.detach().clone().requires_grad_(True)
-    w2 = conv.weight.detach().clone().requires_grad_(True)
-    xin = U2.permute(0, 2, 1).reshape(1, 2 * C, R, 1)           # channel q*(C/2)+i  <- U[q][:, i]
-    y = F.gelu(F.batch_norm(F.conv2d(xin, w2, conv.bias.detach(), groups=4), ref_bn.running_mean, ref_bn.running_var,
-                            ref_bn.weight, ref_bn.bias, True, 0.1, 1e-5))
-    y = y.reshape(2 * C, R).t()
-    y.backward(g)
-    assert torch.allclose(out, y, atol=2e-4, rtol=1e-3)
-    assert torch.allclose(U.grad, U2.grad, atol=2e-4, rtol=1e-3)
-    assert torch.allclose(conv.weight.grad, w2.grad, atol=2e-3, rtol=1e-3)
-    assert torch.allclose(bn.weight.grad, ref_bn.weight.grad, atol=2e-3, rtol=1e-3)
-    assert torch.allclose(bn.bias.grad, ref_bn.bias.grad, atol=2e-3, rtol=1e-3)
+    for R, C in ((900, 64), (1280, 80), (256, 48)):            # 2C channels, 4 groups of C / 2; chunks of 16 / 20 / 12
+        XM = torch.randn(R, 2 * C, device="cuda", requires_grad=True)
+        conv = torch.nn.Conv2d(2 * C, 2 * C, 1, groups=4).cuda()
+        bn, ref_bn = _bn(2 * C), _bn(2 * C)
+        ref_bn.load_state_dict(bn.state_dict())
+        out = fused._GroupedLinearBNAct.apply(XM, conv.weight, conv.bias, bn.weight, bn.bias, bn, 1)
+        g = torch.randn_like(out)
+        out.backward(g)
+        fused.flush_wgrads()
+        XM2 = XM.detach().clone().requires_grad_(True)
+        w2 = conv.weight.detach().clone().requires_grad_(True)
+        xin = xm_interleaved(XM2).t().reshape(1, 2 * C, R, 1)
+        y = F.gelu(F.batch_norm(F.conv2d(xin, w2, conv.bias.detach(), groups=4), ref_bn.running_mean, ref_bn.running_var,
+                                ref_bn.weight, ref_bn.bias, True, 0.1, 1e-5))
+        y = y.reshape(2 * C, R).t()
+        y.backward(g)
+        assert torch.allclose(out, y, atol=2e-4, rtol=1e-3)
+        assert torch.allclose(XM.grad, XM2.grad, atol=2e-4, rtol=1e-3)
+        assert torch.allclose(conv.weight.grad, w2.grad, atol=2e-3, rtol=1e-3)
+        assert torch.allclose(bn.weight.grad, ref_bn.weight.grad, atol=2e-3, rtol=1e-3)
+        assert torch.allclose(bn.bias.grad, ref_bn.bias.grad, atol=2e-3, rtol=1e-3)
 
 
 def test_layout_round_trip_and_token_major_graph_ops():
@@ -124,11 +128,24 @@ def test_layout_round_trip_and_token_major_graph_ops():
     m_cm = ops.max_relative(x.detach().reshape(B * G, C // G, N), edge_cm[0])            # (BG, c, N)
     m_tm = fused._MaxRelativeTM.apply(xtm, None, edge_tm[0], G, 0)                       # (B, N, C)
     assert torch.equal(m_tm.permute(0, 2, 1).reshape(B * G, C // G, N), m_cm)
-    U = fused._MaxRelativeTM.apply(xtm, None, edge_tm[0], G, 1)                          # (4, T, C/2) interleaved
-    Cq = C // 4
-    for q in range(4):
-        assert torch.equal(U[q][:, 0::2], xtm.reshape(B * N, C)[:, q * Cq:(q + 1) * Cq])
-        assert torch.equal(U[q][:, 1::2], m_tm.reshape(B * N, C)[:, q * Cq:(q + 1) * Cq])
+    from util import xm_split
+    XM = fused._MaxRelativeTM.apply(xtm, None, edge_tm[0], G, 1)                         # (T, 2C) operand buffer [x | m]
+    xs, ms = xm_split(XM)
+    assert torch.equal(xs, xtm.reshape(B * N, C)) and torch.equal(ms, m_tm.reshape(B * N, C))
+    # x already in the buffer (the Grapher's fc1 writes it there): only the m chunks are written, same bits
+    XM2 = torch.full((B * N, 2 * C), float("nan"), device="cuda")
+    xv = fused._xm_xview(XM2, B, N, C)
+    xv.copy_(xtm.view(B, N, 4, C // 4))
+    e2 = fused.knn_graph_tm(xv, None, rp, k, 2, G)
+    assert torch.equal(e2, edge_tm)
+    e16 = fused.knn_graph_tm16(xv, None, rp, k, 2, G)
+    assert torch.equal(e16.view(torch.uint16).to(torch.int64), edge_tm[0])
+    XM3 = fused._MaxRelativeTM.apply(xv, None, edge_tm[0], G, 1)
+    assert XM3.data_ptr() == XM2.data_ptr() and torch.equal(XM3, XM)
+    XM2[:, :] = float("nan")
+    xv.copy_(xtm.view(B, N, 4, C // 4))
+    XM4 = fused._MaxRelativeTM.apply(xv, None, e16, G, 1)
+    assert torch.equal(XM4, XM)
 
 
 def test_bf16_outputs_are_the_rounded_fp32_outputs():
@@ -152,7 +169,7 @@ def test_bf16_outputs_are_the_rounded_fp32_outputs():
         assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.to(torch.bfloat16))
         ref = F.gelu(bn(conv(x))).flatten(2).transpose(1, 2).reshape(B * N, 2 * C)
         assert torch.allclose(o32, ref, atol=2e-5, rtol=1e-4)
-        # aggregation operand U (4, T, C/2) = interleaved [x, max-relative]
+        # aggregation operand XM (T, 2C) = [x | max-relative] chunks
         xb = t32.view(B, N, C)
         edge = fused.knn_graph_tm(xb, None, None, k, 1, G)
         for kk in (9, 5):                                     # specialised k = 9 and the generic-k kernel
@@ -221,7 +238,7 @@ def test_bn_statistics_survive_a_large_channel_offset(mode):
 def test_deterministic_scatter_is_bit_reproducible_and_correct():
     """fused.DETERMINISTIC: the neighbour-gradient scatter of the max-relative backward adds each key's fan-in in a fixed
     order -> bit-identical from run to run, and equal (to rounding) to the default LDS-atomic kernel; self and bipartite
-    graphs, the interleaved (mode 1) and plain (mode 0) gradient layouts, and the > 9 600-key global fallback."""
+    graphs, the XM (mode 1) and plain (mode 0) gradient layouts, and the > 9 600-key global fallback."""
     from gkgnet_amd import fused
     torch.manual_seed(6)
     old = fused.DETERMINISTIC
@@ -233,7 +250,7 @@ def test_deterministic_scatter_is_bit_reproducible_and_correct():
             src = None if M is None else torch.randn(B, Mk, C, device="cuda")
             # heavy fan-in: all queries choose among the first 7 keys
             idx = torch.randint(0, 7, (B * G, N, k), device="cuda")
-            g = torch.randn((4, B * N, C // 2) if mode == 1 else (B, N, C), device="cuda")
+            g = torch.randn((B * N, 2 * C) if mode == 1 else (B, N, C), device="cuda")
             outs = {}
             for det in (True, True, False):
                 fused.DETERMINISTIC = det
@@ -263,7 +280,7 @@ def test_affine_act_dual_writes_both_copies(act):
     scale = torch.rand(17, device="cuda")
     o1 = torch.empty(R, C, device="cuda"); o2 = torch.full((R, C), float("nan"), device="cuda")
     o16 = torch.full((R, C), float("nan"), device="cuda", dtype=torch.bfloat16)
-    _lib.check(lib.gkg_affine_act(Y.data_ptr(), a.data_ptr(), c.data_ptr(), res.data_ptr(), o1.data_ptr(), R, C, 1, C, 0, act,
+    _lib.check(lib.gkg_affine_act(Y.data_ptr(), a.data_ptr(), c.data_ptr(), res.data_ptr(), o1.data_ptr(), R, C, 1, C, 0, 0, act,
                                   _lib.F32, scale.data_ptr(), 59, None), "gkg_affine_act")
     _lib.check(lib.gkg_affine_act_dual(Y.data_ptr(), a.data_ptr(), c.data_ptr(), res.data_ptr(), o2.data_ptr(), o16.data_ptr(),
                                        R, C, act, scale.data_ptr(), 59, None), "gkg_affine_act_dual")

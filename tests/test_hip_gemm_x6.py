@@ -10,12 +10,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _planes(lib, w, nb, cout, cin):
+def _planes(lib, w, nb, cout, cin, kperm=0):
     """Forward / dgrad planes of w (nb, cout, cin) through the batched prep entry points."""
     pf = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device="cuda")
     pd = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device="cuda")
     host = ctypes.create_string_buffer(lib.gkg_x6_prep_desc_bytes())
-    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), pd.data_ptr(), cin, cout, nb, 0)
+    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), pd.data_ptr(), cin, cout, nb, 0, kperm)
     assert units > 0
     descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).cuda()
     assert lib.gkg_x6_prep_weights(descs.data_ptr(), 1, units, None) == 0
@@ -74,7 +74,7 @@ def test_wgrad_at_fp32_accuracy(R, cin, cout, nb):
     dy = torch.randn(nb, R, cout, device="cuda", generator=gen)
     dw = torch.zeros(nb, cout, cin, device="cuda")
     _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin, cout,
-                                       nb, None), "wgrad")
+                                       nb, 0, None), "wgrad")
     ref = torch.bmm(dy.double().transpose(1, 2), x.double())
     mag = torch.bmm(dy.double().abs().transpose(1, 2), x.double().abs()) + 1e-30
     e = _rel(dw, ref, mag)
@@ -92,7 +92,7 @@ def test_wgrad_column_slices():
     dyw = torch.randn(R, nb * cout, device="cuda")
     dw = torch.zeros(nb, cout, cin, device="cuda")
     _lib.check(lib.gkg_linear_wgrad_x6(dyw.data_ptr(), nb * cout, cout, xw.data_ptr(), nb * cin, cin, dw.data_ptr(), R, cin,
-                                       cout, nb, None), "wgrad")
+                                       cout, nb, 0, None), "wgrad")
     want = torch.einsum("rqn,rqk->qnk", dyw.view(R, nb, cout).double(), xw.view(R, nb, cin).double())
     assert torch.allclose(dw.double(), want, atol=1e-4, rtol=1e-5)
 
@@ -290,7 +290,7 @@ def test_weight_gradient_tile_shapes(R, cin, cout, nb):
     x = torch.randn(nb, R, cin, device="cuda", generator=gen)
     dw = torch.zeros(nb, cout, cin, device="cuda")
     _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin, cout,
-                                       nb, None), "gkg_linear_wgrad_x6")
+                                       nb, 0, None), "gkg_linear_wgrad_x6")
     torch.cuda.synchronize()
     want = torch.bmm(dy.double().transpose(1, 2), x.double())
     scale = torch.bmm(dy.double().abs().transpose(1, 2), x.double().abs()).max()
@@ -369,7 +369,7 @@ def test_random_shapes_forward_dgrad_wgrad():
         _lib.check(lib.gkg_linear_dgrad_x6(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb, None),
                    "dgrad")
         _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin,
-                                           cout, nb, None), "wgrad")
+                                           cout, nb, 0, None), "wgrad")
         tag = (it, R, cin, cout, nb)
         assert torch.allclose(y.double(), torch.bmm(x.double(), w.double().transpose(1, 2)), atol=2e-5, rtol=1e-5), tag
         assert torch.allclose(dx.double(), torch.bmm(dy.double(), w.double()), atol=2e-5, rtol=1e-5), tag
@@ -424,7 +424,7 @@ def test_split_k_forward_statistics_and_dgrad(R, cin, cout, nb):
         dx = torch.full((nb, R, cin), float("nan"), device="cuda")
         res = torch.randn(nb, R, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
         _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
-                                              res.data_ptr(), ws.data_ptr(), ws.numel(), None), "dgrad sk")
+                                              res.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, None), "dgrad sk")
         torch.cuda.synchronize()
         ys.append(y)
         dxs.append(dx)
@@ -481,7 +481,7 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
                                                    *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), None), "fwd")
             dx = torch.full((nb, R, cin), float("nan"), device="cuda")
             _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
-                                                  res.data_ptr(), ws.data_ptr(), ws.numel(), None), "dgrad")
+                                                  res.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, None), "dgrad")
             torch.cuda.synchronize()
             out.setdefault(flags, []).append((y, dx, stats[:nb * 2 * cout].clone()))
     finally:
@@ -506,3 +506,44 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
     assert _rel(y2, ref_y, mag_y) < 2e-7 and _rel(dx2, ref_dx, mag_dx) < 2e-7
     s2 = st2.view(nb, 2, cout)
     assert torch.allclose(s2[:, 0], ref_y.sum(1), rtol=1e-6, atol=1e-3) and torch.allclose(s2[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("R,C", [(10368, 320), (2560, 320), (1500, 80), (777, 48), (4096, 640)])
+def test_grouped_projection_on_the_xm_operand_buffer(R, C):
+    """The grouped projection behind the aggregation (reference torch_vertex.py:57-61 + torch_nn.py:61) on the XM operand buffer
+    (R, 2C) = [x chunk | m chunk] per conv group (include/gkg_hip.h "XM layout"): planes built with kperm, the activation read with
+    row pitch 2C / batch stride C/2, the input gradient written in the same layout, the weight gradient added in the REFERENCE's
+    interleaved column order — against fp64 on the reference's interleaved operand."""
+    from gkgnet_amd import _lib
+    from util import xm_interleaved
+    lib = _lib.load()
+    nb, ci, co = 4, C // 2, C // 2
+    gen = torch.Generator(device="cuda").manual_seed(R + C)
+    XM = torch.randn(R, 2 * C, device="cuda", generator=gen)
+    w = torch.randn(nb, co, ci, device="cuda", generator=gen) * 0.1           # the reference's layout: columns x_0, m_0, x_1, m_1, ...
+    dy = torch.randn(nb, R, co, device="cuda", generator=gen)
+    pf, pd = _planes(lib, w, nb, co, ci, kperm=1)
+    Ui = xm_interleaved(XM).view(R, nb, ci).permute(1, 0, 2).double()          # (nb, R, ci) in the reference's column order
+    y = torch.full((nb, R, co), float("nan"), device="cuda")
+    _lib.check(lib.gkg_linear_bn_fwd_x6(XM.data_ptr(), 2 * C, ci, pf.data_ptr(), y.data_ptr(), R, ci, co, nb, 0,
+                                        *([None] * 10), 0.0, 0.0, None, None), "fwd")
+    want_y = torch.bmm(Ui, w.double().transpose(1, 2))
+    mag = torch.bmm(Ui.abs(), w.double().abs().transpose(1, 2)) + 1e-30
+    assert _rel(y, want_y, mag) < 2e-7
+    dXM = torch.full((R, 2 * C), float("nan"), device="cuda")
+    _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), co, R * co, pd.data_ptr(), dXM.data_ptr(), R, ci, co, nb, None, None, 0,
+                                          2 * C, ci, None), "dgrad")
+    want_dU = torch.bmm(dy.double(), w.double())                                # (nb, R, ci) interleaved columns
+    got_dU = xm_interleaved(dXM).view(R, nb, ci).permute(1, 0, 2)
+    magd = torch.bmm(dy.double().abs(), w.double().abs()) + 1e-30
+    assert _rel(got_dU, want_dU, magd) < 2e-7
+    dw = torch.zeros(nb, co, ci, device="cuda")
+    _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), co, R * co, XM.data_ptr(), 2 * C, ci, dw.data_ptr(), R, ci, co, nb, 1, None), "wgrad")
+    want_dw = torch.bmm(dy.double().transpose(1, 2), Ui)
+    magw = torch.bmm(dy.double().abs().transpose(1, 2), Ui.abs()) + 1e-30
+    assert _rel(dw, want_dw, magw) < 2e-7
+    # the batched launch takes the same problem (kperm in the descriptor)
+    dw2 = torch.zeros(nb, co, ci, device="cuda")
+    pr = (_lib.WgradProblem * 1)(_lib.WgradProblem(dy.data_ptr(), XM.data_ptr(), dw2.data_ptr(), R * co, ci, co, 2 * C, R, ci, co, nb, 1))
+    _lib.check(lib.gkg_linear_wgrad_x6_batch(pr, 1, 0, None), "wgrad batch")
+    assert _rel(dw2, want_dw, magw) < 2e-7

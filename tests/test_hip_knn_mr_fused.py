@@ -17,15 +17,11 @@ def _tm(a, B, G):
 
 
 def _expect_U(x_tm, m_tm):
-    """The grouped projection's interleaved operand (4, B*N, C/2) from token-major x and m (include/gkg_hip.h gkg_mr_fwd_tm)."""
+    """The grouped projection's operand buffer XM (B*N, 2C) from token-major x and m (include/gkg_hip.h "XM layout")."""
     B, N, C = x_tm.shape
-    Cq = C // 4
-    U = np.empty((4, B * N, 2 * Cq), np.float32)
-    xf, mf = x_tm.reshape(B * N, C), m_tm.reshape(B * N, C)
-    for q in range(4):
-        U[q, :, 0::2] = xf[:, q * Cq:(q + 1) * Cq]
-        U[q, :, 1::2] = mf[:, q * Cq:(q + 1) * Cq]
-    return U
+    h = C // 4
+    xf, mf = x_tm.reshape(B * N, 4, 1, h), m_tm.reshape(B * N, 4, 1, h)
+    return np.ascontiguousarray(np.concatenate([xf, mf], axis=2).reshape(B * N, 2 * C)).astype(np.float32)
 
 
 def _fused(x_tm, y_tm, rp, B, G, c, N, M, k, d, normalize=True, select=0):
@@ -37,22 +33,30 @@ def _fused(x_tm, y_tm, rp, B, G, c, N, M, k, d, normalize=True, select=0):
     C = G * c
     flags = (_lib.KNN_NORMALIZE if normalize else 0) | select
     assert lib.gkg_knn_mr_fused_supported(B, G, c, N, M, k, d, 0 if y_tm is None else 1, 0 if rp is None else 1, flags) == 1
-    U = torch.full((4, B * N, C // 2), float("nan"), device="cuda")
+    U = torch.full((B * N, 2 * C), float("nan"), device="cuda")
     arg = torch.full((B, N, C), -1, dtype=torch.int16, device="cuda")
     nn16 = torch.full((B * G, N, k), -1, dtype=torch.int16, device="cuda")
     ws = torch.empty(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), dtype=torch.uint8, device="cuda")
     e64 = torch.full((2, B * G, N, k), -1, dtype=torch.int64, device="cuda")
-    _lib.check(lib.gkg_knn_mr_fwd_tm(xd.data_ptr(), None if yd is None else yd.data_ptr(), None if rpd is None else rpd.data_ptr(),
-                                     U.data_ptr(), arg.data_ptr(), nn16.data_ptr(), e64[0].data_ptr(), e64[1].data_ptr(), B, G, c,
-                                     N, M, k, d, flags, ws.data_ptr(), ws.numel(), None), "gkg_knn_mr_fwd_tm")
+    yp, rpp = None if yd is None else yd.data_ptr(), None if rpd is None else rpd.data_ptr()
+    # (a) x a plain (B, N, C) matrix: the kernel writes both halves of the operand buffer
+    _lib.check(lib.gkg_knn_mr_fwd_tm(xd.data_ptr(), C, 0, yp, rpp, U.data_ptr(), arg.data_ptr(), nn16.data_ptr(), e64[0].data_ptr(),
+                                     e64[1].data_ptr(), B, G, c, N, M, k, d, flags, ws.data_ptr(), ws.numel(), None), "gkg_knn_mr_fwd_tm")
+    # (b) x lives in the buffer's x half already (what the Grapher's fc1 leaves): the queries, the centre rows and — self graph —
+    # the neighbour rows are read through that view, only the m half is written.  Same bits.
+    Ub = torch.full((B * N, 2 * C), float("nan"), device="cuda")
+    Ub.view(B * N, 4, 2, C // 4)[:, :, 0] = xd.view(B * N, 4, C // 4)
+    argb, nn16b = torch.full_like(arg, -1), torch.full_like(nn16, -1)
+    _lib.check(lib.gkg_knn_mr_fwd_tm(Ub.data_ptr(), 2 * C, C // 4, yp, rpp, Ub.data_ptr(), argb.data_ptr(), nn16b.data_ptr(), None, None,
+                                     B, G, c, N, M, k, d, flags, ws.data_ptr(), ws.numel(), None), "gkg_knn_mr_fwd_tm (in place)")
+    assert torch.equal(Ub.view(torch.int32), U.view(torch.int32)) and torch.equal(argb, arg) and torch.equal(nn16b, nn16)
     # the two-launch form on the same inputs
     edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device="cuda")
-    _lib.check(lib.gkg_knn_fwd_tm(xd.data_ptr(), None if yd is None else yd.data_ptr(), None if rpd is None else rpd.data_ptr(),
-                                  edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k, d, _lib.F32, flags, ws.data_ptr(),
-                                  ws.numel(), None), "gkg_knn_fwd_tm")
+    _lib.check(lib.gkg_knn_fwd_tm(xd.data_ptr(), C, 0, yp, rpp, edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k, d, _lib.F32,
+                                  flags, ws.data_ptr(), ws.numel(), None), "gkg_knn_fwd_tm")
     U2 = torch.empty_like(U)
     arg2 = torch.empty_like(arg)
-    _lib.check(lib.gkg_mr_fwd_tm(xd.data_ptr(), None if yd is None else yd.data_ptr(), edge[0].data_ptr(), U2.data_ptr(),
+    _lib.check(lib.gkg_mr_fwd_tm(xd.data_ptr(), C, 0, yp, edge[0].data_ptr(), U2.data_ptr(),
                                  arg2.data_ptr(), B, G, c, N, M, k, 1, _lib.F32, 1, None), "gkg_mr_fwd_tm")
     torch.cuda.synchronize()
     assert torch.equal(e64, edge)                                                # the optional int64 outputs: gkg_knn_fwd_tm's

@@ -53,9 +53,9 @@ def test_exact_scatter_matches_the_oracle_backward(B, G, C, N, M, k, mode):
     Mk = N if M is None else M
     idx = torch.randint(0, min(Mk, 23), (B * G, N, k), device="cuda", generator=gen)      # heavy fan-in: few distinct keys
     if mode == 1:
-        g = torch.randn(4, B * N, C // 2, device="cuda", generator=gen)
-        gi = g.view(4, B, N, C // 4, 2).permute(1, 2, 0, 3, 4).reshape(B, N, C, 2)
-        direct, gm = gi[..., 0].contiguous(), gi[..., 1].contiguous()
+        g = torch.randn(B * N, 2 * C, device="cuda", generator=gen)              # dXM: [direct chunk | gm chunk] per conv group
+        gi = g.view(B, N, 4, 2, C // 4)
+        direct, gm = gi[:, :, :, 0].reshape(B, N, C).contiguous(), gi[:, :, :, 1].reshape(B, N, C).contiguous()
     else:
         g = torch.randn(B, N, C, device="cuda", generator=gen)
         direct, gm = None, g
@@ -249,9 +249,9 @@ def test_fuzz_token_major_scatter_random_shapes():
         arg = torch.randint(0, M, (B, N, C), device="cuda", generator=gen).to(torch.int16)
         scale = 10.0 ** float(rng.uniform(-4, 3))
         if mode == 1:
-            g = torch.randn(4, B * N, C // 2, device="cuda", generator=gen) * scale
-            gi = g.view(4, B, N, C // 4, 2).permute(1, 2, 0, 3, 4).reshape(B, N, C, 2)
-            direct, gm = gi[..., 0].contiguous(), gi[..., 1].contiguous()
+            g = torch.randn(B * N, 2 * C, device="cuda", generator=gen) * scale
+            gi = g.view(B, N, 4, 2, C // 4)
+            direct, gm = gi[:, :, :, 0].reshape(B, N, C).contiguous(), gi[:, :, :, 1].reshape(B, N, C).contiguous()
         else:
             g = torch.randn(B, N, C, device="cuda", generator=gen) * scale
             direct, gm = torch.zeros_like(g), g

@@ -1,22 +1,36 @@
 """CPU checks of the small autograd Functions around the blocks (gkgnet_amd/layout.py, stem.py) against the plain torch
 operators they replace (reference gkgnet.py:79-118, torch_vertex.py:194-196)."""
+import pytest
 import torch
 import torch.nn.functional as F
 
 
+@pytest.mark.gpu
 def test_avg_pool_token_major_matches_avg_pool2d_forward_and_backward():
+    """gkg_avgpool_tm (plain rows and the x half of an XM operand buffer) vs F.avg_pool2d, forward and backward."""
     from gkgnet_amd.layout import _AvgPoolTM
+    from gkgnet_amd.fused import _xm_xview
     torch.manual_seed(0)
-    for B, H, W, C, r in ((2, 8, 8, 3, 2), (1, 12, 8, 5, 4), (2, 9, 10, 4, 4), (1, 7, 7, 2, 2)):      # the last two: floor mode
-        x = torch.randn(B, H, W, C, dtype=torch.float64, requires_grad=True)
-        xr = x.detach().clone().requires_grad_(True)
-        y = _AvgPoolTM.apply(x, r)
+    dev = torch.device("cuda", 0)
+    for B, H, W, C, r in ((2, 8, 8, 16, 2), (1, 12, 8, 32, 4), (2, 9, 10, 16, 4), (1, 7, 7, 48, 2)):      # the last two: floor mode
+        x0 = torch.randn(B, H * W, C, device=dev)
+        xr = x0.view(B, H, W, C).clone().requires_grad_(True)
         yr = F.avg_pool2d(xr.permute(0, 3, 1, 2), r, r).permute(0, 2, 3, 1)
-        assert y.shape == yr.shape and torch.allclose(y, yr)
         g = torch.randn_like(yr)
-        y.backward(g)
         yr.backward(g)
-        assert torch.allclose(x.grad, xr.grad, atol=1e-12), (B, H, W, C, r)
+        for xm in (False, True):
+            if xm:                                                   # x lives in the x chunks of a (B N, 2C) buffer
+                XM = torch.full((B * H * W, 2 * C), float("nan"), device=dev)
+                x = _xm_xview(XM, B, H * W, C)
+                x.copy_(x0.view(B, H * W, 4, C // 4))
+                x.requires_grad_(True)
+            else:
+                x = x0.clone().requires_grad_(True)
+            y = _AvgPoolTM.apply(x, H, W, r)
+            assert y.shape == (B, (H // r) * (W // r), C)
+            assert torch.allclose(y.view_as(yr), yr, atol=1e-6), (B, H, W, C, r, xm)
+            y.backward(g.reshape(y.shape))
+            assert torch.allclose(x.grad.reshape(B, H, W, C), xr.grad, atol=1e-6), (B, H, W, C, r, xm)
 
 
 def test_add_pos_embed_matches_broadcast_add():

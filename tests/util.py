@@ -73,3 +73,23 @@ def keyed_fill_(state_dict, seed=0):
         else:
             v = torch.randn(t.shape, generator=g) * 0.1
         t.copy_(v.to(t.dtype))
+
+
+# ---- the grouped projection's operand buffer (include/gkg_hip.h "XM layout") ------------------------------------------------
+def xm_pack(x, m):
+    """x, m (T, C) -> XM (T, 2C): row = [x_0 | m_0 | x_1 | m_1 | x_2 | m_2 | x_3 | m_3], chunks of C / 4."""
+    T, C = x.shape
+    return torch.stack([x.reshape(T, 4, C // 4), m.reshape(T, 4, C // 4)], dim=2).reshape(T, 2 * C)
+
+
+def xm_split(XM):
+    """XM (T, 2C) -> (x, m), each (T, C)."""
+    T, C2 = XM.shape
+    v = XM.reshape(T, 4, 2, C2 // 8)
+    return v[:, :, 0].reshape(T, C2 // 2), v[:, :, 1].reshape(T, C2 // 2)
+
+
+def xm_interleaved(XM):
+    """XM (T, 2C) -> the reference's interleaved channel order [x_0, m_0, x_1, m_1, ...] (T, 2C) (torch_vertex.py:57-61)."""
+    x, m = xm_split(XM)
+    return torch.stack([x, m], dim=2).reshape(XM.shape[0], -1)

@@ -23,7 +23,7 @@ def main():
         sel = torch.randint(0, k, (B, N, C), device="cuda")
         arg = torch.gather(idx.view(B, G, N, k).permute(0, 2, 1, 3).reshape(B, N, G, 1, k).expand(B, N, G, C // G, k).reshape(B, N, C, k),
                            3, sel.unsqueeze(-1)).squeeze(-1).to(torch.int16).contiguous()
-        g = torch.randn(4, B * N, C // 2, device="cuda")
+        g = torch.randn(B * N, 2 * C, device="cuda")
         gx = torch.empty(B, N, C, device="cuda")
         gs = None if M is None else torch.empty(B, Mk, C, device="cuda")
         row = {}

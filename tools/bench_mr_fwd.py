@@ -16,11 +16,11 @@ SHAPES = [("cfg2 grapher", 32, 4, 80, 324, None, 1, 1), ("cfg2 label", 32, 4, 80
 
 def run(x, src, idx, B, G, c, N, M, mode, ak, k=9):
     C = G * c
-    out = torch.empty((4, B * N, C // 2) if (mode & 0xff) == 1 else (B, N, C), device="cuda")
+    out = torch.empty((B * N, 2 * C) if (mode & 0xff) == 1 else (B, N, C), device="cuda")
     arg = torch.empty((B, N, C), dtype=torch.int16 if ak else torch.uint8, device="cuda")
 
     def call():
-        _lib.check(lib.gkg_mr_fwd_tm(x.data_ptr(), None if src is None else src.data_ptr(), idx.data_ptr(), out.data_ptr(), arg.data_ptr(),
+        _lib.check(lib.gkg_mr_fwd_tm(x.data_ptr(), 0, 0, None if src is None else src.data_ptr(), idx.data_ptr(), out.data_ptr(), arg.data_ptr(),
                                      B, G, c, N, M, k, mode, 0, ak, None), "gkg_mr_fwd_tm")
     for _ in range(3):
         call()

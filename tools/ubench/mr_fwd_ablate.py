@@ -19,7 +19,7 @@ def build(bits, *extra):
                            os.path.join(CS, "gkg_mr.hip"), os.path.join(CS, "gkg_api.hip")])
     lib = C.CDLL(so)
     lib.gkg_mr_fwd_tm.restype = C.c_int
-    lib.gkg_mr_fwd_tm.argtypes = [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_void_p]
+    lib.gkg_mr_fwd_tm.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]
     return lib
 
 
@@ -33,7 +33,7 @@ def main():
         src = None if M is None else torch.randn(B, Mk, Cc, device="cuda")
         base = (torch.arange(N, device="cuda") * Mk // N).view(1, N, 1)
         idx = ((base + torch.randint(-40, 41, (B * G, N, 9), device="cuda")) % Mk).contiguous()
-        out = torch.empty(4, B * N, Cc // 2, device="cuda")
+        out = torch.empty(B * N, 2 * Cc, device="cuda")
         arg = torch.zeros(B * N * Cc + 512 * 1024, dtype=torch.int16, device="cuda")       # + room for the timeline stamps
         data.append((name, x, src, idx, out, arg, B, G, c, N, Mk))
     for v, bits in list(VARIANTS.items()):
@@ -43,7 +43,7 @@ def main():
         line = f"{v:18s}"
         for name, x, src, idx, out, arg, B, G, c, N, Mk in data:
             def call():
-                rc = lib.gkg_mr_fwd_tm(x.data_ptr(), None if src is None else src.data_ptr(), idx.data_ptr(), out.data_ptr(), arg.data_ptr(),
+                rc = lib.gkg_mr_fwd_tm(x.data_ptr(), 0, 0, None if src is None else src.data_ptr(), idx.data_ptr(), out.data_ptr(), arg.data_ptr(),
                                        B, G, c, N, Mk, 9, 1, 0, 1, None)
                 assert rc == 0
             for _ in range(3):
@@ -71,11 +71,11 @@ def timeline():
         src = None if M is None else torch.randn(B, Mk, Cc, device="cuda")
         base = (torch.arange(N, device="cuda") * Mk // N).view(1, N, 1)
         idx = ((base + torch.randint(-40, 41, (B * G, N, 9), device="cuda")) % Mk).contiguous()
-        out = torch.empty(4, B * N, Cc // 2, device="cuda")
+        out = torch.empty(B * N, 2 * Cc, device="cuda")
         arg = torch.zeros(B * N * Cc + 512 * 1024, dtype=torch.int16, device="cuda")
         for _ in range(3):
             arg[B * N * Cc:].zero_()
-            rc = lib.gkg_mr_fwd_tm(x.data_ptr(), None if src is None else src.data_ptr(), idx.data_ptr(), out.data_ptr(), arg.data_ptr(),
+            rc = lib.gkg_mr_fwd_tm(x.data_ptr(), 0, 0, None if src is None else src.data_ptr(), idx.data_ptr(), out.data_ptr(), arg.data_ptr(),
                                    B, G, c, N, Mk, 9, 1, 0, 1, None)
             assert rc == 0
             torch.cuda.synchronize()
