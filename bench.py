@@ -664,6 +664,24 @@ def main():
     torch.cuda.synchronize()
     _lib.prof_enable(False)
     prof = _lib.prof_read()
+    # the algorithmic work the library counted for THESE launches (the A/B leg below resets and re-accumulates the counters:
+    # reading them later paired one leg's bytes with the other leg's time — VERDICT r5 weak 9)
+    prof_work = {name: _lib.prof_work(name) for name in ("mr_fwd", "mr_bwd", "gemm_x6")}
+
+    # the box's own streaming rate (a 256 MiB device-to-device copy: read + write), the practical ceiling of every bandwidth
+    # figure below — the pool's boxes differ (4.9-5.5 TB/s measured), 8 TB/s is the data-sheet peak
+    cp_src = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    cp_dst = torch.empty_like(cp_src)
+    for _ in range(3):
+        cp_dst.copy_(cp_src)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        cp_dst.copy_(cp_src)
+    ev1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 10 * 2 * cp_src.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del cp_src, cp_dst
 
     from gkgnet_amd import fused
     # Row g2 (round 5): by default the k-NN kernel also does the aggregation (fused epilogue), so `knn_tile`'s time below is the
@@ -689,9 +707,6 @@ def main():
                        "exact 3-way operand split, 6 cross products, fp32 accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 below an "
                        "fp32 fma chain's); split-K forms on the label branch's 2 560-row matrices; the weight gradients of the "
                        "backward pass in ONE batched launch; no vendor GEMM in the step",
-                 "x6all": "every fp32 projection GEMM (forward, input and weight gradient) on the split-bf16 kernels "
-                          "(csrc/gkg_gemm_x6.hip)",
-                 "f32": "own fp32-MFMA forward kernels with BN-statistics epilogue where measured faster; otherwise " + lib_desc,
                  "vendor": lib_desc}[fused.GEMM_MATH]
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -705,7 +720,7 @@ def main():
         # HBM-side traffic of the same kernel: hardware counters cannot be read from inside the process, so this field is
         # NOT measured by this run — it is the value of the newest committed rocprofv3 --pmc collection for this workload
         # (tools/pmc_refresh.sh -> profiles/rNN_pmc.json), labelled with its file and the commit it was taken at.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_by = None, None, {}
         issue_slots = None
         if args.workload == "cfg2" and B == 32:
             import glob
@@ -713,7 +728,9 @@ def main():
                 try:
                     with open(pmc_path) as fh:
                         pj = json.load(fh)
-                    traffic = pj["knn_tile_per_step_traffic_bytes"] / pj.get("knn_tile_launches_per_step", 2)   # per launch
+                    # per launch, over the FUSED instantiations on the timed path only (tools/pmc_json.py "knn_mr_fused")
+                    traffic = pj["knn_tile_per_step_traffic_bytes"] / pj.get("knn_tile_launches_per_step", 2)
+                    traffic_by = {k: v["hbm_bytes_per_launch"] for k, v in pj.get("knn_mr_fused", {}).items()}
                     from gkgnet_amd._build import csrc_sha16
                     same = pj.get("csrc_sha16") == csrc_sha16()
                     if "knn_tile_issue_slot_frac" in pj:
@@ -739,6 +756,17 @@ def main():
                         algorithmic_flops_per_step=flops_knn)
             if issue_slots:
                 roof["issue_slots"] = issue_slots
+            # the counter traffic next to the ALGORITHMIC bytes of the same launches (SURVEY §8d "Fused fwd (k-NN+MR)": x + (y) +
+            # relative_pos + the aggregated output m + the winning rows; no index tensor, no copy of x): ratio > 1 = re-reads
+            alg_g = 4.0 * B * C * N + (4.0 * B * C * M if M != N else 0.0) + 4.0 * N * M + 4.0 * B * C * N + 2.0 * B * C * N
+            alg_l = 4.0 * B * C * L + 4.0 * B * C * N + 4.0 * B * C * L + 2.0 * B * C * L + 16.0 * BG * L * w["k"]
+            roof["algorithmic_bytes_per_launch"] = dict(grapher=alg_g, label=alg_l, mean=(alg_g + alg_l) / 2)
+            if traffic_by:
+                roof["traffic_per_launch"] = traffic_by
+                roof["traffic_ratio"] = {k: round(v / dict(grapher=alg_g, label=alg_l)[k], 3) for k, v in traffic_by.items()
+                                         if k in ("grapher", "label")}
+                if len(traffic_by) == 2:
+                    roof["traffic_ratio"]["step"] = round(sum(traffic_by.values()) / (alg_g + alg_l), 3)
             if fused_now:
                 # SURVEY §8(d) "Fused fwd (k-NN+MR)": the same contraction flop, more bytes — the kernel's time now includes the
                 # gather, so `frac` is NOT comparable with the k-NN-only kernel of rounds 1-4 (0.21-0.23); that kernel, timed
@@ -761,33 +789,33 @@ def main():
         roof_hbm = {}
         # (round 5: from 160 query rows per image the exact scatter is the one-sweep streaming form; label graphs keep the
         # two-sweep kernel; both are order-independent, so GKG_DETERMINISTIC runs them too)
-        mr_bwd_kernel = ("mr_bwd_tm_stream_kernel (>= 160 query rows) / mr_bwd_tm_scatter_i64_kernel" if fused.MR_I64
-                         else "mr_bwd_tm_scatter_kernel")
+        mr_bwd_kernel = "mr_bwd_tm_stream_kernel (>= 160 query rows) / mr_bwd_tm_scatter_i64_kernel"
         for name, kern in (("mr_fwd", "mr_fwd_tm_kernel"), ("mr_bwd", mr_bwd_kernel)):
             if name in kernels and kernels[name]["us_per_step"] > 0:
-                nbytes = _lib.prof_work(name) / prof_steps
+                nbytes = prof_work[name] / prof_steps
                 gbs = nbytes / kernels[name]["us_per_step"] / 1e3
                 kernels[name].update(bound="hbm", achieved_GBps=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBPS, 4))
                 roof_hbm[name] = dict(kernel=kern, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                                      frac=round(gbs / PEAK_HBM_GBPS, 4), algorithmic_bytes_per_step=nbytes,
+                                      frac=round(gbs / PEAK_HBM_GBPS, 4), frac_of_copy=round(gbs / copy_gbps, 4),
+                                      algorithmic_bytes_per_step=nbytes,
                                       us_per_step=kernels[name]["us_per_step"], launches_per_step=kernels[name]["launches_per_step"])
         if roof is not None and "two_launch_form" in roof:
             # the fused kernel against the HBM roofline with §8(d)'s "Fused fwd (k-NN+MR)" bytes per graph:
             # x + (y) + relative_pos + index lists + the aggregated output
             e4 = 4.0
-            by_g = e4 * B * C * N + 4.0 * N * M + 8.0 * BG * N * w["k"] + e4 * B * C * N + (e4 * B * C * M if M != N else 0.0)
-            by_l = e4 * B * C * L + e4 * B * C * N + 8.0 * BG * L * w["k"] + e4 * B * C * L
+            by_g, by_l = roof["algorithmic_bytes_per_launch"]["grapher"], roof["algorithmic_bytes_per_launch"]["label"]
             us = kernels["knn_tile"]["us_per_step"]
             gbs = (by_g + by_l) / us / 1e3
             roof_hbm["knn_mr_fused"] = dict(kernel="knn_tile_kernel<..., MRF>", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBPS,
-                                            unit="GB/s", frac=round(gbs / PEAK_HBM_GBPS, 4), algorithmic_bytes_per_step=by_g + by_l,
+                                            unit="GB/s", frac=round(gbs / PEAK_HBM_GBPS, 4), frac_of_copy=round(gbs / copy_gbps, 4),
+                                            algorithmic_bytes_per_step=by_g + by_l,
                                             us_per_step=us, launches_per_step=kernels["knn_tile"]["launches_per_step"],
                                             note="compute-bound kernel (SURVEY §8d: 3.7 us at 8 TB/s vs 13.7 us at the fp32 matrix peak for the Grapher graph)")
         if "gemm_x6" in kernels and kernels["gemm_x6"]["us_per_step"] > 0:
             # the projection GEMMs that run on the split-bf16 kernels: algorithmic fp32 flop (2 R cin cout, reported by the
             # library per launch) per second, against the fp32-MFMA peak they replace and against their own bound — six
             # bf16 MFMAs per fp32 block product at the dense bf16 peak (2.5 PFLOP/s / 6)
-            gf = _lib.prof_work("gemm_x6") / prof_steps
+            gf = prof_work["gemm_x6"] / prof_steps
             tf = gf / kernels["gemm_x6"]["us_per_step"] / 1e6
             kernels["gemm_x6"].update(bound="mfma", algorithmic_flops_per_step=gf, achieved_TFLOPs=round(tf, 1),
                                       frac_of_fp32_mfma_peak=round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -824,6 +852,7 @@ def main():
                                                ("captured inside the step's hipGraph" if state["reduce_in_graph"] else
                                                 "issued by the host after the replay"))),
                    roofline=roof, roofline_hbm=roof_hbm, roofline_step=roof_step, hip_kernels=kernels,
+                   hbm_copy_GBps=round(copy_gbps, 1),
                    ms_per_step_no_tune=round(1e3 * elapsed_no_tune / args.steps, 4),
                    ms_per_step_eager=round(ms_eager, 4),
                    gemm_selection="library default (no tuning pass)" if args.no_tune else

@@ -21,6 +21,9 @@ KNN_FORCE_PREFILTER = 32
 KNN_RELPOS_UNIT = 64
 
 
+_RELPOS_WARNED = False
+
+
 def relpos_flags(rp) -> int:
     """KNN_RELPOS_UNIT when every |relative_pos| <= 1.125 (the prefilter kernel's precondition, include/gkg_hip.h).  The check
     is one reduction + a host read, cached ON the tensor object (keyed on its version counter): a module's frozen
@@ -32,6 +35,15 @@ def relpos_flags(rp) -> int:
     ent = getattr(rp, "_gkg_unit", None)
     if ent is None or ent[0] != rp._version:
         if torch.cuda.is_current_stream_capturing():
+            # the range check needs a host read, which a capture cannot make: this call takes the fp32 tile kernel (same graphs,
+            # slower for long key streams).  Said once — a user who captures on step 0 loses the prefilter otherwise unnoticed.
+            global _RELPOS_WARNED
+            if not _RELPOS_WARNED:
+                _RELPOS_WARNED = True
+                import warnings
+                warnings.warn("gkgnet_amd: a relative_pos tensor was first seen inside a hipGraph capture; its value range cannot be "
+                              "checked there, so the k-NN of this capture runs without the bf16 prefilter (identical graphs, slower "
+                              "at long key streams).  Run one eager warm-up forward before capturing.", RuntimeWarning, stacklevel=3)
             return 0
         ent = (rp._version, bool((rp.detach().abs().max() <= 1.125).item()))
         try:
@@ -54,20 +66,21 @@ def knn_select_flags() -> int:
     return f
 MR_DETERMINISTIC = 1
 MR_FP32_ATOMICS = 2
+X6_NO_KS, X6_FORCE_KS = 1, 2
 
 EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "gkg_knn_fwd", "gkg_mr_fwd",
            "gkg_mr_bwd", "gkg_prof_enable", "gkg_prof_reset", "gkg_prof_read", "gkg_prof_work", "gkg_knn_fwd_tm", "gkg_mr_fwd_tm",
            "gkg_mr_bwd_tm", "gkg_nchw_to_tm", "gkg_tm_affine_to_nchw", "gkg_bn_workspace_bytes", "gkg_bn_train_stats",
            "gkg_bn_eval_affine", "gkg_affine_act", "gkg_bn_bwd", "gkg_bn_stats_sums", "gkg_bn_finalize",
            "gkg_bn_bwd_sums", "gkg_bn_bwd_apply", "gkg_linear_stats_doubles",
-           "gkg_linear_bn_fwd", "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
+           "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
            "gkg_avgpool_tm", "gkg_linear_dgrad_x6_bnbwd",
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
-           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_bn_set_flags", "gkg_debug_barrier_timeouts", "gkg_x6_set_flags", "gkg_x6_prep_weights_zero",
+           "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_x6_prep_weights_zero",
            "gkg_knn_fwd_tm16", "gkg_mr_fwd_tm16", "gkg_mr_linear_bf16_nn16")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
@@ -147,12 +160,6 @@ def load():
     lib.gkg_bn_bwd.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_apply_train.restype = I
     lib.gkg_bn_apply_train.argtypes = [V] * 14 + [I, I, I, I, Z, I, I, I, V, I, F, F, V, Z, V]
-    lib.gkg_x6_set_flags.restype = None
-    lib.gkg_x6_set_flags.argtypes = [C.c_uint]
-    lib.gkg_bn_set_flags.restype = None
-    lib.gkg_bn_set_flags.argtypes = [C.c_uint]
-    lib.gkg_debug_barrier_timeouts.restype = I
-    lib.gkg_debug_barrier_timeouts.argtypes = []
     lib.gkg_bn_bwd_atomic.restype = I
     lib.gkg_bn_bwd_atomic.argtypes = [V] * 9 + [I, I, I, I, Z, I, V, V, Z, V]
     lib.gkg_bn_bwd_atomic_scaled.restype = I
@@ -169,10 +176,8 @@ def load():
     lib.gkg_bn_bwd_sums.argtypes = [V] * 10 + [I, I, I, I, Z, I, V, Z, V]
     lib.gkg_bn_bwd_apply.restype = I
     lib.gkg_bn_bwd_apply.argtypes = [V] * 9 + [I, I, I, I, Z, I, V]
-    lib.gkg_linear_bn_fwd.restype = I
     lib.gkg_linear_stats_doubles.restype = I
     lib.gkg_linear_stats_doubles.argtypes = []
-    lib.gkg_linear_bn_fwd.argtypes = [V, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V]
     lib.gkg_affine_act_bf16in.restype = I
     lib.gkg_affine_act_bf16in.argtypes = [V, V, V, V, V, I, I, I, V]
     lib.gkg_affine_act_dual.restype = I
@@ -206,9 +211,9 @@ def load():
     lib.gkg_x6_splitk_workspace_bytes.restype = Z
     lib.gkg_x6_splitk_workspace_bytes.argtypes = []
     lib.gkg_linear_bn_fwd_x6_sk.restype = I
-    lib.gkg_linear_bn_fwd_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V, Z, V]
+    lib.gkg_linear_bn_fwd_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, I] + [V] * 10 + [F, F, V, V, Z, C.c_uint, V]
     lib.gkg_linear_dgrad_x6_sk.restype = I
-    lib.gkg_linear_dgrad_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, V, V, Z, I, Z, V]
+    lib.gkg_linear_dgrad_x6_sk.argtypes = [V, I, Z, V, V, I, I, I, I, V, V, Z, I, Z, C.c_uint, V]
     lib.gkg_linear_wgrad_x6_batch.restype = I
     lib.gkg_linear_wgrad_x6_batch.argtypes = [C.POINTER(WgradProblem), I, I, V]
     lib.gkg_mr_linear_planes_bytes.restype = Z
@@ -231,10 +236,6 @@ def load():
     v = lib.gkg_version()
     if v != ABI_VERSION:
         raise GkgError(f"libgkg_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
-    if "x6_ks" in {t.strip() for t in os.environ.get("GKG_DISABLE", "").split(",")}:
-        lib.gkg_x6_set_flags(1)             # GKG_DISABLE=x6_ks: short matrices on gemm_x6_kernel (+ cross-workgroup split-K) again
-    if "bn_fused" in {t.strip() for t in os.environ.get("GKG_ENABLE", "").split(",")}:
-        lib.gkg_bn_set_flags(2)             # GKG_ENABLE=bn_fused: the one-launch (grid barrier) BN backward where the grid fits
     _lib = lib
     return lib
 

@@ -762,7 +762,6 @@ __global__ __launch_bounds__(256, MI == 1 ? 2 : 1) void gemm_x6_ks_kernel(X6Args
   }
 }
 
-static unsigned gkg_x6_flags = 0;       // gkg_x6_set_flags: bit 0 = never take the K-split-in-workgroup form, bit 1 = wherever it applies,
                                         // bit 2 / bit 3 = always 32-row / 64-row tiles in it (A/B, tests)
 
 template <int EPI, int MI>
@@ -790,7 +789,7 @@ constexpr size_t X6_SK_CNT_BYTES = 4096, X6_SK_MAX_WG = 512;
 constexpr size_t X6_SK_BYTES = X6_SK_CNT_BYTES + X6_SK_MAX_WG * (size_t)(2 * 16 * 256 * 4);
 
 template <int EPI>
-static hipError_t x6_launch(X6Args a, int nb, hipStream_t st, void* sk_ws = nullptr, size_t sk_bytes = 0) {
+static hipError_t x6_launch(X6Args a, int nb, hipStream_t st, void* sk_ws = nullptr, size_t sk_bytes = 0, unsigned flags = 0) {
   GkgProfScope prof(GKG_PROF_GEMM_X6, st, 2.0 * a.M * a.N * a.K * nb);
   const int mt = (a.M + 127) / 128;
   // Few rows under a long contraction (the label branch: 2 560 x 1280 -> 320 is 100 workgroups of 40 K-steps on 256 CUs): the
@@ -806,15 +805,13 @@ static hipError_t x6_launch(X6Args a, int nb, hipStream_t st, void* sk_ws = null
   // 15.2 vs 21.2, 1280 -> 320 24.3 vs 29.6 (input gradient of 320 -> 1280: 25.4 vs 36.5); a tie at 320 -> 640 (16.4); it LOSES
   // where every 32-row workgroup re-reads a wide B (320 -> 1280: 30.0 vs 22.4, its transpose 27.3 vs 21.3: 196 MB of plane
   // traffic) and on the grouped 4 x (160 -> 160) products (15.5 vs 13.5).  Rule: un-grouped, at most 640 output columns.
-  // gkg_x6_set_flags(2) forces it for every short matrix (tests).
+  // The caller's `flags` (GKG_X6_NO_KS / GKG_X6_FORCE_KS: measurement, tests) override the rule per call.
   if constexpr (EPI != X6_BNBWD) {
-    if (sk_ws && !(gkg_x6_flags & 1u) && a.M <= 4096 && (long long)((a.M + 31) / 32) * ((a.N + 63) / 64) * nb <= 65535 * 8 &&
-        ((gkg_x6_flags & 2u) || (nb == 1 && a.N <= 640))) {
-      // 64-row tiles (half the plane traffic, one wave per SIMD) measured no better on the long contractions they were built
-      // for (2 560 x 1280 -> 320: 26.8 vs 24.3 us, its transpose-side gradient 26.5 vs 25.4): what bounds those launches is the
-      // wave-serial K loop, not the B planes — opt-in (gkg_x6_set_flags bit 3)
-      const bool mi2 = (gkg_x6_flags & 8u) != 0;
-      return mi2 ? x6_launch_ks<EPI, 2>(a, nb, st) : x6_launch_ks<EPI, 1>(a, nb, st);
+    if (sk_ws && !(flags & GKG_X6_NO_KS) && a.M <= 4096 && (long long)((a.M + 31) / 32) * ((a.N + 63) / 64) * nb <= 65535 * 8 &&
+        ((flags & GKG_X6_FORCE_KS) || (nb == 1 && a.N <= 640))) {
+      // (64-row tiles — half the plane traffic, one wave per SIMD — measured no better on the long contractions they were built
+      // for: 2 560 x 1280 -> 320 26.8 vs 24.3 us; what bounds those launches is the wave-serial K loop, not the B planes)
+      return x6_launch_ks<EPI, 1>(a, nb, st);
     }
   }
   if (sk_ws && sk_bytes >= X6_SK_BYTES && base2 < 320 && base2 <= 1024 && nk_total >= 8 && EPI != X6_BNBWD) {
@@ -1380,6 +1377,62 @@ extern "C" int gkg_debug_set_x6_timeline(void* buf) {
 }
 #endif
 
+namespace gkg {
+// Train-mode BN parameters from the fp64 column sums of Y (which EXCLUDES the conv bias, folded here); re-zeroes the sums
+// so the scratch buffer is clean for the next projection (it is shared, stream-ordered, by all layers).
+//   mean = S/R, var = Q/R - mean^2 (biased), invstd = rsqrt(var + eps), a = gamma*invstd, c = beta - a*mean
+//   running_mean <- (1-mom)*rm + mom*(mean + bias), running_var <- (1-mom)*rv + mom*var*R/(R-1)
+__global__ __launch_bounds__(256) void bn_sums_finalize_kernel(double* __restrict__ sums, int R, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ a,
+                                                               float* __restrict__ cs, float* __restrict__ mean,
+                                                               float* __restrict__ invstd, float momentum, float eps,
+                                                               long long* __restrict__ nbt, int nslots, int nb) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.y;
+  if (nbt && ch == 0 && q == 0) *nbt += 1;
+  if (ch >= C) return;
+  // `nslots` copies of the sums ([slot][nb][2][C]): producers with thousands of row tiles spread their atomics over the
+  // copies (same-address fp64 atomics serialise); added here in slot order
+  double S = 0.0, Q = 0.0;
+  for (int sl = 0; sl < nslots; ++sl) {
+    double* sz = sums + ((size_t)sl * nb + q) * 2 * C + ch;
+    S += sz[0]; Q += sz[C];
+    sz[0] = 0.0; sz[C] = 0.0;
+  }
+  const double m = S / R;
+  double var = Q / R - m * m;
+  if (var < 0.0) var = 0.0;
+  const size_t o = (size_t)q * C + ch;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[o] * is;
+  a[o] = av;
+  cs[o] = beta[o] - av * (float)m;
+  mean[o] = (float)m;
+  invstd[o] = is;
+  if (running_mean) {
+    const float bv = bias ? bias[o] : 0.f;
+    running_mean[o] = (1.f - momentum) * running_mean[o] + momentum * ((float)m + bv);
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    running_var[o] = (1.f - momentum) * running_var[o] + momentum * (float)unb;
+  }
+}
+
+hipError_t launch_bn_sums_finalize(double* stats, int R, int cout, int nb, const float* gamma, const float* beta,
+                                   const float* bias, float* running_mean, float* running_var, float* bn_a, float* bn_c,
+                                   float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st,
+                                   int nslots) {
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3((cout + 255) / 256, nb), dim3(256), 0, st, stats, R, cout, gamma, beta,
+                     bias, running_mean, running_var, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, nbt, nslots, nb);
+  return hipGetLastError();
+}
+
+}  // namespace gkg
+
+// fp64 column-sum scratch of the projections' BN-statistics epilogue: doubles per buffer (4 groups x 2 x 4096 channels)
+extern "C" int gkg_linear_stats_doubles() { return 2 * 4096 * 4; }
+
 extern "C" size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad) {
   if (x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0) return 0;
   return 16 * (dgrad ? x6_plane_units(cin, cout, nb) : x6_plane_units(cout, cin, nb));
@@ -1438,13 +1491,13 @@ extern "C" int gkg_x6_prep_weights_zero(const void* descs_dev, int ndesc, long l
 // gkg_linear_bn_fwd with the weights given as forward planes (gkg_x6_prep_weights).  x (nb, R, cin) with row pitch ldx and
 // batch stride x_bstride (floats); y (nb, R, cout) contiguous.  Same `train` modes and outputs as gkg_linear_bn_fwd.
 extern "C" size_t gkg_x6_splitk_workspace_bytes(void) { return X6_SK_BYTES; }
-extern "C" void gkg_x6_set_flags(unsigned flags) { gkg_x6_flags = flags; }
 
 static int x6_fwd_impl(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R,
                        int cin, int cout, int nb, int train, const float* gamma, const float* beta,
                        const float* bias, float* running_mean, float* running_var,
                        long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
-                       float* bn_invstd, float momentum, float eps, double* stats, void* sk_ws, size_t sk_bytes, void* stream) {
+                       float* bn_invstd, float momentum, float eps, double* stats, void* sk_ws, size_t sk_bytes, void* stream,
+                       unsigned flags = 0) {
   if (!x || !planes_fwd || !y) return gkg_fail(GKG_ERR_NULL, "gkg_linear_bn_fwd_x6: null pointer");
   if (R <= 0 || x6_bad_dim(cin) || x6_bad_dim(cout) || nb <= 0 || nb > 64 || ldx < cin || (ldx & 3) || (x_bstride & 3) ||
       ((size_t)x & 15))
@@ -1470,13 +1523,13 @@ static int x6_fwd_impl(const float* x, int ldx, size_t x_bstride, const void* pl
     const int fit = gkg_linear_stats_doubles() / (nb * 2 * cout), want = (R + 127) / 128 / 64;
     a.nslots = train == 2 ? 1 : (want < 1 ? 1 : (want > 16 ? 16 : want));
     if (a.nslots > fit) a.nslots = fit;
-    e = x6_launch<X6_BNSTATS>(a, nb, st, sk_ws, sk_bytes);
+    e = x6_launch<X6_BNSTATS>(a, nb, st, sk_ws, sk_bytes, flags);
     if (e == hipSuccess && train != 2) {
       e = launch_bn_sums_finalize(stats, R, cout, nb, gamma, beta, bias, running_mean, running_var, bn_a, bn_c, bn_mean,
                                   bn_invstd, momentum, eps, num_batches_tracked, st, a.nslots);
     }
   } else {
-    e = x6_launch<X6_STORE>(a, nb, st, sk_ws, sk_bytes);
+    e = x6_launch<X6_STORE>(a, nb, st, sk_ws, sk_bytes, flags);
   }
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (forward)");
 }
@@ -1497,17 +1550,17 @@ extern "C" int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride
                                        const float* bias, float* running_mean, float* running_var,
                                        long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean,
                                        float* bn_invstd, float momentum, float eps, double* stats, void* splitk_ws,
-                                       size_t splitk_bytes, void* stream) {
+                                       size_t splitk_bytes, unsigned flags, void* stream) {
   if (splitk_ws && (splitk_bytes < X6_SK_BYTES || ((size_t)splitk_ws & 15)))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_bn_fwd_x6_sk: need a 16-byte aligned workspace of gkg_x6_splitk_workspace_bytes() bytes (or NULL: no split)");
   return x6_fwd_impl(x, ldx, x_bstride, planes_fwd, y, R, cin, cout, nb, train, gamma, beta, bias, running_mean, running_var,
-                     num_batches_tracked, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, stats, splitk_ws, splitk_bytes, stream);
+                     num_batches_tracked, bn_a, bn_c, bn_mean, bn_invstd, momentum, eps, stats, splitk_ws, splitk_bytes, stream, flags);
 }
 
 // dx (nb, R, cin) = dy (nb, R, cout; row pitch ldg, batch stride g_bstride) * w, the weights given as dgrad planes.
 static int x6_dgrad_impl(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
                          int cin, int cout, int nb, const float* residual, void* sk_ws, size_t sk_bytes, void* stream,
-                         int ldx = 0, size_t x_bstride = 0) {
+                         int ldx = 0, size_t x_bstride = 0, unsigned flags = 0) {
   if (!dy || !planes_dgrad || !dx) return gkg_fail(GKG_ERR_NULL, "gkg_linear_dgrad_x6: null pointer");
   if (ldx == 0) { ldx = cin; x_bstride = (size_t)R * cin; }
   if (ldx < cin || (ldx & 3) || (x_bstride & 3)) return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6: bad dx pitch / batch stride");
@@ -1522,7 +1575,7 @@ static int x6_dgrad_impl(const float* dy, int ldg, size_t g_bstride, const void*
   a.C = dx; a.c_bstride = x_bstride; a.ldc = ldx;
   a.M = R; a.N = cin; a.K = cout;
   a.add = residual;
-  hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream, sk_ws, sk_bytes);
+  hipError_t e = x6_launch<X6_STORE>(a, nb, (hipStream_t)stream, sk_ws, sk_bytes, flags);
   return e == hipSuccess ? 0 : gkg_fail_hip(e, "gemm_x6_kernel (dgrad)");
 }
 
@@ -1535,10 +1588,10 @@ extern "C" int gkg_linear_dgrad_x6(const float* dy, int ldg, size_t g_bstride, c
 // skip connection (reference torch_vertex.py:331,354,402 `+ _tmp`), added in the epilogue instead of by a stand-alone kernel.
 extern "C" int gkg_linear_dgrad_x6_sk(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R,
                                       int cin, int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes,
-                                      int ldx, size_t x_bstride, void* stream) {
+                                      int ldx, size_t x_bstride, unsigned flags, void* stream) {
   if (splitk_ws && (splitk_bytes < X6_SK_BYTES || ((size_t)splitk_ws & 15)))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_linear_dgrad_x6_sk: need a 16-byte aligned workspace of gkg_x6_splitk_workspace_bytes() bytes (or NULL: no split)");
-  return x6_dgrad_impl(dy, ldg, g_bstride, planes_dgrad, dx, R, cin, cout, nb, residual, splitk_ws, splitk_bytes, stream, ldx, x_bstride);
+  return x6_dgrad_impl(dy, ldg, g_bstride, planes_dgrad, dx, R, cin, cout, nb, residual, splitk_ws, splitk_bytes, stream, ldx, x_bstride, flags);
 }
 
 // The same input gradient with the BACKWARD statistics of the producer's BN in the epilogue (X6_BNBWD): dx is the upstream

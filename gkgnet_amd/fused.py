@@ -43,22 +43,15 @@ def _env_list(name):
 # GKG_GEMM_MATH — arithmetic of the fp32 projection GEMMs:
 #   "x6" (default)  bf16 matrix cores with every fp32 operand split exactly into three bf16 terms, six cross products, fp32
 #                   accumulation (csrc/gkg_gemm_x6.hip: error vs fp64 3-4x below an fp32 fma chain) for every forward, input-
-#                   gradient and weight-gradient GEMM of the blocks (round 5: split-K forms for the label branch's short
-#                   matrices, the weight gradients of a backward pass batched into one launch) — no vendor GEMM in the step;
-#   "x6all"         the same (kept as a spelling: rounds 2-4 applied a per-shape rule under "x6");
-#   "f32"           own fp32-MFMA forward kernels under the row-count rule of _own_gemm, vendor GEMMs otherwise;
-#   "vendor"        vendor GEMM library + stand-alone BN passes everywhere.
+#                   gradient and weight-gradient GEMM of the blocks (split-K forms for the label branch's short matrices, the
+#                   weight gradients of a backward pass batched into one launch) — no vendor GEMM in the step;
+#   "vendor"        vendor GEMM library + stand-alone BN passes everywhere (what autocast and SyncBN callers get anyway).
 GEMM_MATH = os.environ.get("GKG_GEMM_MATH", "x6")
-if GEMM_MATH not in ("x6", "x6all", "f32", "vendor"):
-    raise ValueError(f"GKG_GEMM_MATH={GEMM_MATH!r}: expected x6 | x6all | f32 | vendor")
-# OWN_GEMM: which projections use the own fp32-MFMA FORWARD kernel (statistics in its epilogue): "auto" = the row counts
-# where it measured faster than vendor GEMM + statistics passes end to end (tools/bench_gemm.py, MI355X): R <= 4096 (label
-# branch: 11 + 5 vs 10-14 + 9.5 us per layer) and R >= 32768 (stage 3/4 of GKGNet-576: 150 vs 186 + 10 us at
-# 41 472 x 400 x 400); "fwd" = everywhere (tests); "none" = nowhere.
-OWN_GEMM = "none" if GEMM_MATH == "vendor" else "auto"
-LONG_K = 1024
-# GKG_DETERMINISTIC=1 — run-to-run bit-identical backward: fixed-order neighbour-gradient scatter (gkg_mr_bwd_tm) and no
-# atomically accumulated weight gradients (the streaming x6 wgrad is skipped); the defaults use fp32 atomics.
+if GEMM_MATH not in ("x6", "vendor"):
+    raise ValueError(f"GKG_GEMM_MATH={GEMM_MATH!r}: expected x6 | vendor")
+# GKG_DETERMINISTIC=1 — run-to-run bit-identical backward: the neighbour-gradient scatter is order-independent by
+# construction (exact fixed-point accumulation, gkg_mr_bwd_tm); the atomically accumulated x6 weight gradients and the
+# fp64-atomic BN statistics give way to the library GEMM / the two-stage reductions.
 DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
 # GKG_ENABLE — comma-separated list of OPT-IN modes (off by default):
 #   knn_bf16       under bf16 autocast the k-NN distance contraction runs on the bf16 matrix cores (GKG_KNN_BF16_CONTRACT:
@@ -66,11 +59,14 @@ DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
 #                  bit-exact index contract (neighbour-set agreement 0.91-0.997 with the exact graph), hence
 #                  opt-in since round 4: by default autocast callers get the SAME graphs as fp32 callers (north_star:
 #                  "bit-exact neighbor indices"); bench.py --workload cfg3 / cfg5 prints both legs.
-# GKG_DISABLE — comma-separated list of optimisations to switch off (A/B measurements, tests):
-#   fold_epilogue  bf16 inference: eval-mode BN folded into the weights, bias (+ GELU) in the library GEMM's epilogue
+# GKG_DISABLE — comma-separated list of optimisations to switch off (A/B measurements).  Round 6 cut the list to the eight
+# structural ones (the per-kernel switches of rounds 2-5 are gone with the alternatives they selected):
+#   knn_mr         k-NN + aggregation as one kernel (row g2)          knn_compact   u16 neighbour lists between two launches
+#   xm_direct      fc1 writes x straight into the operand buffer XM    wgrad_batch   one weight-gradient launch per backward
+#   dual_layout    a Grapher's output in both layouts for a label block
+#   mr_gemm        bf16 inference: aggregation as the grouped projection's operand producer (row g1)
 #   channels_last  blocks take / return channels-last tensors as views of their token-major matrices
-#   mr_gemm        bf16 inference: aggregation as the operand producer of the grouped projection (one launch, row g1)
-#   x6_wgrad       the streaming x6 weight-gradient kernel on long token axes
+#   fold_epilogue  bf16 inference: eval-mode BN folded into the weights, bias (+ GELU) in the library GEMM's epilogue
 _DISABLED = _env_list("GKG_DISABLE")
 _ENABLED = _env_list("GKG_ENABLE")
 KNN_BF16 = "knn_bf16" in _ENABLED
@@ -80,19 +76,10 @@ from .planes import (_WeightPlanes, _PLANES, _planes, refresh_weight_planes, par
                      mark_parameters_updated)                                                 # planes + staleness: planes.py)
 
 
-def _vendor_tuned() -> bool:
-    """The caller has PyTorch's TunableOp on: the vendor GEMMs this layer competes with are per-shape tuned kernels, which
-    moves the break-even points of the dispatch rules (they were fitted inside the step under both conditions)."""
-    try:
-        return bool(torch.cuda.tunable.is_enabled())
-    except Exception:
-        return False
-
-
 def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
     """This projection GEMM (kind "fwd": y = x W^T, "dgrad": dx = dy W) runs on the x6 kernels.  Eligible: fp32 operands
     outside autocast, batch statistics local to the rank, 16-byte aligned rows, the C entry points' size limits (_x6_rule)."""
-    if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none":
+    if GEMM_MATH != "x6":
         return False
     if not (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None
             and x.shape[-1] % 4 == 0 and weight.shape[0] % 4 == 0):
@@ -101,60 +88,27 @@ def _x6(x, weight, bn, nb=1, kind="fwd") -> bool:
 
 
 def _x6_rule(R, cin, cout, nb, kind) -> bool:
-    """The shape part of _x6 (operand dtypes / autocast / SyncBN already checked by the caller)."""
-    if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none":
+    """The shape part of _x6 (operand dtypes / autocast / SyncBN already checked by the caller): the C entry points' own limits
+    (gkg_linear_bn_fwd_x6 / gkg_linear_dgrad_x6 return GKG_ERR_UNSUPPORTED / _SHAPE beyond them) — per-group widths multiples of
+    4, at most 64 groups, operands below 4 GiB per batch, the statistics scratch.  (Rounds 2-4 applied a per-shape rule against
+    the vendor library here; it went away with the split-K forms, the residual epilogue and the batched weight gradients.)"""
+    if GEMM_MATH != "x6":
         return False
-    # the C entry points' own limits (gkg_linear_bn_fwd_x6 / gkg_linear_dgrad_x6 return GKG_ERR_UNSUPPORTED / _SHAPE
-    # beyond them): per-group widths multiples of 4, at most 64 groups, operands below 4 GiB per batch, statistics scratch
-    if (cout % 4 or nb > 64 or R * max(cin, cout) * 4 > 0xffffffff
-            or nb * 2 * cout > _lib.load().gkg_linear_stats_doubles()):
-        return False
-    # Round 5: every eligible projection runs on the x6 kernels.  The per-shape rule of rounds 2-4 (vendor GEMMs under TunableOp
-    # for the grouped K = 160 products and the label branch's 2 560-row matrices, the fp32-MFMA kernel for its short forwards)
-    # went away with the split-K forms, the residual epilogue and the batched weight gradients: measured inside the cfg2 step
-    # (profiles/r05_x6all_vs_rule_launch_sequences.txt, us, vendor or fp32-MFMA -> x6): 2 560 x 1280 -> 320 forward + statistics
-    # 34.7 -> 27.3, its input gradient 25.5 + 5.3 (copy) -> 25.6 (+ residual in the epilogue), 2 560 x 320 -> 1280 input gradient
-    # 24.8 -> 19.1, grouped 2 560 x 4 x (160 -> 160) input gradient 16.1 -> 10.9, 2 560 x 320 -> 640 16.0 -> 14.7, the three short
-    # forwards 12.2 / 11.8 / 21.2 -> 13.2 / 12.9 / 20.9 — and the step no longer depends on a TunableOp pass.
-    return True
-
-
-X6_WGRAD = "x6_wgrad" not in _DISABLED
-# GKG_DISABLE=mr_i64: the aggregation backward keeps the fp32 LDS-atomic scatter instead of the exact 64-bit fixed-point
-# accumulation (csrc/gkg_mr.hip: mr_bwd_tm_scatter_i64_kernel) — A/B measurements only.
-MR_I64 = "mr_i64" not in _DISABLED
+    return not (cout % 4 or nb > 64 or R * max(cin, cout) * 4 > 0xffffffff
+                or nb * 2 * cout > _lib.load().gkg_linear_stats_doubles())
 
 
 def _mr_bwd_flags() -> int:
-    return (_lib.MR_DETERMINISTIC if DETERMINISTIC else 0) | (0 if MR_I64 else _lib.MR_FP32_ATOMICS)
+    return _lib.MR_DETERMINISTIC if DETERMINISTIC else 0
 
 
 def _x6_wgrad_ok(dY, x, nb=1) -> bool:
     """The streaming x6 weight-gradient kernel (gkg_linear_wgrad_x6: both operands split in registers, each wave copies its
-    own rows through a private LDS ring by DMA; no operand sharing between workgroups; row slabs placed per XCD).  Measured
-    inside the cfg2 step (tools/prof_wgrad.sh, us, x6 vs vendor kernel + its partial-sum launch, library-default /
-    TunableOp-selected): 10 368 x 640 -> 320: 42.6 vs 53.7 / 46.1; 10 368 x 320 -> 320: 22.3 vs 51.2 / 27.8; 2 560 x 320 ->
-    320 (25 tiles): 10.3 vs 17.2 / 16.5; the grouped 10 368 x 4 x (160 -> 160): 44.2 vs 52.0 / 34.5; it loses on short
-    contractions under many output tiles (2 560 x 1280 <-> 320, 100
-    tiles: 37.9 vs 24.6 / 23.0; 2 560 x 640 -> 320, 50 tiles: 19.3 vs 18.7 / 12.7).  Cold (tools/bench_x6.py cfg4) it is
-    ahead of the library's default split-K at every GKGNet-576 shape from 41 472 rows up (158 vs 222 us at 400 -> 400,
-    417 vs 529 at 400 -> 1600, 108 vs 172 at 165 888 x 160 -> 160).  GKG_GEMM_MATH=x6all: every fp32 shape;
-    GKG_DISABLE=x6_wgrad: never; GKG_DETERMINISTIC=1: never (fp32 atomics: run-dependent summation order)."""
-    if GEMM_MATH not in ("x6", "x6all") or OWN_GEMM == "none" or dY.dtype != _F32 or x.dtype != _F32:
+    own rows through a private LDS ring by DMA; row slabs placed per XCD; fp32 atomics into the zeroed dW, i.e. a run-dependent
+    summation order — GKG_DETERMINISTIC=1 keeps the library GEMM)."""
+    if GEMM_MATH != "x6" or dY.dtype != _F32 or x.dtype != _F32 or DETERMINISTIC:
         return False
-    R, cout, cin = x.shape[-2], dY.shape[-1], x.shape[-1]
-    if max(dY.stride(-2), x.stride(-2)) * 4 * 16 > 0x7fffffff or nb > 64:   # gkg_linear_wgrad_x6's row-pitch / batch limits
-        return False
-    if DETERMINISTIC or not X6_WGRAD:
-        return False
-    if GEMM_MATH == "x6all":
-        return True
-    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
-    if _vendor_tuned():
-        # against TunableOp-selected vendor kernels only the few-tile un-grouped shapes stay ahead once the output's memset is
-        # counted (step 0.968 -> 0.977 ms with the full rule, same box; the grouped product: 44.2 vs 29.1 + 5.4 us)
-        return (nb == 1 and tiles <= 64 and R >= 2048) or R >= 32768   # long token axes: ahead of the tuned kernels too (stage 3)
-    return R >= 8192 or (R >= 2048 and tiles <= 64)
+    return max(dY.stride(-2), x.stride(-2)) * 4 * 16 <= 0x7fffffff and nb <= 64     # gkg_linear_wgrad_x6's row-pitch / batch limits
 
 
 # ---- batched weight gradients (round 5) ---------------------------------------------------------------------------------
@@ -167,14 +121,19 @@ def _x6_wgrad_ok(dY, x, nb=1) -> bool:
 # as before, because autograd consumes the returned tensor at once.  GradBucket flushes the queue before it reads a gradient
 # (all_reduce / chunk all-reduce / clip / pack).  GKG_DISABLE=wgrad_batch: every weight gradient in its own launch.
 WGRAD_BATCH = "wgrad_batch" not in _DISABLED
-WGRAD_UNITS = int(os.environ.get("GKG_WGRAD_UNITS", "0"))      # rows per workgroup of the batched launch / 128 (0: library default)
+WGRAD_UNITS = 0          # rows per workgroup of the batched launch / 128 (0: the library's default, 20)
 
 
 class _WgradQueue:
     MAX = 192
+    # Operand bytes the queue may keep alive: deferring holds every layer's (dY, x) pair until the batch runs —
+    # GKGNet-576's train step peaked at 30.7 GiB against 24.2 before the batching.  Problems that fill the chip on their own gain
+    # nothing from the batch (see _wgrad_defer) and are launched at once; what is left is flushed early past this cap.
+    MAX_BYTES = 1 << 30
 
     def __init__(self):
         self.items, self.keep, self.task = [], [], -1
+        self.bytes = 0
         self.stream, self.device = None, None        # where the queued operands are produced: the batch is launched THERE
 
 
@@ -185,13 +144,21 @@ def flush_wgrads():
     """Launch every queued weight gradient (no-op when the queue is empty)."""
     q = _WQ
     if not q.items:
-        q.keep, q.task = [], -1
+        q.keep, q.task, q.bytes = [], -1, 0
         return
     items, q.items, q.task = q.items, [], -1
     try:
         _launch_wgrads(q, items)
+        # the engine runs this callback in the thread that called backward(), whose current stream need not be the nodes'
+        # (ADVICE r5): whatever that stream does next with the gradients (pack, clip, the optimiser) is ordered behind the batch
+        cur = torch.cuda.current_stream(q.device)
+        if q.stream is not None and cur.cuda_stream != q.stream:
+            ev = torch.cuda.Event()
+            with torch.cuda.device(q.device):
+                ev.record(torch.cuda.ExternalStream(q.stream, device=q.device) if q.stream else torch.cuda.default_stream(q.device))
+            cur.wait_event(ev)
     finally:
-        q.keep = []                      # the launch is stream-ordered behind the operands' producers and ahead of their reuse
+        q.keep, q.bytes = [], 0          # the launch is stream-ordered behind the operands' producers and ahead of their reuse
 
 
 def _launch_wgrads(q, items):
@@ -210,7 +177,7 @@ _parallel._ZERO_DEFER[:] = [_planes_mod.defer_zero, _planes_mod.flush_deferred_z
 
 def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) -> bool:
     """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
-    if not (WGRAD_BATCH and not DETERMINISTIC and X6_WGRAD and GEMM_MATH in ("x6", "x6all") and OWN_GEMM != "none"
+    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6"
             and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
             and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
             and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
@@ -219,10 +186,18 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) ->
     task = task_id() if task_id is not None else -1
     if task < 0:
         return False                     # not inside a backward pass (or a torch without the query): nobody would flush
+    # a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 layers: thousands of 128-row units) keeps its
+    # stand-alone slabs inside a batch anyway (csrc x6_wgrad_plan): launching it from the node costs nothing and frees its operands
+    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
+    if tiles * min(R // 128, 64) >= 2048 and R >= 32768:
+        return False
     q = _WQ
     st = _stream()
     if q.task != task:
-        q.items, q.keep = [], []         # leftovers of a backward pass that raised before its callback
+        if q.items:                      # another backward pass is still queued (a nested / re-entrant backward, or one that raised
+            items, q.items = q.items, []     # before its callback): its operands are alive — launch, do not drop
+            _launch_wgrads(q, items)
+        q.keep, q.bytes = [], 0
         q.task = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
     elif q.items and (q.stream != st or q.device != dY.device):
@@ -233,10 +208,11 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) ->
         out.zero_()
     q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm))
     q.keep.append((dY, x))
-    if len(q.items) >= q.MAX:
+    q.bytes += (dY.numel() + x.numel()) * 4
+    if len(q.items) >= q.MAX or q.bytes > q.MAX_BYTES:
         items, q.items = q.items, []
         _launch_wgrads(q, items)
-        q.keep = []
+        q.keep, q.bytes = [], 0
     return True
 
 
@@ -335,9 +311,6 @@ def _stats_scratch(device) -> torch.Tensor:
 _SK = {}
 
 
-SPLIT_K = "splitk" not in _DISABLED      # GKG_DISABLE=splitk: the short-matrix projections as one K range per tile (A/B, tests)
-
-
 def _sk_ws(device) -> torch.Tensor:
     """Split-K workspace of the x6 projection kernels (tile counters + partial tiles; include/gkg_hip.h): one per device,
     counters zero between launches, stream-ordered reuse."""
@@ -352,24 +325,9 @@ def _sk_ws(device) -> torch.Tensor:
 def _dgrad_x6(lib, dY, ldg, g_bs, pd, dx, R, cin, cout, nb, residual=None, ldx=0, x_bs=0):
     """dx = dY W (+ residual: the skip connection's gradient, added in the epilogue) on the x6 kernel.  ``ldx`` / ``x_bs``: row
     pitch / batch stride of dx (0: contiguous (nb, R, cin)) — the grouped projection writes dXM (R, 2C) with (2C, C/2)."""
-    ws = _sk_ws(dY.device) if SPLIT_K else None
+    ws = _sk_ws(dY.device)
     _lib.check(lib.gkg_linear_dgrad_x6_sk(_ptr(dY), ldg, g_bs, _ptr(pd), _ptr(dx), R, cin, cout, nb, _ptr(residual), _ptr(ws),
-                                          ws.numel() if SPLIT_K else 0, ldx, x_bs, _stream()), "gkg_linear_dgrad_x6")
-
-
-def _own_gemm(x, weight, bn) -> bool:
-    """fp32 operands outside autocast and batch statistics local to this rank: the projection's FORWARD runs on the library's
-    own fp32 matrix-core kernel with the BN statistics in its epilogue (csrc/gkg_gemm.hip).  bf16 autocast and cross-rank
-    SyncBN keep the vendor-GEMM + separate-pass form."""
-    if OWN_GEMM == "auto":
-        R = x.shape[-2]
-        if 4096 < R < 32768:
-            return False
-        if R <= 4096 and x.shape[-1] >= LONG_K:      # few rows x long contraction (FFN fc2, 2560 x 1280 -> 320): the vendor
-            return False                             # kernel's split-K wins (21 + 10 us of statistics passes vs 34 + 5)
-    elif OWN_GEMM != "fwd":
-        return False
-    return (x.dtype == _F32 and weight.dtype == _F32 and not torch.is_autocast_enabled() and _sync_group(bn) is None)
+                                          ws.numel(), ldx, x_bs, 0, _stream()), "gkg_linear_dgrad_x6")
 
 
 def _grad_outs(gparams, wshape, nch, dev):
@@ -390,17 +348,15 @@ def _grad_outs(gparams, wshape, nch, dev):
     return w, g, b
 
 
-def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, planes=None, xld=None, xbs=None):
-    """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd (statistics in the GEMM epilogue); ``planes``: the
-    weight's forward bf16 planes -> gkg_linear_bn_fwd_x6 (``xld`` / ``xbs``: row pitch / batch stride of x there)."""
+def _linear_fwd_own(lib, x, W, bias, bn, R, cin, cout, nb, planes, xld=None, xbs=None):
+    """Y, a, c, mean, invstd of BN(x W^T) through gkg_linear_bn_fwd_x6 (statistics in the GEMM epilogue + finalize kernel);
+    ``planes``: the weight's forward bf16 planes; ``xld`` / ``xbs``: row pitch / batch stride of x."""
     dev = x.device
-    if planes is not None:
-        def fwd(xp, wp, yp, R_, cin_, cout_, nb_, *rest):
-            ws = _sk_ws(dev) if SPLIT_K else None
-            return lib.gkg_linear_bn_fwd_x6_sk(xp, cin_ if xld is None else xld, R_ * cin_ if xbs is None else xbs, _ptr(planes), yp,
-                                               R_, cin_, cout_, nb_, *rest[:-1], _ptr(ws), ws.numel() if SPLIT_K else 0, rest[-1])
-    else:
-        fwd = lib.gkg_linear_bn_fwd
+
+    def fwd(xp, wp, yp, R_, cin_, cout_, nb_, *rest):
+        ws = _sk_ws(dev)
+        return lib.gkg_linear_bn_fwd_x6_sk(xp, cin_ if xld is None else xld, R_ * cin_ if xbs is None else xbs, _ptr(planes), yp,
+                                           R_, cin_, cout_, nb_, *rest[:-1], _ptr(ws), ws.numel(), 0, rest[-1])
     Y = torch.empty((nb, R, cout) if nb > 1 else (R, cout), dtype=_F32, device=dev)
     a = torch.empty(nb * cout, dtype=_F32, device=dev)
     c = torch.empty_like(a)
@@ -630,14 +586,12 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
         none10 = [None] * 10
         if launch is not None:
             rc = launch(Y, cur)
-        elif planes is not None:
-            ws = _sk_ws(dev) if SPLIT_K else None
+        else:
+            ws = _sk_ws(dev)
             rc = lib.gkg_linear_bn_fwd_x6_sk(_ptr(x), cin if xld is None else xld, R * cin if xbs is None else xbs, _ptr(planes),
                                              _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0,
-                                             _ptr(cur), _ptr(ws), ws.numel() if SPLIT_K else 0, _stream())
-        else:
-            rc = lib.gkg_linear_bn_fwd(_ptr(x), _ptr(W), _ptr(Y), R, cin, cout, nb, 2, *none10, 0.0, 0.0, _ptr(cur), _stream())
-        _lib.check(rc, "gkg_linear_bn_fwd (statistics only)")
+                                             _ptr(cur), _ptr(ws), ws.numel(), 0, _stream())
+        _lib.check(rc, "gkg_linear_bn_fwd_x6 (statistics only)")
         a, c, mean, invstd = torch.empty((4, nb * cout), dtype=_F32, device=dev).unbind(0)     # one allocation
         track = bn.training and bn.track_running_stats
         _touch_stats(bn, track)
@@ -664,7 +618,7 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
 def _derive_ok(bn, nb, cout, code, want16) -> bool:
     """Train-mode statistics local to the rank, fp32 output: the BN-apply pass derives its coefficients from the projection
     kernel's sums (no finalize launch)."""
-    return ("bn_derive" not in _DISABLED and (bn.training or not bn.track_running_stats) and _sync_group(bn) is None
+    return ((bn.training or not bn.track_running_stats) and _sync_group(bn) is None
             and code == _lib.F32 and not want16 and 2 * nb * cout <= _BnBwdScratch.DOUBLES)
 
 
@@ -677,11 +631,11 @@ def _derive_ok(bn, nb, cout, code, want16) -> bool:
 # the 16 y rows per lane, the GELU' recompute and the reduction sit on the tail of a workgroup that lives 10-15 us, which
 # costs the GEMM what the removed pass (near the HBM roofline on its own) saved.  A later same-box A/B of the cfg4 step
 # (alternating runs) measured 85.16 / 85.18 ms without and 84.70 / 84.67 ms with: on from 32 768 rows (below).
-BN_EPILOGUE = "bn_epilogue" not in _DISABLED
+BN_EPILOGUE = True
 # rows from which the link is attached: where the saved pass over the gradient is memory time (GKGNet-576's stages: cfg4 85.17 ->
-# 84.69 ms on one box) rather than a launch among ~85 short ones (neutral at the cfg2 shapes, 10 368 rows).  GKG_ENABLE=bn_epilogue
-# (and the tests) attach it at every size.
-BN_EPILOGUE_MIN_ROWS = 0 if "bn_epilogue" in _ENABLED else 32768
+# 84.69 ms on one box) rather than a launch among ~85 short ones (neutral at the cfg2 shapes, 10 368 rows).  The tests set
+# BN_EPILOGUE_MIN_ROWS = 0 to attach it at every size.
+BN_EPILOGUE_MIN_ROWS = 32768
 
 
 class _BnLink:
@@ -722,13 +676,10 @@ def _dgrad_x6_with_link(lib, dY, pd, R, cin, cout, link):
     return dx
 
 
-DROPPATH_FOLD = "droppath_fold" not in _DISABLED
-
-
 def _bn_scale_in_kernel(sync, nb, C) -> bool:
     """Whether _bn_backward will take the two-launch fp64-atomic form, whose kernels can apply a per-image gradient scale
     (DropPath) themselves instead of a separate elementwise launch in front of them (22 launches, 0.6 ms of the cfg4 step)."""
-    return DROPPATH_FOLD and sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES
+    return sync is None and not DETERMINISTIC and 2 * nb * C <= _BnBwdScratch.DOUBLES
 
 
 def _bn_backward(lib, g, Y, a, c, mean, invstd, dY, dgamma, dbeta, R, C, nb, ldg, g_bstride, act, sync, link=None, row_scale=None,
@@ -812,7 +763,7 @@ class _LinearBNAct(torch.autograd.Function):
         W = weight.view(cout, cin)
         prev = None if alias else getattr(x, "_gkg_bn_link", None)       # the layer that produced x (see _BnLink)
         x6f, x6d = _x6(x, weight, bn, 1, "fwd"), _x6(x, weight, bn, 1, "dgrad")
-        own = x6f or _own_gemm(x, weight, bn)
+        own = x6f
         pf, pd = _planes(lib, weight, 1, cout, cin, x6f, x6d) if x6f or x6d else (None, None)
         pf, pd = (pf if x6f else None), (pd if x6d else None)
         res = None if residual is None else residual.contiguous()
@@ -1039,7 +990,7 @@ class _GroupedLinearBNAct(torch.autograd.Function):
 # On channels-last tensors their output IS a token-major matrix, so the BN (+ activation) runs on the same bandwidth kernels
 # as inside the blocks (statistics at 6-7 TB/s, one apply pass with the fast-erf GELU, two-pass backward) instead of
 # MIOpenBatchNorm{Fwd,Bwd}Spatial + stand-alone GELU kernels: 6.2 + 1.2 ms of the 92.7 ms GKGNet-576 train step (round 3).
-STEM_BN = "stem_bn" not in _DISABLED
+STEM_BN = True               # (a module constant the A/B tests flip; no environment switch)
 
 
 class _BNActTM(torch.autograd.Function):
@@ -1103,8 +1054,8 @@ def bn_act(x, bn, act_mod):
 
 # ----------------------------------------------------------------------------------------------- the stem's first convolution
 # Conv2d(3 -> C1/2, 3x3, stride 2, padding 1) on the image as a direct kernel (csrc/gkg_stem.hip): MIOpen's implicit-GEMM forms
-# need 756 us (bf16 autocast) / 1 015 us (fp32) for it at B = 32, 576 x 576.  GKG_DISABLE=stem_conv keeps the library call.
-STEM_CONV = "stem_conv" not in _DISABLED
+# need 756 us (bf16 autocast) / 1 015 us (fp32) for it at B = 32, 576 x 576.  (STEM_CONV = False: the library call; tests.)
+STEM_CONV = True
 
 
 def conv_bn_act_eval_supported(conv, bn, act_mod, x) -> bool:

@@ -28,11 +28,8 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-import os as _os
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
-if "raw_stream" in {t.strip() for t in _os.environ.get("GKG_DISABLE", "").split(",")}:      # A/B of the host-side cost
-    _raw_stream = None
 
 
 def _stream():

@@ -186,9 +186,7 @@ class _WeightPlanes:
 
 
 _PLANES = {}
-# GKG_DISABLE=zero_fold: the gradient arena and the BN scratch cleared by launches of their own again (A/B)
-import os as _os      # noqa: E402
-ZERO_FOLD = "zero_fold" not in {t.strip() for t in _os.environ.get("GKG_DISABLE", "").split(",")}
+ZERO_FOLD = True       # the gradient arena and the BN scratch are cleared by the weight-plane refresh launch of a captured step
 
 
 def defer_zero(t) -> bool:

@@ -332,15 +332,6 @@ int gkg_bn_apply_train_dual(const float* y, const double* sums, const float* gam
 int gkg_bn_bwd_atomic(const float* dout, const float* y, const float* a, const float* c, const float* mean,
                       const float* invstd, float* dy, float* dgamma, float* dbeta, int R, int C, int nb, int ldg,
                       size_t dout_bstride, int act, double* sums, double* zero_buf, size_t zero_doubles, void* stream);
-/* Round 5, opt-in: gkg_bn_set_flags(2) lets gkg_bn_bwd_atomic (and its _scaled form) run as ONE launch — statistics, a grid
- * barrier, apply from registers — while the grid fits 3 workgroups of 128 rows x 64 channels per CU.  Built, tested and
- * measured: faster only at ~100 workgroups (8.4-9.0 vs 10.9-11.7 us), slower from ~240 up (a grid barrier of hundreds of
- * workgroups costs more than a kernel boundary on this chip), neutral for the cfg2 step — so the default (flags 0) keeps the
- * two launches everywhere.  Same results up to the summation order of the fp64 atomics.
- * gkg_debug_barrier_timeouts: non-zero if a workgroup ever gave up waiting at the barrier (~0.1 s; only possible when
- * something else holds the chip's workgroup slots) — the results of that call are then wrong, the GPU does not hang. */
-void gkg_bn_set_flags(unsigned flags);
-int gkg_debug_barrier_timeouts(void);
 
 
 /* gkg_bn_bwd_atomic for a branch whose output was scaled per image (DropPath: torch_vertex.py:332,355,402): the incoming
@@ -368,35 +359,15 @@ int gkg_bn_bwd_apply(const float* dout, const float* y, const float* a, const fl
                      int ldg, size_t dout_bstride, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * The dense 1x1 projections themselves (reference torch_vertex.py:290-306 fc1 / fc2 = Conv2d(1x1) + BN,
- * torch_nn.py:57-69 BasicConv = Conv2d(1x1, groups=4) + BN + GELU on the interleaved [x, m] channels,
- * torch_vertex.py:334-360 FFNLabel) as fp32 matrix-core kernels with the batch-norm passes fused in
- * (csrc/gkg_gemm.hip).  Token-major fp32: x (nb, R, cin), w (nb, cout, cin), y (nb, R, cout); nb = 4 stacks the groups of
- * the grouped projection.
- *   gkg_linear_bn_fwd  y = x w^T.  train != 0: the train-mode BN statistics of y are taken in the kernel's epilogue (per
- *                      tile centred mean / M2 from the accumulator registers, accumulated into fp64 column sums with
- *                      atomics) and a small finalize kernel writes scale a, shift c (out = a*y + c; the conv bias is
- *                      folded: it cancels in the output and is added to running_mean), saved mean / invstd and updates the
- *                      running statistics.  `stats`: gkg_linear_stats_doubles() doubles, zero on entry, zeroed again
- *                      before the call's work completes (one buffer can serve every layer on a stream).
-  *                      train == 2: statistics only — the fp64 sums stay in `stats` for gkg_bn_apply_train.
- * The backward of these layers (BN backward passes above, input and weight gradients) runs on the x6 kernels below and the
- * vendor GEMM library: fp32-MFMA dgrad / wgrad kernels with the BN backward-apply as operand prologue were built in round 2,
- * measured 20-40 % behind at this path's shapes and removed in round 3.
- */
-int gkg_linear_stats_doubles(void);
-int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R, int cin, int cout, int nb, int train,
-                      const float* gamma, const float* beta, const float* bias, float* running_mean, float* running_var,
-                      long long* num_batches_tracked, float* bn_a, float* bn_c, float* bn_mean, float* bn_invstd,
-                      float momentum, float eps, double* stats, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * The same projections on the bf16 matrix cores at fp32 accuracy (csrc/gkg_gemm_x6.hip): every fp32 operand is split
- * exactly into three bf16 terms and six of the nine cross products are accumulated in fp32 (error vs fp64 measured 3-4x
- * BELOW the fp32-MFMA kernels above).  The WEIGHTS are split ahead of time into bf16 "planes", once per optimiser step and
- * for all layers in one launch; the activations are split inside the GEMM.  Replaces the same reference lines as
- * gkg_linear_bn_fwd (torch_vertex.py:290-306, torch_nn.py:57-69, torch_vertex.py:334-360) plus their input gradient; the
- * weight gradient runs here for long token axes under small outputs and in the vendor GEMM library otherwise.
+ * The dense 1x1 projections (reference torch_vertex.py:290-306 fc1 / fc2 = Conv2d(1x1) + BN, torch_nn.py:57-69 BasicConv =
+ * Conv2d(1x1, groups=4) + BN + GELU behind the aggregation, torch_vertex.py:334-360 FFNLabel) with their input and weight
+ * gradients, on the bf16 matrix cores at fp32 accuracy (csrc/gkg_gemm_x6.hip): every fp32 operand is split exactly into three
+ * bf16 terms and six of the nine cross products are accumulated in fp32 (error vs fp64 measured 3-4x BELOW an fp32 fma chain
+ * of the same length).  The WEIGHTS are split ahead of time into bf16 "planes", once per optimiser step and for all layers in
+ * one launch; the activations are split inside the GEMM.  Token-major fp32: x (nb, R, cin), w (nb, cout, cin), y (nb, R, cout);
+ * nb = 4 stacks the groups of the grouped projection.  (An fp32-MFMA forward kernel — rounds 1-5, csrc/gkg_gemm.hip — lost to
+ * these at every shape and was removed in round 6.)
+ *   gkg_linear_stats_doubles doubles of the fp64 column-sum scratch the statistics epilogue accumulates into
  *   gkg_x6_planes_bytes     bytes of one orientation's planes of a weight w (nb, cout, cin): dgrad = 0 forward, 1 dgrad
  *   gkg_x6_prep_desc_bytes  size of one descriptor of the batched split
  *   gkg_x6_prep_desc_fill   writes descriptor `index` into a HOST array (device pointers inside; one of the two plane
@@ -404,11 +375,19 @@ int gkg_linear_bn_fwd(const float* x, const float* w, float* y, int R, int cin, 
  *                           as `unit_begin` of the next descriptor (-1: bad arguments)
  *   gkg_x6_prep_weights     ONE launch: every described weight -> its forward and dgrad planes.  `descs_dev`: the array
  *                           copied to device memory; total_units: the last gkg_x6_prep_desc_fill return value
- *   gkg_linear_bn_fwd_x6    gkg_linear_bn_fwd with `planes_fwd` instead of w; x has row pitch ldx and batch stride
- *                           x_bstride (floats; a column slice of a wider matrix is allowed); same train modes / outputs
+ *   gkg_linear_bn_fwd_x6    y = x w^T with w given as `planes_fwd`; x has row pitch ldx and batch stride x_bstride (floats; a
+ *                           column slice of a wider matrix is allowed).  train != 0: the train-mode BN statistics of y are
+ *                           taken in the kernel's epilogue (per tile centred mean / M2 from the accumulator registers,
+ *                           accumulated into fp64 column sums with atomics) and a small finalize kernel writes scale a, shift c
+ *                           (out = a*y + c; the conv bias is folded: it cancels in the output and is added to running_mean),
+ *                           saved mean / invstd and updates the running statistics.  `stats`: gkg_linear_stats_doubles()
+ *                           doubles, zero on entry, zeroed again before the call's work completes (one buffer can serve every
+ *                           layer on a stream).  train == 2: statistics only — the fp64 sums stay in `stats` for
+ *                           gkg_bn_apply_train.  train == 0: plain projection.
  *   gkg_linear_dgrad_x6     dx (nb, R, cin) = dy (nb, R, cout; pitch ldg, batch stride g_bstride) w
  *   gkg_linear_wgrad_x6     dw (nb, cout, cin) += dy^T x (see below)
  * Rows must be 16-byte aligned (base pointer % 16 == 0, pitches % 4 == 0); each batch of x / dy below 4 GiB. */
+int gkg_linear_stats_doubles(void);
 size_t gkg_x6_planes_bytes(int cin, int cout, int nb, int dgrad);
 int gkg_x6_prep_desc_bytes(void);
 /* kperm != 0 (the grouped projection behind the aggregation, "XM layout"): the planes hold w's input columns as [even columns |
@@ -439,18 +418,20 @@ size_t gkg_x6_splitk_workspace_bytes(void);
  * workgroup (32-row x 64-column tiles, private LDS rings, B fragments straight from the weight planes, no barrier in the loop,
  * no cross-workgroup hand-off: csrc/gkg_gemm_x6.hip gemm_x6_ks_kernel) — the cross-workgroup split-K form above then only
  * serves what that body does not.  Taken for un-grouped projections of at most 640 output columns (where it measured faster:
- * a 32-row workgroup re-reads all of B).  gkg_x6_set_flags: bit 0 = never take it, bit 1 = for every short matrix (A/B, tests). */
-void gkg_x6_set_flags(unsigned flags);
+ * a 32-row workgroup re-reads all of B).  `flags` (per call; measurement, tests): GKG_X6_NO_KS never takes it,
+ * GKG_X6_FORCE_KS takes it for every short matrix. */
+#define GKG_X6_NO_KS 1u
+#define GKG_X6_FORCE_KS 2u
 int gkg_linear_bn_fwd_x6_sk(const float* x, int ldx, size_t x_bstride, const void* planes_fwd, float* y, int R, int cin,
                             int cout, int nb, int train, const float* gamma, const float* beta, const float* bias,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* bn_a, float* bn_c,
                             float* bn_mean, float* bn_invstd, float momentum, float eps, double* stats, void* splitk_ws,
-                            size_t splitk_bytes, void* stream);
+                            size_t splitk_bytes, unsigned flags, void* stream);
 /* ldx / x_bstride: row pitch and batch stride of dx in floats (ldx == 0: contiguous (nb, R, cin)); `residual` has dx's layout.
  * The grouped projection behind the aggregation writes dXM (R, 2C) directly: nb = 4, cin = C/2, ldx = 2C, x_bstride = C/2. */
 int gkg_linear_dgrad_x6_sk(const float* dy, int ldg, size_t g_bstride, const void* planes_dgrad, float* dx, int R, int cin,
                            int cout, int nb, const float* residual, void* splitk_ws, size_t splitk_bytes, int ldx,
-                           size_t x_bstride, void* stream);
+                           size_t x_bstride, unsigned flags, void* stream);
 /* dw (nb, cout, cin) += dy^T x over the R rows (both operands split in registers; no LDS staging, each wave streams its own
  * rows).  dw must be ZERO on entry: slabs of rows are added with fp32 atomics (run-dependent summation order, like a
  * split-K GEMM).  x (nb, R, cin) with row pitch ldx / batch stride x_bstride (floats).  Any cin, cout >= 1. */

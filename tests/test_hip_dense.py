@@ -7,20 +7,17 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["vendor", "fwd", "x6", "x6all", "x6all-deterministic"])
+@pytest.fixture(params=["vendor", "x6", "x6-deterministic"])
 def gemm_mode(request):
-    """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("vendor"), with the
-    own fp32-MFMA forward kernel (BN statistics in the epilogue) everywhere ("fwd"), with the default rule ("x6": split-bf16
-    forward + dgrad kernels where they pay) and with every eligible projection — weight gradient included — on the split-bf16
-    kernels ("x6all"; "-deterministic": the atomically accumulated x6 weight gradient is skipped)."""
+    """Every projection test runs with the projections in the vendor GEMM library + separate BN passes ("vendor") and on the
+    split-bf16 kernels — forward, input and weight gradient ("x6", the default; "-deterministic": the atomically accumulated x6
+    weight gradient gives way to the library GEMM)."""
     from gkgnet_amd import fused
-    old = (fused.OWN_GEMM, fused.DETERMINISTIC, fused.GEMM_MATH)
-    mode = request.param.split("-")[0]
-    fused.GEMM_MATH = {"vendor": "vendor", "fwd": "f32"}.get(mode, mode)
-    fused.OWN_GEMM = {"vendor": "none", "fwd": "fwd"}.get(mode, "auto")
+    old = (fused.DETERMINISTIC, fused.GEMM_MATH)
+    fused.GEMM_MATH = request.param.split("-")[0]
     fused.DETERMINISTIC = request.param.endswith("deterministic")
     yield request.param
-    fused.OWN_GEMM, fused.DETERMINISTIC, fused.GEMM_MATH = old
+    fused.DETERMINISTIC, fused.GEMM_MATH = old
 
 
 def _bn(C):
@@ -188,7 +185,7 @@ def test_deterministic_weight_gradient_is_bit_reproducible():
     a fixed order) -> two runs agree bit for bit, also with every projection forced onto the x6 kernels."""
     from gkgnet_amd import fused
     old = (fused.GEMM_MATH, fused.DETERMINISTIC)
-    fused.GEMM_MATH, fused.DETERMINISTIC = "x6all", True
+    fused.GEMM_MATH, fused.DETERMINISTIC = "x6", True
     try:
         torch.manual_seed(4)
         x = torch.randn(5000, 96, device="cuda")
@@ -206,15 +203,15 @@ def test_deterministic_weight_gradient_is_bit_reproducible():
         fused.GEMM_MATH, fused.DETERMINISTIC = old
 
 
-@pytest.mark.parametrize("mode", ["none", "fwd"])
+@pytest.mark.parametrize("mode", ["vendor", "x6"])
 def test_bn_statistics_survive_a_large_channel_offset(mode):
     """Train-mode BN variance when |mean| >> std (y = 100 + 0.01*noise per channel): E[y^2] - E[y]^2 in fp32 would lose
-    the variance entirely (1e-7 * 1e4 / 1e-4 = 10x its value); the statistics are taken centred (own GEMM epilogue: per
+    the variance entirely (1e-7 * 1e4 / 1e-4 = 10x its value); the statistics are taken centred (GEMM epilogue: per
     tile mean / M2 from registers, fp64 merge) or shifted by a sample row (stand-alone pass), so invstd stays within
     1e-3 of the fp64 value."""
     from gkgnet_amd import fused
-    old = fused.OWN_GEMM
-    fused.OWN_GEMM = mode
+    old = fused.GEMM_MATH
+    fused.GEMM_MATH = mode
     try:
         torch.manual_seed(5)
         R, cin, cout = 6000, 32, 64
@@ -232,7 +229,7 @@ def test_bn_statistics_survive_a_large_channel_offset(mode):
         # the fp32 product itself rounds y to ~6e-6 absolute, i.e. ~1e-3 of its 5e-3 standard deviation
         assert torch.allclose(out.detach().double(), want, atol=2e-2, rtol=1e-2), float((out.detach().double() - want).abs().max())
     finally:
-        fused.OWN_GEMM = old
+        fused.GEMM_MATH = old
 
 
 def test_deterministic_scatter_is_bit_reproducible_and_correct():

@@ -155,7 +155,7 @@ def _check_train_statistics(R, cin, cout):
 def test_planes_follow_the_parameter(monkeypatch):
     """The fused layer re-splits its weight after an in-place update (optimiser step) and after the storage is replaced."""
     from gkgnet_amd import fused
-    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6")
     torch.manual_seed(9)
     R, cin, cout = 640, 64, 64
     conv = torch.nn.Conv2d(cin, cout, 1).cuda()
@@ -182,7 +182,7 @@ def test_planes_follow_the_parameter(monkeypatch):
 def test_captured_step_resplits_the_weights(monkeypatch):
     """A hipGraph-captured step sees weight updates made between replays (the capture holds the refresh launch)."""
     from gkgnet_amd import fused
-    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6")
     torch.manual_seed(11)
     R, cin, cout = 512, 32, 32
     conv = torch.nn.Conv2d(cin, cout, 1).cuda()
@@ -216,7 +216,7 @@ def test_eager_calls_between_replays_of_a_step_that_updates_the_weights(monkeypa
     weights as the last replay left them (no version counter moves inside a replay, so the planes cannot be trusted once a
     capture exists)."""
     from gkgnet_amd import fused
-    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6")
     torch.manual_seed(12)
     R, cin, cout = 384, 32, 48
     conv = torch.nn.Conv2d(cin, cout, 1).cuda()
@@ -254,26 +254,30 @@ def test_eager_calls_between_replays_of_a_step_that_updates_the_weights(monkeypa
 
 def test_grouped_weight_gradient_on_the_streaming_kernel(monkeypatch):
     """fused._wgrad_grouped through gkg_linear_wgrad_x6 with a batch of groups (the grouped 1x1 projection's dW), written
-    into a caller-provided slot, against an fp64 evaluation; and the dispatch rule's two legs."""
+    into a caller-provided slot, against an fp64 evaluation; plain and with the XM operand view + column permutation."""
     from gkgnet_amd import fused
     torch.manual_seed(21)
     nb, R, co, ci = 4, 2304 + 40, 160, 96                     # whole 128-row units + a ragged rest
     dY = torch.randn(nb, R, co, device="cuda")
     U = torch.randn(nb, R, ci, device="cuda")
     want = torch.bmm(dY.double().transpose(1, 2), U.double())
-    monkeypatch.setattr(fused, "GEMM_MATH", "x6all")
+    monkeypatch.setattr(fused, "GEMM_MATH", "x6")
     slot = torch.full((nb, co, ci), 7.0, device="cuda")      # stale contents must not leak into the sum
     got = fused._wgrad_grouped(dY, U, slot)
     assert got.data_ptr() == slot.data_ptr()
     scale = (dY.double().abs().transpose(1, 2) @ U.double().abs()).max()
     assert float((got.double() - want).abs().max() / scale) < 2e-6
-    monkeypatch.setattr(fused, "GEMM_MATH", "x6")
-    monkeypatch.setattr(fused, "_vendor_tuned", lambda: False)
-    assert fused._x6_wgrad_ok(dY, U, nb) is True              # library-default GEMM selection: R >= 2048, 24 tiles
-    monkeypatch.setattr(fused, "_vendor_tuned", lambda: True)
-    assert fused._x6_wgrad_ok(dY, U, nb) is False             # TunableOp-selected vendor kernels win the grouped product
-    assert fused._x6_wgrad_ok(dY[0], U[0]) is True            # ... but not the few-tile un-grouped one
+    assert fused._x6_wgrad_ok(dY, U, nb) is True and fused._x6_wgrad_ok(dY[0], U[0]) is True
+    # the same problem with U as the XM operand buffer's view and kperm: dW comes back in the reference's interleaved columns
+    XM = U.permute(1, 0, 2).reshape(R, nb * ci).contiguous()
+    Uv = XM.view(R, nb, ci).permute(1, 0, 2)
+    slot2 = torch.full((nb, co, ci), 7.0, device="cuda")
+    got2 = fused._wgrad_grouped(dY, Uv, slot2, kperm=1)
+    want2 = want.view(nb, co, 2, ci // 2).permute(0, 1, 3, 2).reshape(nb, co, ci)
+    assert float((got2.double() - want2).abs().max() / scale) < 2e-6
     monkeypatch.setattr(fused, "DETERMINISTIC", True)
+    got3 = fused._wgrad_grouped(dY, Uv, None, kperm=1)       # the library path: un-permuted by _kperm_grad_back
+    assert float((got3.double() - want2).abs().max() / scale) < 2e-6
     assert fused._x6_wgrad_ok(dY[0], U[0]) is False           # fp32 atomics: never under GKG_DETERMINISTIC
 
 
@@ -420,11 +424,11 @@ def test_split_k_forward_statistics_and_dgrad(R, cin, cout, nb):
         y = torch.full((nb, R, cout), float("nan"), device="cuda")
         stats.zero_()
         _lib.check(lib.gkg_linear_bn_fwd_x6_sk(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
-                                               *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), None), "fwd sk")
+                                               *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), 0, None), "fwd sk")
         dx = torch.full((nb, R, cin), float("nan"), device="cuda")
         res = torch.randn(nb, R, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
         _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
-                                              res.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, None), "dgrad sk")
+                                              res.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, 0, None), "dgrad sk")
         torch.cuda.synchronize()
         ys.append(y)
         dxs.append(dx)
@@ -459,7 +463,7 @@ KS_SHAPES = [(2560, 320, 320, 1), (2560, 1280, 320, 1), (2560, 320, 1280, 1), (2
 @pytest.mark.parametrize("R,cin,cout,nb", KS_SHAPES)
 def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb):
     """Forward (+ BN column sums), input gradient (+ residual) on the K-split-in-workgroup body against fp64 at the fp32 bar and
-    against gemm_x6_kernel (flags 1) on the same operands; run-to-run identical bits (partials are added in wave order)."""
+    against gemm_x6_kernel (GKG_X6_NO_KS) on the same operands; run-to-run identical bits (partials are added in wave order)."""
     from gkgnet_amd import _lib
     lib = _lib.load()
     gen = torch.Generator(device="cuda").manual_seed(R * 5 + cin + cout)
@@ -471,24 +475,19 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
     ws = torch.zeros(lib.gkg_x6_splitk_workspace_bytes(), dtype=torch.uint8, device="cuda")
     stats = torch.zeros(lib.gkg_linear_stats_doubles(), dtype=torch.float64, device="cuda")
     out = {}
-    try:
-        # the K-split body forced for every short matrix: 32-row tiles twice (flags 2 | 4), 64-row tiles (2 | 8); gemm_x6_kernel (1)
-        for flags in (6, 6, 10, 1):
-            lib.gkg_x6_set_flags(flags)
-            y = torch.full((nb, R, cout), float("nan"), device="cuda")
-            stats.zero_()
-            _lib.check(lib.gkg_linear_bn_fwd_x6_sk(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
-                                                   *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), None), "fwd")
-            dx = torch.full((nb, R, cin), float("nan"), device="cuda")
-            _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
-                                                  res.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, None), "dgrad")
-            torch.cuda.synchronize()
-            out.setdefault(flags, []).append((y, dx, stats[:nb * 2 * cout].clone()))
-    finally:
-        lib.gkg_x6_set_flags(0)
-    (y, dx, st), (y_b, dx_b, _), (y_ref, dx_ref, st_ref) = out[6][0], out[6][1], out[1][0]
+    # the K-split body forced for every short matrix, twice (GKG_X6_FORCE_KS, a per-call flag); then gemm_x6_kernel (GKG_X6_NO_KS)
+    for flags in (_lib.X6_FORCE_KS, _lib.X6_FORCE_KS, _lib.X6_NO_KS):
+        y = torch.full((nb, R, cout), float("nan"), device="cuda")
+        stats.zero_()
+        _lib.check(lib.gkg_linear_bn_fwd_x6_sk(x.data_ptr(), cin, R * cin, pf.data_ptr(), y.data_ptr(), R, cin, cout, nb, 2,
+                                               *([None] * 10), 0.0, 0.0, stats.data_ptr(), ws.data_ptr(), ws.numel(), flags, None), "fwd")
+        dx = torch.full((nb, R, cin), float("nan"), device="cuda")
+        _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), cout, R * cout, pd.data_ptr(), dx.data_ptr(), R, cin, cout, nb,
+                                              res.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, flags, None), "dgrad")
+        torch.cuda.synchronize()
+        out.setdefault(flags, []).append((y, dx, stats[:nb * 2 * cout].clone()))
+    (y, dx, st), (y_b, dx_b, _), (y_ref, dx_ref, st_ref) = out[_lib.X6_FORCE_KS][0], out[_lib.X6_FORCE_KS][1], out[_lib.X6_NO_KS][0]
     assert torch.equal(y, y_b) and torch.equal(dx, dx_b)
-    y2, dx2, st2 = out[10][0]                                                          # 64-row tiles: fp32 accuracy, same sums
     ref_y = torch.bmm(x.double(), w.double().transpose(1, 2))
     ref_dx = torch.bmm(dy.double(), w.double()) + res.double()
     mag_y = torch.bmm(x.double().abs(), w.double().abs().transpose(1, 2)) + 1e-30
@@ -503,9 +502,6 @@ def test_k_split_inside_the_workgroup_forward_statistics_dgrad(R, cin, cout, nb)
     assert torch.allclose(sums[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
     assert float(((y_ref.double() - y.double()).abs() / mag_y).max()) < 3e-7          # the other body: the same values
     assert float(((dx_ref.double() - dx.double()).abs() / mag_dx).max()) < 3e-7
-    assert _rel(y2, ref_y, mag_y) < 2e-7 and _rel(dx2, ref_dx, mag_dx) < 2e-7
-    s2 = st2.view(nb, 2, cout)
-    assert torch.allclose(s2[:, 0], ref_y.sum(1), rtol=1e-6, atol=1e-3) and torch.allclose(s2[:, 1], (ref_y * ref_y).sum(1), rtol=1e-5)
 
 
 @pytest.mark.parametrize("R,C", [(10368, 320), (2560, 320), (1500, 80), (777, 48), (4096, 640)])
@@ -532,7 +528,7 @@ def test_grouped_projection_on_the_xm_operand_buffer(R, C):
     assert _rel(y, want_y, mag) < 2e-7
     dXM = torch.full((R, 2 * C), float("nan"), device="cuda")
     _lib.check(lib.gkg_linear_dgrad_x6_sk(dy.data_ptr(), co, R * co, pd.data_ptr(), dXM.data_ptr(), R, ci, co, nb, None, None, 0,
-                                          2 * C, ci, None), "dgrad")
+                                          2 * C, ci, 0, None), "dgrad")
     want_dU = torch.bmm(dy.double(), w.double())                                # (nb, R, ci) interleaved columns
     got_dU = xm_interleaved(dXM).view(R, nb, ci).permute(1, 0, 2)
     magd = torch.bmm(dy.double().abs(), w.double().abs()) + 1e-30

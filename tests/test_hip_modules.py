@@ -196,8 +196,9 @@ def test_autocast_bf16_label_module_and_ffn_inference():
     assert (r16 - r32).abs().max().item() < 5e-2 * r32.abs().max().item()
 
 
-FLIP_BOUND = (20, 10)        # label graph vs the oracle's own: index slots / neighbour sets that may differ (MI355X, round 4: 0 / 0)
-REPLAY_FLIP_BOUND = 40       # per k-NN call, HIP k-NN on the oracle's tensors vs the HIP run's graphs (round 4: 1 of 41 472, 0 of 10 240)
+FLIP_BOUND = (2, 2)          # label graph vs the oracle's own: index slots / neighbour sets that may differ (measured on MI355X, rounds
+                             # 4-6: 0 / 0; bound = 2 x measured + 2: a real numerics drift must not pass — VERDICT r5 weak 1a)
+REPLAY_FLIP_BOUND = 4        # per k-NN call, HIP k-NN on the oracle's tensors vs the HIP run's graphs (measured: 1 of 41 472, 0 of 10 240)
 
 
 def test_cfg2_full_size_grapher_and_label_vs_oracle(record_property):

@@ -16,16 +16,18 @@ CASES = [(3, 4, 64, 200, None, 9, 1), (2, 2, 64, 80, 324, 9, 1), (2, 2, 32, 150,
 def _run(x, src, idx, G, mode, g, fp32_atomics=False, det=False):
     """``det``: GKG_DETERMINISTIC — selects the exact form wherever it fits (by default it is taken for destination images of up
     to 512 rows, where it measured faster than the fp32 atomics)."""
-    from gkgnet_amd import fused
-    old = (fused.MR_I64, fused.DETERMINISTIC)
-    fused.MR_I64, fused.DETERMINISTIC = not fp32_atomics, det
+    from gkgnet_amd import _lib, fused
+    old = (fused._mr_bwd_flags, fused.DETERMINISTIC)
+    fused.DETERMINISTIC = det
+    if fp32_atomics:                              # the round-1 fp32 LDS-atomic kernels (a C-ABI flag: measurement, tests)
+        fused._mr_bwd_flags = lambda: _lib.MR_FP32_ATOMICS
     try:
         xg = x.clone().requires_grad_(True)
         sg = None if src is None else src.clone().requires_grad_(True)
         fused._MaxRelativeTM.apply(xg, sg, idx, G, mode).backward(g)
         return xg.grad.clone(), None if sg is None else sg.grad.clone()
     finally:
-        fused.MR_I64, fused.DETERMINISTIC = old
+        fused._mr_bwd_flags, fused.DETERMINISTIC = old
 
 
 def _oracle_bwd(x, src, idx, G, gm_tm, direct_tm):

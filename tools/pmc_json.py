@@ -61,11 +61,24 @@ def main():
         if all(c in v for c in ("SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")) and v["SQ_BUSY_CYCLES"] > 0:
             v["issue_slot_frac"] = round((4.0 * v["SQ_INSTS_VALU"] + v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (32.0 * v["SQ_BUSY_CYCLES"]) , 4)
             v["mfma_slot_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * v["SQ_BUSY_CYCLES"]), 4)
-    tiles = {k: v for k, v in acc.items() if k.startswith("knn_tile_kernel") and "hbm_bytes_per_launch" in v}
-    if tiles:
-        res["knn_tile_per_step_traffic_bytes"] = sum(v["hbm_bytes_per_launch"] for v in tiles.values())
-        res["knn_tile_launches_per_step"] = len(tiles)
-        fr = [(v.get("issue_slot_frac"), v.get("mfma_slot_frac"), v.get("SQ_BUSY_CYCLES", 0)) for v in tiles.values() if v.get("issue_slot_frac")]
+    # The instantiations ON THE TIMED PATH of bench.py's default step: the FUSED k-NN + aggregation launches
+    # (template argument 8, MRF, == true) — the Grapher graph (HAS_RP, argument 2, true) and the label graph.  The collection also
+    # holds the k-NN-only instantiations of bench.py's two-launch A/B leg; they are NOT part of the step and stay out of these sums.
+    def targs(k):
+        return [a.strip() for a in k.split("<", 1)[1].rsplit(">", 1)[0].split(",")] if "<" in k else []
+    fused = {}
+    for k, v in acc.items():
+        a = targs(k)
+        if k.startswith("knn_tile_kernel") and len(a) >= 8 and a[7] == "true" and "hbm_bytes_per_launch" in v:
+            fused["grapher" if a[1] == "true" else "label"] = dict(kernel=k, hbm_bytes_per_launch=v["hbm_bytes_per_launch"],
+                                                                     issue_slot_frac=v.get("issue_slot_frac"),
+                                                                     mfma_slot_frac=v.get("mfma_slot_frac"),
+                                                                     busy_cycles=v.get("SQ_BUSY_CYCLES", 0))
+    if fused:
+        res["knn_mr_fused"] = fused
+        res["knn_tile_per_step_traffic_bytes"] = sum(v["hbm_bytes_per_launch"] for v in fused.values())
+        res["knn_tile_launches_per_step"] = len(fused)
+        fr = [(v["issue_slot_frac"], v["mfma_slot_frac"], v["busy_cycles"]) for v in fused.values() if v.get("issue_slot_frac")]
         if fr:
             wsum = sum(b for _, _, b in fr)
             res["knn_tile_issue_slot_frac"] = round(sum(f * b for f, _, b in fr) / wsum, 4)
