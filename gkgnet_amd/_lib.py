@@ -19,6 +19,7 @@ KNN_SELECT_BUFFERED = 8
 KNN_NO_PREFILTER = 16
 KNN_FORCE_PREFILTER = 32
 KNN_RELPOS_UNIT = 64
+KNN_X_PREPARED = 128
 
 
 _RELPOS_WARNED = False
@@ -76,7 +77,7 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_affine_act_dual", "gkg_edge_stats", "gkg_edge_fwd", "gkg_edge_bwd_stats", "gkg_edge_bwd", "gkg_stream_capture_id", "gkg_x6_planes_bytes", "gkg_x6_prep_desc_bytes",
            "gkg_x6_prep_desc_fill", "gkg_x6_prep_weights", "gkg_linear_bn_fwd_x6", "gkg_linear_dgrad_x6", "gkg_linear_wgrad_x6",
            "gkg_mr_linear_planes_bytes", "gkg_mr_linear_bf16", "gkg_bn_bwd_atomic", "gkg_bn_apply_train",
-           "gkg_avgpool_tm", "gkg_linear_dgrad_x6_bnbwd",
+           "gkg_avgpool_tm", "gkg_bn_apply_knn_prep", "gkg_linear_dgrad_x6_bnbwd",
            "gkg_bn_bwd_apply_from_sums", "gkg_stem_conv3x3s2_supported", "gkg_stem_conv3x3s2_fwd", "gkg_affine_act_bf16in", "gkg_bn_bwd_atomic_scaled",
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
@@ -132,6 +133,8 @@ def load():
     lib.gkg_mr_fwd_tm.argtypes = [V, I, I] + [V] * 4 + [I] * 9 + [V]
     lib.gkg_mr_fwd_tm16.restype = I
     lib.gkg_mr_fwd_tm16.argtypes = [V, I, I] + [V] * 4 + [I] * 9 + [V]
+    lib.gkg_bn_apply_knn_prep.restype = I
+    lib.gkg_bn_apply_knn_prep.argtypes = [V] * 13 + [I] * 11 + [C.c_uint, I, V, Z, F, F, V, Z, V]
     lib.gkg_avgpool_tm.restype = I
     lib.gkg_avgpool_tm.argtypes = [V, I, I, V, I, I, I, I, I, V]
     lib.gkg_knn_fwd_tm16.restype = I

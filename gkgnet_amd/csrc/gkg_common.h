@@ -65,10 +65,43 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
   return cdf + z * 0.39894228040143267794f * gauss;
 }
 
+// Train-mode BN whose statistics came out of the projection kernel's epilogue as fp64 column sums (gkg_linear_bn_fwd* with
+// train == 2): the CONSUMER of the projection — the BN-apply pass — derives scale / shift itself instead of a one-block
+// finalize launch in between.  Every workgroup computes the coefficients of its channels once (into LDS), the first
+// workgroup of each group also writes what the backward needs (a, c, mean, invstd) and updates the running statistics, and
+// clears `zero_buf`: the OTHER of two alternating scratch buffers, i.e. what the previous projection accumulated into (see
+// gkg_bn_bwd_atomic for the protocol).  Same arithmetic as bn_sums_finalize_kernel.
+struct BnDerive {
+  const double* sums;       // [nb][2][C]; null: the caller passes a / c
+  const float* gamma; const float* beta; const float* bias;
+  float* running_mean; float* running_var; long long* nbt;
+  float* a_out; float* c_out; float* mean_out; float* invstd_out;
+  int R; float momentum, eps;
+  double* zero_buf; size_t zero_doubles;
+};
+
+__device__ __forceinline__ void bn_derive_channel(const BnDerive& d, size_t o, double S, double Q, bool side, float& av, float& cv) {
+  const double m = S / d.R;
+  double var = Q / d.R - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)d.eps));
+  av = d.gamma[o] * is;
+  cv = d.beta[o] - av * (float)m;
+  if (side) {
+    d.a_out[o] = av; d.c_out[o] = cv; d.mean_out[o] = (float)m; d.invstd_out[o] = is;
+    if (d.running_mean) {
+      const float bv = d.bias ? d.bias[o] : 0.f;
+      d.running_mean[o] = (1.f - d.momentum) * d.running_mean[o] + d.momentum * ((float)m + bv);
+      const double unb = d.R > 1 ? var * (double)d.R / (double)(d.R - 1) : var;
+      d.running_var[o] = (1.f - d.momentum) * d.running_var[o] + d.momentum * (float)unb;
+    }
+  }
+}
+
 }  // namespace gkg
 
 namespace gkg {
-// gkg_gemm.hip: BN scale / shift / saved statistics / running-stat update from the fp64 column sums (re-zeroes them)
+// gkg_gemm_x6.hip: BN scale / shift / saved statistics / running-stat update from the fp64 column sums (re-zeroes them)
 hipError_t launch_bn_sums_finalize(double* stats, int R, int cout, int nb, const float* gamma, const float* beta,
                                    const float* bias, float* running_mean, float* running_var, float* bn_a, float* bn_c,
                                    float* bn_mean, float* bn_invstd, float momentum, float eps, long long* nbt, hipStream_t st,

@@ -54,13 +54,44 @@ struct PrepStrides { int G; size_t sb, sg, sc, sn; int chunk; };      // chunk >
 // zeros) — the kernel stages a query's copy of those two channels as (1, 1), so the matrix cores add |y|^2 to every distance and
 // the selection loses a v_readlane + s_nop + v_add per candidate; the planes have `rows` = Tn rounded up to 32 rows, the pad rows
 // hold MASKED_SQ there (keys past M mask themselves).  cp16 >= c + 2 in that mode.
-struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; uint16_t* tb_lo; int rows; };
+// raw != null (round 6, queries of a fused block only): the input is a projection's PRE-BN output and this pass is also its
+// BN-apply (kernel argument `d`: scale / shift derived from the projection's fp64 column sums, or given) — every token is
+// affine-transformed as it is gathered, stored to `raw` (a token-major view: row pitch raw_ld, chunk raw_chunk — the x half of
+// the grouped projection's operand buffer) and normalised from the same registers: the Grapher's fc1 BN-apply and the k-NN's
+// token preparation in ONE pass over the tokens (reference torch_vertex.py:326 -> torch_edge.py:167-173).
+struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; uint16_t* tb_lo; int rows;
+                 float* raw; int raw_ld, raw_chunk; };
+
+// scale / shift of the group's c channels into LDS (tab[0..c) = a, tab[c..2c) = shift): derived from the column sums like every
+// BN-apply pass (gkg_common.h bn_derive_channel; the first workgroup of image 0's groups writes the saved statistics and updates the
+// running ones), or copied from the caller's a / c
+__device__ __forceinline__ void prep_affine_table(const BnDerive& d, const float* __restrict__ a_in, const float* __restrict__ c_in,
+                                                  float* tab, int c, int C, int bg, int G, int nthreads) {
+  const int g = bg % G;
+  const bool side = blockIdx.x == 0 && bg < G;                 // image 0: one workgroup per group
+  for (int ch = threadIdx.x; ch < c; ch += nthreads) {
+    const size_t o = (size_t)g * c + ch;
+    float av, cv;
+    if (d.sums) bn_derive_channel(d, o, d.sums[o], d.sums[C + o], side, av, cv);
+    else { av = a_in[o]; cv = c_in[o]; }
+    tab[ch] = av; tab[c + ch] = cv;
+  }
+  if (d.sums && blockIdx.x == 0 && bg == 0) {
+    if (threadIdx.x == 0 && d.nbt) *d.nbt += 1;
+    for (size_t i = threadIdx.x; i < d.zero_doubles; i += nthreads) d.zero_buf[i] = 0.0;
+  }
+  __syncthreads();
+}
 
 template <typename T, bool NORM, int PT>
-__global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
-  extern __shared__ float col[];          // [c][PT]
+__global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad, BnDerive d,
+                                                        const float* __restrict__ aff_a, const float* __restrict__ aff_c) {
+  extern __shared__ float col[];          // [c][PT] (+ [2][c] scale / shift when s1.raw)
   const bool second = (int)blockIdx.x >= nbx1;
   const PrepSet& S = second ? s2 : s1;
+  const bool affine = !second && s1.raw != nullptr;              // uniform per workgroup
+  float* tab = col + (size_t)c * PT;
+  if (affine) prep_affine_table(d, aff_a, aff_c, tab, c, s1.ps.G * c, blockIdx.y, s1.ps.G, PT);
   const T* __restrict__ t = static_cast<const T*>(S.t);
   float* __restrict__ th = S.th;
   float* __restrict__ sq = S.sq;
@@ -92,10 +123,20 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
     const int goff = (bg % ps.G) * (int)ps.sg;      // the group's first channel; quad q sits xm_col(goff + 4 q) - goff floats into tp
     const float* tpf = reinterpret_cast<const float*>(tp) - goff;
     int q = 0;
+    float* rawp = affine ? S.raw + ((size_t)(bg / ps.G) * Tn + n) * S.raw_ld : nullptr;
+    auto apply = [&](float4& v, int q4) __attribute__((always_inline)) {       // BN-apply of 4 channels + the raw store
+      if (affine) {
+        v.x = __builtin_fmaf(tab[q4], v.x, tab[c + q4]); v.y = __builtin_fmaf(tab[q4 + 1], v.y, tab[c + q4 + 1]);
+        v.z = __builtin_fmaf(tab[q4 + 2], v.z, tab[c + q4 + 2]); v.w = __builtin_fmaf(tab[q4 + 3], v.w, tab[c + q4 + 3]);
+        *reinterpret_cast<float4*>(rawp + xm_col(goff + q4, S.raw_chunk)) = v;
+      }
+    };
     for (; q + 8 <= (c >> 2); q += 8) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(tpf + xm_col(goff + 4 * (q + u), ps.chunk));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) apply(v[u], 4 * (q + u));
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         cp[(4 * (q + u) + 0) * PT] = v[u].x; cp[(4 * (q + u) + 1) * PT] = v[u].y;
@@ -103,7 +144,8 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
       }
     }
     for (; q < (c >> 2); ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(tpf + xm_col(goff + 4 * q, ps.chunk));
+      float4 v = *reinterpret_cast<const float4*>(tpf + xm_col(goff + 4 * q, ps.chunk));
+      apply(v, 4 * q);
       cp[(4 * q + 0) * PT] = v.x; cp[(4 * q + 1) * PT] = v.y; cp[(4 * q + 2) * PT] = v.z; cp[(4 * q + 3) * PT] = v.w;
     }
   } else {
@@ -205,12 +247,16 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
 // 256 / TK channel lanes per token, and the ordered |th|^2 chain runs on the normalised tile.  Same operations in the same
 // order per value: bit-identical outputs.
 template <bool NORM, int TK>
-__global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
-  extern __shared__ float col[];          // [c][TK + 1]
+__global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad, BnDerive d,
+                                                              const float* __restrict__ aff_a, const float* __restrict__ aff_c) {
+  extern __shared__ float col[];          // [c][TK + 1] (+ [2][c] scale / shift when s1.raw)
   constexpr int LP = TK + 1, CL = 256 / TK;      // channel lanes per token
   const int tid = threadIdx.x;
   const bool second = (int)blockIdx.x >= nbx1;
   const PrepSet& S = second ? s2 : s1;
+  const bool affine = !second && s1.raw != nullptr;              // uniform per workgroup
+  float* tab = col + (size_t)c * LP;
+  if (affine) prep_affine_table(d, aff_a, aff_c, tab, c, s1.ps.G * c, blockIdx.y, s1.ps.G, 256);
   const int Tn = S.Tn;
   const PrepStrides ps = S.ps;
   const int n0 = ((int)blockIdx.x - (second ? nbx1 : 0)) * TK;
@@ -227,6 +273,18 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
     for (int u = 0; u < TK / 16; ++u) {
       const int tok = (tid >> 4) + 16 * u;
       v[u] = tok < nt ? *reinterpret_cast<const float4*>(tp + (size_t)tok * ps.sn + xo) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (affine) {                                   // BN-apply of the 4 channels + the raw store (the x half of the operand buffer)
+      const float4 a4 = *reinterpret_cast<const float4*>(tab + 4 * q), c4 = *reinterpret_cast<const float4*>(tab + c + 4 * q);
+      const int ro = xm_col(goff + 4 * q, S.raw_chunk);
+#pragma unroll
+      for (int u = 0; u < TK / 16; ++u) {
+        const int tok = (tid >> 4) + 16 * u;
+        v[u].x = __builtin_fmaf(a4.x, v[u].x, c4.x); v[u].y = __builtin_fmaf(a4.y, v[u].y, c4.y);
+        v[u].z = __builtin_fmaf(a4.z, v[u].z, c4.z); v[u].w = __builtin_fmaf(a4.w, v[u].w, c4.w);
+        if (tok < nt)
+          *reinterpret_cast<float4*>(S.raw + ((size_t)(bg / ps.G) * Tn + n0 + tok) * S.raw_ld + ro) = v[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < TK / 16; ++u) {
@@ -404,26 +462,29 @@ extern "C" size_t gkg_knn_workspace_bytes(int BG, int c, int N, int M, int k, in
   return p.total;
 }
 
+// BN-apply producer of the queries (PrepSet::raw): coefficients derived from column sums (d.sums) or given (a, c)
+struct PrepAffine { BnDerive d; const float* a; const float* c; };
+
 template <typename T, int PT>
-static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
+static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st, const PrepAffine& pa) {
   const int nbx1 = ((s1.tb_lo ? s1.rows : s1.Tn) + PT - 1) / PT;
   const int nbx2 = s2 ? ((s2->tb_lo ? s2->rows : s2->Tn) + PT - 1) / PT : 0;
   dim3 grid(nbx1 + nbx2, BG);
-  const size_t lds = (size_t)c * PT * sizeof(float);
+  const size_t lds = (size_t)c * PT * sizeof(float) + (s1.raw ? (size_t)2 * c * sizeof(float) : 0);
   const PrepSet second = s2 ? *s2 : s1;
-  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
-  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
+  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
+  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
 }
 
 template <int TK>
-static void launch_prep_coop(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
+static void launch_prep_coop(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st, const PrepAffine& pa) {
   const int nbx1 = (s1.Tn + TK - 1) / TK;
   const int nbx2 = s2 ? (s2->Tn + TK - 1) / TK : 0;
   dim3 grid(nbx1 + nbx2, BG);
-  const size_t lds = (size_t)c * (TK + 1) * sizeof(float);
+  const size_t lds = (size_t)c * (TK + 1) * sizeof(float) + (s1.raw ? (size_t)2 * c * sizeof(float) : 0);
   const PrepSet second = s2 ? *s2 : s1;
-  if (norm) hipLaunchKernelGGL((token_prep_coop_kernel<true, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad);
-  else hipLaunchKernelGGL((token_prep_coop_kernel<false, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad);
+  if (norm) hipLaunchKernelGGL((token_prep_coop_kernel<true, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
+  else hipLaunchKernelGGL((token_prep_coop_kernel<false, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
 }
 
 static bool prep_coop_ok(const PrepSet& s) {       // fp32 token-major rows of whole float4s, fp32 channel-major output
@@ -431,20 +492,24 @@ static bool prep_coop_ok(const PrepSet& s) {       // fp32 token-major rows of w
 }
 
 template <typename T>
-static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st) {
+static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int c, int cpad, bool norm, hipStream_t st,
+                              const PrepAffine& pa = PrepAffine{}) {
   GkgProfScope prof(GKG_PROF_TOKEN_PREP, st);
   if (sizeof(T) == 4 && (c & 3) == 0 && prep_coop_ok(s1) && (!s2 || prep_coop_ok(*s2)) &&
       (size_t)(s1.Tn + (s2 ? s2->Tn : 0)) * BG <= 262144) {                          // latency-bound sizes only
-    if (c <= 192) launch_prep_coop<64>(s1, s2, BG, c, cpad, norm, st);               // <= 49 KB tile
-    else if (c <= 384) launch_prep_coop<32>(s1, s2, BG, c, cpad, norm, st);
-    else launch_prep_coop<16>(s1, s2, BG, c, cpad, norm, st);
+    if (c <= 192) launch_prep_coop<64>(s1, s2, BG, c, cpad, norm, st, pa);               // <= 49 KB tile
+    else if (c <= 384) launch_prep_coop<32>(s1, s2, BG, c, cpad, norm, st, pa);
+    else launch_prep_coop<16>(s1, s2, BG, c, cpad, norm, st, pa);
     return hipGetLastError();
   }
-  if (c <= 192) launch_prep_pt<T, 64>(s1, s2, BG, c, cpad, norm, st);          // <= 48 KB column block
-  else if (c <= 384) launch_prep_pt<T, 32>(s1, s2, BG, c, cpad, norm, st);
-  else launch_prep_pt<T, 16>(s1, s2, BG, c, cpad, norm, st);                    // c <= 600 (plan limit)
+  if (c <= 192) launch_prep_pt<T, 64>(s1, s2, BG, c, cpad, norm, st, pa);          // <= 48 KB column block
+  else if (c <= 384) launch_prep_pt<T, 32>(s1, s2, BG, c, cpad, norm, st, pa);
+  else launch_prep_pt<T, 16>(s1, s2, BG, c, cpad, norm, st, pa);                    // c <= 600 (plan limit)
   return hipGetLastError();
 }
+
+// The queries' BN-apply riding in their preparation pass (gkg_bn_apply_knn_prep)
+struct KnnProducer { PrepAffine aff; float* raw; int raw_ld, raw_chunk; };
 
 // Fused aggregation request of gkg_knn_mr_fwd_tm (token-major fp32 callers): outputs of knn_tile_kernel<..., MRF = true>.
 struct KnnMrFuse {
@@ -463,7 +528,17 @@ static bool knn_mr_plan_ok(const KnnPlan& p, int c, int N, int M, int k, bool pf
 static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                         int BG, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                         void* workspace, size_t workspace_bytes, void* stream, int G_tm, const KnnMrFuse* mr = nullptr,
-                        bool probe_only = false, uint16_t* nn16_only = nullptr, int ldx = 0, int xchunk = 0) {
+                        bool probe_only = false, uint16_t* nn16_only = nullptr, int ldx = 0, int xchunk = 0,
+                        const KnnProducer* prod = nullptr) {
+  // prod != null (gkg_bn_apply_knn_prep): PREPARATION ONLY — `x` is a projection's pre-BN output (B, N, C); the queries' pass
+  // applies the BN, stores the result to prod->raw and leaves the normalised copies / norms (/ prefilter planes) in the workspace
+  // exactly where the k-NN call with the same arguments + GKG_KNN_X_PREPARED expects them (same plan, same decisions: this IS that
+  // call up to its preparation launch); y / relpos / mr are only tested for presence.
+  const bool prep_only = prod != nullptr;
+  const bool x_prepared = (flags & GKG_KNN_X_PREPARED) != 0;
+  if (prep_only && x_prepared) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: GKG_KNN_X_PREPARED makes no sense here");
+  if ((prep_only || x_prepared) && (G_tm <= 0 || dtype != GKG_F32 || (c & 3)))
+    return gkg_fail(GKG_ERR_UNSUPPORTED, "prepared queries: token-major fp32 callers with c % 4 == 0 only");
   // ldx / xchunk (token-major fp32 callers, G_tm > 0): x as a view — row pitch ldx floats (0: G_tm * c), chunk xchunk
   // (gkg_common.h "XM layout": xchunk = C / 4 with ldx = 2 C is the x half of the grouped projection's operand buffer)
   if (G_tm > 0) {
@@ -475,7 +550,7 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
     return gkg_fail(GKG_ERR_SHAPE, "gkg_knn_fwd: x views are a token-major feature");
   }
   // nn16_only (gkg_knn_fwd_tm16): the neighbour lists as u16 rows INSTEAD of the int64 plane (M <= 65 536)
-  if (!probe_only && (!x || (!nn_idx && !mr && !nn16_only) || !workspace)) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
+  if (!probe_only && (!x || (!nn_idx && !mr && !nn16_only && !prep_only) || !workspace)) return gkg_fail(GKG_ERR_NULL, "gkg_knn_fwd: x, nn_idx and workspace must be non-null");
   if (dtype != GKG_F32 && dtype != GKG_BF16 && dtype != GKG_F16) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_knn_fwd: dtype must be GKG_F32, GKG_BF16 or GKG_F16");
   KnnPlan p;
   int rc = make_plan(BG, c, N, M, k, dilation, y != nullptr, &p);
@@ -556,10 +631,20 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
   uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
   const PrepSet sx{x, xh, sqx, N, strides(N, ldx, xchunk), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), pf ? cp16p : cp16,
-                   pf ? xpl + (size_t)BG * Nr * cp16p : nullptr, Nr};
+                   pf ? xpl + (size_t)BG * Nr * cp16p : nullptr, Nr,
+                   prod ? prod->raw : nullptr, prod ? prod->raw_ld : 0, prod ? prod->raw_chunk : 0};
   const PrepSet sy{y, yh, sqy, M, strides(M, G_tm * c, 0), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), pf ? cp16p : cp16,
-                   pf ? ypl + (size_t)BG * Mr * cp16p : nullptr, Mr};
-  if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
+                   pf ? ypl + (size_t)BG * Mr * cp16p : nullptr, Mr, nullptr, 0, 0};
+  if (prep_only) {                               // the queries only (with their BN-apply); the keys belong to the k-NN call
+    if (bf) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_bn_apply_knn_prep: not with the bf16 contraction");
+    e = launch_prep<float>(sx, nullptr, BG, c, p.cpad, norm, st, prod->aff);
+    return e == hipSuccess ? 0 : gkg_fail_hip(e, "token_prep (BN-apply producer)");
+  }
+  if (x_prepared) {                              // the queries' copies are in place (gkg_bn_apply_knn_prep): keys only, if any
+    if (bf) return gkg_fail(GKG_ERR_UNSUPPORTED, "GKG_KNN_X_PREPARED: not with the bf16 contraction");
+    e = y ? launch_prep<float>(sy, nullptr, BG, c, p.cpad, norm, st) : hipSuccess;
+  }
+  else if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else e = launch_prep<uint16_t>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   if (e != hipSuccess) return gkg_fail_hip(e, "token_prep");
@@ -721,4 +806,37 @@ extern "C" int gkg_knn_mr_fwd_tm(const float* x, int ldx, int xchunk, const floa
   if (center_out && !nn_idx_out) return gkg_fail(GKG_ERR_NULL, "gkg_knn_mr_fwd_tm: center_out without nn_idx_out");
   return knn_fwd_impl(x, y, relpos, nn_idx_out, center_out, B * G, c, N, M, k, dilation, GKG_F32, flags, workspace, workspace_bytes,
                       stream, G, &mr, false, nullptr, ldx, xchunk);
+}
+
+
+// The Grapher's fc1 BN-apply (train mode, statistics from the projection's fp64 column sums: gkg_bn_apply_train's contract with
+// nb == 1, act == 0, no residual) and the k-NN's token preparation of the SAME tokens in one pass (round 6):
+//   y (B N, C) pre-BN projection output -> x = a y + c, written to `out` (row pitch ldo floats; ochunk > 0: the x half of the
+//   grouped projection's operand buffer, include/gkg_hip.h "XM layout") AND normalised into `knn_workspace` — the workspace of the
+//   k-NN call (gkg_knn_fwd_tm / _tm16 / gkg_knn_mr_fwd_tm) with the SAME (B, G, c, N, M, k, dilation, y / relative_pos presence,
+//   flags) that follows with GKG_KNN_X_PREPARED set and x = `out`: it then launches no preparation for the queries (none at all
+//   for a self graph).  fused_mr != 0: that call is gkg_knn_mr_fwd_tm.  Same arithmetic, same bits as apply + token_prep.
+extern "C" int gkg_bn_apply_knn_prep(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
+                                     float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c_out,
+                                     float* mean, float* invstd, float* out, int ldo, int ochunk, int B, int G, int c, int N, int M,
+                                     int k, int dilation, int has_y, int has_relpos, unsigned knn_flags, int fused_mr,
+                                     void* knn_workspace, size_t knn_workspace_bytes, float momentum, float eps, double* zero_buf,
+                                     size_t zero_doubles, void* stream) {
+  if (!y || !sums || !gamma || !beta || !a || !c_out || !mean || !invstd || !out || !knn_workspace)
+    return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_knn_prep: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_knn_prep: running stats come in pairs");
+  if (B <= 0 || G <= 0 || c <= 0 || (c & 3) || N <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: bad sizes (c % 4 == 0)");
+  const int C = G * c;
+  if (ldo == 0) ldo = C;
+  if (ldo < C || (ldo & 3) || ochunk < 0 || (ochunk & 3) || (ochunk > 0 && (C % ochunk || ldo < 2 * C)) || ((size_t)out & 15) || ((size_t)y & 15) ||
+      (zero_doubles && !zero_buf))
+    return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: bad output view");
+  KnnProducer prod{};
+  prod.aff.d = BnDerive{sums, gamma, beta, bias, running_mean, running_var, num_batches_tracked, a, c_out, mean, invstd, B * N, momentum,
+                        eps, zero_buf, zero_doubles};
+  prod.raw = out; prod.raw_ld = ldo; prod.raw_chunk = ochunk;
+  static const float dummy = 0.f;
+  static KnnMrFuse mr_dummy{nullptr, nullptr, nullptr};
+  return knn_fwd_impl(y, has_y ? &dummy : nullptr, has_relpos ? &dummy : nullptr, nullptr, nullptr, B * G, c, N, M, k, dilation, GKG_F32,
+                      knn_flags, knn_workspace, knn_workspace_bytes, stream, G, fused_mr ? &mr_dummy : nullptr, false, nullptr, 0, 0, &prod);
 }

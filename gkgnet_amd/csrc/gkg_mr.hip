@@ -1316,8 +1316,12 @@ extern "C" int gkg_mr_bwd_tm(const float* gin, const int64_t* nn_idx, const uint
     auto sfits = [&](int cw) { return (size_t)M * cw * 8 + 16 <= (size_t)MR_LDS_BUDGET && C % cw == 0 && c % cw == 0; };
     if (!CW || !sv) CW = sfits(16) ? 16 : (sfits(8) ? 8 : 4);
     if ((sv && (size_t)M * CW * 8 + 16 <= 150 * 1024 && C % CW == 0 && c % CW == 0) || sfits(CW)) {
-      const bool nt256 = sv && ((flags >> 20) & 3) == 2;
-      const bool u8 = sv ? ((flags >> 22) & 1) != 0 : M > 512;       // long sweeps: 8 rows in flight
+      // long sweeps over a pooled key image (GKGNet-576 stages 1 / 2: N = 16 M / 4 M, M = 1 296): 256-thread workgroups with 4 rows
+      // in flight — two workgroups per CU overlap one's store phase with the other's sweep (round 6, on the XM gradient layout,
+      // us: stage 1 379.6 -> 334.9, stage 2 145.7 -> 141.0; the self graphs keep 512 threads: 36 x 36 89.7 vs 93.5)
+      const bool long_sweep = M > 512 && (long)N >= 4L * M;
+      const bool nt256 = sv ? ((flags >> 20) & 3) == 2 : long_sweep;
+      const bool u8 = sv ? ((flags >> 22) & 1) != 0 : (M > 512 && !long_sweep);       // 8 rows in flight
       const size_t lds = (size_t)M * CW * 8 + 16;
       int bitsN = 0;
       while ((1 << bitsN) <= N) ++bitsN;

@@ -574,7 +574,7 @@ from .bn_scratch import _BnBwdScratch, _BnFwdScratch      # noqa: E402  (fp64 co
 
 
 def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, out, ldo, obs, act, nchw_B, scale, rows_per_scale,
-                           launch=None, out_tm=None, xld=None, xbs=None, ochunk=0):
+                           launch=None, out_tm=None, xld=None, xbs=None, ochunk=0, knn_prep=None):
     """Projection (statistics in its epilogue) -> BN-apply straight from the fp64 sums: two launches, no finalize kernel.
     Returns (Y, a, c, mean, invstd).  ``launch(Y, sums) -> rc``: a caller-supplied producer of Y and its column sums (the
     fused aggregation + projection kernel) instead of the plain projection of ``x``."""
@@ -595,7 +595,17 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
         a, c, mean, invstd = torch.empty((4, nb * cout), dtype=_F32, device=dev).unbind(0)     # one allocation
         track = bn.training and bn.track_running_stats
         _touch_stats(bn, track)
-        if out_tm is not None:           # channel-major AND token-major result, residual token-major (gkg_bn_apply_train_dual)
+        if knn_prep is not None:         # the apply pass is also the k-NN's token preparation (gkg_bn_apply_knn_prep): knn_prep = _KnnKey
+            kp = knn_prep
+            kp.ws = _ws(lib.gkg_knn_workspace_bytes(kp.B * kp.G, kp.c, kp.N, kp.M, kp.k, kp.d, _lib.F32, _lib.KNN_NORMALIZE), dev)
+            _lib.check(lib.gkg_bn_apply_knn_prep(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
+                                                 _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                                 _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
+                                                 _ptr(invstd), _ptr(out), ldo, ochunk, kp.B, kp.G, kp.c, kp.N, kp.M, kp.k, kp.d,
+                                                 kp.has_y, kp.has_rp, kp.flags, kp.fused_mr, _ptr(kp.ws), kp.ws.numel(),
+                                                 float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
+                       "gkg_bn_apply_knn_prep")
+        elif out_tm is not None:         # channel-major AND token-major result, residual token-major (gkg_bn_apply_train_dual)
             _lib.check(lib.gkg_bn_apply_train_dual(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
                                                    _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
                                                    _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
@@ -747,7 +757,7 @@ class _LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, bn, act, nchw, out_lowp=False, w16=None, scale=None,
-                rows_per_scale=0, want16=False, alias=False, dual=False, xm=None):
+                rows_per_scale=0, want16=False, alias=False, dual=False, xm=None, knn=None):
         """``alias``: also return ``x`` itself as a second output (a view).  A caller that uses the layer's input again
         as the residual of a later layer takes the alias for that: both gradient contributions then arrive at THIS node
         and the input-gradient GEMM adds the residual one in its epilogue (``addmm``), instead of autograd summing two
@@ -756,7 +766,9 @@ class _LinearBNAct(torch.autograd.Function):
         returned in both layouts, ``(out (B, C, H, W), out_tm (R, cout))`` — see DUAL_LAYOUT below.
         ``xm`` = (B, N) (fp32 token-major output, no residual): the result is written into the x half of a fresh XM operand
         buffer (R, 2 cout) and returned as its (B, N, 4, cout / 4) view (see _xm_xview) — a Grapher's fc1, whose output the
-        aggregation and the grouped projection read in place."""
+        aggregation and the grouped projection read in place.  ``knn`` (a _KnnKey, with ``xm``): the k-NN problem whose queries
+        this output is — the BN-apply pass then also leaves the queries' normalised copies in that call's workspace
+        (gkg_bn_apply_knn_prep) and the returned view carries the key (``_gkg_knn``): no token-preparation launch downstream."""
         lib = _lib.load()
         R, cin = x.shape
         cout = weight.shape[0]
@@ -791,7 +803,8 @@ class _LinearBNAct(torch.autograd.Function):
         if fused_apply:                               # projection (statistics epilogue) -> apply from the sums: 2 launches
             Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, pf, res, out,
                                                            ldo, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale,
-                                                           out_tm=out_tm, ochunk=ochunk)
+                                                           out_tm=out_tm, ochunk=ochunk,
+                                                           knn_prep=knn if (xm is not None and act == 0 and scale is None) else None)
         elif own:                                     # projection kernel with the BN statistics in its epilogue
             Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
         else:
@@ -825,6 +838,8 @@ class _LinearBNAct(torch.autograd.Function):
         ctx.link = _bn_link(out, Y, a, c, mean, invstd, act, 1, cout, R, bn, sync, scale) if (nchw is None and xm is None) else None
         if xm is not None:
             out = _xm_xview(out, xm[0], xm[1], cout)
+            if knn is not None and fused_apply and getattr(knn, "ws", None) is not None:
+                out._gkg_knn = knn               # the queries' prepared copies are in knn.ws (see _knn_prepared)
         if alias:
             ctx.set_materialize_grads(False)
             return out, x.view_as(x)
@@ -842,9 +857,9 @@ class _LinearBNAct(torch.autograd.Function):
         if ctx.dual:
             dtm, dalias = dalias, None
             if dout is None and dtm is None:
-                return (None,) * 17
+                return (None,) * 18
         elif dout is None:                                 # only the alias was used downstream
-            return (dalias,) + (None,) * 16
+            return (dalias,) + (None,) * 17
         R, cin = x.shape
         cout = weight.shape[0]
         dres = dout if has_res else None
@@ -906,7 +921,7 @@ class _LinearBNAct(torch.autograd.Function):
         elif dalias is not None:
             dx = dalias
         dW = _wgrad(dY, x, dWv).view_as(weight)
-        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _GroupedLinearBNAct(torch.autograd.Function):
@@ -1211,6 +1226,31 @@ def _as_tokens(x):
     return x if _is_xm_half(x) else x.contiguous()
 
 
+class _KnnKey:
+    """One k-NN problem as the C entry points see it: what gkg_bn_apply_knn_prep (the producer of the queries) and the k-NN call
+    must agree on for the prepared queries in ``ws`` to be THAT call's (same workspace plan, same kernel choice)."""
+    __slots__ = ("B", "G", "c", "N", "M", "k", "d", "has_y", "has_rp", "flags", "fused_mr", "ws")
+
+    def __init__(self, B, G, c, N, M, k, d, has_y, relative_pos, fused_mr):
+        self.B, self.G, self.c, self.N, self.M, self.k, self.d = B, G, c, N, M, k, d
+        self.has_y, self.has_rp, self.fused_mr = int(bool(has_y)), int(relative_pos is not None), int(bool(fused_mr))
+        self.flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
+        self.ws = None
+
+    def same(self, B, G, c, N, M, k, d, has_y, has_rp, flags, fused_mr) -> bool:
+        return ((self.B, self.G, self.c, self.N, self.M, self.k, self.d, self.has_y, self.has_rp, self.flags, self.fused_mr)
+                == (B, G, c, N, M, k, d, int(bool(has_y)), int(bool(has_rp)), flags, int(bool(fused_mr))))
+
+
+def _knn_prepared(x, B, G, c, N, M, k, d, has_y, has_rp, flags, fused_mr):
+    """(workspace, flags) for a k-NN call on queries ``x``: the producer's workspace + GKG_KNN_X_PREPARED when x carries prepared
+    copies for exactly this problem (fc1's BN-apply left them: _LinearBNAct ``knn``), else a fresh workspace."""
+    key = getattr(x, "_gkg_knn", None)
+    if key is not None and key.ws is not None and key.same(B, G, c, N, M, k, d, has_y, has_rp, flags, fused_mr) and not (flags & _lib.KNN_BF16_CONTRACT):
+        return key.ws, flags | _lib.KNN_X_PREPARED
+    return _ws(_lib.load().gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), x.device), flags
+
+
 def _rp_arg(relative_pos, N, M):
     rp = relative_pos.detach().to(_F32).reshape(-1, relative_pos.shape[-1]).contiguous()
     if tuple(rp.shape) != (N, M):
@@ -1234,7 +1274,7 @@ def knn_graph_tm(x, y, relative_pos, k, dilation, G):
         rp = _rp_arg(relative_pos, N, M)
         flags |= _lib.relpos_flags(relative_pos)
     edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device=x.device)
-    ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
+    ws, flags = _knn_prepared(x, B, G, c, N, M, k, dilation, y is not None, rp is not None, flags, False)
     rc = lib.gkg_knn_fwd_tm(_ptr(x), ldx, xchunk, _ptr(y), _ptr(rp), edge[0].data_ptr(), edge[1].data_ptr(), B, G, c, N, M, k,
                             dilation, _lib.F32, flags, _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "gkg_knn_fwd_tm")
@@ -1267,7 +1307,7 @@ def knn_graph_tm16(x, y, relative_pos, k, dilation, G):
         rp = _rp_arg(relative_pos, N, M)
         flags |= _lib.relpos_flags(relative_pos)
     nn16 = torch.empty((B * G, N, k), dtype=torch.int16, device=x.device)
-    ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, dilation, _lib.F32, _lib.KNN_NORMALIZE), x.device)
+    ws, flags = _knn_prepared(x, B, G, c, N, M, k, dilation, y is not None, rp is not None, flags, False)
     _lib.check(lib.gkg_knn_fwd_tm16(_ptr(x), ldx, xchunk, _ptr(y), _ptr(rp), _ptr(nn16), B, G, c, N, M, k, dilation, _lib.F32, flags,
                                     _ptr(ws), ws.numel(), _stream()), "gkg_knn_fwd_tm16")
     return nn16
@@ -1349,7 +1389,7 @@ class _KnnMaxRelativeTM(torch.autograd.Function):
         arg = torch.empty((B, N, C), dtype=torch.int16, device=x.device)
         # the (2, B*G, N, k) int64 edge_index only for callers that return the graph (GrapherLabel / tests): written by the kernel
         edge = torch.empty((2, B * G, N, k) if want_nn else (0,), dtype=torch.int64, device=x.device)
-        ws = _ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), x.device)
+        ws, flags = _knn_prepared(x, B, G, c, N, M, k, d, src is not None, rp is not None, flags, True)
         _lib.check(lib.gkg_knn_mr_fwd_tm(_ptr(x), ldx, xchunk, _ptr(src), _ptr(rp), _ptr(XM), _ptr(arg), None,
                                          edge[0].data_ptr() if want_nn else None, edge[1].data_ptr() if want_nn else None, B, G, c,
                                          N, M, k, d, flags, _ptr(ws), ws.numel(), _stream()), "gkg_knn_mr_fwd_tm")
@@ -1374,20 +1414,33 @@ class _KnnMaxRelativeTM(torch.autograd.Function):
         return gx.view(xshape), gsrc, None, None, None, None, None
 
 
-def _knn_mr_ok(x, src, relative_pos, k, d, G, nn_, lp) -> bool:
-    """The fused k-NN + aggregation kernel applies (see KNN_MR)."""
-    if not (KNN_MR and not lp and knn_graph_tm is _KNN_GRAPH_TM and x.dtype == _F32 and (x.is_contiguous() or _is_xm_half(x))
-            and (src is None or (src.dtype == _F32 and src.is_contiguous()))):
+def _knn_mr_shapes_ok(B, N, C, M, has_src, relative_pos, k, d, G, nn_, lp) -> bool:
+    """The shape / mode part of _knn_mr_ok (what is known before the tensors exist: fc1 asks on behalf of its output)."""
+    if not (KNN_MR and not lp and knn_graph_tm is _KNN_GRAPH_TM) or (KNN_BF16 and torch.is_autocast_enabled()):
         return False
-    if KNN_BF16 and torch.is_autocast_enabled():
-        return False
-    B, N, C, _, _ = _tm_view(x)
-    M = N if src is None else src.shape[1]
     if C % 16 or M > 65536 or len(nn_) != 3:
         return False
     flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
-    return bool(_lib.load().gkg_knn_mr_fused_supported(B, G, C // G, N, M, k, d, 0 if src is None else 1,
+    return bool(_lib.load().gkg_knn_mr_fused_supported(B, G, C // G, N, M, k, d, 1 if has_src else 0,
                                                        0 if relative_pos is None else 1, flags))
+
+
+def _knn_mr_ok(x, src, relative_pos, k, d, G, nn_, lp) -> bool:
+    """The fused k-NN + aggregation kernel applies (see KNN_MR)."""
+    if not (x.dtype == _F32 and (x.is_contiguous() or _is_xm_half(x)) and (src is None or (src.dtype == _F32 and src.is_contiguous()))):
+        return False
+    B, N, C, _, _ = _tm_view(x)
+    M = N if src is None else src.shape[1]
+    return _knn_mr_shapes_ok(B, N, C, M, src is not None, relative_pos, k, d, G, nn_, lp)
+
+
+def _knn_key_for(B, N, C, M, has_src, relative_pos, gc, groups, lp, want_edge):
+    """The _KnnKey of the k-NN call _graph_and_project will make for these shapes (fc1 prepares its queries), or None when the
+    queries cannot be prepared ahead (bf16 contraction, a patched ``knn_graph_tm``: tests that record or force graphs)."""
+    if lp or knn_graph_tm is not _KNN_GRAPH_TM or (KNN_BF16 and torch.is_autocast_enabled()) or (C // groups) % 4:
+        return None
+    fused_mr = _knn_mr_shapes_ok(B, N, C, M, has_src, relative_pos, gc.k, gc.d, groups, gc.gconv.nn, lp)
+    return _KnnKey(B, groups, C // groups, N, M, gc.k, gc.d, has_src, relative_pos, fused_mr)
 
 
 def _aggregate_project(x1b, yb, nn_idx, groups, nn_, C, lp):
@@ -1482,18 +1535,18 @@ def fused_supported(mod, x, groups: int) -> bool:
 
 
 def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, rows_per_scale=0, want16=False, alias=False,
-         dual=False, xm=None):
+         dual=False, xm=None, knn=None):
     """``scale`` (one factor per image; token-major outputs: per ``rows_per_scale`` consecutive rows) multiplies the BN
     output before the residual is added: the reference's DropPath on the branch (torch_vertex.py:332,355,402).
     ``alias``: returns ``(out, x')`` with ``x'`` the input again, to be used as a later layer's residual (see
     _LinearBNAct.forward)."""
     if alias:
         if not (torch.is_grad_enabled() and x.requires_grad):
-            return _lin(x, seq, act, residual, nchw, out_lowp, scale, rows_per_scale, want16, xm=xm), x
+            return _lin(x, seq, act, residual, nchw, out_lowp, scale, rows_per_scale, want16, xm=xm, knn=knn), x
         conv, bn = seq[0], seq[1]
         w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
         return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
-                                  rows_per_scale, want16, True, False, xm)
+                                  rows_per_scale, want16, True, False, xm, knn)
     conv, bn = seq[0], seq[1]
     if (FOLD_EPILOGUE and out_lowp and x.dtype == torch.bfloat16 and residual is None and nchw is None and scale is None
             and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and conv.weight.dim() == 4
@@ -1510,7 +1563,7 @@ def _lin(x, seq, act=0, residual=None, nchw=None, out_lowp=False, scale=None, ro
         return torch.addmm(_folded_shift32(conv, bn), x, wf.t(), out_dtype=_F32)
     w16 = _w16_of(conv) if x.dtype == torch.bfloat16 else None
     return _LinearBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, bn, act, nchw, out_lowp, w16, scale,
-                              rows_per_scale, want16, False, dual, xm)
+                              rows_per_scale, want16, False, dual, xm, knn)
 
 
 # ---- a block output in both layouts (round 5) ---------------------------------------------------------------------------
@@ -1550,6 +1603,9 @@ def _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge):
 # outside the bf16-inference form (whose fused kernel never materialises the operand).  GKG_DISABLE=xm_direct: fc1 writes a plain
 # (T, C) matrix and the aggregation copies x into the buffer next to m (A/B, tests).
 XM_DIRECT = "xm_direct" not in _DISABLED
+# fc1's BN-apply pass is also the k-NN's token preparation (gkg_bn_apply_knn_prep; needs XM_DIRECT).  A module constant for the
+# A/B tests (identical bits either way), no environment switch.
+KNN_PREP = True
 
 
 def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
@@ -1564,10 +1620,13 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
     dual = (DUAL_LAYOUT and not cl and not lp and scale is None and torch.is_grad_enabled() and xt.dtype == _F32
             and getattr(mod, "_gkg_want_tm", False))
     xm = (B, N) if (XM_DIRECT and not lp and xt.dtype == _F32 and not torch.is_autocast_enabled() and C % 16 == 0) else None
+    # fc1's BN-apply also prepares the k-NN's queries (normalised copies, norms): no token-preparation launch behind it
+    Mk = (H // gc.r) * (W // gc.r) if gc.r > 1 else N
+    knn = _knn_key_for(B, N, C, Mk, gc.r > 1, relative_pos, gc, groups, lp, want_edge) if (xm is not None and KNN_PREP) else None
     if dual:
-        x1, xt_r = _lin(xt, mod.fc1, alias=True, xm=xm)             # xt_r: xt again, the (token-major) residual of fc2
+        x1, xt_r = _lin(xt, mod.fc1, alias=True, xm=xm, knn=knn)    # xt_r: xt again, the (token-major) residual of fc2
     else:
-        x1 = _lin(xt, mod.fc1, xm=xm)                               # fc1 + BN
+        x1 = _lin(xt, mod.fc1, xm=xm, knn=knn)                      # fc1 + BN
     x1b = x1 if xm is not None else x1.view(B, N, C)
     yb = None
     if gc.r > 1:                                                    # pooled keys (torch_vertex.py:194-196)
@@ -1604,9 +1663,11 @@ def grapher_label_forward(mod, e, features, groups: int):
     e2 = e.float().reshape(B * L, C).contiguous()
     lp = lowp_inference()
     xm = (B, L) if (XM_DIRECT and not lp and not torch.is_autocast_enabled() and C % 16 == 0) else None
-    x1, e2r = _lin(e2, mod.fc1, alias=True, xm=xm)                   # e2r: e2 again, for the residual of fc2 (one gradient node)
+    ftc = ft.contiguous()
+    knn = _knn_key_for(B, L, C, ftc.shape[1], True, None, gc, groups, lp, True) if (xm is not None and KNN_PREP) else None
+    x1, e2r = _lin(e2, mod.fc1, alias=True, xm=xm, knn=knn)          # e2r: e2 again, for the residual of fc2 (one gradient node)
     x1b = x1 if xm is not None else x1.view(B, L, C)
-    a2, edge = _graph_and_project(x1b, ft.contiguous(), None, gc, groups, C, lp, True)      # GrapherLabel returns its graph
+    a2, edge = _graph_and_project(x1b, ftc, None, gc, groups, C, lp, True)      # GrapherLabel returns its graph
     h2 = _lin(a2, mod.fc2, residual=e2r, scale=_drop_scale(mod.drop_path, B, e.device), rows_per_scale=L)
     f1, h2r = _lin(h2, mod.ffn.fc1, act=1, out_lowp=lp, alias=True)
     out = _lin(f1, mod.ffn.fc2, residual=h2r, scale=_drop_scale(mod.ffn.drop_path, B, e.device), rows_per_scale=L)

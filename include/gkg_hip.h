@@ -67,6 +67,10 @@ extern "C" {
                                     * bound when a bias is given.  Without it a call with a bias always takes knn_tile_kernel (same results,
                                     * no range assumption) */
 
+#define GKG_KNN_X_PREPARED 128u     /* token-major fp32 callers: the queries' normalised copies / norms (/ prefilter planes) are already
+                                    * in `workspace`, left there by gkg_bn_apply_knn_prep called with the same problem — the call
+                                    * launches no preparation for them (none at all for a self graph) */
+
 /* argument errors */
 #define GKG_ERR_NULL -1        /* required pointer is NULL */
 #define GKG_ERR_SHAPE -2       /* non-positive / inconsistent sizes, k*dilation > M, ... */
@@ -187,6 +191,20 @@ int gkg_edge_bwd(const float* g, const float* qs, const float* qc, const int64_t
 int gkg_knn_fwd_tm(const void* x, int ldx, int xchunk, const void* y, const float* relpos, int64_t* nn_idx, int64_t* center,
                    int B, int G, int c, int N, int M, int k, int dilation, int dtype, unsigned flags,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The Grapher's fc1 BN-apply and the k-NN's token preparation in ONE pass (round 6; reference torch_vertex.py:326 fc1's BN ->
+ * torch_edge.py:167-173 F.normalize + |x|^2).  y (B N, C = G c) is fc1's pre-BN projection output whose train-mode batch
+ * statistics lie in `sums` (gkg_linear_bn_fwd_x6 with train == 2; everything about sums / a / c / mean / invstd / running
+ * statistics / zero_buf is gkg_bn_apply_train's contract with nb == 1, act == 0, no residual).  x = a y + c goes to `out` (row
+ * pitch ldo floats, 0 = C; ochunk > 0: the x half of the grouped projection's operand buffer, "XM layout") and, from the same
+ * registers, normalised into `knn_workspace`: the workspace of the k-NN call (gkg_knn_fwd_tm / gkg_knn_fwd_tm16 /
+ * gkg_knn_mr_fwd_tm — fused_mr != 0 for the latter) with the SAME B, G, c, N, M, k, dilation, presence of y / relative_pos and
+ * flags, which follows with GKG_KNN_X_PREPARED set and x = out.  Same operations in the same order per value as gkg_bn_apply_train
+ * followed by that call's own preparation: bit-identical x, graphs and aggregation. */
+int gkg_bn_apply_knn_prep(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c_out,
+                          float* mean, float* invstd, float* out, int ldo, int ochunk, int B, int G, int c, int N, int M, int k,
+                          int dilation, int has_y, int has_relpos, unsigned knn_flags, int fused_mr, void* knn_workspace,
+                          size_t knn_workspace_bytes, float momentum, float eps, double* zero_buf, size_t zero_doubles, void* stream);
 /* Pooled key set of a Grapher with r > 1 (reference torch_vertex.py:194-196, F.avg_pool2d(x, r, r)) from a token-major map
  * x (B, H, W, C) given as a view -> out (B, H/r, W/r, C) plain fp32 (floor mode; window sum in (h, w) order, one division). */
 int gkg_avgpool_tm(const float* x, int ldx, int xchunk, float* out, int B, int H, int W, int C, int r, void* stream);
