@@ -20,6 +20,7 @@ KNN_NO_PREFILTER = 16
 KNN_FORCE_PREFILTER = 32
 KNN_RELPOS_UNIT = 64
 KNN_X_PREPARED = 128
+KNN_Y_PREPARED = 256
 
 
 _RELPOS_WARNED = False
@@ -134,7 +135,7 @@ def load():
     lib.gkg_mr_fwd_tm16.restype = I
     lib.gkg_mr_fwd_tm16.argtypes = [V, I, I] + [V] * 4 + [I] * 9 + [V]
     lib.gkg_bn_apply_knn_prep.restype = I
-    lib.gkg_bn_apply_knn_prep.argtypes = [V] * 13 + [I] * 11 + [C.c_uint, I, V, Z, F, F, V, Z, V]
+    lib.gkg_bn_apply_knn_prep.argtypes = [V] * 13 + [I] * 11 + [C.c_uint, I, I, V, V, V, Z, F, F, V, Z, V]
     lib.gkg_avgpool_tm.restype = I
     lib.gkg_avgpool_tm.argtypes = [V, I, I, V, I, I, I, I, I, V]
     lib.gkg_knn_fwd_tm16.restype = I

@@ -59,8 +59,11 @@ struct PrepStrides { int G; size_t sb, sg, sc, sn; int chunk; };      // chunk >
 // affine-transformed as it is gathered, stored to `raw` (a token-major view: row pitch raw_ld, chunk raw_chunk — the x half of
 // the grouped projection's operand buffer) and normalised from the same registers: the Grapher's fc1 BN-apply and the k-NN's
 // token preparation in ONE pass over the tokens (reference torch_vertex.py:326 -> torch_edge.py:167-173).
+// res_tm / nchw (the KEYS of a label graph produced by the Grapher in front of it, reference torch_vertex.py:331 -> :392-403): the
+// pass is that Grapher's fc2 BN-apply — a y + c + res_tm[token] goes to `raw` (the token-major companion the label block reads as
+// values), to `nchw` (B, C, Tn: the block's channel-major output) and, normalised, into the label k-NN's workspace as its keys.
 struct PrepSet { const void* t; float* th; float* sq; int Tn; PrepStrides ps; uint16_t* tb; int cp16; uint16_t* tb_lo; int rows;
-                 float* raw; int raw_ld, raw_chunk; };
+                 float* raw; int raw_ld, raw_chunk; const float* res_tm; float* nchw; };
 
 // scale / shift of the group's c channels into LDS (tab[0..c) = a, tab[c..2c) = shift): derived from the column sums like every
 // BN-apply pass (gkg_common.h bn_derive_channel; the first workgroup of image 0's groups writes the saved statistics and updates the
@@ -83,13 +86,13 @@ __device__ __forceinline__ void prep_affine_table(const BnDerive& d, const float
   __syncthreads();
 }
 
-template <typename T, bool NORM, int PT>
-__global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad, BnDerive d,
-                                                        const float* __restrict__ aff_a, const float* __restrict__ aff_c) {
-  extern __shared__ float col[];          // [c][PT] (+ [2][c] scale / shift when s1.raw)
+template <typename T, bool NORM, int PT, bool PROD>
+__device__ __forceinline__ void token_prep_body(const PrepSet& s1, const PrepSet& s2, int nbx1, int c, int cpad, const BnDerive& d,
+                                                const float* __restrict__ aff_a, const float* __restrict__ aff_c) {
+  extern __shared__ float col[];          // [c][PT] (+ [2][c] scale / shift: PROD)
   const bool second = (int)blockIdx.x >= nbx1;
   const PrepSet& S = second ? s2 : s1;
-  const bool affine = !second && s1.raw != nullptr;              // uniform per workgroup
+  constexpr bool affine = PROD;                                  // a producer launch has ONE set: the BN-applied operand
   float* tab = col + (size_t)c * PT;
   if (affine) prep_affine_table(d, aff_a, aff_c, tab, c, s1.ps.G * c, blockIdx.y, s1.ps.G, PT);
   const T* __restrict__ t = static_cast<const T*>(S.t);
@@ -128,6 +131,10 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
       if (affine) {
         v.x = __builtin_fmaf(tab[q4], v.x, tab[c + q4]); v.y = __builtin_fmaf(tab[q4 + 1], v.y, tab[c + q4 + 1]);
         v.z = __builtin_fmaf(tab[q4 + 2], v.z, tab[c + q4 + 2]); v.w = __builtin_fmaf(tab[q4 + 3], v.w, tab[c + q4 + 3]);
+        if (S.res_tm) {
+          const float4 r4 = *reinterpret_cast<const float4*>(S.res_tm + ((size_t)(bg / ps.G) * Tn + n) * (size_t)(ps.G * c) + goff + q4);
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
         *reinterpret_cast<float4*>(rawp + xm_col(goff + q4, S.raw_chunk)) = v;
       }
     };
@@ -174,9 +181,11 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
     float q2p = 0.0f;
     {
       float* op = th + (size_t)bg * cpad * Tn + n;
+      float* np_ = (affine && S.nchw) ? S.nchw + ((size_t)(bg / ps.G) * (ps.G * c) + (size_t)(bg % ps.G) * c) * Tn + n : nullptr;
 #pragma unroll 8
       for (int ch = 0; ch < c; ++ch) {
         float v = cp[ch * PT];
+        if (np_) np_[(size_t)ch * Tn] = v;
         if (NORM) { v = v / den; cp[ch * PT] = v; }      // the planes below split the normalised value: one division per element
         op[(size_t)ch * Tn] = v;
         q2p = __builtin_fmaf(v, v, q2p);
@@ -228,15 +237,29 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
     return;
   }
   float* op = th + (size_t)bg * cpad * Tn + n;
+  float* np_ = (affine && S.nchw) ? S.nchw + ((size_t)(bg / ps.G) * (ps.G * c) + (size_t)(bg % ps.G) * c) * Tn + n : nullptr;
 #pragma unroll 8
   for (int ch = 0; ch < c; ++ch) {
     float v = cp[ch * PT];
+    if (np_) np_[(size_t)ch * Tn] = v;
     if (NORM) v = v / den;
     op[(size_t)ch * Tn] = v;
     q2 = __builtin_fmaf(v, v, q2);
   }
   for (int chp = c; chp < cpad; ++chp) op[(size_t)chp * Tn] = 0.0f;
   sq[(size_t)bg * Tn + n] = q2;
+}
+
+template <typename T, bool NORM, int PT>
+__global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
+  token_prep_body<T, NORM, PT, false>(s1, s2, nbx1, c, cpad, BnDerive{}, nullptr, nullptr);
+}
+// The same pass as a projection's BN-apply (PrepSet::raw): what a trace shows for the Grapher's fc1 / the label block's fc1 / the
+// Grapher's fc2 in front of a label block — one launch = BN-apply (+ residual, + both layouts) + the k-NN's token preparation
+template <bool NORM, int PT>
+__global__ __launch_bounds__(PT) void bn_apply_knn_prep_kernel(PrepSet s1, int c, int cpad, BnDerive d, const float* __restrict__ aff_a,
+                                                               const float* __restrict__ aff_c) {
+  token_prep_body<float, NORM, PT, true>(s1, s1, 0x7fffffff, c, cpad, d, aff_a, aff_c);
 }
 
 // Small problems (a few ten thousand token-groups: the 18 x 18 stages, the label graphs): one thread per token-group leaves
@@ -246,15 +269,15 @@ __global__ __launch_bounds__(PT) void token_prep_kernel(PrepSet s1, PrepSet s2, 
 // ordered norm chain of its token from LDS (no exchange), the divisions and the channel-major stores are spread over
 // 256 / TK channel lanes per token, and the ordered |th|^2 chain runs on the normalised tile.  Same operations in the same
 // order per value: bit-identical outputs.
-template <bool NORM, int TK>
-__global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad, BnDerive d,
-                                                              const float* __restrict__ aff_a, const float* __restrict__ aff_c) {
-  extern __shared__ float col[];          // [c][TK + 1] (+ [2][c] scale / shift when s1.raw)
+template <bool NORM, int TK, bool PROD>
+__device__ __forceinline__ void token_prep_coop_body(const PrepSet& s1, const PrepSet& s2, int nbx1, int c, int cpad, const BnDerive& d,
+                                                     const float* __restrict__ aff_a, const float* __restrict__ aff_c) {
+  extern __shared__ float col[];          // [c][TK + 1] (+ [2][c] scale / shift: PROD)
   constexpr int LP = TK + 1, CL = 256 / TK;      // channel lanes per token
   const int tid = threadIdx.x;
   const bool second = (int)blockIdx.x >= nbx1;
   const PrepSet& S = second ? s2 : s1;
-  const bool affine = !second && s1.raw != nullptr;              // uniform per workgroup
+  constexpr bool affine = PROD;
   float* tab = col + (size_t)c * LP;
   if (affine) prep_affine_table(d, aff_a, aff_c, tab, c, s1.ps.G * c, blockIdx.y, s1.ps.G, 256);
   const int Tn = S.Tn;
@@ -282,8 +305,14 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
         const int tok = (tid >> 4) + 16 * u;
         v[u].x = __builtin_fmaf(a4.x, v[u].x, c4.x); v[u].y = __builtin_fmaf(a4.y, v[u].y, c4.y);
         v[u].z = __builtin_fmaf(a4.z, v[u].z, c4.z); v[u].w = __builtin_fmaf(a4.w, v[u].w, c4.w);
-        if (tok < nt)
-          *reinterpret_cast<float4*>(S.raw + ((size_t)(bg / ps.G) * Tn + n0 + tok) * S.raw_ld + ro) = v[u];
+        if (tok < nt) {
+          const size_t trow = (size_t)(bg / ps.G) * Tn + n0 + tok;
+          if (S.res_tm) {
+            const float4 r4 = *reinterpret_cast<const float4*>(S.res_tm + trow * (size_t)(ps.G * c) + goff + 4 * q);
+            v[u].x += r4.x; v[u].y += r4.y; v[u].z += r4.z; v[u].w += r4.w;
+          }
+          *reinterpret_cast<float4*>(S.raw + trow * S.raw_ld + ro) = v[u];
+        }
       }
     }
 #pragma unroll
@@ -307,9 +336,11 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
   __syncthreads();                          // everyone has read the raw tile
   // ---- (3) normalise + store: channel lane cl takes channels cl, cl + CL, ...
   float* op = S.th + (size_t)bg * cpad * Tn + n0 + tok;
+  float* np_ = (affine && S.nchw && tok < nt) ? S.nchw + ((size_t)(bg / ps.G) * (ps.G * c) + (size_t)(bg % ps.G) * c) * Tn + n0 + tok : nullptr;
 #pragma unroll 4
   for (int ch = cl; ch < c; ch += CL) {
     float v = cp[ch * LP];
+    if (np_) np_[(size_t)ch * Tn] = v;                    // the block's channel-major output (coalesced along the tokens)
     if (NORM) v = v / den;
     col[ch * LP + tok] = v;
     if (tok < nt) op[(size_t)ch * Tn] = v;
@@ -324,6 +355,16 @@ __global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSe
     for (int ch = 0; ch < c; ++ch) { const float v = cp[ch * LP]; q2 = __builtin_fmaf(v, v, q2); }
     S.sq[(size_t)bg * Tn + n0 + tok] = q2;
   }
+}
+
+template <bool NORM, int TK>
+__global__ __launch_bounds__(256) void token_prep_coop_kernel(PrepSet s1, PrepSet s2, int nbx1, int c, int cpad) {
+  token_prep_coop_body<NORM, TK, false>(s1, s2, nbx1, c, cpad, BnDerive{}, nullptr, nullptr);
+}
+template <bool NORM, int TK>
+__global__ __launch_bounds__(256) void bn_apply_knn_prep_coop_kernel(PrepSet s1, int c, int cpad, BnDerive d, const float* __restrict__ aff_a,
+                                                                     const float* __restrict__ aff_c) {
+  token_prep_coop_body<NORM, TK, true>(s1, s1, 0x7fffffff, c, cpad, d, aff_a, aff_c);
 }
 
 // ------------------------------------------------------------------------------------------ split merge
@@ -472,8 +513,15 @@ static void launch_prep_pt(const PrepSet& s1, const PrepSet* s2, int BG, int c, 
   dim3 grid(nbx1 + nbx2, BG);
   const size_t lds = (size_t)c * PT * sizeof(float) + (s1.raw ? (size_t)2 * c * sizeof(float) : 0);
   const PrepSet second = s2 ? *s2 : s1;
-  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
-  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
+  if (s1.raw) {                                  // BN-apply producer: fp32 tokens, one set
+    if constexpr (sizeof(T) == 4) {
+      if (norm) hipLaunchKernelGGL((bn_apply_knn_prep_kernel<true, PT>), grid, dim3(PT), lds, st, s1, c, cpad, pa.d, pa.a, pa.c);
+      else hipLaunchKernelGGL((bn_apply_knn_prep_kernel<false, PT>), grid, dim3(PT), lds, st, s1, c, cpad, pa.d, pa.a, pa.c);
+    }
+    return;
+  }
+  if (norm) hipLaunchKernelGGL((token_prep_kernel<T, true, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
+  else hipLaunchKernelGGL((token_prep_kernel<T, false, PT>), grid, dim3(PT), lds, st, s1, second, nbx1, c, cpad);
 }
 
 template <int TK>
@@ -483,8 +531,13 @@ static void launch_prep_coop(const PrepSet& s1, const PrepSet* s2, int BG, int c
   dim3 grid(nbx1 + nbx2, BG);
   const size_t lds = (size_t)c * (TK + 1) * sizeof(float) + (s1.raw ? (size_t)2 * c * sizeof(float) : 0);
   const PrepSet second = s2 ? *s2 : s1;
-  if (norm) hipLaunchKernelGGL((token_prep_coop_kernel<true, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
-  else hipLaunchKernelGGL((token_prep_coop_kernel<false, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad, pa.d, pa.a, pa.c);
+  if (s1.raw) {
+    if (norm) hipLaunchKernelGGL((bn_apply_knn_prep_coop_kernel<true, TK>), grid, dim3(256), lds, st, s1, c, cpad, pa.d, pa.a, pa.c);
+    else hipLaunchKernelGGL((bn_apply_knn_prep_coop_kernel<false, TK>), grid, dim3(256), lds, st, s1, c, cpad, pa.d, pa.a, pa.c);
+    return;
+  }
+  if (norm) hipLaunchKernelGGL((token_prep_coop_kernel<true, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad);
+  else hipLaunchKernelGGL((token_prep_coop_kernel<false, TK>), grid, dim3(256), lds, st, s1, second, nbx1, c, cpad);
 }
 
 static bool prep_coop_ok(const PrepSet& s) {       // fp32 token-major rows of whole float4s, fp32 channel-major output
@@ -509,7 +562,7 @@ static hipError_t launch_prep(const PrepSet& s1, const PrepSet* s2, int BG, int 
 }
 
 // The queries' BN-apply riding in their preparation pass (gkg_bn_apply_knn_prep)
-struct KnnProducer { PrepAffine aff; float* raw; int raw_ld, raw_chunk; };
+struct KnnProducer { PrepAffine aff; float* raw; int raw_ld, raw_chunk; int as_keys; const float* res_tm; float* nchw; };
 
 // Fused aggregation request of gkg_knn_mr_fwd_tm (token-major fp32 callers): outputs of knn_tile_kernel<..., MRF = true>.
 struct KnnMrFuse {
@@ -535,7 +588,9 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   // exactly where the k-NN call with the same arguments + GKG_KNN_X_PREPARED expects them (same plan, same decisions: this IS that
   // call up to its preparation launch); y / relpos / mr are only tested for presence.
   const bool prep_only = prod != nullptr;
-  const bool x_prepared = (flags & GKG_KNN_X_PREPARED) != 0;
+  const bool x_prepared = (flags & GKG_KNN_X_PREPARED) != 0, y_prepared = (flags & GKG_KNN_Y_PREPARED) != 0;
+  if (y_prepared && (!y || prep_only || G_tm <= 0 || dtype != GKG_F32 || (c & 3)))
+    return gkg_fail(GKG_ERR_SHAPE, "GKG_KNN_Y_PREPARED: a token-major fp32 k-NN call with keys");
   if (prep_only && x_prepared) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: GKG_KNN_X_PREPARED makes no sense here");
   if ((prep_only || x_prepared) && (G_tm <= 0 || dtype != GKG_F32 || (c & 3)))
     return gkg_fail(GKG_ERR_UNSUPPORTED, "prepared queries: token-major fp32 callers with c % 4 == 0 only");
@@ -630,19 +685,25 @@ static int knn_fwd_impl(const void* x, const void* y, const float* relpos, int64
   }
   uint16_t* xpl = (uint16_t*)(ws + p.off_xp);
   uint16_t* ypl = (uint16_t*)(ws + p.off_yp);
+  const bool pq = prod && !prod->as_keys, pk = prod && prod->as_keys;
   const PrepSet sx{x, xh, sqx, N, strides(N, ldx, xchunk), pf ? xpl : (bf ? (uint16_t*)xh : nullptr), pf ? cp16p : cp16,
                    pf ? xpl + (size_t)BG * Nr * cp16p : nullptr, Nr,
-                   prod ? prod->raw : nullptr, prod ? prod->raw_ld : 0, prod ? prod->raw_chunk : 0};
-  const PrepSet sy{y, yh, sqy, M, strides(M, G_tm * c, 0), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), pf ? cp16p : cp16,
-                   pf ? ypl + (size_t)BG * Mr * cp16p : nullptr, Mr, nullptr, 0, 0};
-  if (prep_only) {                               // the queries only (with their BN-apply); the keys belong to the k-NN call
+                   pq ? prod->raw : nullptr, pq ? prod->raw_ld : 0, pq ? prod->raw_chunk : 0, nullptr, nullptr};
+  // (a keys producer reads its pre-BN input through `x`: the presence-only `y` is a dummy there)
+  const PrepSet sy{pk ? x : y, yh, sqy, M, strides(M, G_tm * c, 0), pf ? ypl : (bf ? (uint16_t*)yh : nullptr), pf ? cp16p : cp16,
+                   pf ? ypl + (size_t)BG * Mr * cp16p : nullptr, Mr,
+                   pk ? prod->raw : nullptr, pk ? prod->raw_ld : 0, pk ? prod->raw_chunk : 0, pk ? prod->res_tm : nullptr,
+                   pk ? prod->nchw : nullptr};
+  if (prep_only) {                               // ONE operand (with its BN-apply): the other belongs to its own producer / the k-NN call
     if (bf) return gkg_fail(GKG_ERR_UNSUPPORTED, "gkg_bn_apply_knn_prep: not with the bf16 contraction");
-    e = launch_prep<float>(sx, nullptr, BG, c, p.cpad, norm, st, prod->aff);
+    if (pk && !y) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: a keys producer needs a k-NN problem with keys");
+    e = launch_prep<float>(pk ? sy : sx, nullptr, BG, c, p.cpad, norm, st, prod->aff);
     return e == hipSuccess ? 0 : gkg_fail_hip(e, "token_prep (BN-apply producer)");
   }
-  if (x_prepared) {                              // the queries' copies are in place (gkg_bn_apply_knn_prep): keys only, if any
-    if (bf) return gkg_fail(GKG_ERR_UNSUPPORTED, "GKG_KNN_X_PREPARED: not with the bf16 contraction");
-    e = y ? launch_prep<float>(sy, nullptr, BG, c, p.cpad, norm, st) : hipSuccess;
+  if (x_prepared || y_prepared) {                // copies already in place (gkg_bn_apply_knn_prep): only what is missing
+    if (bf) return gkg_fail(GKG_ERR_UNSUPPORTED, "GKG_KNN_X/Y_PREPARED: not with the bf16 contraction");
+    if (!x_prepared) e = launch_prep<float>(sx, nullptr, BG, c, p.cpad, norm, st);
+    else e = (y && !y_prepared) ? launch_prep<float>(sy, nullptr, BG, c, p.cpad, norm, st) : hipSuccess;
   }
   else if (dtype == GKG_F32) e = launch_prep<float>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
   else if (dtype == GKG_F16) e = launch_prep<_Float16>(sx, y ? &sy : nullptr, BG, c, p.cpad, norm, st);
@@ -820,10 +881,13 @@ extern "C" int gkg_bn_apply_knn_prep(const float* y, const double* sums, const f
                                      float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c_out,
                                      float* mean, float* invstd, float* out, int ldo, int ochunk, int B, int G, int c, int N, int M,
                                      int k, int dilation, int has_y, int has_relpos, unsigned knn_flags, int fused_mr,
+                                     int as_keys, const float* res_tm, float* out_nchw,
                                      void* knn_workspace, size_t knn_workspace_bytes, float momentum, float eps, double* zero_buf,
                                      size_t zero_doubles, void* stream) {
   if (!y || !sums || !gamma || !beta || !a || !c_out || !mean || !invstd || !out || !knn_workspace)
     return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_knn_prep: null pointer");
+  if (!as_keys && (res_tm || out_nchw)) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: res_tm / out_nchw belong to a keys producer");
+  if (as_keys && (!has_y || ochunk != 0 || ((size_t)res_tm & 15))) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: a keys producer writes plain rows for a problem with keys");
   if ((running_mean == nullptr) != (running_var == nullptr)) return gkg_fail(GKG_ERR_NULL, "gkg_bn_apply_knn_prep: running stats come in pairs");
   if (B <= 0 || G <= 0 || c <= 0 || (c & 3) || N <= 0) return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: bad sizes (c % 4 == 0)");
   const int C = G * c;
@@ -832,9 +896,10 @@ extern "C" int gkg_bn_apply_knn_prep(const float* y, const double* sums, const f
       (zero_doubles && !zero_buf))
     return gkg_fail(GKG_ERR_SHAPE, "gkg_bn_apply_knn_prep: bad output view");
   KnnProducer prod{};
-  prod.aff.d = BnDerive{sums, gamma, beta, bias, running_mean, running_var, num_batches_tracked, a, c_out, mean, invstd, B * N, momentum,
-                        eps, zero_buf, zero_doubles};
+  prod.aff.d = BnDerive{sums, gamma, beta, bias, running_mean, running_var, num_batches_tracked, a, c_out, mean, invstd,
+                        B * (as_keys ? M : N), momentum, eps, zero_buf, zero_doubles};
   prod.raw = out; prod.raw_ld = ldo; prod.raw_chunk = ochunk;
+  prod.as_keys = as_keys ? 1 : 0; prod.res_tm = res_tm; prod.nchw = out_nchw;
   static const float dummy = 0.f;
   static KnnMrFuse mr_dummy{nullptr, nullptr, nullptr};
   return knn_fwd_impl(y, has_y ? &dummy : nullptr, has_relpos ? &dummy : nullptr, nullptr, nullptr, B * G, c, N, M, k, dilation, GKG_F32,

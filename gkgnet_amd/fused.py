@@ -597,12 +597,16 @@ def _train_apply_from_sums(lib, x, W, bias, bn, R, cin, cout, nb, planes, res, o
         _touch_stats(bn, track)
         if knn_prep is not None:         # the apply pass is also the k-NN's token preparation (gkg_bn_apply_knn_prep): knn_prep = _KnnKey
             kp = knn_prep
-            kp.ws = _ws(lib.gkg_knn_workspace_bytes(kp.B * kp.G, kp.c, kp.N, kp.M, kp.k, kp.d, _lib.F32, _lib.KNN_NORMALIZE), dev)
+            if kp.ws is None:            # (a label block's fc1 prepares its queries into the workspace the keys already live in)
+                kp.ws = _ws(lib.gkg_knn_workspace_bytes(kp.B * kp.G, kp.c, kp.N, kp.M, kp.k, kp.d, _lib.F32, _lib.KNN_NORMALIZE), dev)
             _lib.check(lib.gkg_bn_apply_knn_prep(_ptr(Y), _ptr(cur), _ptr(bn.weight), _ptr(bn.bias), _ptr(bias),
                                                  _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
                                                  _ptr(bn.num_batches_tracked) if track else None, _ptr(a), _ptr(c), _ptr(mean),
-                                                 _ptr(invstd), _ptr(out), ldo, ochunk, kp.B, kp.G, kp.c, kp.N, kp.M, kp.k, kp.d,
-                                                 kp.has_y, kp.has_rp, kp.flags, kp.fused_mr, _ptr(kp.ws), kp.ws.numel(),
+                                                 _ptr(invstd), _ptr(out_tm if kp.as_keys else out), 0 if kp.as_keys else ldo,
+                                                 0 if kp.as_keys else ochunk, kp.B, kp.G, kp.c, kp.N, kp.M, kp.k, kp.d, kp.has_y,
+                                                 kp.has_rp, kp.flags, kp.fused_mr, kp.as_keys,
+                                                 _ptr(res) if kp.as_keys else None, _ptr(out) if kp.as_keys else None,
+                                                 _ptr(kp.ws), kp.ws.numel(),
                                                  float(bn.momentum), float(bn.eps), _ptr(other), zero, _stream()),
                        "gkg_bn_apply_knn_prep")
         elif out_tm is not None:         # channel-major AND token-major result, residual token-major (gkg_bn_apply_train_dual)
@@ -804,7 +808,9 @@ class _LinearBNAct(torch.autograd.Function):
             Y, a, c, mean, invstd = _train_apply_from_sums(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, pf, res, out,
                                                            ldo, 0, act, 0 if nchw is None else nchw[0], scale, rows_per_scale,
                                                            out_tm=out_tm, ochunk=ochunk,
-                                                           knn_prep=knn if (xm is not None and act == 0 and scale is None) else None)
+                                                           knn_prep=knn if (act == 0 and scale is None and
+                                                                            ((xm is not None and not knn.as_keys) or (dual and knn.as_keys))
+                                                                            if knn is not None else False) else None)
         elif own:                                     # projection kernel with the BN statistics in its epilogue
             Y, a, c, mean, invstd = _linear_fwd_own(lib, x, W.contiguous(), bias, bn, R, cin, cout, 1, planes=pf)
         else:
@@ -845,6 +851,8 @@ class _LinearBNAct(torch.autograd.Function):
             return out, x.view_as(x)
         if dual:
             ctx.set_materialize_grads(False)
+            if knn is not None and knn.as_keys and fused_apply and knn.ws is not None:
+                out_tm._gkg_knn_keys = knn       # the label graph's keys are prepared in knn.ws (grapher_label_forward)
             return out, out_tm
         return out
 
@@ -1229,13 +1237,18 @@ def _as_tokens(x):
 class _KnnKey:
     """One k-NN problem as the C entry points see it: what gkg_bn_apply_knn_prep (the producer of the queries) and the k-NN call
     must agree on for the prepared queries in ``ws`` to be THAT call's (same workspace plan, same kernel choice)."""
-    __slots__ = ("B", "G", "c", "N", "M", "k", "d", "has_y", "has_rp", "flags", "fused_mr", "ws")
+    __slots__ = ("B", "G", "c", "N", "M", "k", "d", "has_y", "has_rp", "flags", "fused_mr", "ws", "as_keys", "y_ready")
 
     def __init__(self, B, G, c, N, M, k, d, has_y, relative_pos, fused_mr):
         self.B, self.G, self.c, self.N, self.M, self.k, self.d = B, G, c, N, M, k, d
         self.has_y, self.has_rp, self.fused_mr = int(bool(has_y)), int(relative_pos is not None), int(bool(fused_mr))
         self.flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
         self.ws = None
+        self.as_keys = 0         # 1: this producer call prepares the problem's KEYS (a Grapher's fc2 in front of a GrapherLabel)
+        self.y_ready = False     # the keys' copies are already in ``ws`` (the k-NN call then sets GKG_KNN_Y_PREPARED)
+
+    def tuple(self):
+        return (self.B, self.G, self.c, self.N, self.M, self.k, self.d, self.has_y, self.has_rp, self.flags, self.fused_mr)
 
     def same(self, B, G, c, N, M, k, d, has_y, has_rp, flags, fused_mr) -> bool:
         return ((self.B, self.G, self.c, self.N, self.M, self.k, self.d, self.has_y, self.has_rp, self.flags, self.fused_mr)
@@ -1247,7 +1260,7 @@ def _knn_prepared(x, B, G, c, N, M, k, d, has_y, has_rp, flags, fused_mr):
     copies for exactly this problem (fc1's BN-apply left them: _LinearBNAct ``knn``), else a fresh workspace."""
     key = getattr(x, "_gkg_knn", None)
     if key is not None and key.ws is not None and key.same(B, G, c, N, M, k, d, has_y, has_rp, flags, fused_mr) and not (flags & _lib.KNN_BF16_CONTRACT):
-        return key.ws, flags | _lib.KNN_X_PREPARED
+        return key.ws, flags | _lib.KNN_X_PREPARED | (_lib.KNN_Y_PREPARED if key.y_ready else 0)
     return _ws(_lib.load().gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), x.device), flags
 
 
@@ -1636,8 +1649,18 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
         out = _lin(a2, mod.fc2, residual=x, scale=scale, rows_per_scale=N, want16=lp)
         return _cl_out(out, B, H, W), edge
     if dual:
-        out, out_tm = _lin(a2, mod.fc2, residual=xt_r, nchw=(B, C, H, W), dual=True)
+        # ... and, once the label block behind has said which k-NN problem it solves over this map (_gkg_label_knn), the same pass
+        # prepares that problem's KEYS (gkg_bn_apply_knn_prep as_keys): the label graph launches no token preparation at all
+        lk = getattr(mod, "_gkg_label_knn", None) if KNN_PREP else None
+        kk = None
+        if lk is not None and knn_graph_tm is _KNN_GRAPH_TM and not (KNN_BF16 and torch.is_autocast_enabled()):
+            G2, L2, k2, d2, fm2 = lk
+            if C % G2 == 0 and (C // G2) % 4 == 0:
+                kk = _KnnKey(B, G2, C // G2, L2, N, k2, d2, True, None, fm2)
+                kk.as_keys = 1
+        out, out_tm = _lin(a2, mod.fc2, residual=xt_r, nchw=(B, C, H, W), dual=True, knn=kk)
         out._gkg_tm = (out._version, out_tm)                        # the token-major companion (grapher_label_forward)
+        out._gkg_producer = weakref.ref(mod)
         return out, edge
     out = _lin(a2, mod.fc2, residual=x, nchw=(B, C, H, W), scale=scale)      # ... back to NCHW
     if DUAL_LAYOUT:
@@ -1650,11 +1673,13 @@ def grapher_label_forward(mod, e, features, groups: int):
     B, L, C = e.shape
     gc = mod.graph_conv
     ent = getattr(features, "_gkg_tm", None)
+    keys_key = None
     if is_channels_last(features):                                           # keys / values (B, HW, C): a view
         ft = features.permute(0, 2, 3, 1).reshape(B, -1, C)
     elif (DUAL_LAYOUT and ent is not None and ent[0] == features._version and features.dim() == 4 and features.dtype == _F32
           and ent[1].shape == (B * features.shape[2] * features.shape[3], C)):
         ft = ent[1].view(B, -1, C)                                           # the producing block's token-major companion
+        keys_key = getattr(ent[1], "_gkg_knn_keys", None)                    # ... which may carry this graph's prepared keys
     else:
         prod = getattr(features, "_gkg_producer", None)
         if prod is not None and prod() is not None:
@@ -1665,6 +1690,13 @@ def grapher_label_forward(mod, e, features, groups: int):
     xm = (B, L) if (XM_DIRECT and not lp and not torch.is_autocast_enabled() and C % 16 == 0) else None
     ftc = ft.contiguous()
     knn = _knn_key_for(B, L, C, ftc.shape[1], True, None, gc, groups, lp, True) if (xm is not None and KNN_PREP) else None
+    if knn is not None:
+        kk = keys_key
+        if kk is not None and kk.ws is not None and kk.tuple() == knn.tuple():      # the producing Grapher prepared the keys: its
+            knn.ws, knn.y_ready = kk.ws, True                                        # workspace is this call's
+        prod = getattr(features, "_gkg_producer", None)
+        if prod is not None and prod() is not None:
+            prod()._gkg_label_knn = (groups, L, gc.k, gc.d, knn.fused_mr)            # ... from its next call on
     x1, e2r = _lin(e2, mod.fc1, alias=True, xm=xm, knn=knn)          # e2r: e2 again, for the residual of fc2 (one gradient node)
     x1b = x1 if xm is not None else x1.view(B, L, C)
     a2, edge = _graph_and_project(x1b, ftc, None, gc, groups, C, lp, True)      # GrapherLabel returns its graph

@@ -70,6 +70,8 @@ extern "C" {
 #define GKG_KNN_X_PREPARED 128u     /* token-major fp32 callers: the queries' normalised copies / norms (/ prefilter planes) are already
                                     * in `workspace`, left there by gkg_bn_apply_knn_prep called with the same problem — the call
                                     * launches no preparation for them (none at all for a self graph) */
+#define GKG_KNN_Y_PREPARED 256u     /* likewise for the KEYS (gkg_bn_apply_knn_prep with as_keys: a label graph's keys, produced by the
+                                    * Grapher in front of it) */
 
 /* argument errors */
 #define GKG_ERR_NULL -1        /* required pointer is NULL */
@@ -199,12 +201,18 @@ int gkg_knn_fwd_tm(const void* x, int ldx, int xchunk, const void* y, const floa
  * registers, normalised into `knn_workspace`: the workspace of the k-NN call (gkg_knn_fwd_tm / gkg_knn_fwd_tm16 /
  * gkg_knn_mr_fwd_tm — fused_mr != 0 for the latter) with the SAME B, G, c, N, M, k, dilation, presence of y / relative_pos and
  * flags, which follows with GKG_KNN_X_PREPARED set and x = out.  Same operations in the same order per value as gkg_bn_apply_train
- * followed by that call's own preparation: bit-identical x, graphs and aggregation. */
+ * followed by that call's own preparation: bit-identical x, graphs and aggregation.
+ * as_keys != 0 — the KEYS of the problem instead (a GrapherLabel's keys are the feature map a Grapher in front of it returns,
+ * torch_vertex.py:331 -> :392-403): y (B M, C) is that Grapher's fc2 pre-BN output, res_tm (B M, C) or NULL its token-major
+ * residual; a y + c + res_tm goes to `out` (B M, C) plain (the token-major companion the label block gathers its values from), to
+ * out_nchw (B, C, M) or NULL (the block's channel-major result) and, normalised, into the keys' part of the label call's workspace;
+ * that call then sets GKG_KNN_Y_PREPARED (and GKG_KNN_X_PREPARED when its own fc1 prepared the queries into the same workspace). */
 int gkg_bn_apply_knn_prep(const float* y, const double* sums, const float* gamma, const float* beta, const float* bias,
                           float* running_mean, float* running_var, long long* num_batches_tracked, float* a, float* c_out,
                           float* mean, float* invstd, float* out, int ldo, int ochunk, int B, int G, int c, int N, int M, int k,
-                          int dilation, int has_y, int has_relpos, unsigned knn_flags, int fused_mr, void* knn_workspace,
-                          size_t knn_workspace_bytes, float momentum, float eps, double* zero_buf, size_t zero_doubles, void* stream);
+                          int dilation, int has_y, int has_relpos, unsigned knn_flags, int fused_mr, int as_keys, const float* res_tm,
+                          float* out_nchw, void* knn_workspace, size_t knn_workspace_bytes, float momentum, float eps, double* zero_buf,
+                          size_t zero_doubles, void* stream);
 /* Pooled key set of a Grapher with r > 1 (reference torch_vertex.py:194-196, F.avg_pool2d(x, r, r)) from a token-major map
  * x (B, H, W, C) given as a view -> out (B, H/r, W/r, C) plain fp32 (floor mode; window sum in (h, w) order, one division). */
 int gkg_avgpool_tm(const float* x, int ldx, int xchunk, float* out, int B, int H, int W, int C, int r, void* stream);

@@ -62,8 +62,8 @@ def test_prepared_queries_give_identical_bits(case):
             _lib.check(lib.gkg_bn_apply_knn_prep(Y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, rm.data_ptr(),
                                                  rv.data_ptr(), nbt.data_ptr(), a.data_ptr(), cs.data_ptr(), mean.data_ptr(),
                                                  invstd.data_ptr(), out.data_ptr(), ld, chunk, B, G, c, N, Mk, k, d,
-                                                 0 if y is None else 1, 1 if relpos else 0, flags, fused_mr, ws.data_ptr(), wsb,
-                                                 0.1, 1e-5, None, 0, None), "gkg_bn_apply_knn_prep")
+                                                 0 if y is None else 1, 1 if relpos else 0, flags, fused_mr, 0, None, None,
+                                                 ws.data_ptr(), wsb, 0.1, 1e-5, None, 0, None), "gkg_bn_apply_knn_prep")
             f |= _lib.KNN_X_PREPARED
         else:
             _lib.check(lib.gkg_bn_apply_train(Y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, rm.data_ptr(),
@@ -147,3 +147,89 @@ def test_blocks_identical_bits_and_fewer_preparation_launches(r, monkeypatch):
         assert torch.allclose(u, v, rtol=1e-4, atol=1e-3)            # weight gradients: atomically accumulated (run-dependent order)
     for u, v in zip(a[6], b[6]):
         assert torch.equal(u, v)
+
+
+def test_keys_producer_matches_apply_dual_plus_own_preparation():
+    """as_keys: a Grapher's fc2 BN-apply (+ token-major residual, both output layouts) that also prepares the KEYS of the label graph
+    behind it, against gkg_bn_apply_train_dual followed by the label call's own preparation — same bits everywhere."""
+    from gkgnet_amd import _lib
+    lib = _lib.load()
+    for (B, G, c, L, M, k) in [(32, 4, 80, 80, 324, 9), (3, 2, 40, 80, 1296, 9), (2, 2, 32, 20, 5184, 9)]:
+        C = G * c
+        Y, sums, gamma, beta = _setup(B, G, c, M, 3 * M + c)
+        g = torch.Generator(device="cuda").manual_seed(M)
+        res = torch.randn(B * M, C, device="cuda", generator=g)
+        xq = torch.randn(B, L, C, device="cuda", generator=g)                     # the label queries
+        flags = _lib.KNN_NORMALIZE
+        fused_mr = lib.gkg_knn_mr_fused_supported(B, G, c, L, M, k, 1, 1, 0, flags)
+        wsb = lib.gkg_knn_workspace_bytes(B * G, c, L, M, k, 1, _lib.F32, _lib.KNN_NORMALIZE)
+
+        def run(producer):
+            nchw = torch.full((B, C, M), float("nan"), device="cuda")
+            tm = torch.full((B * M, C), float("nan"), device="cuda")
+            a, cs, mean, invstd = _bn_outs(C)
+            ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+            f = flags
+            if producer:
+                _lib.check(lib.gkg_bn_apply_knn_prep(Y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, None,
+                                                     None, a.data_ptr(), cs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), tm.data_ptr(),
+                                                     0, 0, B, G, c, L, M, k, 1, 1, 0, flags, fused_mr, 1, res.data_ptr(), nchw.data_ptr(),
+                                                     ws.data_ptr(), wsb, 0.1, 1e-5, None, 0, None), "gkg_bn_apply_knn_prep (keys)")
+                f |= _lib.KNN_Y_PREPARED
+            else:
+                _lib.check(lib.gkg_bn_apply_train_dual(Y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, None,
+                                                       None, a.data_ptr(), cs.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                       res.data_ptr(), nchw.data_ptr(), tm.data_ptr(), B, C, M, 0.1, 1e-5, None, 0, None),
+                           "gkg_bn_apply_train_dual")
+            nn16 = torch.empty((B * G, L, k), dtype=torch.int16, device="cuda")
+            _lib.check(lib.gkg_knn_fwd_tm16(xq.data_ptr(), 0, 0, tm.data_ptr(), None, nn16.data_ptr(), B, G, c, L, M, k, 1, _lib.F32, f,
+                                            ws.data_ptr(), wsb, None), "gkg_knn_fwd_tm16")
+            torch.cuda.synchronize()
+            return dict(nchw=nchw, tm=tm, a=a, c=cs, mean=mean, invstd=invstd, nn16=nn16)
+
+        r0, r1 = run(False), run(True)
+        for key in r0:
+            t0, t1 = r0[key], r1[key]
+            same = torch.equal(t0.view(torch.int32), t1.view(torch.int32)) if t0.dtype == torch.float32 else torch.equal(t0, t1)
+            assert same, (B, G, c, L, M, key)
+
+
+def test_second_step_prepares_the_label_keys_in_the_grapher(monkeypatch):
+    """Two steps of Grapher -> GrapherLabel: from the second step on (after the label block has told its producer which k-NN it
+    solves) the Grapher's last pass prepares the label graph's keys, the label block's fc1 its queries — no stand-alone token
+    preparation launch anywhere — and nothing changes in the results."""
+    from gkgnet_amd import fused, _lib
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+
+    def two_steps(prep):
+        monkeypatch.setattr(fused, "KNN_PREP", prep)
+        torch.manual_seed(5)
+        C, H, L, B = 64, 12, 20, 48
+        g = Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=True, use_multi_group=True,
+                    num_group=2).cuda().train()
+        gl = GrapherLabel(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=False, num_nodes=L,
+                          use_multi_group=True, num_group=2).cuda().train()
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        outs = []
+        for step in range(2):
+            x = torch.randn(B, C, H, H, device="cuda", generator=gen).requires_grad_(True)
+            e = torch.randn(B, L, C, device="cuda", generator=gen).requires_grad_(True)
+            cx, ce = torch.randn(B, C, H, H, device="cuda", generator=gen), torch.randn(B, L, C, device="cuda", generator=gen)
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            out = g(x)
+            e2, edge = gl(e, out)
+            torch.autograd.backward([out, e2], [cx, ce])
+            torch.cuda.synchronize()
+            _lib.prof_enable(False)
+            outs.append((_lib.prof_read()["token_prep"][1], out.detach().clone(), e2.detach().clone(), edge.clone(), x.grad.clone(),
+                         e.grad.clone()))
+        return outs
+
+    on, off = two_steps(True), two_steps(False)
+    assert [o[0] for o in off] == [2, 2]
+    # step 1: fc1 producer (Grapher), fc1 producer (label) + the label keys' own launch; step 2: three producers, each one a BN-apply
+    assert [o[0] for o in on] == [3, 3]
+    for a, b in zip(on, off):
+        for u, v in zip(a[1:], b[1:]):
+            assert torch.equal(u, v)
