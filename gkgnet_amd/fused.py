@@ -184,8 +184,9 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) ->
         return False
     task_id = getattr(torch._C, "_current_graph_task_id", None)
     task = task_id() if task_id is not None else -1
-    if task < 0:
-        return False                     # not inside a backward pass (or a torch without the query): nobody would flush
+    if task < 0 or torch.is_grad_enabled():
+        return False                     # not inside a backward pass (nobody would flush), or one that builds a graph (create_graph:
+                                         # autograd clones what the node returns)
     # a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 layers: thousands of 128-row units) keeps its
     # stand-alone slabs inside a batch anyway (csrc x6_wgrad_plan): launching it from the node costs nothing and frees its operands
     tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
@@ -208,6 +209,9 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) ->
         out.zero_()
     q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm))
     q.keep.append((dY, x))
+    owner = getattr(out, "_gkg_owner", None)
+    if owner is not None:
+        owner._gkg_deferred = True       # the slot, not p.grad, holds this gradient until the batch has run (GradBucket._resident)
     q.bytes += (dY.numel() + x.numel()) * 4
     if len(q.items) >= q.MAX or q.bytes > q.MAX_BYTES:
         items, q.items = q.items, []

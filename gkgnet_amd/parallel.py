@@ -135,6 +135,7 @@ class GradBucket:
         for p in self.params:
             p.grad = None
             p._gkg_handed = False
+            p._gkg_deferred = False
             p._gkg_clean = prezero
         if prezero:
             # inside a captured step the clear rides in the step's first launch (the weight-plane refresh: planes.defer_zero)
@@ -147,14 +148,24 @@ class GradBucket:
 
     def _resident(self, p) -> bool:
         g = p.grad
-        return g is not None and g.data_ptr() == self.flat.data_ptr() + self._offset[p] * self.flat.element_size() \
-            and g.is_contiguous()
+        if g is not None and g.data_ptr() == self.flat.data_ptr() + self._offset[p] * self.flat.element_size() and g.is_contiguous():
+            return True
+        if getattr(p, "_gkg_deferred", False):
+            # the batched weight-gradient launch wrote THIS slot after the backward node had returned its view; if autograd did not
+            # adopt that view as p.grad (it cloned: extra references, a hook that replaced the tensor), p.grad is a copy of the
+            # still-zero slot and copying it back would wipe the real gradient: the slot is the truth
+            p.grad = self._view(p)
+            return True
+        return False
 
     def pack(self):
         """Bring every gradient into the flat bucket: gradients the fused kernels already wrote in place are left alone,
         the others are copied with one batched copy; parameters without a gradient get zeros.  Re-points ``p.grad`` at
         the bucket views."""
         flush_pending_grads()
+        if _ZERO_DEFER:
+            _ZERO_DEFER[1]()             # a clear handed to a weight-plane refresh that never ran (no x6 projection, no gradient slot
+                                         # taken in this step): nothing has been written yet, so it is still correct to clear now
         src, dst, zero = [], [], []
         for p in self.params:
             if self._resident(p):
@@ -183,6 +194,8 @@ class GradBucket:
         (chunk i only after chunks 0..i-1), whatever order the hooks fired in — ranks whose backward completes the
         chunks in different orders (unused parameters on some ranks) still issue identical collective sequences."""
         while self._issued < len(self.chunks) and (upto_all or self._issued in self._complete):
+            if _ZERO_DEFER:
+                _ZERO_DEFER[1]()
             if world > 1:
                 flush_pending_grads()             # weight gradients queued for the batched launch: this chunk is about to be read
             start, end, plist = self.chunks[self._issued]
@@ -271,6 +284,7 @@ def grad_view(p: torch.nn.Parameter, shape=None):
     v = flat[o:o + p.numel()]
     v = v.view(p.shape if shape is None else shape)
     v._gkg_slot = True                            # a bucket slot: kernels may fill it after the backward node has returned it
+    v._gkg_owner = p                              # (fused._wgrad_defer marks the parameter: see GradBucket._resident)
     if getattr(p, "_gkg_clean", False):           # zeroed by release(prezero=True) and not written since
         p._gkg_clean = False
         v._gkg_zero = True

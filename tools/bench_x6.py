@@ -51,7 +51,7 @@ def planes(w, nb, cout, cin):
     pf = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 0), dtype=torch.uint8, device="cuda")
     pd = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, nb, 1), dtype=torch.uint8, device="cuda")
     host = ctypes.create_string_buffer(lib.gkg_x6_prep_desc_bytes())
-    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), pd.data_ptr(), cin, cout, nb, 0)
+    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), pd.data_ptr(), cin, cout, nb, 0, 0)
     descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).cuda()
     _lib.check(lib.gkg_x6_prep_weights(descs.data_ptr(), 1, units, None), "prep")
     return pf, pd
@@ -66,7 +66,7 @@ for R, cin, cout, nb in SHAPES:
     dw = torch.zeros(nb, cout, cin, device="cuda")
     vw = 0.0 if X6_ONLY else timeit(lambda: fused._wgrad(dy[0], x[0]) if nb == 1 else fused._wgrad_grouped(dy, x))
     xw = timeit(lambda: (dw.zero_(), lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(),
-                                                              R, cin, cout, nb, st())))
+                                                              R, cin, cout, nb, 0, st())))
     print(f"R={R:6d} {cin:4d}->{cout:4d} nb={nb}: wgrad vendor (split-K bmm) {vw:6.1f}  x6 (incl. memset) {xw:6.1f}", flush=True)
     if WGRAD_ONLY:
         continue

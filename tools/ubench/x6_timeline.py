@@ -35,7 +35,7 @@ PHASES = ["issue DMA", "wait 1st stage", "K loop", "stores issued", "stores done
 def planes(w, cout, cin):
     pf = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, 1, 0), dtype=torch.uint8, device="cuda")
     host = ctypes.create_string_buffer(lib.gkg_x6_prep_desc_bytes())
-    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), None, cin, cout, 1, 0)
+    units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), None, cin, cout, 1, 0, 0)
     descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).cuda()
     _lib.check(lib.gkg_x6_prep_weights(descs.data_ptr(), 1, units, None), "prep")
     return pf

@@ -27,7 +27,7 @@ def run():
         y = torch.empty(R, cout, device="cuda")
         pf = torch.empty(lib.gkg_x6_planes_bytes(cin, cout, 1, 0), dtype=torch.uint8, device="cuda")
         host = ctypes.create_string_buffer(lib.gkg_x6_prep_desc_bytes())
-        units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), None, cin, cout, 1, 0)
+        units = lib.gkg_x6_prep_desc_fill(host, 0, w.data_ptr(), pf.data_ptr(), None, cin, cout, 1, 0, 0)
         descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).cuda()
         _lib.check(lib.gkg_x6_prep_weights(descs.data_ptr(), 1, units, None), "prep")
         for _ in range(3):
@@ -41,7 +41,7 @@ def run():
             flush.add_(1.0)
             dw.zero_()
             _lib.check(lib.gkg_linear_wgrad_x6(dy.data_ptr(), cout, R * cout, x.data_ptr(), cin, R * cin, dw.data_ptr(), R, cin, cout,
-                                               1, None), "wgrad")
+                                               1, 0, None), "wgrad")
         torch.cuda.synchronize()
 
 
