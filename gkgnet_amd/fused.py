@@ -175,23 +175,17 @@ _parallel._FLUSH.append(flush_wgrads)
 _parallel._ZERO_DEFER[:] = [_planes_mod.defer_zero, _planes_mod.flush_deferred_zero]
 
 
-def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) -> bool:
-    """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
-    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6"
-            and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
-            and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
-            and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
-        return False
+def _wq_task() -> int:
+    """Id of the backward pass this thread is executing (-1: none — nobody would flush a queue —, or one that builds a graph:
+    create_graph makes autograd clone what a node returns, so a slot filled later would never reach p.grad)."""
     task_id = getattr(torch._C, "_current_graph_task_id", None)
     task = task_id() if task_id is not None else -1
-    if task < 0 or torch.is_grad_enabled():
-        return False                     # not inside a backward pass (nobody would flush), or one that builds a graph (create_graph:
-                                         # autograd clones what the node returns)
-    # a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 layers: thousands of 128-row units) keeps its
-    # stand-alone slabs inside a batch anyway (csrc x6_wgrad_plan): launching it from the node costs nothing and frees its operands
-    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
-    if tiles * min(R // 128, 64) >= 2048 and R >= 32768:
-        return False
+    return -1 if torch.is_grad_enabled() else task
+
+
+def _wq_open(task, device):
+    """The queue of backward pass ``task`` on the current stream: registers the flush callback on first use, launches what another
+    pass / stream / device left behind."""
     q = _WQ
     st = _stream()
     if q.task != task:
@@ -201,22 +195,61 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) ->
         q.keep, q.bytes = [], 0
         q.task = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-    elif q.items and (q.stream != st or q.device != dY.device):
+    elif q.items and (q.stream != st or q.device != device):
         items, q.items = q.items, []     # another stream / device: what is queued goes out where it was produced
         _launch_wgrads(q, items)
-    q.stream, q.device = st, dY.device
-    if not getattr(out, "_gkg_zero", False):
-        out.zero_()
-    q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm))
-    q.keep.append((dY, x))
+    q.stream, q.device = st, device
+    return q
+
+
+def _wq_push(q, problem, out, keep, nbytes):
+    q.items.append(problem)
+    q.keep.append(keep)
     owner = getattr(out, "_gkg_owner", None)
     if owner is not None:
         owner._gkg_deferred = True       # the slot, not p.grad, holds this gradient until the batch has run (GradBucket._resident)
-    q.bytes += (dY.numel() + x.numel()) * 4
+    q.bytes += nbytes
     if len(q.items) >= q.MAX or q.bytes > q.MAX_BYTES:
         items, q.items = q.items, []
         _launch_wgrads(q, items)
         q.keep, q.bytes = [], 0
+
+
+def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) -> bool:
+    """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
+    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6"
+            and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
+            and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
+            and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
+        return False
+    task = _wq_task()
+    if task < 0:
+        return False
+    # a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 layers: thousands of 128-row units) keeps its
+    # stand-alone slabs inside a batch anyway (csrc x6_wgrad_plan): launching it from the node costs nothing and frees its operands
+    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
+    if tiles * min(R // 128, 64) >= 2048 and R >= 32768:
+        return False
+    q = _wq_open(task, dY.device)
+    if not getattr(out, "_gkg_zero", False):
+        out.zero_()
+    _wq_push(q, _lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm), out,
+             (dY, x), (dY.numel() + x.numel()) * 4)
+    return True
+
+
+def _wgrad_defer_block(problems, n, outs, keep, device) -> bool:
+    """The block driver's weight-gradient problems (prebuilt GkgWgradProblem array, dW slots already zero): all of them into the
+    backward pass's batched launch, or none (False: the caller launches them now)."""
+    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6" and all(getattr(o, "_gkg_slot", False) for o in outs)
+            and all(problems[i].R % 128 == 0 for i in range(n))):
+        return False
+    task = _wq_task()
+    if task < 0:
+        return False
+    q = _wq_open(task, device)
+    for i in range(n):
+        _wq_push(q, _lib.WgradProblem.from_buffer_copy(problems[i]), outs[i], keep if i == 0 else None, 0)
     return True
 
 
@@ -1632,6 +1665,18 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
     N = H * W
     gc = mod.graph_conv
     lp = lowp_inference()
+    if not lp:
+        from . import block
+        want_tm = DUAL_LAYOUT and getattr(mod, "_gkg_want_tm", False)
+        if block.grapher_ok(mod, x, relative_pos, groups, want_edge, want_tm):
+            # the whole block as ONE library call per direction (block.py / csrc/gkg_block.hip): same launches, same bits
+            res = block.grapher_forward(mod, x, relative_pos, groups, want_tm)
+            out = res[0] if want_tm else res
+            if want_tm:
+                out._gkg_tm = (out._version, res[1])
+            if DUAL_LAYOUT:
+                out._gkg_producer = weakref.ref(mod)
+            return out, None
     xt, x, cl = _block_entry(x, lp)                                 # (T, C) and the residual branch
     scale = _drop_scale(mod.drop_path, B, x.device)
     dual = (DUAL_LAYOUT and not cl and not lp and scale is None and torch.is_grad_enabled() and xt.dtype == _F32
@@ -1701,6 +1746,11 @@ def grapher_label_forward(mod, e, features, groups: int):
         prod = getattr(features, "_gkg_producer", None)
         if prod is not None and prod() is not None:
             prod()._gkg_label_knn = (groups, L, gc.k, gc.d, knn.fused_mr)            # ... from its next call on
+    if not lp:
+        from . import block
+        if block.label_ok(mod, e, ftc, groups):
+            out, edge = block.label_forward(mod, e2, ftc, groups, keys_key)          # ONE library call per direction (block.py)
+            return out.view(B, L, C), edge
     x1, e2r = _lin(e2, mod.fc1, alias=True, xm=xm, knn=knn)          # e2r: e2 again, for the residual of fc2 (one gradient node)
     x1b = x1 if xm is not None else x1.view(B, L, C)
     a2, edge = _graph_and_project(x1b, ftc, None, gc, groups, C, lp, True)      # GrapherLabel returns its graph
