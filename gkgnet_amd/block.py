@@ -11,12 +11,12 @@ below the BN-epilogue row count; everything else keeps the composition.  GKG_DIS
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
 from . import _lib, fused
 from .ops import _ptr, _stream
-from .parallel import grad_view
 
 _F32 = torch.float32
 V, I, Z, F, U = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_uint
@@ -127,68 +127,204 @@ def label_ok(mod, e, ft, groups) -> bool:
             and _proj_ok(mod.ffn.fc1, T, Cc, Cf, 1) and _proj_ok(mod.ffn.fc2, T, Cf, Cc, 1))
 
 
+# ----------------------------------------------------------------------------------------------- plans
+# What a block call needs to know about its module is the same on every step: which tensors the five projections read, their
+# sizes, the layout of the two arenas, the static half of the descriptor.  A _Plan holds it (built on the first eligible call,
+# through the full eligibility test above) and a per-call guard that is a few dozen identity / pointer comparisons; Grapher.forward
+# and GrapherLabel.forward ask try_grapher / try_label first and reach the C entry point after ~40 us of Python instead of ~150.
+_PLANS = weakref.WeakKeyDictionary()           # module -> {(shape key, switches): _Plan}
+
+
+def _switches():
+    return (ENABLED, fused.ENABLED, fused.GEMM_MATH, fused.DETERMINISTIC, fused.XM_DIRECT, fused.KNN_MR, fused.KNN_COMPACT,
+            fused.KNN_PREP, fused.KNN_BF16, fused.BN_EPILOGUE_MIN_ROWS, fused.knn_graph_tm is fused._KNN_GRAPH_TM)
+
+
+class _Proj:
+    """One 1x1 projection + BN of a block: the tensors its kernels read through raw pointers, and its sizes."""
+    __slots__ = ("conv", "bn", "W", "bias", "gamma", "beta", "rm", "rv", "nbt", "nb", "cin", "cout", "kperm", "trs", "mom", "eps",
+                 "wshape", "nch")
+
+    def __init__(self, seq, nb, cin, cout, kperm, wshape, ident):
+        conv, bn = seq[0], seq[1]
+        self.conv, self.bn = conv, bn
+        self.W, self.bias, self.gamma, self.beta = conv.weight, conv.bias, bn.weight, bn.bias
+        self.trs = bool(bn.track_running_stats)
+        self.rm, self.rv, self.nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+        self.nb, self.cin, self.cout, self.kperm = nb, cin, cout, kperm
+        self.mom, self.eps = bn.momentum, bn.eps
+        self.wshape, self.nch = wshape, nb * cout
+        ident += [(seq._modules, "0", conv), (seq._modules, "1", bn), (conv._parameters, "weight", self.W),
+                  (conv._parameters, "bias", self.bias), (bn._parameters, "weight", self.gamma), (bn._parameters, "bias", self.beta),
+                  (bn._buffers, "running_mean", self.rm), (bn._buffers, "running_var", self.rv),
+                  (bn._buffers, "num_batches_tracked", self.nbt)]
+
+    def static(self, p: ProjBN):
+        track = self.trs
+        p.gamma, p.beta, p.bias = _ptr(self.gamma), _ptr(self.beta), _ptr(self.bias)
+        p.running_mean = _ptr(self.rm) if track else None
+        p.running_var = _ptr(self.rv) if track else None
+        p.nbt = _ptr(self.nbt) if track else None
+        p.momentum, p.eps = float(self.mom), float(self.eps)
+        p.cin, p.cout, p.nb = self.cin, self.cout, self.nb
+
+    def baked(self):
+        return [t for t in (self.gamma, self.beta, self.bias) + ((self.rm, self.rv, self.nbt) if self.trs else ()) if t is not None]
+
+
+def _layout(sizes):
+    """Arena layout: element offsets of 16-byte aligned fp32 pieces -> (offsets, total elements)."""
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 3) & ~3
+    return offs, o
+
+
+class _Plan:
+    __slots__ = ("kind", "projs", "ident", "tensors", "ptrs", "tmpl", "fwd_offs", "fwd_total", "bwd_offs", "bwd_total", "drops",
+                 "sync", "gc", "nn_", "k", "d", "groups", "dims", "rp", "rp_view", "fast", "params", "fm", "has_bucket", "__weakref__")
+
+    def valid(self) -> bool:
+        for dct, key, obj in self.ident:
+            if dct.get(key) is not obj:
+                return False
+        for p in self.projs:
+            bn = p.bn
+            if not bn.training or bn.track_running_stats != p.trs or bn.momentum != p.mom or bn.eps != p.eps:
+                return False
+        if self.ptrs != [t.data_ptr() for t in self.tensors]:
+            return False
+        for dp in self.drops:
+            if _drops(dp):
+                return False
+        gc = self.gc
+        if gc.k != self.k or gc.d != self.d:
+            return False
+        if self.sync:
+            for p in self.projs:
+                if fused._sync_group(p.bn) is not None:
+                    return False
+        return True
+
+
+def _finish_plan(plan, mod, cls, projs, ident, drops, gc, nn_, groups, dims, relative_pos, fwd_sizes, bwd_sizes):
+    plan.projs, plan.ident, plan.drops, plan.gc, plan.nn_, plan.groups, plan.dims = projs, ident, drops, gc, nn_, groups, dims
+    plan.k, plan.d = gc.k, gc.d
+    plan.tensors = [t for p in projs for t in p.baked()]
+    plan.ptrs = [t.data_ptr() for t in plan.tensors]
+    plan.sync = any(isinstance(p.bn, torch.nn.SyncBatchNorm) for p in projs)
+    plan.fwd_offs, plan.fwd_total = _layout(fwd_sizes)
+    plan.bwd_offs, plan.bwd_total = _layout(bwd_sizes)
+    plan.params = tuple(t for p in projs for t in (p.W, p.gamma, p.beta))
+    plan.fm = {}
+    own = mod._parameters.get("relative_pos", mod.__dict__.get("relative_pos"))
+    plan.rp = relative_pos
+    plan.fast = relative_pos is None or relative_pos is own        # a re-interpolated bias is a new tensor every call: slow path
+    plan.rp_view = None
+    if relative_pos is not None and plan.fast:
+        ident.append((mod._parameters, "relative_pos", relative_pos))
+    d = cls()
+    names = [f[0] for f in cls._fields_ if f[1] is ProjBN]
+    for nm, p in zip(names, projs):
+        p.static(getattr(d, nm))
+    plan.tmpl = bytes(d)
+    return plan
+
+
+def _plan_grapher(mod, x, relative_pos, groups):
+    plans = _PLANS.setdefault(mod, {})
+    key = ("g", tuple(x.shape), groups, _switches())
+    plan = plans.get(key)
+    if plan is not None and plan.valid() and (plan.rp is relative_pos or not plan.fast):
+        return plan
+    B, Cc, H, W = x.shape
+    T = B * H * W
+    gc = mod.graph_conv
+    nn_ = gc.gconv.nn
+    ident = [(mod._modules, "fc1", mod.fc1), (mod._modules, "fc2", mod.fc2), (mod._modules, "graph_conv", gc),
+             (mod._modules, "drop_path", mod.drop_path), (gc._modules, "gconv", gc.gconv), (gc.gconv._modules, "nn", nn_)]
+    projs = [_Proj(mod.fc1, 1, Cc, Cc, 0, (Cc, Cc), ident), _Proj(nn_, 4, Cc // 2, Cc // 2, 1, (4, Cc // 2, Cc // 2), ident),
+             _Proj(mod.fc2, 1, 2 * Cc, Cc, 0, (Cc, 2 * Cc), ident)]
+    plan = _Plan()
+    plan.kind = "g"
+    # forward arena: xt, XM, A2, Y1, Y2, Y3, bn1, bn2, bn3, winning rows (u16)   backward: g3, dY3, gx1, dY1, dxt, dA2, dY2, dXM
+    fwd = [T * Cc, T * 2 * Cc, T * 2 * Cc, T * Cc, 4 * T * (Cc // 2), T * Cc, 4 * Cc, 8 * Cc, 4 * Cc, T * (Cc // 2)]
+    bwd = [T * Cc] * 5 + [T * 2 * Cc] * 3
+    _finish_plan(plan, mod, GrapherBlock, projs, ident, [mod.drop_path], gc, nn_, groups, (B, Cc, H, W), relative_pos, fwd, bwd)
+    plans[key] = plan
+    return plan
+
+
+def _plan_label(mod, e2, ft, groups):
+    plans = _PLANS.setdefault(mod, {})
+    B, M, Cc = ft.shape
+    T = e2.shape[0]
+    key = ("l", T, tuple(ft.shape), groups, _switches())
+    plan = plans.get(key)
+    if plan is not None and plan.valid():
+        return plan
+    L = T // B
+    gc = mod.graph_conv
+    nn_ = gc.gconv.nn
+    ffn = mod.ffn
+    Cf = ffn.fc1[0].weight.shape[0]
+    ident = [(mod._modules, "fc1", mod.fc1), (mod._modules, "fc2", mod.fc2), (mod._modules, "graph_conv", gc),
+             (mod._modules, "drop_path", mod.drop_path), (mod._modules, "ffn", ffn), (ffn._modules, "fc1", ffn.fc1),
+             (ffn._modules, "fc2", ffn.fc2), (ffn._modules, "drop_path", ffn.drop_path), (ffn._modules, "act", ffn.act),
+             (gc._modules, "gconv", gc.gconv), (gc.gconv._modules, "nn", nn_)]
+    projs = [_Proj(mod.fc1, 1, Cc, Cc, 0, (Cc, Cc), ident), _Proj(nn_, 4, Cc // 2, Cc // 2, 1, (4, Cc // 2, Cc // 2), ident),
+             _Proj(mod.fc2, 1, 2 * Cc, Cc, 0, (Cc, 2 * Cc), ident), _Proj(ffn.fc1, 1, Cc, Cf, 0, (Cf, Cc), ident),
+             _Proj(ffn.fc2, 1, Cf, Cc, 0, (Cc, Cf), ident)]
+    plan = _Plan()
+    plan.kind = "l"
+    # forward arena: XM, A2, h2, f1, Y1..Y5, bn1..bn5, winning rows      backward: dY5, dh2, dY3, gx1, dY1, df1, dY4, dA2, dY2, dXM
+    fwd = [T * 2 * Cc, T * 2 * Cc, T * Cc, T * Cf, T * Cc, 4 * T * (Cc // 2), T * Cc, T * Cf, T * Cc, 4 * Cc, 8 * Cc, 4 * Cc, 4 * Cf,
+           4 * Cc, T * (Cc // 2)]
+    bwd = [T * Cc] * 5 + [T * Cf] * 2 + [T * 2 * Cc] * 3
+    _finish_plan(plan, mod, LabelBlock, projs, ident, [mod.drop_path, ffn.drop_path], gc, nn_, groups, (B, Cc, L, M, Cf), None, fwd, bwd)
+    plans[key] = plan
+    return plan
+
+
 # ----------------------------------------------------------------------------------------------- descriptor pieces
-def _fill_proj(lib, p: ProjBN, seq, nb, cin, cout, kperm, scratch, keep):
-    """Forward half of a projection's descriptor: planes, BN parameters, the forward BN pass's scratch buffers."""
-    conv, bn = seq[0], seq[1]
-    pf, pd = fused._planes(lib, conv.weight, nb, cout, cin, True, True, kperm=kperm)
-    track = bn.training and bn.track_running_stats
-    fused._touch_stats(bn, track)
-    cur, other, zero = scratch.acquire(lib, 2 * nb * cout)
-    p.planes_fwd, p.planes_dgrad = _ptr(pf), _ptr(pd)
-    p.gamma, p.beta, p.bias = _ptr(bn.weight), _ptr(bn.bias), _ptr(conv.bias)
-    p.running_mean = _ptr(bn.running_mean) if track else None
-    p.running_var = _ptr(bn.running_var) if track else None
-    p.nbt = _ptr(bn.num_batches_tracked) if track else None
-    p.momentum, p.eps = float(bn.momentum), float(bn.eps)
-    p.cin, p.cout, p.nb = cin, cout, nb
-    p.fsum, p.fzero, p.fzero_n = _ptr(cur), _ptr(other), zero
-    keep.append((pf, pd))
+def _proj_fwd(lib, p: ProjBN, pr: _Proj, scratch, keep, y_ptr, bn_ptr):
+    """The per-call half of a projection's forward descriptor: weight planes (refreshed when the weight moved), the BN pass's
+    scratch buffers, where Y and the BN coefficients go."""
+    pf, pd = fused._planes(lib, pr.W, pr.nb, pr.cout, pr.cin, True, True, kperm=pr.kperm)
+    if pr.trs:
+        ep = pr.bn.__dict__.get("_gkg_epoch")
+        if ep is not None:
+            pr.bn.__dict__["_gkg_epoch"] = ep + 1             # fused._touch_stats: the kernels update the running statistics
+    cur, other, zero = scratch.acquire(lib, 2 * pr.nch)
+    p.planes_fwd, p.planes_dgrad = pf.data_ptr(), pd.data_ptr()
+    p.fsum, p.fzero, p.fzero_n = cur.data_ptr(), other.data_ptr(), zero
+    p.Y, p.bn = y_ptr, bn_ptr
+    keep.append(pf)
+    keep.append(pd)
 
 
-def _fill_proj_bwd(lib, p: ProjBN, params, wshape, nch, scratch, dev):
+def _proj_bwd(lib, p: ProjBN, pr: _Proj, scratch, dev):
     """Backward half: the BN pass's scratch buffers and the gradient outputs (bucket slots when the parameters have them)."""
-    dWv, dgamma, dbeta = fused._grad_outs(params, wshape, nch, dev)
+    dWv, dgamma, dbeta = fused._grad_outs((pr.W, pr.gamma, pr.beta), pr.wshape, pr.nch, dev)
     if not getattr(dWv, "_gkg_zero", False):
         dWv.zero_()                                      # the weight-gradient kernels ADD into dw
-    cur, other, zero = scratch.acquire(lib, 2 * nch)
-    p.bsum, p.bzero, p.bzero_n = _ptr(cur), _ptr(other), zero
-    p.dw, p.dgamma, p.dbeta = _ptr(dWv), _ptr(dgamma), _ptr(dbeta)
+    cur, other, zero = scratch.acquire(lib, 2 * pr.nch)
+    p.bsum, p.bzero, p.bzero_n = cur.data_ptr(), other.data_ptr(), zero
+    p.dw, p.dgamma, p.dbeta = dWv.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
     return dWv, dgamma, dbeta
 
 
-class _Arena:
-    """One allocation, carved into fp32 tensors (16-byte aligned pieces)."""
-
-    def __init__(self, device):
-        self.device, self.sizes = device, []
-
-    def add(self, *shape):
-        n = 1
-        for s in shape:
-            n *= s
-        self.sizes.append((shape, (n + 3) & ~3))
-        return len(self.sizes) - 1
-
-    def build(self):
-        buf = torch.empty(sum(n for _, n in self.sizes), dtype=_F32, device=self.device)
-        out, o = [], 0
-        for shape, n in self.sizes:
-            m = 1
-            for s in shape:
-                m *= s
-            out.append(buf[o:o + m].view(shape))
-            o += n
-        return buf, out
-
-
-def _graph_op(lib, g: GraphOp, x_like, B, G, c, N, M, k, d, relative_pos, has_y, want_edge, nn_, dev, keys_key, keep):
+def _graph_op(lib, plan, g: GraphOp, B, G, c, N, M, relative_pos, has_y, want_edge, dev, keys_key, keep):
     """The block's k-NN + aggregation: kernel form, flags, workspace (shared with a keys producer when the Grapher in front prepared
-    this graph's keys).  -> (key object for the prepared queries, edge tensor | None)."""
-    C_ = G * c
-    fm = fused._knn_mr_shapes_ok(B, N, C_, M, has_y, relative_pos, k, d, G, nn_, False)
-    key = fused._KnnKey(B, G, c, N, M, k, d, has_y, relative_pos, fm)
-    flags = key.flags
+    this graph's keys).  -> (key object of this k-NN problem, edge tensor | None)."""
+    k, d = plan.k, plan.d
+    flags0 = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
+    fm = plan.fm.get(flags0)
+    if fm is None:
+        fm = plan.fm[flags0] = bool(fused._knn_mr_shapes_ok(B, N, G * c, M, has_y, relative_pos, k, d, G, plan.nn_, False))
+    key = fused._KnnKey(B, G, c, N, M, k, d, has_y, relative_pos, fm, flags0)
+    flags = flags0
     if fused.KNN_PREP:
         flags |= _lib.KNN_X_PREPARED
         if keys_key is not None and keys_key.ws is not None and keys_key.tuple() == key.tuple():
@@ -198,20 +334,24 @@ def _graph_op(lib, g: GraphOp, x_like, B, G, c, N, M, k, d, relative_pos, has_y,
         key.ws = fused._ws(lib.gkg_knn_workspace_bytes(B * G, c, N, M, k, d, _lib.F32, _lib.KNN_NORMALIZE), dev)
     rp = None
     if relative_pos is not None:
-        rp = fused._rp_arg(relative_pos, N, M)
+        rp = plan.rp_view if relative_pos is plan.rp else None
+        if rp is None or rp.data_ptr() != relative_pos.data_ptr():
+            rp = fused._rp_arg(relative_pos, N, M)
+            if relative_pos is plan.rp and plan.fast and rp.data_ptr() == relative_pos.data_ptr():
+                plan.rp_view = rp                      # a reshaped view of the module's own parameter: the same view every call
     g.G, g.k, g.d, g.fused_mr = G, k, d, int(fm)
     g.relpos, g.knn_flags, g.mr_flags = _ptr(rp), flags, fused._mr_bwd_flags()
-    g.knn_ws, g.knn_ws_bytes = _ptr(key.ws), key.ws.numel()
+    g.knn_ws, g.knn_ws_bytes = key.ws.data_ptr(), key.ws.numel()
     edge = None
-    g.nn16 = g.nn_idx = g.center = None
     if want_edge:
         edge = torch.empty((2, B * G, N, k), dtype=torch.int64, device=dev)
         g.nn_idx, g.center = edge[0].data_ptr(), edge[1].data_ptr()
     elif not fm:
         nn16 = torch.empty((B * G, N, k), dtype=torch.int16, device=dev)
-        g.nn16 = _ptr(nn16)
+        g.nn16 = nn16.data_ptr()
         keep.append(nn16)
-    keep.append((rp, key.ws))
+    keep.append(rp)
+    keep.append(key.ws)
     return key, edge
 
 
@@ -226,50 +366,43 @@ def _issue_wgrads(lib, wq, n, outs, keep, device):
 # ----------------------------------------------------------------------------------------------- Grapher
 class _GrapherBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, wc, gc_, bc, w2, g2, b2, mod, relative_pos, groups, dual):
+    def forward(ctx, x, w1, g1, b1, wc, gc_, bc, w2, g2, b2, plan, relative_pos, label_knn, dual):
         lib = _lib.load()
         _bind(lib)
-        gcv = mod.graph_conv
-        nn_ = gcv.gconv.nn
-        B, Cc, H, W = x.shape
+        B, Cc, H, W = plan.dims
         N, T, dev = H * W, B * H * W, x.device
+        groups = plan.groups
         x = x.contiguous()
-        d = GrapherBlock()
+        d = GrapherBlock.from_buffer_copy(plan.tmpl)
         keep = []
         scratch = fused._BnFwdScratch.of(dev)
-        ar = _Arena(dev)
-        ixt, iXM, iA2 = ar.add(T, Cc), ar.add(T, 2 * Cc), ar.add(T, 2 * Cc)
-        iY1, iY2, iY3 = ar.add(T, Cc), ar.add(4, T, Cc // 2), ar.add(T, Cc)
-        ib1, ib2, ib3 = ar.add(4, Cc), ar.add(4, 2 * Cc), ar.add(4, Cc)
-        iarg = ar.add(T, Cc // 2)                               # (T, C) u16
-        buf, t = ar.build()
+        buf = torch.empty(plan.fwd_total, dtype=_F32, device=dev)
+        base = buf.data_ptr()
+        oxt, oXM, oA2, oY1, oY2, oY3, ob1, ob2, ob3, oarg = [base + 4 * o for o in plan.fwd_offs]
         out = torch.empty((B, Cc, H, W), dtype=_F32, device=dev)
         out_tm = torch.empty((T, Cc), dtype=_F32, device=dev) if dual else None
         d.B, d.C, d.H, d.W = B, Cc, H, W
-        d.x, d.out, d.out_tm = _ptr(x), _ptr(out), _ptr(out_tm)
-        d.xt, d.XM, d.A2 = _ptr(t[ixt]), _ptr(t[iXM]), _ptr(t[iA2])
+        d.x, d.out, d.out_tm = x.data_ptr(), out.data_ptr(), _ptr(out_tm)
+        d.xt, d.XM, d.A2 = oxt, oXM, oA2
+        p1, pc, p2 = plan.projs
         scratch.hold = 1                 # every layer's buffers are handed out before the first launch (bn_scratch.one_call)
         try:
-            _fill_proj(lib, d.fc1, mod.fc1, 1, Cc, Cc, 0, scratch, keep)
-            _fill_proj(lib, d.conv, nn_, 4, Cc // 2, Cc // 2, 1, scratch, keep)
-            _fill_proj(lib, d.fc2, mod.fc2, 1, 2 * Cc, Cc, 0, scratch, keep)
-            d.fc1.Y, d.fc1.bn = _ptr(t[iY1]), _ptr(t[ib1])
-            d.conv.Y, d.conv.bn = _ptr(t[iY2]), _ptr(t[ib2])
-            d.fc2.Y, d.fc2.bn = _ptr(t[iY3]), _ptr(t[ib3])
-            _graph_op(lib, d.graph, x, B, groups, Cc // groups, N, N, gcv.k, gcv.d, relative_pos, False, False, nn_, dev, None, keep)
-            d.graph.arg = _ptr(t[iarg])
+            _proj_fwd(lib, d.fc1, p1, scratch, keep, oY1, ob1)
+            _proj_fwd(lib, d.conv, pc, scratch, keep, oY2, ob2)
+            _proj_fwd(lib, d.fc2, p2, scratch, keep, oY3, ob3)
+            _graph_op(lib, plan, d.graph, B, groups, Cc // groups, N, N, relative_pos, False, False, dev, None, keep)
+            d.graph.arg = oarg
             sk = fused._sk_ws(dev)
-            d.sk_ws, d.sk_bytes = _ptr(sk), sk.numel()
+            d.sk_ws, d.sk_bytes = sk.data_ptr(), sk.numel()
             kk = None
-            lk = getattr(mod, "_gkg_label_knn", None) if (dual and fused.KNN_PREP) else None
-            if lk is not None:
-                G2, L2, k2, d2, fm2 = lk
+            if label_knn is not None and dual and fused.KNN_PREP:
+                G2, L2, k2, d2, fm2 = label_knn
                 if Cc % G2 == 0 and (Cc // G2) % 4 == 0:
                     kk = fused._KnnKey(B, G2, Cc // G2, L2, N, k2, d2, True, None, fm2)
                     kk.as_keys = 1
                     kk.ws = fused._ws(lib.gkg_knn_workspace_bytes(B * G2, Cc // G2, L2, N, k2, d2, _lib.F32, _lib.KNN_NORMALIZE), dev)
                     d.keys_G, d.keys_L, d.keys_k, d.keys_d, d.keys_fused_mr, d.keys_flags = G2, L2, k2, d2, int(fm2), kk.flags
-                    d.keys_ws, d.keys_ws_bytes = _ptr(kk.ws), kk.ws.numel()
+                    d.keys_ws, d.keys_ws_bytes = kk.ws.data_ptr(), kk.ws.numel()
             _lib.check(lib.gkg_grapher_fwd(C.byref(d), _stream()), "gkg_grapher_fwd")
         except Exception:
             scratch.poison()
@@ -280,8 +413,7 @@ class _GrapherBlockFn(torch.autograd.Function):
             out_tm._gkg_knn_keys = kk
         ctx.save_for_backward(buf, w1, wc, w2)
         ctx.desc = d
-        ctx.params = ((w1, g1, b1), (wc, gc_, bc), (w2, g2, b2))
-        ctx.dims = (B, Cc, H, W, dual)
+        ctx.plan = plan
         if dual:
             ctx.set_materialize_grads(False)
             return out, out_tm
@@ -290,96 +422,108 @@ class _GrapherBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dtm=None):
         lib = _lib.load()
-        B, Cc, H, W, dual = ctx.dims
+        plan = ctx.plan
+        B, Cc, H, W = plan.dims
         if dout is None and dtm is None:
             return (None,) * 14
-        T, dev = B * H * W, ctx.saved_tensors[0].device
+        buf, w1, wc, w2 = ctx.saved_tensors
+        T, dev = B * H * W, buf.device
         d = ctx.desc
-        ar = _Arena(dev)
-        names = [ar.add(T, Cc) for _ in range(5)] + [ar.add(T, 2 * Cc) for _ in range(3)]
-        buf, t = ar.build()
-        g3, dY3, gx1, dY1, dxt, dA2, dY2, dXM = t
+        tbuf = torch.empty(plan.bwd_total, dtype=_F32, device=dev)
+        base = tbuf.data_ptr()
+        d.g3, d.dY3, d.gx1, d.dY1, d.dxt, d.dA2, d.dY2, d.dXM = [base + 4 * o for o in plan.bwd_offs]
         dx = torch.empty((B, Cc, H, W), dtype=_F32, device=dev)
         if dout is None:                                          # only the token-major companion was used downstream
             dout = torch.zeros((B, Cc, H, W), dtype=_F32, device=dev)
         dout_c = dout.contiguous()
         dtm_c = None if dtm is None else dtm.contiguous()
-        d.dout, d.dout_tm, d.dx = _ptr(dout_c), _ptr(dtm_c), _ptr(dx)
-        d.g3, d.dY3, d.dA2, d.dY2, d.dXM, d.gx1, d.dY1, d.dxt = (_ptr(g3), _ptr(dY3), _ptr(dA2), _ptr(dY2), _ptr(dXM), _ptr(gx1), _ptr(dY1),
-                                                                 _ptr(dxt))
+        d.dout, d.dout_tm, d.dx = dout_c.data_ptr(), _ptr(dtm_c), dx.data_ptr()
         scratch = fused._BnBwdScratch.of(dev)
         wq = (_lib.WgradProblem * 3)()
+        p1, pc, p2 = plan.projs
         scratch.hold = 1                 # every layer's buffers are handed out before the first launch (bn_scratch.one_call)
         try:
-            o2 = _fill_proj_bwd(lib, d.fc2, ctx.params[2], (Cc, 2 * Cc), Cc, scratch, dev)
-            oc = _fill_proj_bwd(lib, d.conv, ctx.params[1], (4, Cc // 2, Cc // 2), 2 * Cc, scratch, dev)
-            o1 = _fill_proj_bwd(lib, d.fc1, ctx.params[0], (Cc, Cc), Cc, scratch, dev)
+            o2 = _proj_bwd(lib, d.fc2, p2, scratch, dev)
+            oc = _proj_bwd(lib, d.conv, pc, scratch, dev)
+            o1 = _proj_bwd(lib, d.fc1, p1, scratch, dev)
             _lib.check(lib.gkg_grapher_bwd(C.byref(d), wq, _stream()), "gkg_grapher_bwd")
         except Exception:
             scratch.poison()
             raise
         finally:
             scratch.hold = 0
-        _issue_wgrads(lib, wq, 3, (o2[0], oc[0], o1[0]), (buf, ctx.saved_tensors[0], dout_c, dtm_c), dev)
-        w1, wc, w2 = ctx.saved_tensors[1:]
+        _issue_wgrads(lib, wq, 3, (o2[0], oc[0], o1[0]), (buf, tbuf, dout_c, dtm_c), dev)
         return (dx, o1[0].view_as(w1), o1[1], o1[2], oc[0].view_as(wc), oc[1], oc[2], o2[0].view_as(w2), o2[1], o2[2], None, None, None, None)
 
 
+def _run_grapher(plan, mod, x, relative_pos, dual):
+    res = _GrapherBlockFn.apply(x, *plan.params, plan, relative_pos, mod.__dict__.get("_gkg_label_knn"), dual)
+    out = res[0] if dual else res
+    if dual:
+        out._gkg_tm = (out._version, res[1])
+    if fused.DUAL_LAYOUT:
+        out._gkg_producer = weakref.ref(mod)
+    return out
+
+
 def grapher_forward(mod, x, relative_pos, groups, dual):
-    nn_ = mod.graph_conv.gconv.nn
-    res = _GrapherBlockFn.apply(x, mod.fc1[0].weight, mod.fc1[1].weight, mod.fc1[1].bias, nn_[0].weight, nn_[1].weight, nn_[1].bias,
-                                mod.fc2[0].weight, mod.fc2[1].weight, mod.fc2[1].bias, mod, relative_pos, groups, dual)
-    return res
+    """After grapher_ok(): the block through the driver (fused.grapher_forward; builds the plan the next calls go through)."""
+    return _run_grapher(_plan_grapher(mod, x, relative_pos, groups), mod, x, relative_pos, dual)
+
+
+def try_grapher(mod, x):
+    """Grapher.forward's first question: a step this module has taken before (same shapes, same switches, same tensors behind the
+    same names) goes straight to the driver -> the block's output; None: ask the long way (fused.fused_supported ...)."""
+    plans = _PLANS.get(mod)
+    if plans is None or not (ENABLED and x.is_cuda and x.dtype == _F32 and torch.is_grad_enabled()
+                             and not torch.is_autocast_enabled()):
+        return None
+    plan = plans.get(("g", tuple(x.shape), mod.graph_conv.num_head, _switches()))
+    if plan is None or not plan.fast or not x.is_contiguous() or not plan.valid():
+        return None
+    return _run_grapher(plan, mod, x, plan.rp, fused.DUAL_LAYOUT and mod.__dict__.get("_gkg_want_tm", False))
 
 
 # ----------------------------------------------------------------------------------------------- GrapherLabel
 class _LabelBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e2, ft, w1, g1, b1, wc, gc_, bc, w2, g2, b2, w4, g4, b4, w5, g5, b5, mod, groups, keys_key):
+    def forward(ctx, e2, ft, w1, g1, b1, wc, gc_, bc, w2, g2, b2, w4, g4, b4, w5, g5, b5, plan, keys_key, producer):
         lib = _lib.load()
         _bind(lib)
-        gcv = mod.graph_conv
-        nn_ = gcv.gconv.nn
-        B, M, Cc = ft.shape
-        T = e2.shape[0]
-        L, dev = T // B, e2.device
-        Cf = w4.shape[0]
-        d = LabelBlock()
+        B, Cc, L, M, Cf = plan.dims
+        T, dev = B * L, e2.device
+        groups = plan.groups
+        d = LabelBlock.from_buffer_copy(plan.tmpl)
         keep = []
         scratch = fused._BnFwdScratch.of(dev)
-        ar = _Arena(dev)
-        iXM, iA2, ih2, if1 = ar.add(T, 2 * Cc), ar.add(T, 2 * Cc), ar.add(T, Cc), ar.add(T, Cf)
-        iY1, iY2, iY3, iY4, iY5 = ar.add(T, Cc), ar.add(4, T, Cc // 2), ar.add(T, Cc), ar.add(T, Cf), ar.add(T, Cc)
-        ib1, ib2, ib3, ib4, ib5 = ar.add(4, Cc), ar.add(4, 2 * Cc), ar.add(4, Cc), ar.add(4, Cf), ar.add(4, Cc)
-        iarg = ar.add(T, Cc // 2)
-        buf, t = ar.build()
+        buf = torch.empty(plan.fwd_total, dtype=_F32, device=dev)
+        base = buf.data_ptr()
+        oXM, oA2, oh2, of1, oY1, oY2, oY3, oY4, oY5, ob1, ob2, ob3, ob4, ob5, oarg = [base + 4 * o for o in plan.fwd_offs]
         out = torch.empty((T, Cc), dtype=_F32, device=dev)
         d.B, d.C, d.L, d.M = B, Cc, L, M
-        d.e, d.ft, d.out = _ptr(e2), _ptr(ft), _ptr(out)
-        d.XM, d.A2, d.h2, d.f1 = _ptr(t[iXM]), _ptr(t[iA2]), _ptr(t[ih2]), _ptr(t[if1])
+        d.e, d.ft, d.out = e2.data_ptr(), ft.data_ptr(), out.data_ptr()
+        d.XM, d.A2, d.h2, d.f1 = oXM, oA2, oh2, of1
         scratch.hold = 1                 # every layer's buffers are handed out before the first launch (bn_scratch.one_call)
         try:
-            _fill_proj(lib, d.fc1, mod.fc1, 1, Cc, Cc, 0, scratch, keep)
-            _fill_proj(lib, d.conv, nn_, 4, Cc // 2, Cc // 2, 1, scratch, keep)
-            _fill_proj(lib, d.fc2, mod.fc2, 1, 2 * Cc, Cc, 0, scratch, keep)
-            _fill_proj(lib, d.ffn1, mod.ffn.fc1, 1, Cc, Cf, 0, scratch, keep)
-            _fill_proj(lib, d.ffn2, mod.ffn.fc2, 1, Cf, Cc, 0, scratch, keep)
-            for p, iy, ib in ((d.fc1, iY1, ib1), (d.conv, iY2, ib2), (d.fc2, iY3, ib3), (d.ffn1, iY4, ib4), (d.ffn2, iY5, ib5)):
-                p.Y, p.bn = _ptr(t[iy]), _ptr(t[ib])
-            _, edge = _graph_op(lib, d.graph, e2, B, groups, Cc // groups, L, M, gcv.k, gcv.d, None, True, True, nn_, dev, keys_key, keep)
-            d.graph.arg = _ptr(t[iarg])
+            for p, pr, oy, ob in zip((d.fc1, d.conv, d.fc2, d.ffn1, d.ffn2), plan.projs, (oY1, oY2, oY3, oY4, oY5), (ob1, ob2, ob3, ob4, ob5)):
+                _proj_fwd(lib, p, pr, scratch, keep, oy, ob)
+            key, edge = _graph_op(lib, plan, d.graph, B, groups, Cc // groups, L, M, None, True, True, dev, keys_key, keep)
+            d.graph.arg = oarg
             sk = fused._sk_ws(dev)
-            d.sk_ws, d.sk_bytes = _ptr(sk), sk.numel()
+            d.sk_ws, d.sk_bytes = sk.data_ptr(), sk.numel()
             _lib.check(lib.gkg_grapher_label_fwd(C.byref(d), _stream()), "gkg_grapher_label_fwd")
         except Exception:
             scratch.poison()
             raise
         finally:
             scratch.hold = 0
+        if producer is not None and fused.KNN_PREP:
+            lk = (groups, L, plan.k, plan.d, key.fused_mr)                 # the Grapher in front prepares this graph's keys
+            if producer.__dict__.get("_gkg_label_knn") != lk:              # from its next call on (fused.grapher_label_forward)
+                producer._gkg_label_knn = lk
         ctx.save_for_backward(buf, e2, ft, w1, wc, w2, w4, w5)
         ctx.desc = d
-        ctx.params = ((w1, g1, b1), (wc, gc_, bc), (w2, g2, b2), (w4, g4, b4), (w5, g5, b5))
-        ctx.dims = (B, Cc, L, M, Cf)
+        ctx.plan = plan
         ctx.mark_non_differentiable(edge)
         ctx.set_materialize_grads(False)
         return out, edge
@@ -389,30 +533,29 @@ class _LabelBlockFn(torch.autograd.Function):
         lib = _lib.load()
         if dout is None:
             return (None,) * 20
-        B, Cc, L, M, Cf = ctx.dims
+        plan = ctx.plan
+        B, Cc, L, M, Cf = plan.dims
         T = B * L
         buf, e2, ft, w1, wc, w2, w4, w5 = ctx.saved_tensors
         dev = buf.device
         d = ctx.desc
-        ar = _Arena(dev)
-        ids = [ar.add(T, Cc) for _ in range(5)] + [ar.add(T, Cf) for _ in range(2)] + [ar.add(T, 2 * Cc) for _ in range(3)]
-        tbuf, t = ar.build()
-        dY5, dh2, dY3, gx1, dY1, df1, dY4, dA2, dY2, dXM = t
+        tbuf = torch.empty(plan.bwd_total, dtype=_F32, device=dev)
+        base = tbuf.data_ptr()
+        d.dY5, d.dh2, d.dY3, d.gx1, d.dY1, d.df1, d.dY4, d.dA2, d.dY2, d.dXM = [base + 4 * o for o in plan.bwd_offs]
         de = torch.empty((T, Cc), dtype=_F32, device=dev)
         dft = torch.empty((B, M, Cc), dtype=_F32, device=dev)
         dout_c = dout.contiguous()
-        d.dout, d.de, d.dft = _ptr(dout_c), _ptr(de), _ptr(dft)
-        d.dY5, d.df1, d.dY4, d.dh2, d.dY3, d.dA2, d.dY2, d.dXM, d.gx1, d.dY1 = (_ptr(dY5), _ptr(df1), _ptr(dY4), _ptr(dh2), _ptr(dY3), _ptr(dA2),
-                                                                                   _ptr(dY2), _ptr(dXM), _ptr(gx1), _ptr(dY1))
+        d.dout, d.de, d.dft = dout_c.data_ptr(), de.data_ptr(), dft.data_ptr()
         scratch = fused._BnBwdScratch.of(dev)
         wq = (_lib.WgradProblem * 5)()
+        p1, pc, p3, p4, p5 = plan.projs
         scratch.hold = 1                 # every layer's buffers are handed out before the first launch (bn_scratch.one_call)
         try:
-            o5 = _fill_proj_bwd(lib, d.ffn2, ctx.params[4], (Cc, Cf), Cc, scratch, dev)
-            o4 = _fill_proj_bwd(lib, d.ffn1, ctx.params[3], (Cf, Cc), Cf, scratch, dev)
-            o3 = _fill_proj_bwd(lib, d.fc2, ctx.params[2], (Cc, 2 * Cc), Cc, scratch, dev)
-            oc = _fill_proj_bwd(lib, d.conv, ctx.params[1], (4, Cc // 2, Cc // 2), 2 * Cc, scratch, dev)
-            o1 = _fill_proj_bwd(lib, d.fc1, ctx.params[0], (Cc, Cc), Cc, scratch, dev)
+            o5 = _proj_bwd(lib, d.ffn2, p5, scratch, dev)
+            o4 = _proj_bwd(lib, d.ffn1, p4, scratch, dev)
+            o3 = _proj_bwd(lib, d.fc2, p3, scratch, dev)
+            oc = _proj_bwd(lib, d.conv, pc, scratch, dev)
+            o1 = _proj_bwd(lib, d.fc1, p1, scratch, dev)
             _lib.check(lib.gkg_grapher_label_bwd(C.byref(d), wq, _stream()), "gkg_grapher_label_bwd")
         except Exception:
             scratch.poison()
@@ -424,9 +567,26 @@ class _LabelBlockFn(torch.autograd.Function):
                 o4[0].view_as(w4), o4[1], o4[2], o5[0].view_as(w5), o5[1], o5[2], None, None, None)
 
 
-def label_forward(mod, e2, ft, groups, keys_key):
-    nn_ = mod.graph_conv.gconv.nn
-    return _LabelBlockFn.apply(e2, ft, mod.fc1[0].weight, mod.fc1[1].weight, mod.fc1[1].bias, nn_[0].weight, nn_[1].weight, nn_[1].bias,
-                               mod.fc2[0].weight, mod.fc2[1].weight, mod.fc2[1].bias, mod.ffn.fc1[0].weight, mod.ffn.fc1[1].weight,
-                               mod.ffn.fc1[1].bias, mod.ffn.fc2[0].weight, mod.ffn.fc2[1].weight, mod.ffn.fc2[1].bias, mod, groups,
-                               keys_key)
+def label_forward(mod, e2, ft, groups, keys_key, producer=None):
+    """After label_ok(): the block through the driver (fused.grapher_label_forward; builds the plan the next calls go through)."""
+    plan = _plan_label(mod, e2, ft, groups)
+    return _LabelBlockFn.apply(e2, ft, *plan.params, plan, keys_key, producer)
+
+
+def try_label(mod, e, features):
+    """GrapherLabel.forward's first question (see try_grapher): -> (E', edge_index) or None."""
+    plans = _PLANS.get(mod)
+    if plans is None or not (ENABLED and e.is_cuda and e.dtype == _F32 and e.dim() == 3 and e.is_contiguous() and features.is_cuda
+                             and features.dtype == _F32 and features.dim() == 4 and torch.is_grad_enabled()
+                             and not torch.is_autocast_enabled()):
+        return None
+    B, L, Cc = e.shape
+    if features.shape[0] != B or features.shape[1] != Cc or fused.is_channels_last(features):
+        return None
+    key = ("l", B * L, (B, features.shape[2] * features.shape[3], Cc), mod.graph_conv.num_head, _switches())
+    plan = plans.get(key)
+    if plan is None or not plan.valid():
+        return None
+    ft, keys_key, producer = fused._label_features(features, B, Cc)
+    out, edge = _LabelBlockFn.apply(e.view(B * L, Cc), ft, *plan.params, plan, keys_key, producer)
+    return out.view(B, L, Cc), edge

@@ -1276,10 +1276,10 @@ class _KnnKey:
     must agree on for the prepared queries in ``ws`` to be THAT call's (same workspace plan, same kernel choice)."""
     __slots__ = ("B", "G", "c", "N", "M", "k", "d", "has_y", "has_rp", "flags", "fused_mr", "ws", "as_keys", "y_ready")
 
-    def __init__(self, B, G, c, N, M, k, d, has_y, relative_pos, fused_mr):
+    def __init__(self, B, G, c, N, M, k, d, has_y, relative_pos, fused_mr, flags=None):
         self.B, self.G, self.c, self.N, self.M, self.k, self.d = B, G, c, N, M, k, d
         self.has_y, self.has_rp, self.fused_mr = int(bool(has_y)), int(relative_pos is not None), int(bool(fused_mr))
-        self.flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
+        self.flags = (_lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)) if flags is None else flags
         self.ws = None
         self.as_keys = 0         # 1: this producer call prepares the problem's KEYS (a Grapher's fc2 in front of a GrapherLabel)
         self.y_ready = False     # the keys' copies are already in ``ws`` (the k-NN call then sets GKG_KNN_Y_PREPARED)
@@ -1670,13 +1670,7 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
         want_tm = DUAL_LAYOUT and getattr(mod, "_gkg_want_tm", False)
         if block.grapher_ok(mod, x, relative_pos, groups, want_edge, want_tm):
             # the whole block as ONE library call per direction (block.py / csrc/gkg_block.hip): same launches, same bits
-            res = block.grapher_forward(mod, x, relative_pos, groups, want_tm)
-            out = res[0] if want_tm else res
-            if want_tm:
-                out._gkg_tm = (out._version, res[1])
-            if DUAL_LAYOUT:
-                out._gkg_producer = weakref.ref(mod)
-            return out, None
+            return block.grapher_forward(mod, x, relative_pos, groups, want_tm), None      # (companion / producer marks set there)
     xt, x, cl = _block_entry(x, lp)                                 # (T, C) and the residual branch
     scale = _drop_scale(mod.drop_path, B, x.device)
     dual = (DUAL_LAYOUT and not cl and not lp and scale is None and torch.is_grad_enabled() and xt.dtype == _F32
@@ -1717,12 +1711,13 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
     return out, edge
 
 
-def grapher_label_forward(mod, e, features, groups: int):
-    """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
-    B, L, C = e.shape
-    gc = mod.graph_conv
+def _label_features(features, B, C):
+    """The feature map as a GrapherLabel reads it -> (keys / values token-major (B, HW, C), contiguous; the prepared-keys object the
+    producing block left on its token-major companion | None; the producing module | None)."""
     ent = getattr(features, "_gkg_tm", None)
     keys_key = None
+    prod = getattr(features, "_gkg_producer", None)
+    prod = prod() if prod is not None else None
     if is_channels_last(features):                                           # keys / values (B, HW, C): a view
         ft = features.permute(0, 2, 3, 1).reshape(B, -1, C)
     elif (DUAL_LAYOUT and ent is not None and ent[0] == features._version and features.dim() == 4 and features.dtype == _F32
@@ -1730,22 +1725,29 @@ def grapher_label_forward(mod, e, features, groups: int):
         ft = ent[1].view(B, -1, C)                                           # the producing block's token-major companion
         keys_key = getattr(ent[1], "_gkg_knn_keys", None)                    # ... which may carry this graph's prepared keys
     else:
-        prod = getattr(features, "_gkg_producer", None)
-        if prod is not None and prod() is not None:
-            prod()._gkg_want_tm = True                                       # ... which it emits from its next call on
+        if prod is not None and not prod.__dict__.get("_gkg_want_tm", False):
+            prod._gkg_want_tm = True                                         # ... which it emits from its next call on
         ft = to_token_major(features.float().contiguous()).view(B, -1, C)
+    return ft.contiguous(), keys_key, prod
+
+
+def grapher_label_forward(mod, e, features, groups: int):
+    """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
+    B, L, C = e.shape
+    gc = mod.graph_conv
+    ftc, keys_key, prod = _label_features(features, B, C)
     e2 = e.float().reshape(B * L, C).contiguous()
     lp = lowp_inference()
     xm = (B, L) if (XM_DIRECT and not lp and not torch.is_autocast_enabled() and C % 16 == 0) else None
-    ftc = ft.contiguous()
     knn = _knn_key_for(B, L, C, ftc.shape[1], True, None, gc, groups, lp, True) if (xm is not None and KNN_PREP) else None
     if knn is not None:
         kk = keys_key
         if kk is not None and kk.ws is not None and kk.tuple() == knn.tuple():      # the producing Grapher prepared the keys: its
             knn.ws, knn.y_ready = kk.ws, True                                        # workspace is this call's
-        prod = getattr(features, "_gkg_producer", None)
-        if prod is not None and prod() is not None:
-            prod()._gkg_label_knn = (groups, L, gc.k, gc.d, knn.fused_mr)            # ... from its next call on
+        if prod is not None:
+            lk = (groups, L, gc.k, gc.d, knn.fused_mr)
+            if prod.__dict__.get("_gkg_label_knn") != lk:
+                prod._gkg_label_knn = lk                                             # ... from its next call on
     if not lp:
         from . import block
         if block.label_ok(mod, e, ftc, groups):
