@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libgkg_hip.so")
-SOURCES = ["gkg_api.hip", "gkg_knn.hip", "gkg_knn_f32.hip", "gkg_knn_f32_norp.hip", "gkg_knn_f32_mr.hip", "gkg_knn_f32_mr_norp.hip", "gkg_knn_bf.hip", "gkg_knn_bf_norp.hip", "gkg_knn_pf.hip", "gkg_knn_pf_norp.hip", "gkg_mr.hip", "gkg_dense.hip", "gkg_gemm_x6.hip", "gkg_edge.hip", "gkg_mrgemm.hip", "gkg_stem.hip"]
+SOURCES = ["gkg_api.hip", "gkg_knn.hip", "gkg_knn_f32.hip", "gkg_knn_f32_norp.hip", "gkg_knn_f32_mr.hip", "gkg_knn_f32_mr_norp.hip", "gkg_knn_bf.hip", "gkg_knn_bf_norp.hip", "gkg_knn_pf.hip", "gkg_knn_pf_norp.hip", "gkg_mr.hip", "gkg_dense.hip", "gkg_gemm_x6.hip", "gkg_edge.hip", "gkg_mrgemm.hip", "gkg_stem.hip", "gkg_block.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-I" + INCLUDE, "-I" + CSRC] + \
         os.environ.get("GKG_BUILD_FLAGS", "").split()          # measurement builds (-D switches of the ablation tools)

@@ -83,7 +83,8 @@ EXPORTS = ("gkg_version", "gkg_last_error_string", "gkg_knn_workspace_bytes", "g
            "gkg_linear_wgrad_x6_batch", "gkg_x6_splitk_workspace_bytes", "gkg_linear_bn_fwd_x6_sk", "gkg_linear_dgrad_x6_sk",
            "gkg_tm_affine_to_nchw_dual", "gkg_nchw_to_tm_add", "gkg_bn_apply_train_dual",
            "gkg_knn_mr_fused_supported", "gkg_knn_mr_fwd_tm", "gkg_x6_prep_weights_zero",
-           "gkg_knn_fwd_tm16", "gkg_mr_fwd_tm16", "gkg_mr_linear_bf16_nn16")
+           "gkg_knn_fwd_tm16", "gkg_mr_fwd_tm16", "gkg_mr_linear_bf16_nn16",
+           "gkg_grapher_fwd", "gkg_grapher_bwd", "gkg_grapher_label_fwd", "gkg_grapher_label_bwd")
 PROF_KERNELS = ("token_prep", "knn_tile", "knn_merge", "mr_fwd", "mr_bwd", "gemm_x6")
 
 _lib = None

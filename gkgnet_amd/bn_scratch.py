@@ -2,6 +2,8 @@
 bookkeeping of which of the two alternating buffers is clean."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -38,6 +40,7 @@ class _BnBwdScratch:
         self.poisoned = False
         self.last_stream = None
         self.last_raw = None
+        self.hold = 0                   # one_call(): 1 = the next acquire may reset, 2 = later acquires of the same call may not
         self.pending = None             # a _BnLink whose consumer has accumulated into a buffer while the clear of the other one
                                         # waits for the producer's apply pass (fused._dgrad_x6_with_link)
 
@@ -67,7 +70,7 @@ class _BnBwdScratch:
                     here.wait_stream(self.last_stream)
                 self.last_stream = here
                 self.last_raw = raw
-            if self.captured or self.poisoned:
+            if (self.captured or self.poisoned) and self.hold != 2:
                 self._reset()
         if self.pending is not None:
             # an acquire between a consumer's dgrad epilogue and its producer's apply pass (another ready BN backward node was
@@ -81,7 +84,21 @@ class _BnBwdScratch:
         zero = self.dirty[self.cur ^ 1]
         self.dirty[self.cur], self.dirty[self.cur ^ 1] = n, 0
         self.cur ^= 1
+        if self.hold == 1:
+            self.hold = 2
         return cur, other, zero
+
+    @contextlib.contextmanager
+    def one_call(self):
+        """Several acquire() calls whose launches are all issued afterwards, together (the block driver fills every layer's
+        descriptor first): the clear that an eager call owes after a capture or a failed launch is enqueued by the FIRST
+        acquire only — a later one would clear, ahead of the block's launches, a buffer the bookkeeping then hands to a layer
+        while an earlier layer's sums are still in it."""
+        self.hold = 1
+        try:
+            yield self
+        finally:
+            self.hold = 0
 
     def fold_reset(self, cap):
         """The first use of the pair inside hipGraph capture ``cap`` would clear both buffers with a launch of its own: when the

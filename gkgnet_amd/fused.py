@@ -175,23 +175,17 @@ _parallel._FLUSH.append(flush_wgrads)
 _parallel._ZERO_DEFER[:] = [_planes_mod.defer_zero, _planes_mod.flush_deferred_zero]
 
 
-def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) -> bool:
-    """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
-    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6"
-            and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
-            and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
-            and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
-        return False
+def _wq_task() -> int:
+    """Id of the backward pass this thread is executing (-1: none — nobody would flush a queue —, or one that builds a graph:
+    create_graph makes autograd clone what a node returns, so a slot filled later would never reach p.grad)."""
     task_id = getattr(torch._C, "_current_graph_task_id", None)
     task = task_id() if task_id is not None else -1
-    if task < 0 or torch.is_grad_enabled():
-        return False                     # not inside a backward pass (nobody would flush), or one that builds a graph (create_graph:
-                                         # autograd clones what the node returns)
-    # a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 layers: thousands of 128-row units) keeps its
-    # stand-alone slabs inside a batch anyway (csrc x6_wgrad_plan): launching it from the node costs nothing and frees its operands
-    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
-    if tiles * min(R // 128, 64) >= 2048 and R >= 32768:
-        return False
+    return -1 if torch.is_grad_enabled() else task
+
+
+def _wq_open(task, device):
+    """The queue of backward pass ``task`` on the current stream: registers the flush callback on first use, launches what another
+    pass / stream / device left behind."""
     q = _WQ
     st = _stream()
     if q.task != task:
@@ -201,22 +195,61 @@ def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) ->
         q.keep, q.bytes = [], 0
         q.task = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-    elif q.items and (q.stream != st or q.device != dY.device):
+    elif q.items and (q.stream != st or q.device != device):
         items, q.items = q.items, []     # another stream / device: what is queued goes out where it was produced
         _launch_wgrads(q, items)
-    q.stream, q.device = st, dY.device
-    if not getattr(out, "_gkg_zero", False):
-        out.zero_()
-    q.items.append(_lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm))
-    q.keep.append((dY, x))
+    q.stream, q.device = st, device
+    return q
+
+
+def _wq_push(q, problem, out, keep, nbytes):
+    q.items.append(problem)
+    q.keep.append(keep)
     owner = getattr(out, "_gkg_owner", None)
     if owner is not None:
         owner._gkg_deferred = True       # the slot, not p.grad, holds this gradient until the batch has run (GradBucket._resident)
-    q.bytes += (dY.numel() + x.numel()) * 4
+    q.bytes += nbytes
     if len(q.items) >= q.MAX or q.bytes > q.MAX_BYTES:
         items, q.items = q.items, []
         _launch_wgrads(q, items)
         q.keep, q.bytes = [], 0
+
+
+def _wgrad_defer(dY, x, out, R, cin, cout, nb, ldg, g_bs, ldx, x_bs, kperm=0) -> bool:
+    """Queue dW = dY^T x for the batched launch.  True: queued (``out`` will hold the gradient when the backward pass ends)."""
+    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6"
+            and out is not None and getattr(out, "_gkg_slot", False) and dY.dtype == _F32 and x.dtype == _F32
+            and R % 128 == 0 and cin % 4 == 0 and cout % 4 == 0 and ldg % 4 == 0 and ldx % 4 == 0 and g_bs % 4 == 0 and x_bs % 4 == 0
+            and dY.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and R * max(ldg, ldx) * 4 < 0xffffffff and nb <= 64):
+        return False
+    task = _wq_task()
+    if task < 0:
+        return False
+    # a problem that fills the chip on its own (GKGNet-576's stage-1 / stage-2 layers: thousands of 128-row units) keeps its
+    # stand-alone slabs inside a batch anyway (csrc x6_wgrad_plan): launching it from the node costs nothing and frees its operands
+    tiles = nb * ((cout + 63) // 64) * ((cin + 63) // 64)
+    if tiles * min(R // 128, 64) >= 2048 and R >= 32768:
+        return False
+    q = _wq_open(task, dY.device)
+    if not getattr(out, "_gkg_zero", False):
+        out.zero_()
+    _wq_push(q, _lib.WgradProblem(dY.data_ptr(), x.data_ptr(), out.data_ptr(), g_bs, x_bs, ldg, ldx, R, cin, cout, nb, kperm), out,
+             (dY, x), (dY.numel() + x.numel()) * 4)
+    return True
+
+
+def _wgrad_defer_block(problems, n, outs, keep, device) -> bool:
+    """The block driver's weight-gradient problems (prebuilt GkgWgradProblem array, dW slots already zero): all of them into the
+    backward pass's batched launch, or none (False: the caller launches them now)."""
+    if not (WGRAD_BATCH and not DETERMINISTIC and GEMM_MATH == "x6" and all(getattr(o, "_gkg_slot", False) for o in outs)
+            and all(problems[i].R % 128 == 0 for i in range(n))):
+        return False
+    task = _wq_task()
+    if task < 0:
+        return False
+    q = _wq_open(task, device)
+    for i in range(n):
+        _wq_push(q, _lib.WgradProblem.from_buffer_copy(problems[i]), outs[i], keep if i == 0 else None, 0)
     return True
 
 
@@ -1243,10 +1276,10 @@ class _KnnKey:
     must agree on for the prepared queries in ``ws`` to be THAT call's (same workspace plan, same kernel choice)."""
     __slots__ = ("B", "G", "c", "N", "M", "k", "d", "has_y", "has_rp", "flags", "fused_mr", "ws", "as_keys", "y_ready")
 
-    def __init__(self, B, G, c, N, M, k, d, has_y, relative_pos, fused_mr):
+    def __init__(self, B, G, c, N, M, k, d, has_y, relative_pos, fused_mr, flags=None):
         self.B, self.G, self.c, self.N, self.M, self.k, self.d = B, G, c, N, M, k, d
         self.has_y, self.has_rp, self.fused_mr = int(bool(has_y)), int(relative_pos is not None), int(bool(fused_mr))
-        self.flags = _lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)
+        self.flags = (_lib.KNN_NORMALIZE | _lib.knn_select_flags() | _lib.relpos_flags(relative_pos)) if flags is None else flags
         self.ws = None
         self.as_keys = 0         # 1: this producer call prepares the problem's KEYS (a Grapher's fc2 in front of a GrapherLabel)
         self.y_ready = False     # the keys' copies are already in ``ws`` (the k-NN call then sets GKG_KNN_Y_PREPARED)
@@ -1632,6 +1665,12 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
     N = H * W
     gc = mod.graph_conv
     lp = lowp_inference()
+    if not lp:
+        from . import block
+        want_tm = DUAL_LAYOUT and getattr(mod, "_gkg_want_tm", False)
+        if block.grapher_ok(mod, x, relative_pos, groups, want_edge, want_tm):
+            # the whole block as ONE library call per direction (block.py / csrc/gkg_block.hip): same launches, same bits
+            return block.grapher_forward(mod, x, relative_pos, groups, want_tm), None      # (companion / producer marks set there)
     xt, x, cl = _block_entry(x, lp)                                 # (T, C) and the residual branch
     scale = _drop_scale(mod.drop_path, B, x.device)
     dual = (DUAL_LAYOUT and not cl and not lp and scale is None and torch.is_grad_enabled() and xt.dtype == _F32
@@ -1672,12 +1711,13 @@ def grapher_forward(mod, x, relative_pos, groups: int, want_edge: bool = True):
     return out, edge
 
 
-def grapher_label_forward(mod, e, features, groups: int):
-    """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
-    B, L, C = e.shape
-    gc = mod.graph_conv
+def _label_features(features, B, C):
+    """The feature map as a GrapherLabel reads it -> (keys / values token-major (B, HW, C), contiguous; the prepared-keys object the
+    producing block left on its token-major companion | None; the producing module | None)."""
     ent = getattr(features, "_gkg_tm", None)
     keys_key = None
+    prod = getattr(features, "_gkg_producer", None)
+    prod = prod() if prod is not None else None
     if is_channels_last(features):                                           # keys / values (B, HW, C): a view
         ft = features.permute(0, 2, 3, 1).reshape(B, -1, C)
     elif (DUAL_LAYOUT and ent is not None and ent[0] == features._version and features.dim() == 4 and features.dtype == _F32
@@ -1685,22 +1725,34 @@ def grapher_label_forward(mod, e, features, groups: int):
         ft = ent[1].view(B, -1, C)                                           # the producing block's token-major companion
         keys_key = getattr(ent[1], "_gkg_knn_keys", None)                    # ... which may carry this graph's prepared keys
     else:
-        prod = getattr(features, "_gkg_producer", None)
-        if prod is not None and prod() is not None:
-            prod()._gkg_want_tm = True                                       # ... which it emits from its next call on
+        if prod is not None and not prod.__dict__.get("_gkg_want_tm", False):
+            prod._gkg_want_tm = True                                         # ... which it emits from its next call on
         ft = to_token_major(features.float().contiguous()).view(B, -1, C)
+    return ft.contiguous(), keys_key, prod
+
+
+def grapher_label_forward(mod, e, features, groups: int):
+    """Fused GrapherLabel.forward (reference torch_vertex.py:392-403).  Returns (E' (B,L,C), edge_index (2,BG,L,k))."""
+    B, L, C = e.shape
+    gc = mod.graph_conv
+    ftc, keys_key, prod = _label_features(features, B, C)
     e2 = e.float().reshape(B * L, C).contiguous()
     lp = lowp_inference()
     xm = (B, L) if (XM_DIRECT and not lp and not torch.is_autocast_enabled() and C % 16 == 0) else None
-    ftc = ft.contiguous()
     knn = _knn_key_for(B, L, C, ftc.shape[1], True, None, gc, groups, lp, True) if (xm is not None and KNN_PREP) else None
     if knn is not None:
         kk = keys_key
         if kk is not None and kk.ws is not None and kk.tuple() == knn.tuple():      # the producing Grapher prepared the keys: its
             knn.ws, knn.y_ready = kk.ws, True                                        # workspace is this call's
-        prod = getattr(features, "_gkg_producer", None)
-        if prod is not None and prod() is not None:
-            prod()._gkg_label_knn = (groups, L, gc.k, gc.d, knn.fused_mr)            # ... from its next call on
+        if prod is not None:
+            lk = (groups, L, gc.k, gc.d, knn.fused_mr)
+            if prod.__dict__.get("_gkg_label_knn") != lk:
+                prod._gkg_label_knn = lk                                             # ... from its next call on
+    if not lp:
+        from . import block
+        if block.label_ok(mod, e, ftc, groups):
+            out, edge = block.label_forward(mod, e2, ftc, groups, keys_key)          # ONE library call per direction (block.py)
+            return out.view(B, L, C), edge
     x1, e2r = _lin(e2, mod.fc1, alias=True, xm=xm, knn=knn)          # e2r: e2 again, for the residual of fc2 (one gradient node)
     x1b = x1 if xm is not None else x1.view(B, L, C)
     a2, edge = _graph_and_project(x1b, ftc, None, gc, groups, C, lp, True)      # GrapherLabel returns its graph

@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import fused
+from . import block, fused
 from .dense import PointwiseConv2d
 from .graph import DyGraphConv2d, DyGraphConv2dMultiGroup, DyGraphLabel, DyGraphLabelMultiGroup
 from .layers import DropPath, act_layer, build_norm
@@ -42,6 +42,9 @@ class Grapher(nn.Module):
         return resize_relative_pos(relative_pos, self.n, self.r, H, W)
 
     def forward(self, x):
+        out = block.try_grapher(self, x)              # a step this module has taken before: straight to the block driver
+        if out is not None:
+            return out
         H, W = x.shape[2:]
         relative_pos = self._get_relative_pos(self.relative_pos, H, W)
         groups = self.graph_conv.num_head
@@ -94,6 +97,10 @@ class GrapherLabel(nn.Module):
         self.ffn = FFNLabel(in_channels, in_channels * 4, act=act, drop_path=drop_path)
 
     def forward(self, x, features):
+        res = block.try_label(self, x, features)      # (see Grapher.forward)
+        if res is not None:
+            from .graph import DyGraphLabel
+            return res[0], (res[1] if isinstance(self.graph_conv, DyGraphLabel) else res[1][0])
         B, C = features.shape[:2]
         groups = self.graph_conv.num_head
         if fused.fused_supported(self, x, groups) and features.is_cuda and features.dtype in (torch.float32, torch.bfloat16, torch.float16):

@@ -501,6 +501,71 @@ int gkg_bn_bwd_apply_from_sums(const float* dout, const float* y, const float* a
                                size_t dout_bstride, int act, const double* sums, double* zero_buf, size_t zero_doubles,
                                void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Block-level entry points (round 6; csrc/gkg_block.hip): ONE call runs the whole launch sequence of a Grapher / GrapherLabel
+ * block's forward or backward (reference torch_vertex.py:325-333, :392-403 + FFNLabel :334-360) from a descriptor — the host side
+ * allocates, fills the descriptor and calls.  Every launch inside is one of the entry points above, in the order and with the
+ * arguments of the per-layer composition: bit-identical results.  Scope: fp32, train-mode BatchNorm with rank-local statistics,
+ * no DropPath scaling, un-pooled keys (r == 1), C % 16 == 0, every projection on the split-bf16 kernels.  The library allocates
+ * nothing and keeps no state: all buffers — including, per BN pass, the fp64 column-sum buffer to accumulate into and the region
+ * of the OTHER buffer to clear (the caller's alternating pair, see gkg_bn_bwd_atomic) — come in the descriptor.
+ *   GkgProjBN   one 1x1 projection + BatchNorm: weight as x6 planes (gkg_x6_prep_weights; the grouped projection behind the
+ *               aggregation with kperm), BN parameters, what the forward saves for the backward (Y: pre-BN output (nb, R, cout);
+ *               bn: [4][nb cout] = a, c, mean, invstd), the backward's outputs (dgamma, dbeta; dw: where the weight-gradient
+ *               problem it emits will add — zero on entry).
+ *   GkgGraphOp  the k-NN + aggregation of the block: flags as gkg_knn_fwd (GKG_KNN_X_PREPARED: fc1's BN-apply prepares the
+ *               queries — gkg_bn_apply_knn_prep; GKG_KNN_Y_PREPARED: the keys are already in knn_ws); fused_mr: one kernel
+ *               (gkg_knn_mr_fused_supported), else k-NN + aggregation with u16 lists (nn16) or — a caller that returns the
+ *               graph — int64 lists (nn_idx, center).  arg (B N, C) u16: the winning rows (saved for the backward).
+ * Weight gradients: the backward calls FILL wq[] (3 / 5 problems, in backward order) for gkg_linear_wgrad_x6_batch; the caller
+ * launches them at once or queues them with the rest of its backward pass (operands: dY buffers and saved activations must stay
+ * valid until then). */
+typedef struct GkgProjBN {
+  const void* planes_fwd; const void* planes_dgrad;
+  const float* gamma; const float* beta; const float* bias;
+  float* running_mean; float* running_var; long long* nbt;
+  float momentum, eps;
+  int cin, cout, nb;
+  double* fsum; double* fzero; size_t fzero_n;      /* forward BN pass: accumulate into / clear */
+  double* bsum; double* bzero; size_t bzero_n;      /* backward BN pass */
+  float* Y; float* bn;
+  float* dw; float* dgamma; float* dbeta;
+} GkgProjBN;
+typedef struct GkgGraphOp {
+  int G, k, d, fused_mr;
+  const float* relpos; unsigned knn_flags, mr_flags;
+  void* knn_ws; size_t knn_ws_bytes;
+  uint16_t* arg; uint16_t* nn16; int64_t* nn_idx; int64_t* center;
+} GkgGraphOp;
+typedef struct GkgGrapherBlock {
+  int B, C, H, W;
+  const float* x; float* out; float* out_tm;                 /* out_tm (B N, C) or NULL: the token-major companion */
+  float* xt; float* XM; float* A2;                            /* saved: (T, C), (T, 2C), (T, 2C) */
+  GkgProjBN fc1, conv, fc2;
+  GkgGraphOp graph;
+  void* sk_ws; size_t sk_bytes;                               /* gkg_x6_splitk_workspace_bytes() */
+  /* optional (with out_tm): the label graph behind this block — its keys are prepared by the last pass (gkg_bn_apply_knn_prep as_keys) */
+  int keys_G, keys_L, keys_k, keys_d, keys_fused_mr; unsigned keys_flags; void* keys_ws; size_t keys_ws_bytes;
+  /* backward */
+  const float* dout; const float* dout_tm; float* dx;
+  float* g3; float* dY3; float* dA2; float* dY2; float* dXM; float* gx1; float* dY1; float* dxt;
+} GkgGrapherBlock;
+typedef struct GkgLabelBlock {
+  int B, C, L, M;
+  const float* e; const float* ft; float* out;               /* e (B L, C), keys / values ft (B, M, C), out (B L, C) */
+  float* XM; float* A2; float* h2; float* f1;                 /* saved: (T, 2C), (T, 2C), (T, C), (T, Cf) */
+  GkgProjBN fc1, conv, fc2, ffn1, ffn2;
+  GkgGraphOp graph;
+  void* sk_ws; size_t sk_bytes;
+  /* backward */
+  const float* dout; float* de; float* dft;
+  float* dY5; float* df1; float* dY4; float* dh2; float* dY3; float* dA2; float* dY2; float* dXM; float* gx1; float* dY1;
+} GkgLabelBlock;
+int gkg_grapher_fwd(const GkgGrapherBlock* b, void* stream);
+int gkg_grapher_bwd(const GkgGrapherBlock* b, GkgWgradProblem* wq /* [3] */, void* stream);
+int gkg_grapher_label_fwd(const GkgLabelBlock* b, void* stream);
+int gkg_grapher_label_bwd(const GkgLabelBlock* b, GkgWgradProblem* wq /* [5] */, void* stream);
+
 /*
  * The backbone's first stem convolution (reference gkgnet.py:79-81: Conv2d(3 -> C1/2, 3x3, stride 2, padding 1) on the image),
  * as a direct kernel — with 3 input channels the library's implicit-GEMM forms run at a few TFLOP/s — writing the

@@ -1,0 +1,166 @@
+"""Round 6: the block-level entry points (csrc/gkg_block.hip, gkgnet_amd/block.py) — a Grapher / GrapherLabel block's forward and
+backward as ONE library call each (reference torch_vertex.py:325-333, :392-403, FFNLabel :334-360).  The C driver issues the
+launches of the per-layer composition in ``fused.py`` in the same order with the same arguments, so everything must agree BIT FOR
+BIT: outputs, the returned graph, input gradients, BN parameter gradients, running statistics; the weight gradients (atomically
+accumulated slabs: run-dependent order) to rounding.  Two steps, so that the dual layout and the prepared label keys engage."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(driver: bool, monkeypatch, C=64, H=12, L=20, B=48, G=2, bucket=False, d=2, plans=True):
+    from gkgnet_amd import block, fused, parallel
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    monkeypatch.setattr(block, "ENABLED", driver)
+    torch.manual_seed(11)
+    g = Grapher(C, 9, d, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=True, use_multi_group=True,
+                num_group=G).cuda().train()
+    gl = GrapherLabel(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=False, num_nodes=L,
+                      use_multi_group=True, num_group=G).cuda().train()
+    params = list(g.parameters()) + list(gl.parameters())
+    bk = parallel.GradBucket(params) if bucket else None
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    calls = {"g": 0, "l": 0}
+    rg, rl = block._GrapherBlockFn.forward, block._LabelBlockFn.forward        # (the first step reaches them through the full
+    monkeypatch.setattr(block._GrapherBlockFn, "forward",                       # eligibility test, later ones through the plan)
+                        staticmethod(lambda *a: (calls.__setitem__("g", calls["g"] + 1), rg(*a))[1]))
+    monkeypatch.setattr(block._LabelBlockFn, "forward", staticmethod(lambda *a: (calls.__setitem__("l", calls["l"] + 1), rl(*a))[1]))
+    steps = []
+    for step in range(3):
+        x = torch.randn(B, C, H, H, device="cuda", generator=gen).requires_grad_(True)
+        e = torch.randn(B, L, C, device="cuda", generator=gen).requires_grad_(True)
+        cx, ce = torch.randn(B, C, H, H, device="cuda", generator=gen), torch.randn(B, L, C, device="cuda", generator=gen)
+        if bk is not None:
+            bk.release(prezero=True)
+        else:
+            for p in params:
+                p.grad = None
+        if not plans:
+            block._PLANS.clear()                      # every step through the full eligibility test (fused.grapher_forward ...)
+        out = g(x)
+        e2, edge = gl(e, out)
+        torch.autograd.backward([out, e2], [cx, ce])
+        if bk is not None:
+            bk.pack()
+        torch.cuda.synchronize()
+        steps.append(dict(out=out.detach().clone(), e2=e2.detach().clone(), edge=edge.clone(), dx=x.grad.clone(), de=e.grad.clone(),
+                          grads=[None if p.grad is None else p.grad.clone() for p in params],
+                          bufs=[b.clone() for b in list(g.buffers()) + list(gl.buffers())],
+                          names=[n for n, _ in list(g.named_parameters()) + list(gl.named_parameters())]))
+    monkeypatch.setattr(block._GrapherBlockFn, "forward", staticmethod(rg))
+    monkeypatch.setattr(block._LabelBlockFn, "forward", staticmethod(rl))
+    return calls, steps
+
+
+def _first_difference(on, off):
+    for step, (a, b) in enumerate(zip(on, off)):
+        for key in ("out", "e2", "edge", "dx", "de"):
+            if not torch.equal(a[key], b[key]):
+                return (step, key, float((a[key].float() - b[key].float()).abs().max()), int((a[key] != b[key]).sum()))
+        for u, v in zip(a["bufs"], b["bufs"]):
+            if not torch.equal(u, v):
+                return (step, "buffers")
+        for name, u, v in zip(a["names"], a["grads"], b["grads"]):
+            if (u is None) != (v is None):
+                return (step, name, "presence")
+            if u is None:
+                continue
+            if u.dim() >= 2:                                           # weight gradients: slabs added with fp32 atomics
+                ok = torch.allclose(u, v, rtol=1e-4, atol=1e-3 * float(v.abs().max()) + 1e-6)
+            else:                                                      # BN gammas / betas: plain stores of fp64-accumulated sums
+                ok = torch.allclose(u, v, rtol=1e-5, atol=1e-5 * float(v.abs().max()) + 1e-7)
+            if not ok:
+                return (step, name)
+    return None
+
+
+@pytest.mark.parametrize("bucket,plans", [(False, True), (True, True), (False, False)])
+@pytest.mark.parametrize("shape", [dict(C=64, H=12, L=20, B=48, G=2, d=2), dict(C=80, H=9, L=7, B=5, G=4, d=1)])
+def test_block_driver_is_bit_identical_to_the_composition(bucket, plans, shape, monkeypatch):
+    """The non-deterministic default accumulates the BN column sums with fp64 atomics; their addends are exact multiples of an fp32
+    quantum (rows x an fp32 tile mean), so S / R lands on an fp32 rounding TIE for about one channel in a few hundred, and there
+    the run-dependent order of the atomics decides the last bit of the saved mean (measured with tools/debug/dbg_block.py: two
+    runs of the SAME path differ that way).  A pair of runs that hits such a tie differently is repeated;
+    a difference between the driver and the composition would show in every pair."""
+    diff = None
+    for attempt in range(4):
+        c1, on = _run(True, monkeypatch, bucket=bucket, plans=plans, **shape)
+        c0, off = _run(False, monkeypatch, bucket=bucket, **shape)
+        assert c1 == {"g": 3, "l": 3} and c0 == {"g": 0, "l": 0}      # the driver ran (every step) / did not run
+        diff = _first_difference(on, off)
+        if diff is None:
+            return
+    raise AssertionError(f"driver and composition differ in 4 of 4 pairs of runs: {diff}")
+
+
+def test_ineligible_calls_keep_the_composition(monkeypatch):
+    """Eval mode, DropPath, pooled keys and autocast are outside the driver's scope: the composition runs (and the driver does not)."""
+    from gkgnet_amd import block
+    from gkgnet_amd.grapher import Grapher
+    calls = []
+    real = block._GrapherBlockFn.forward
+    monkeypatch.setattr(block._GrapherBlockFn, "forward", staticmethod(lambda *a: (calls.append(1), real(*a))[1]))
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 12, 12, device="cuda")
+    g = Grapher(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=144, relative_pos=True, use_multi_group=True, num_group=2).cuda()
+    g.train()(x.requires_grad_(True)).sum().backward()
+    assert len(calls) == 1
+    g.eval()
+    with torch.no_grad():
+        g(x)
+    gp = Grapher(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 2, n=144, relative_pos=True, use_multi_group=True, num_group=2).cuda().train()
+    gp(x).sum().backward()                                              # r = 2: pooled keys
+    gd = Grapher(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=144, drop_path=0.3, relative_pos=True, use_multi_group=True,
+                 num_group=2).cuda().train()
+    gd(x).sum().backward()                                              # active DropPath
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        g.train()(x).float().sum().backward()
+    assert len(calls) == 1
+
+
+def test_a_plan_is_dropped_when_the_module_changes(monkeypatch):
+    """The per-module plan (block._Plan) bakes pointers of the BN tensors into the descriptor and skips the eligibility test: a
+    module whose tensors, sub-modules or mode changed must fall back to the full test (and get a new plan or the composition)."""
+    from gkgnet_amd import block
+    from gkgnet_amd.grapher import Grapher
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 12, 12, device="cuda")
+    g = Grapher(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=144, relative_pos=True, use_multi_group=True, num_group=2).cuda().train()
+    ref = Grapher(64, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=144, relative_pos=True, use_multi_group=True, num_group=2).cuda().train()
+    ref.load_state_dict(g.state_dict())
+    monkeypatch.setattr(block, "ENABLED", True)
+    g(x)
+    assert block.try_grapher(g, x) is not None                                     # the plan answers
+    # (1) a parameter replaced by a new tensor object
+    with torch.no_grad():
+        g.fc1[1].weight = torch.nn.Parameter(g.fc1[1].weight.detach() * 2.0)
+        ref.fc1[1].weight.mul_(2.0)
+    assert block.try_grapher(g, x) is None
+    monkeypatch.setattr(block, "ENABLED", False)
+    want = ref(x)
+    monkeypatch.setattr(block, "ENABLED", True)
+    # running statistics: both modules have seen a different number of batches by now; compare on fresh copies of the buffers
+    g.load_state_dict(ref.state_dict())
+    for m in (g, ref):
+        for b in m.modules():
+            if isinstance(b, torch.nn.BatchNorm2d):
+                b.reset_running_stats()
+    monkeypatch.setattr(block, "ENABLED", False)
+    want = ref(x)
+    monkeypatch.setattr(block, "ENABLED", True)
+    got = g(x)
+    assert torch.equal(got, want)
+    # (2) storage moved under the same Parameter object
+    g.fc2[1].bias.data = g.fc2[1].bias.data.clone()
+    assert block.try_grapher(g, x) is None
+    g(x)
+    assert block.try_grapher(g, x) is not None
+    # (3) a BN switched to eval mode: outside the driver's scope altogether
+    g.fc2[1].eval()
+    assert block.try_grapher(g, x) is None
+    g.fc2[1].train()
+    # (4) DropPath switched on
+    from gkgnet_amd.layers import DropPath
+    g.drop_path = DropPath(0.5)
+    assert block.try_grapher(g, x) is None

@@ -78,7 +78,8 @@ def test_block_takes_the_compact_path_and_matches_the_int64_path(C, G, HW, r, tr
     """A Grapher whose graph does not take the one-kernel form (key counts above the fused form's lists / pooled keys through the
     prefilter ...) runs k-NN -> aggregation over u16 lists; forcing the int64 path (GKG_DISABLE-style switch) gives the same
     output bit for bit and the same gradients."""
-    from gkgnet_amd import fused
+    from gkgnet_amd import block, fused
+    monkeypatch.setattr(block, "ENABLED", False)             # the per-layer composition's calls are counted below
     m = _grapher(C, G, 9, HW, r, 3)
     m.train(train)
     x = torch.randn(2, C, HW, HW, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))

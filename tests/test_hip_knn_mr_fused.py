@@ -147,9 +147,11 @@ def test_unsupported_shapes_are_reported():
 
 
 def _block(knn_mr: bool, monkeypatch):
-    from gkgnet_amd import fused
+    from gkgnet_amd import block, fused
     from gkgnet_amd.grapher import Grapher, GrapherLabel
     monkeypatch.setattr(fused, "KNN_MR", knn_mr)
+    monkeypatch.setattr(block, "ENABLED", False)     # this test counts the per-layer composition's calls (the block driver issues
+                                                     # the same launches from C: tests/test_hip_block_driver.py holds it to these bits)
     torch.manual_seed(21)
     C, H, L, B = 64, 12, 20, 48                     # 96 problems x 3 / 1 query tiles: no key splits, the fused form applies
     g = Grapher(C, 9, 2, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=True, use_multi_group=True,
