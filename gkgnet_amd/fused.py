@@ -62,7 +62,7 @@ DETERMINISTIC = os.environ.get("GKG_DETERMINISTIC", "0") != "0"
 # GKG_DISABLE — comma-separated list of optimisations to switch off (A/B measurements).  Round 6 cut the list to the eight
 # structural ones (the per-kernel switches of rounds 2-5 are gone with the alternatives they selected):
 #   knn_mr         k-NN + aggregation as one kernel (row g2)          knn_compact   u16 neighbour lists between two launches
-#   xm_direct      fc1 writes x straight into the operand buffer XM    wgrad_batch   one weight-gradient launch per backward
+#   block_driver   a block's forward / backward as ONE library call     wgrad_batch   one weight-gradient launch per backward
 #   dual_layout    a Grapher's output in both layouts for a label block
 #   mr_gemm        bf16 inference: aggregation as the grouped projection's operand producer (row g1)
 #   channels_last  blocks take / return channels-last tensors as views of their token-major matrices
@@ -1650,9 +1650,9 @@ def _graph_and_project(x1b, yb, relative_pos, gc, groups, C, lp, want_edge):
 
 
 # fc1's output written straight into the grouped projection's operand buffer (see _LinearBNAct.forward ``xm``): fp32 blocks
-# outside the bf16-inference form (whose fused kernel never materialises the operand).  GKG_DISABLE=xm_direct: fc1 writes a plain
-# (T, C) matrix and the aggregation copies x into the buffer next to m (A/B, tests).
-XM_DIRECT = "xm_direct" not in _DISABLED
+# outside the bf16-inference form (whose fused kernel never materialises the operand).  False: fc1 writes a plain (T, C) matrix
+# and the aggregation copies x into the buffer next to m — a module constant for the A/B tests, no environment switch.
+XM_DIRECT = True
 # fc1's BN-apply pass is also the k-NN's token preparation (gkg_bn_apply_knn_prep; needs XM_DIRECT).  A module constant for the
 # A/B tests (identical bits either way), no environment switch.
 KNN_PREP = True
