@@ -143,7 +143,7 @@ def _switches():
 class _Proj:
     """One 1x1 projection + BN of a block: the tensors its kernels read through raw pointers, and its sizes."""
     __slots__ = ("conv", "bn", "W", "bias", "gamma", "beta", "rm", "rv", "nbt", "nb", "cin", "cout", "kperm", "trs", "mom", "eps",
-                 "wshape", "nch")
+                 "wshape", "nch", "wreal")
 
     def __init__(self, seq, nb, cin, cout, kperm, wshape, ident):
         conv, bn = seq[0], seq[1]
@@ -153,7 +153,7 @@ class _Proj:
         self.rm, self.rv, self.nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
         self.nb, self.cin, self.cout, self.kperm = nb, cin, cout, kperm
         self.mom, self.eps = bn.momentum, bn.eps
-        self.wshape, self.nch = wshape, nb * cout
+        self.wshape, self.nch, self.wreal = wshape, nb * cout, conv.weight.shape
         ident += [(seq._modules, "0", conv), (seq._modules, "1", bn), (conv._parameters, "weight", self.W),
                   (conv._parameters, "bias", self.bias), (bn._parameters, "weight", self.gamma), (bn._parameters, "bias", self.beta),
                   (bn._buffers, "running_mean", self.rm), (bn._buffers, "running_var", self.rv),
@@ -191,7 +191,8 @@ class _Plan:
                 return False
         for p in self.projs:
             bn = p.bn
-            if not bn.training or bn.track_running_stats != p.trs or bn.momentum != p.mom or bn.eps != p.eps:
+            if (not bn.training or bn.track_running_stats != p.trs or bn.momentum != p.mom or bn.eps != p.eps
+                    or p.W.shape != p.wreal or p.W.dtype != _F32):
                 return False
         if self.ptrs != [t.data_ptr() for t in self.tensors]:
             return False
