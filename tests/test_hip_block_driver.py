@@ -164,3 +164,70 @@ def test_a_plan_is_dropped_when_the_module_changes(monkeypatch):
     from gkgnet_amd.layers import DropPath
     g.drop_path = DropPath(0.5)
     assert block.try_grapher(g, x) is None
+
+
+def _dp_worker(rank, world, store_path, result_path):
+    """Two data-parallel ranks (sharing GPU 0 over gloo): the block driver under the chunked gradient bucket whose all-reduces start
+    from hooks DURING the backward (the driver's weight gradients sit in the pass-wide batched launch until a chunk is about to be
+    read), against the composition in the same mode and against driver + pack() + one flat all-reduce."""
+    import torch.distributed as dist
+    from gkgnet_amd import block, parallel
+    from gkgnet_amd.grapher import Grapher, GrapherLabel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", store=dist.FileStore(store_path, world), rank=rank, world_size=world)
+    try:
+        C, H, L, B, G = 64, 12, 20, 16, 2
+        gen = torch.Generator().manual_seed(5)
+        data = [t.cuda() for t in (torch.randn(world * B, C, H, H, generator=gen), torch.randn(world * B, L, C, generator=gen),
+                                   torch.randn(world * B, C, H, H, generator=gen), torch.randn(world * B, L, C, generator=gen))]
+        sl = slice(rank * B, (rank + 1) * B)
+        results = {}
+        for mode in ("driver+hooks", "composition+hooks", "driver+flat"):
+            block.ENABLED = not mode.startswith("composition")
+            torch.manual_seed(11)
+            g = Grapher(C, 9, 2, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=True, use_multi_group=True,
+                        num_group=G).cuda().train()
+            gl = GrapherLabel(C, 9, 1, "mr", "gelu", "batch", True, False, 0.2, 1, n=H * H, relative_pos=False, num_nodes=L,
+                              use_multi_group=True, num_group=G).cuda().train()
+            params = list(g.parameters()) + list(gl.parameters())
+            bucket = parallel.GradBucket(params, bucket_bytes=16 << 10)             # several chunks
+            assert len(bucket.chunks) > 3
+            if mode.endswith("hooks"):
+                bucket.install_overlap_hooks()
+            for step in range(3):                                                    # (dual layout / prepared keys from step 1)
+                x, e = data[0][sl].clone().requires_grad_(True), data[1][sl].clone().requires_grad_(True)
+                bucket.release(prezero=True)
+                out = g(x)
+                e2, _ = gl(e, out)
+                torch.autograd.backward([out, e2], [data[2][sl], data[3][sl]])
+                if mode.endswith("hooks"):
+                    bucket.wait()
+                else:
+                    bucket.pack()
+                    bucket.all_reduce()
+                torch.cuda.synchronize()
+            results[mode] = (bucket.flat.clone(), x.grad.clone(), e.grad.clone())
+        ref = results["composition+hooks"]
+        for mode in ("driver+hooks", "driver+flat"):
+            got = results[mode]
+            scale = float(ref[0].abs().max())
+            assert float((got[0] - ref[0]).abs().max()) <= 2e-4 * scale, (mode, float((got[0] - ref[0]).abs().max()), scale)
+            assert torch.allclose(got[1], ref[1], atol=1e-5, rtol=1e-4) and torch.allclose(got[2], ref[2], atol=1e-5, rtol=1e-4), mode
+        other = results["driver+hooks"][0].clone()
+        dist.broadcast(other, 0)                                                     # every rank holds the same averaged gradients
+        assert torch.equal(other, results["driver+hooks"][0])
+        with open(result_path + f".{rank}", "w") as fh:
+            fh.write("ok")
+    finally:
+        block.ENABLED = True
+        dist.destroy_process_group()
+
+
+def test_block_driver_under_the_overlapped_gradient_bucket_two_ranks():
+    import os
+    import tempfile
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        store, res = os.path.join(d, "store"), os.path.join(d, "res")
+        mp.spawn(_dp_worker, args=(2, store, res), nprocs=2, join=True)
+        assert all(os.path.exists(res + f".{r}") for r in range(2))
