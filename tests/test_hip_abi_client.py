@@ -12,7 +12,7 @@ EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abi_client", "ab
 def _exe():
     if not os.path.exists(EXE):
         import __graft_entry__ as g
-        g.build_abi_client()
+        g.build()                        # (library, oracle, then the client: the link needs both shared objects)
     return EXE
 
 
