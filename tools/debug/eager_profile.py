@@ -76,6 +76,11 @@ def main():
         cls.forward = staticmethod(timed(f"py {nm}.forward (incl. C)", cls.forward))
         cls.backward = staticmethod(timed(f"py {nm}.backward (incl. C)", cls.backward))
     fused.flush_wgrads = timed("py flush_wgrads (incl. C)", fused.flush_wgrads)
+    for nm in ("_proj_fwd", "_proj_bwd", "_graph_op", "_issue_wgrads", "try_grapher", "try_label", "_run_grapher"):
+        setattr(block, nm, timed("  block." + nm, getattr(block, nm)))
+    block._Plan.valid = timed("  block._Plan.valid", block._Plan.valid)
+    fused._grad_outs = timed("  fused._grad_outs", fused._grad_outs)
+    fused._label_features = timed("  fused._label_features", fused._label_features)
     bucket.pack = timed("py bucket.pack", bucket.pack)
     bucket.release = timed("py bucket.release", bucket.release)
     torch.cuda.synchronize()
